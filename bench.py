@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: corner residual+Jacobian evals/s (mode E) on synthetic calib frames.
+
+    python bench.py --gpus N --steps K --warmup W [--frames F] [--model eucm]
+
+One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  A "step" is one pass
+of the hot path over one batch: every rank evaluates r[2] + J[2 x D] for all corners of its frame
+shard (F frames x 144 corners per GPU -- weak scaling; mode E needs no collective).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+The workload defaults to the north-star headline (10 000 frames x 144 corners, EUCM, per GPU);
+`--frames 1000` is BASELINE.json configs[1].  PyTorch is used only for the process group, the
+barrier and HIP events; the kernels are the hand-written HIP library behind include/ccal.h.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (144 corners each)")
+    ap.add_argument("--model", default="eucm", choices=["ucm", "eucm", "kb4", "opencv5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (mode N / solver) measurements")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
+
+    # ---- synthetic calib frames for this rank (weak scaling: F frames per GPU) -------------------
+    sp = synth.make_problem(args.frames, args.model, seed=0xC0FFEE + 1000003 * rank)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = Context(local_rank, stream=stream.cuda_stream)
+    prob = Problem.from_synth(ctx, sp)
+    D = prob.block_dim(0)
+    n_corners = prob.n_corners
+    r_out = torch.empty(n_corners * 2, dtype=torch.float64, device=dev)
+    J_out = torch.empty(prob.j_len, dtype=torch.float64, device=dev)
+    prob.upload_params(sp.intr0, sp.poses0, sp.extr0)
+
+    def step():
+        prob.eval_dev(r_out.data_ptr(), J_out.data_ptr(), apply_loss=False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record(stream)
+            step()
+            b.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(n_corners)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_corners = float(tot.item())
+    else:
+        total_corners = float(n_corners)
+
+    out = None
+    if rank == 0:
+        # algorithmic bytes of one launch on this GPU: per corner 5 f32 in + r[2] + J[2][D] f64 out,
+        # per frame one 48-B pose
+        bytes_per_corner = 20 + 16 + 16 * D
+        algo_bytes = n_corners * bytes_per_corner + sp.n_slots * 48
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "corner residual+Jacobian evals/sec; LM iters/sec to converge (EUCM, TUM-VI cam0)",
+            "value": total_corners * args.steps / elapsed,
+            "unit": "corner residual+Jacobian evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.frames} frames x 144 corners per GPU, {args.model.upper()}, "
+                                   f"mode E (r[2] + J[2x{D}] per corner materialised in HBM), 6x6 AprilGrid",
+                       "frames_per_gpu": args.frames, "corners_per_frame": 144, "model": args.model,
+                       "block_jacobian_cols": D, "sharding": "frames" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_eval", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
+        }
+
+    # ---- secondary: fused normal equations (mode N) and solver iterations/s ----------------------
+    if rank == 0 and not args.no_extra:
+        extra = {}
+        try:
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    prob.build_normal_dev(0.0)
+                torch.cuda.synchronize()
+                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                nb = 50
+                a.record(stream)
+                for _ in range(nb):
+                    prob.build_normal_dev(0.0)
+                b.record(stream)
+                torch.cuda.synchronize()
+            ms = a.elapsed_time(b) / nb
+            extra["mode_N_build_ms"] = ms
+            extra["mode_N_evals_per_s"] = n_corners / (ms * 1e-3)
+            for name, method in (("gn", 0), ("lm", 1)):
+                intr, poses, _, rep = prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+                extra[f"{name}_iterations"] = rep.iterations
+                extra[f"{name}_solve_ms"] = rep.solve_ms
+                extra[f"{name}_iters_per_s"] = rep.iterations / (rep.solve_ms * 1e-3) if rep.solve_ms > 0 else None
+                extra[f"{name}_final_cost"] = rep.final_cost
+                extra[f"{name}_status"] = rep.status
+                extra[f"{name}_max_rel_intrinsics_err_vs_gt"] = float(
+                    np.abs(intr[0, :4] / sp.intr_gt[0, :4] - 1).max())
+        except Exception as e:  # noqa: BLE001
+            extra["error"] = repr(e)
+        out["extra"] = extra
+
+    # ---- CPU baseline: the oracle (restatement of the reference's per-corner dual-number path) ----
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        sample_frames = min(args.frames, 1000)
+        sub = sp.shard(0, max(1, args.frames // sample_frames)) if args.frames > sample_frames else sp
+        op = ob.OracleProblem.from_synth(sub)
+        cores = ob.hardware_threads()
+        op.eval(sub.intr0, sub.poses0, threads=cores)                     # warm-up
+        reps, t_used, tmin = 0, 0.0, 1e30
+        while t_used < 10.0 and reps < 200:
+            t1 = time.perf_counter()
+            op.eval(sub.intr0, sub.poses0, threads=cores)
+            dt = time.perf_counter() - t1
+            t_used += dt; tmin = min(tmin, dt); reps += 1
+        t1 = time.perf_counter()
+        op.eval(sub.intr0, sub.poses0, threads=1)
+        t_single = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": op.n_corners * reps / t_used, "unit": "corner residual+Jacobian evals/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{sub.n_slots} frames x 144 corners of the same workload, {reps} repetitions, "
+                      f"oracle Dual<{D}> per-corner evaluation on {cores} threads (best {op.n_corners / tmin:.3e}/s); "
+                      f"single thread {op.n_corners / t_single:.3e}/s",
+            "single_thread_value": op.n_corners / t_single,
+            "note": "C++ stack-dual restatement of the Rust path; faster than tiny-solver's heap-backed duals, "
+                    "so GPU/CPU ratios are conservative",
+        }
+        out["gpu_over_cpu"] = out["value"] / world / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

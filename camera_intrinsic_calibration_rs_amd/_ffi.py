@@ -1,0 +1,112 @@
+"""ctypes binding of the C ABI in include/ccal.h.
+
+Fails loudly when the HIP library has not been built: there is no CPU fallback in the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PMAX = 10
+MAX_CAMS = 8
+KMAX = 64
+
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NONFINITE, ERR_NOT_PD, ERR_NO_CONVERGENCE, ERR_UNSUPPORTED = range(7)
+STATUS_NAMES = ["CCAL_OK", "CCAL_ERR_INVALID_ARG", "CCAL_ERR_HIP", "CCAL_ERR_NONFINITE", "CCAL_ERR_NOT_PD",
+                "CCAL_ERR_NO_CONVERGENCE", "CCAL_ERR_UNSUPPORTED"]
+METHOD_GN, METHOD_LM = 0, 1
+
+_dp = C.POINTER(C.c_double)
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("n_cams", C.c_int32), ("model", _ip), ("width", _dp), ("height", _dp),
+        ("xy_same_focal", C.c_int32), ("n_slots", C.c_int32), ("n_obs", C.c_int32),
+        ("obs_cam", _ip), ("obs_slot", _ip), ("obs_offsets", _lp),
+        ("p3d_x", _fp), ("p3d_y", _fp), ("p3d_z", _fp), ("p2d_u", _fp), ("p2d_v", _fp),
+        ("huber_delta", C.c_double),
+    ]
+
+
+class SolverOpts(C.Structure):
+    _fields_ = [
+        ("method", C.c_int32), ("max_iterations", C.c_int32),
+        ("min_abs_error_decrease", C.c_double), ("min_rel_error_decrease", C.c_double), ("min_error", C.c_double),
+        ("lm_initial_radius", C.c_double), ("lm_min_diagonal", C.c_double), ("lm_max_diagonal", C.c_double),
+        ("verbose", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Report(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("iterations", C.c_int32), ("lm_accepted", C.c_int32), ("lm_rejected", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms", C.c_double), ("reserved", C.c_double),
+    ]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libccal_hip.so")
+
+# every symbol include/ccal.h declares: (name, restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = [
+    ("ccal_ctx_create", C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    ("ccal_ctx_destroy", None, [_vp]),
+    ("ccal_last_error", C.c_char_p, [_vp]),
+    ("ccal_version", C.c_char_p, []),
+    ("ccal_model_num_params", C.c_int, [C.c_int]),
+    ("ccal_problem_create", C.c_int, [_vp, C.POINTER(ProblemDesc), C.POINTER(_vp)]),
+    ("ccal_problem_destroy", None, [_vp]),
+    ("ccal_set_defaults", C.c_int, [C.POINTER(SolverOpts)]),
+    ("ccal_set_bounds", C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double]),
+    ("ccal_clear_bounds", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("ccal_fix_param", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("ccal_unfix_param", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("ccal_apply_reference_bounds", C.c_int, [_vp]),
+    ("ccal_disable_distortions", C.c_int, [_vp, C.c_int, _dp]),
+    ("ccal_set_allreduce", C.c_int, [_vp, ALLREDUCE_FN, _vp]),
+    ("ccal_num_corners", C.c_int64, [_vp]),
+    ("ccal_reduced_dim", C.c_int, [_vp]),
+    ("ccal_block_dim", C.c_int, [_vp, C.c_int]),
+    ("ccal_eff_num_params", C.c_int, [_vp, C.c_int]),
+    ("ccal_jacobian_len", C.c_int64, [_vp]),
+    ("ccal_eval", C.c_int, [_vp, _dp, _dp, _dp, C.c_int, _dp, _dp]),
+    ("ccal_upload_params", C.c_int, [_vp, _dp, _dp, _dp]),
+    ("ccal_download_params", C.c_int, [_vp, _dp, _dp, _dp]),
+    ("ccal_eval_dev", C.c_int, [_vp, C.c_int, _vp, _vp]),
+    ("ccal_sync", C.c_int, [_vp]),
+    ("ccal_build_normal", C.c_int, [_vp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp]),
+    ("ccal_build_normal_dev", C.c_int, [_vp, C.c_double]),
+    ("ccal_solve", C.c_int, [_vp, C.POINTER(SolverOpts), _dp, _dp, _dp, C.POINTER(Report)]),
+    ("ccal_reprojection_errors", C.c_int, [_vp, _dp, _dp, _dp, _dp]),
+    ("ccal_validation", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+]
+
+_lib = None
+
+
+class CcalLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libccal_hip.so (built by __graft_entry__.build()).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CcalLibraryMissing(
+            f"{LIB_PATH} not found: the HIP engine is not built (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C camera_intrinsic_calibration_rs_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)   # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,321 @@
+// C ABI of the engine (include/ccal.h): context, problem residency, mode E entry points,
+// constraints, validation.  The solver loop lives in ccal_solver.hip.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "ccal_internal.hpp"
+#include "ccal_normal.hpp"
+
+using namespace ccal;
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return CCAL_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+static int fail(ccal_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <class T>
+static int upload(ccal_ctx* ctx, T** dst, const T* src, size_t n) {
+    HIP_TRY(ctx, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return CCAL_OK;
+}
+
+extern "C" {
+
+const char* ccal_version(void) { return "ccal-mi355x 0.1.0 (gfx950)"; }
+int ccal_model_num_params(int model) { return (model >= 0 && model <= 3) ? model_np(model) : -1; }
+
+int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
+    if (!out) return CCAL_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return CCAL_ERR_HIP;
+    ccal_ctx* c = new (std::nothrow) ccal_ctx();
+    if (!c) return CCAL_ERR_HIP;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return CCAL_ERR_HIP; }
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CCAL_ERR_HIP; }
+        c->own_stream = true;
+    }
+    *out = c;
+    return CCAL_OK;
+}
+void ccal_ctx_destroy(ccal_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+const char* ccal_last_error(const ccal_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int ccal_sync(ccal_ctx* ctx) {
+    if (!ctx) return CCAL_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+int ccal_set_defaults(ccal_solver_opts* o) {
+    if (!o) return CCAL_ERR_INVALID_ARG;
+    o->method = CCAL_METHOD_GN; o->max_iterations = 100;
+    o->min_abs_error_decrease = 1e-5; o->min_rel_error_decrease = 1e-5; o->min_error = 1e-10;
+    o->lm_initial_radius = 1e4; o->lm_min_diagonal = 1e-6; o->lm_max_diagonal = 1e32;
+    o->verbose = 0; o->reserved = 0;
+    return CCAL_OK;
+}
+
+int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem** out) {
+    if (!ctx || !d || !out) return CCAL_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (d->n_cams < 1 || d->n_cams > CCAL_MAX_CAMS || d->n_slots < 0 || d->n_obs < 0 || !d->model ||
+        (d->n_obs > 0 && (!d->obs_cam || !d->obs_slot || !d->obs_offsets)))
+        return fail(ctx, CCAL_ERR_INVALID_ARG, "bad problem description");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ccal_problem* p = new (std::nothrow) ccal_problem();
+    if (!p) return fail(ctx, CCAL_ERR_HIP, "out of host memory");
+    p->ctx = ctx; p->n_cams = d->n_cams; p->n_slots = d->n_slots; p->n_obs = d->n_obs;
+    p->one_focal = d->xy_same_focal != 0; p->huber_delta = d->huber_delta;
+    p->cams.resize(d->n_cams);
+    int K = 0;
+    for (int c = 0; c < d->n_cams; ++c) {
+        CamLayout& cl = p->cams[c];
+        cl.model = d->model[c];
+        if (cl.model < 0 || cl.model > 3) { delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "unknown camera model"); }
+        cl.P = model_np(cl.model); cl.Peff = cl.P - (p->one_focal ? 1 : 0);
+        cl.D = cl.Peff + (c == 0 ? 6 : 12);
+        cl.col_theta = K; K += cl.Peff;
+        if (c > 0) { cl.col_extr = K; K += 6; }
+        cl.width = d->width ? d->width[c] : 0.0; cl.height = d->height ? d->height[c] : 0.0;
+    }
+    if (K > CCAL_KMAX) { delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "reduced system too large"); }
+    p->K = K;
+    p->h_obs_off.assign(d->obs_offsets, d->obs_offsets + d->n_obs + 1);
+    p->h_obs_cam.assign(d->obs_cam, d->obs_cam + d->n_obs);
+    p->h_obs_slot.assign(d->obs_slot, d->obs_slot + d->n_obs);
+    if (d->n_obs == 0) p->h_obs_off.assign(1, 0);
+    p->h_joff.resize(d->n_obs + 1);
+    int64_t j = 0;
+    for (int o = 0; o < d->n_obs; ++o) {
+        const int cam = p->h_obs_cam[o], slot = p->h_obs_slot[o];
+        const int64_t n = p->h_obs_off[o + 1] - p->h_obs_off[o];
+        if (cam < 0 || cam >= d->n_cams || slot < 0 || slot >= d->n_slots || n < 0 || p->h_obs_off[0] != 0) {
+            delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "bad observation frame table");
+        }
+        p->h_joff[o] = j; j += n * 2 * p->cams[cam].D;
+        p->cams[cam].obs.push_back(o);
+    }
+    p->h_joff[d->n_obs] = j; p->j_len = j;
+    p->n_corners = p->h_obs_off[d->n_obs];
+    const size_t nc = (size_t)p->n_corners;
+    if (nc && (!d->p3d_x || !d->p3d_y || !d->p3d_z || !d->p2d_u || !d->p2d_v)) { delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "null corner arrays"); }
+    int rc;
+#define UP(dst, src, n) if ((rc = upload(ctx, &p->dst, src, n)) != CCAL_OK) { ccal_problem_destroy(p); return rc; }
+    UP(d_x, d->p3d_x, nc) UP(d_y, d->p3d_y, nc) UP(d_z, d->p3d_z, nc) UP(d_u, d->p2d_u, nc) UP(d_v, d->p2d_v, nc)
+    UP(d_obs_off, p->h_obs_off.data(), p->h_obs_off.size())
+    UP(d_joff, p->h_joff.data(), p->h_joff.size())
+    UP(d_obs_cam, p->h_obs_cam.data(), p->h_obs_cam.size())
+    UP(d_obs_slot, p->h_obs_slot.data(), p->h_obs_slot.size())
+    for (int c = 0; c < d->n_cams; ++c) { UP(cams[c].d_obs, p->cams[c].obs.data(), p->cams[c].obs.size()) }
+#undef UP
+    const size_t ni = (size_t)d->n_cams * CCAL_PMAX, np6 = (size_t)std::max(d->n_slots, 1) * 6, ne = (size_t)d->n_cams * 6;
+    double** bufs[6] = { &p->d_intr, &p->d_poses, &p->d_extr, &p->d_intr_c, &p->d_poses_c, &p->d_extr_c };
+    const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
+    for (int i = 0; i < 6; ++i) {
+        if (hipMalloc((void**)bufs[i], sz[i] * sizeof(double)) != hipSuccess ||
+            hipMemsetAsync(*bufs[i], 0, sz[i] * sizeof(double), ctx->stream) != hipSuccess) {
+            ccal_problem_destroy(p); return fail(ctx, CCAL_ERR_HIP, "hipMalloc(params) failed");
+        }
+    }
+    p->lo.assign(ni, 0.0); p->hi.assign(ni, 0.0); p->has_bound.assign(ni, 0); p->fixed.assign(ni, 0);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ccal_problem_destroy(p); return fail(ctx, CCAL_ERR_HIP, "upload failed"); }
+    *out = p;
+    return CCAL_OK;
+}
+
+void ccal_problem_destroy(ccal_problem* p) {
+    if (!p) return;
+    void* ptrs[] = { p->d_x, p->d_y, p->d_z, p->d_u, p->d_v, p->d_obs_off, p->d_joff, p->d_obs_cam, p->d_obs_slot,
+                     p->d_intr, p->d_poses, p->d_extr, p->d_intr_c, p->d_poses_c, p->d_extr_c, p->d_r, p->d_J, p->d_err };
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    for (auto& c : p->cams) if (c.d_obs) (void)hipFree(c.d_obs);
+    normal_ws_destroy(p);
+    delete p;
+}
+
+int64_t ccal_num_corners(const ccal_problem* p) { return p ? p->n_corners : -1; }
+int ccal_reduced_dim(const ccal_problem* p) { return p ? p->K : -1; }
+int ccal_block_dim(const ccal_problem* p, int cam) { return (p && cam >= 0 && cam < p->n_cams) ? p->cams[cam].D : -1; }
+int ccal_eff_num_params(const ccal_problem* p, int cam) { return (p && cam >= 0 && cam < p->n_cams) ? p->cams[cam].Peff : -1; }
+int64_t ccal_jacobian_len(const ccal_problem* p) { return p ? p->j_len : -1; }
+
+static bool idx_ok(const ccal_problem* p, int cam, int idx) {
+    return p && cam >= 0 && cam < p->n_cams && idx >= 0 && idx < p->cams[cam].Peff;
+}
+int ccal_set_bounds(ccal_problem* p, int cam, int idx, double lo, double hi) {
+    if (!idx_ok(p, cam, idx) || !(lo <= hi)) return CCAL_ERR_INVALID_ARG;
+    p->lo[cam * CCAL_PMAX + idx] = lo; p->hi[cam * CCAL_PMAX + idx] = hi; p->has_bound[cam * CCAL_PMAX + idx] = 1;
+    return CCAL_OK;
+}
+int ccal_clear_bounds(ccal_problem* p, int cam, int idx) {
+    if (!idx_ok(p, cam, idx)) return CCAL_ERR_INVALID_ARG;
+    p->has_bound[cam * CCAL_PMAX + idx] = 0; return CCAL_OK;
+}
+int ccal_fix_param(ccal_problem* p, int cam, int idx) {
+    if (!idx_ok(p, cam, idx)) return CCAL_ERR_INVALID_ARG;
+    p->fixed[cam * CCAL_PMAX + idx] = 1; return CCAL_OK;
+}
+int ccal_unfix_param(ccal_problem* p, int cam, int idx) {
+    if (!idx_ok(p, cam, idx)) return CCAL_ERR_INVALID_ARG;
+    p->fixed[cam * CCAL_PMAX + idx] = 0; return CCAL_OK;
+}
+
+// set_problem_parameter_bound (src/util.rs:29-49).  The distortion bounds come from
+// camera-intrinsic-model's distortion_params_bound(), whose source is absent: the values below are this
+// build's documented assumption and can be overridden with ccal_set_bounds.
+int ccal_apply_reference_bounds(ccal_problem* p) {
+    if (!p) return CCAL_ERR_INVALID_ARG;
+    const int shift = p->one_focal ? 1 : 0;
+    for (int c = 0; c < p->n_cams; ++c) {
+        const CamLayout& cl = p->cams[c];
+        ccal_set_bounds(p, c, 0, 0.0, 10000.0);
+        ccal_set_bounds(p, c, 1 - shift, 0.0, 10000.0);
+        ccal_set_bounds(p, c, 2 - shift, 0.0, cl.width);
+        ccal_set_bounds(p, c, 3 - shift, 0.0, cl.height);
+        switch (cl.model) {
+            case kUCM: ccal_set_bounds(p, c, 4 - shift, 1e-6, 1.0); break;
+            case kEUCM: ccal_set_bounds(p, c, 4 - shift, 1e-6, 1.0); ccal_set_bounds(p, c, 5 - shift, 1e-6, 100.0); break;
+            case kKB4: for (int i = 4; i < 8; ++i) ccal_set_bounds(p, c, i - shift, -1.0, 1.0); break;
+            default: for (int i = 4; i < 9; ++i) ccal_set_bounds(p, c, i - shift, -1.0, 1.0); break;
+        }
+    }
+    return CCAL_OK;
+}
+// set_problem_parameter_disabled (src/util.rs:50-71): fix the last k distortion parameters at 0.
+int ccal_disable_distortions(ccal_problem* p, int n_disabled, double* intr_io) {
+    if (!p || n_disabled < 0) return CCAL_ERR_INVALID_ARG;
+    const int shift = p->one_focal ? 1 : 0;
+    for (int c = 0; c < p->n_cams; ++c) {
+        for (int i = 0; i < n_disabled; ++i) {
+            const int eff = p->cams[c].P - 1 - shift - i;
+            if (eff < 0) return CCAL_ERR_INVALID_ARG;
+            ccal_fix_param(p, c, eff);
+            if (intr_io) intr_io[c * CCAL_PMAX + eff + shift] = 0.0;   // eff -> full index
+        }
+    }
+    return CCAL_OK;
+}
+int ccal_set_allreduce(ccal_problem* p, ccal_allreduce_fn fn, void* user) {
+    if (!p) return CCAL_ERR_INVALID_ARG;
+    p->allreduce = fn; p->allreduce_user = user;
+    return CCAL_OK;
+}
+
+int ccal_upload_params(ccal_problem* p, const double* intr, const double* poses, const double* extr) {
+    if (!p) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (intr) HIP_TRY(ctx, hipMemcpyAsync(p->d_intr, intr, sizeof(double) * p->n_cams * CCAL_PMAX, hipMemcpyHostToDevice, ctx->stream));
+    if (poses && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(p->d_poses, poses, sizeof(double) * p->n_slots * 6, hipMemcpyHostToDevice, ctx->stream));
+    if (extr) HIP_TRY(ctx, hipMemcpyAsync(p->d_extr, extr, sizeof(double) * p->n_cams * 6, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused by the caller
+    return CCAL_OK;
+}
+int ccal_download_params(ccal_problem* p, double* intr, double* poses, double* extr) {
+    if (!p) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    if (intr) HIP_TRY(ctx, hipMemcpyAsync(intr, p->d_intr, sizeof(double) * p->n_cams * CCAL_PMAX, hipMemcpyDeviceToHost, ctx->stream));
+    if (poses && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(poses, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToHost, ctx->stream));
+    if (extr) HIP_TRY(ctx, hipMemcpyAsync(extr, p->d_extr, sizeof(double) * p->n_cams * 6, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (intr && p->one_focal) for (int c = 0; c < p->n_cams; ++c) intr[c * CCAL_PMAX + 1] = intr[c * CCAL_PMAX];   // fy = f (src/util.rs:467-470)
+    return CCAL_OK;
+}
+
+static KArgs make_args(const ccal_problem* p, int cam) {
+    KArgs a = {};
+    a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
+    a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
+    a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
+    a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
+    a.huber_delta = p->huber_delta;
+    return a;
+}
+
+int ccal_eval_dev(ccal_problem* p, int apply_loss, double* r_dev, double* J_dev) {
+    if (!p || !r_dev || !J_dev) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    for (int c = 0; c < p->n_cams; ++c) {
+        KArgs a = make_args(p, c);
+        a.apply_loss = apply_loss; a.r_out = r_dev; a.J_out = J_dev;
+        HIP_TRY(ctx, launch_eval(p, c, a, ctx->stream));
+    }
+    return CCAL_OK;
+}
+
+int ccal_eval(ccal_problem* p, const double* intr, const double* poses, const double* extr,
+              int apply_loss, double* r_out, double* J_out) {
+    if (!p || !intr || (!poses && p->n_slots) || !r_out || !J_out) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    int rc = ccal_upload_params(p, intr, poses, extr);
+    if (rc != CCAL_OK) return rc;
+    if (!p->d_r) HIP_TRY(ctx, hipMalloc((void**)&p->d_r, sizeof(double) * std::max<int64_t>(2 * p->n_corners, 2)));
+    if (!p->d_J) HIP_TRY(ctx, hipMalloc((void**)&p->d_J, sizeof(double) * std::max<int64_t>(p->j_len, 2)));
+    rc = ccal_eval_dev(p, apply_loss, p->d_r, p->d_J);
+    if (rc != CCAL_OK) return rc;
+    if (p->n_corners) {
+        HIP_TRY(ctx, hipMemcpyAsync(r_out, p->d_r, sizeof(double) * 2 * p->n_corners, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(J_out, p->d_J, sizeof(double) * p->j_len, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr, double* err_out) {
+    if (!p || !intr || (!poses && p->n_slots) || !err_out) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    int rc = ccal_upload_params(p, intr, poses, extr);
+    if (rc != CCAL_OK) return rc;
+    if (!p->d_err) HIP_TRY(ctx, hipMalloc((void**)&p->d_err, sizeof(double) * std::max<int64_t>(p->n_corners, 1)));
+    for (int c = 0; c < p->n_cams; ++c) {
+        KArgs a = make_args(p, c);
+        a.err_out = p->d_err;
+        HIP_TRY(ctx, launch_reproj_err(p, c, a, ctx->stream));
+    }
+    if (p->n_corners) HIP_TRY(ctx, hipMemcpyAsync(err_out, p->d_err, sizeof(double) * p->n_corners, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+// validation() statistics of one camera (src/util.rs:778-795): errors of that camera's corners,
+// sorted; median = e[len/2]; avg_99 = sum_{i < len*99/100} e_i / (len*99/100).
+int ccal_validation(ccal_problem* p, int cam, const double* intr, const double* poses, const double* extr,
+                    double* avg_99, double* median) {
+    if (!p || cam < 0 || cam >= p->n_cams || !avg_99 || !median) return CCAL_ERR_INVALID_ARG;
+    std::vector<double> all((size_t)std::max<int64_t>(p->n_corners, 1));
+    int rc = ccal_reprojection_errors(p, intr, poses, extr, all.data());
+    if (rc != CCAL_OK) return rc;
+    std::vector<double> e;
+    for (int o : p->cams[cam].obs)
+        e.insert(e.end(), all.begin() + p->h_obs_off[o], all.begin() + p->h_obs_off[o + 1]);
+    if (e.empty()) return fail(p->ctx, CCAL_ERR_INVALID_ARG, "camera has no observations");
+    std::sort(e.begin(), e.end());
+    *median = e[e.size() / 2];
+    const size_t n99 = e.size() * 99 / 100;
+    double s = 0.0;
+    for (size_t i = 0; i < n99; ++i) s += e[i] / (double)n99;
+    *avg_99 = s;
+    return CCAL_OK;
+}
+
+}  // extern "C"

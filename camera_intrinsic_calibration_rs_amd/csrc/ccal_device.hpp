@@ -1,0 +1,308 @@
+// Device-side math of the reprojection hot path (gfx950 / CDNA4, f64).
+//
+// What the reference does per corner with forward-mode dual numbers
+// (src/optimization/factors.rs:152-173 and 204-228: rebuild the model, exp-map the rvec,
+// transform, project, subtract) is re-derived here analytically and split by how often each
+// piece changes:
+//   per frame  : R(rvec), dR/drvec_k, composed transforms      -> frame_setup_*  (once per wave)
+//   per corner : p = R X + t, projection + its 2x3 / 2xP partials, chain rule    (once per lane)
+// Column order of a block Jacobian follows the reference's variable order
+// [params, rvec, tvec(, rvec_i_0, tvec_i_0)] (src/util.rs:411, 621-627).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ccal_models.hpp"
+
+namespace ccal {
+
+// Frame constants, laid out in LDS (doubles).  cam0 factor uses FC_RC/FC_TC/FC_A only.
+//   p      = RC X + TC
+//   dp/drvec_0_b[k] = A_k X                (A_k = dR0/dw_k for cam 0, R1 dR0/dw_k for cam c>0)
+//   dp/dtvec_0_b    = I (cam 0) or R1
+//   dp/drvec_c_0[k] = B_k X + BK_k         (B_k = dR1/dw_k R0, BK_k = dR1/dw_k t0)
+//   dp/dtvec_c_0    = I
+constexpr int FC_RC = 0, FC_TC = 9, FC_A = 12, FC_R1 = 39, FC_B = 48, FC_BK = 75, FC_SIZE = 84;
+
+// R = exp([w]x) and G_k = dR/dw_k (row-major 3x3 each), series below theta^2 < 0.04.
+// The reference's quaternion path (nalgebra from_scaled_axis) returns the identity as a constant at
+// exactly rvec == 0, i.e. a zero rvec-Jacobian there; we use the true limit dR/dw_k = [e_k]x instead
+// ("rvec = 0").
+__device__ inline void so3_exp_jac(const double w[3], double R[9], double G[27]) {
+    const double wx = w[0], wy = w[1], wz = w[2];
+    const double t2 = wx * wx + wy * wy + wz * wz;
+    double a, b, c, d;
+    if (t2 < 0.04) {
+        a = 1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800 + t2 * (1.0 / 6227020800.0))))));
+        b = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 + t2 * (-1.0 / 479001600 + t2 * (1.0 / 87178291200.0))))));
+        c = -1.0 / 3 + t2 * (1.0 / 30 + t2 * (-1.0 / 840 + t2 * (1.0 / 45360 + t2 * (-1.0 / 3991680 + t2 * (1.0 / 518918400.0)))));
+        d = -1.0 / 12 + t2 * (1.0 / 180 + t2 * (-1.0 / 6720 + t2 * (1.0 / 453600 + t2 * (-1.0 / 47900160 + t2 * (1.0 / 7264857600.0)))));
+    } else {
+        const double t = sqrt(t2);
+        double s, co;
+        sincos(t, &s, &co);
+        const double it2 = 1.0 / t2;
+        a = s / t;
+        const double sh = sin(0.5 * t);
+        b = 2.0 * sh * sh * it2;          // (1 - cos t) / t^2 without cancellation
+        c = (co - a) * it2;
+        d = (a - 2.0 * b) * it2;
+    }
+    const double xx = wx * wx, yy = wy * wy, zz = wz * wz, xy = wx * wy, xz = wx * wz, yz = wy * wz;
+    // R = I + a W + b W^2,  W^2 = w w^T - t2 I
+    R[0] = 1.0 - b * (yy + zz); R[1] = b * xy - a * wz;     R[2] = b * xz + a * wy;
+    R[3] = b * xy + a * wz;     R[4] = 1.0 - b * (xx + zz); R[5] = b * yz - a * wx;
+    R[6] = b * xz - a * wy;     R[7] = b * yz + a * wx;     R[8] = 1.0 - b * (xx + yy);
+    // G_k = c w_k W + a E_k + d w_k W^2 + b (E_k W + W E_k)
+    const double W[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
+    const double W2[9] = { -(yy + zz), xy, xz, xy, -(xx + zz), yz, xz, yz, -(xx + yy) };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double wk = w[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                // E_k[i][j] = -eps_{ijk}
+                const int e = (i == j || j == k || i == k) ? 0 : (((j - i + 3) % 3 == 1) ? 1 : -1);   // eps_{ijk}
+                const double Ek = -(double)e;
+                const double sym = (j == k ? w[i] : 0.0) + (i == k ? w[j] : 0.0) - (i == j ? 2.0 * wk : 0.0);
+                G[k * 9 + i * 3 + j] = c * wk * W[i * 3 + j] + a * Ek + d * wk * W2[i * 3 + j] + b * sym;
+            }
+        }
+    }
+}
+
+__device__ inline void mat3_mul(const double* A, const double* B, double* C) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+}
+__device__ inline void mat3_vec(const double* A, const double* v, double* o) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2];
+}
+
+// Fill the frame constants for one observation frame.  pose = rvec,tvec of T_0_b; extr = rvec,tvec
+// of T_c_0 (OTHER only).  Every lane computes the same values; `fc` may be registers or LDS.
+template <bool OTHER>
+__device__ inline void frame_setup(const double* pose, const double* extr, double* fc) {
+    double R0[9], G0[27];
+    so3_exp_jac(pose, R0, G0);
+    if constexpr (!OTHER) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fc[FC_RC + i] = R0[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fc[FC_TC + i] = pose[3 + i];
+#pragma unroll
+        for (int i = 0; i < 27; ++i) fc[FC_A + i] = G0[i];
+    } else {
+        double R1[9], G1[27], tmp[9], v[3];
+        so3_exp_jac(extr, R1, G1);
+        mat3_mul(R1, R0, tmp);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fc[FC_RC + i] = tmp[i];
+        mat3_vec(R1, pose + 3, v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fc[FC_TC + i] = v[i] + extr[3 + i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            mat3_mul(R1, G0 + 9 * k, tmp);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fc[FC_A + 9 * k + i] = tmp[i];
+            mat3_mul(G1 + 9 * k, R0, tmp);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fc[FC_B + 9 * k + i] = tmp[i];
+            mat3_vec(G1 + 9 * k, pose + 3, v);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fc[FC_BK + 3 * k + i] = v[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fc[FC_R1 + i] = R1[i];
+    }
+}
+
+// Normalised projection m = (mx, my) with partials w.r.t. the camera-frame point (dmx[3], dmy[3])
+// and w.r.t. the distortion parameters th[4..P) (ddx[ND], ddy[ND]).
+template <int MODEL>
+__device__ __forceinline__ void project_partials(const double* th, double x, double y, double z,
+                                                 double& mx, double& my, double* dmx, double* dmy,
+                                                 double* ddx, double* ddy) {
+    if constexpr (MODEL == kUCM || MODEL == kEUCM) {
+        const double alpha = th[4];
+        const double beta = (MODEL == kEUCM) ? th[5] : 1.0;
+        const double r2 = x * x + y * y;
+        const double rho = sqrt(beta * r2 + z * z);
+        const double n = alpha * rho + (1.0 - alpha) * z;
+        const double inv = 1.0 / n;
+        const double irho = 1.0 / rho;
+        mx = x * inv; my = y * inv;
+        const double ab = alpha * beta * irho;
+        const double nx = ab * x, ny = ab * y, nz = alpha * z * irho + (1.0 - alpha);
+        const double mxi = mx * inv, myi = my * inv;
+        dmx[0] = inv - mxi * nx; dmx[1] = -mxi * ny;      dmx[2] = -mxi * nz;
+        dmy[0] = -myi * nx;      dmy[1] = inv - myi * ny; dmy[2] = -myi * nz;
+        const double na = rho - z;
+        ddx[0] = -mxi * na; ddy[0] = -myi * na;
+        if constexpr (MODEL == kEUCM) {
+            const double nb = 0.5 * alpha * r2 * irho;
+            ddx[1] = -mxi * nb; ddy[1] = -myi * nb;
+        }
+    } else if constexpr (MODEL == kKB4) {
+        const double r2 = x * x + y * y;
+        const double r = sqrt(r2);
+        if (r > 1e-8) {
+            const double t = atan2(r, z);
+            const double t2 = t * t;
+            const double k1 = th[4], k2 = th[5], k3 = th[6], k4 = th[7];
+            const double td = t * (1.0 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4))));
+            const double tdp = 1.0 + t2 * (3.0 * k1 + t2 * (5.0 * k2 + t2 * (7.0 * k3 + t2 * 9.0 * k4)));
+            const double ir = 1.0 / r;
+            const double s = td * ir;
+            const double id2 = 1.0 / (r2 + z * z);
+            const double tq = z * ir * id2;                 // theta_x = tq x, theta_y = tq y
+            const double tz = -r * id2;
+            const double g = ir * (tdp * tq - s * ir);      // s_x = g x, s_y = g y
+            const double sz = ir * tdp * tz;
+            mx = x * s; my = y * s;
+            dmx[0] = s + x * x * g; dmx[1] = x * y * g;     dmx[2] = x * sz;
+            dmy[0] = x * y * g;     dmy[1] = s + y * y * g; dmy[2] = y * sz;
+            const double xr = x * ir, yr = y * ir;
+            const double t3 = t2 * t, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+            ddx[0] = xr * t3; ddx[1] = xr * t5; ddx[2] = xr * t7; ddx[3] = xr * t9;
+            ddy[0] = yr * t3; ddy[1] = yr * t5; ddy[2] = yr * t7; ddy[3] = yr * t9;
+        } else {
+            const double iz = 1.0 / z;
+            mx = x * iz; my = y * iz;
+            dmx[0] = iz; dmx[1] = 0.0; dmx[2] = -mx * iz;
+            dmy[0] = 0.0; dmy[1] = iz; dmy[2] = -my * iz;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { ddx[i] = 0.0; ddy[i] = 0.0; }
+        }
+    } else {   // OPENCV5 [k1,k2,p1,p2,k3]
+        const double k1 = th[4], k2 = th[5], p1 = th[6], p2 = th[7], k3 = th[8];
+        const double iz = 1.0 / z;
+        const double xn = x * iz, yn = y * iz;
+        const double xx = xn * xn, yy = yn * yn, xy = xn * yn;
+        const double r2 = xx + yy;
+        const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+        const double drad = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3);
+        mx = xn * rad + 2.0 * p1 * xy + p2 * (r2 + 2.0 * xx);
+        my = yn * rad + p1 * (r2 + 2.0 * yy) + 2.0 * p2 * xy;
+        const double xd_x = rad + 2.0 * xx * drad + 2.0 * p1 * yn + 6.0 * p2 * xn;
+        const double xd_y = 2.0 * xy * drad + 2.0 * p1 * xn + 2.0 * p2 * yn;
+        const double yd_x = xd_y;
+        const double yd_y = rad + 2.0 * yy * drad + 6.0 * p1 * yn + 2.0 * p2 * xn;
+        dmx[0] = xd_x * iz; dmx[1] = xd_y * iz; dmx[2] = -(xd_x * xn + xd_y * yn) * iz;
+        dmy[0] = yd_x * iz; dmy[1] = yd_y * iz; dmy[2] = -(yd_x * xn + yd_y * yn) * iz;
+        const double r4 = r2 * r2, r6 = r4 * r2;
+        ddx[0] = xn * r2; ddx[1] = xn * r4; ddx[2] = 2.0 * xy;        ddx[3] = r2 + 2.0 * xx; ddx[4] = xn * r6;
+        ddy[0] = yn * r2; ddy[1] = yn * r4; ddy[2] = r2 + 2.0 * yy;   ddy[3] = 2.0 * xy;      ddy[4] = yn * r6;
+    }
+}
+
+// Residual only (validation / cost): u, v of one corner.
+template <int MODEL>
+__device__ __forceinline__ void project_uv(const double* th, double x, double y, double z, double& u, double& v) {
+    double mx, my;
+    if constexpr (MODEL == kUCM || MODEL == kEUCM) {
+        const double beta = (MODEL == kEUCM) ? th[5] : 1.0;
+        const double rho = sqrt(beta * (x * x + y * y) + z * z);
+        const double inv = 1.0 / (th[4] * rho + (1.0 - th[4]) * z);
+        mx = x * inv; my = y * inv;
+    } else if constexpr (MODEL == kKB4) {
+        const double r = sqrt(x * x + y * y);
+        if (r > 1e-8) {
+            const double t = atan2(r, z), t2 = t * t;
+            const double s = t * (1.0 + t2 * (th[4] + t2 * (th[5] + t2 * (th[6] + t2 * th[7])))) / r;
+            mx = x * s; my = y * s;
+        } else { mx = x / z; my = y / z; }
+    } else {
+        const double iz = 1.0 / z, xn = x * iz, yn = y * iz, xx = xn * xn, yy = yn * yn, xy = xn * yn, r2 = xx + yy;
+        const double rad = 1.0 + r2 * (th[4] + r2 * (th[5] + r2 * th[8]));
+        mx = xn * rad + 2.0 * th[6] * xy + th[7] * (r2 + 2.0 * xx);
+        my = yn * rad + th[6] * (r2 + 2.0 * yy) + 2.0 * th[7] * xy;
+    }
+    u = th[0] * mx + th[2]; v = th[1] * my + th[3];
+}
+
+// One residual block: r[2] and the two Jacobian rows Ju[D], Jv[D].
+//   th : FULL model parameters (fy == fx when ONE_FOCAL), fc : frame constants.
+template <int MODEL, bool ONE_FOCAL, bool OTHER>
+__device__ __forceinline__ void corner_block(const double* th, const double* fc,
+                                             double X, double Y, double Z, double uo, double vo,
+                                             double& ru, double& rv, double* Ju, double* Jv) {
+    constexpr int P = model_np(MODEL);
+    constexpr int ND = P - 4;
+    constexpr int PE = P - (ONE_FOCAL ? 1 : 0);
+    const double px = fc[FC_RC + 0] * X + fc[FC_RC + 1] * Y + fc[FC_RC + 2] * Z + fc[FC_TC + 0];
+    const double py = fc[FC_RC + 3] * X + fc[FC_RC + 4] * Y + fc[FC_RC + 5] * Z + fc[FC_TC + 1];
+    const double pz = fc[FC_RC + 6] * X + fc[FC_RC + 7] * Y + fc[FC_RC + 8] * Z + fc[FC_TC + 2];
+    double mx, my, dmx[3], dmy[3], ddx[ND], ddy[ND];
+    project_partials<MODEL>(th, px, py, pz, mx, my, dmx, dmy, ddx, ddy);
+    const double fx = th[0], fy = th[1];
+    ru = fx * mx + th[2] - uo;
+    rv = fy * my + th[3] - vo;
+    // intrinsics columns
+    if constexpr (ONE_FOCAL) {       // [f, cx, cy, dist..]  (factors.rs:155-158: f feeds both fx and fy)
+        Ju[0] = mx; Ju[1] = 1.0; Ju[2] = 0.0;
+        Jv[0] = my; Jv[1] = 0.0; Jv[2] = 1.0;
+    } else {                         // [fx, fy, cx, cy, dist..]
+        Ju[0] = mx;  Ju[1] = 0.0; Ju[2] = 1.0; Ju[3] = 0.0;
+        Jv[0] = 0.0; Jv[1] = my;  Jv[2] = 0.0; Jv[3] = 1.0;
+    }
+    constexpr int D0 = ONE_FOCAL ? 3 : 4;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { Ju[D0 + i] = fx * ddx[i]; Jv[D0 + i] = fy * ddy[i]; }
+    // d(u,v)/dp
+    const double ju[3] = { fx * dmx[0], fx * dmx[1], fx * dmx[2] };
+    const double jv[3] = { fy * dmy[0], fy * dmy[1], fy * dmy[2] };
+    // rvec_0_b columns: A_k X
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double* A = fc + FC_A + 9 * k;
+        const double qx = A[0] * X + A[1] * Y + A[2] * Z;
+        const double qy = A[3] * X + A[4] * Y + A[5] * Z;
+        const double qz = A[6] * X + A[7] * Y + A[8] * Z;
+        Ju[PE + k] = ju[0] * qx + ju[1] * qy + ju[2] * qz;
+        Jv[PE + k] = jv[0] * qx + jv[1] * qy + jv[2] * qz;
+    }
+    if constexpr (!OTHER) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Ju[PE + 3 + k] = ju[k]; Jv[PE + 3 + k] = jv[k]; }
+    } else {
+        const double* R1 = fc + FC_R1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {   // tvec_0_b: d p / d t0 = R1
+            Ju[PE + 3 + k] = ju[0] * R1[k] + ju[1] * R1[3 + k] + ju[2] * R1[6 + k];
+            Jv[PE + 3 + k] = jv[0] * R1[k] + jv[1] * R1[3 + k] + jv[2] * R1[6 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {   // rvec_c_0: B_k X + BK_k
+            const double* B = fc + FC_B + 9 * k;
+            const double* bk = fc + FC_BK + 3 * k;
+            const double qx = B[0] * X + B[1] * Y + B[2] * Z + bk[0];
+            const double qy = B[3] * X + B[4] * Y + B[5] * Z + bk[1];
+            const double qz = B[6] * X + B[7] * Y + B[8] * Z + bk[2];
+            Ju[PE + 6 + k] = ju[0] * qx + ju[1] * qy + ju[2] * qz;
+            Jv[PE + 6 + k] = jv[0] * qx + jv[1] * qy + jv[2] * qz;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { Ju[PE + 9 + k] = ju[k]; Jv[PE + 9 + k] = jv[k]; }
+    }
+}
+
+// Point in the camera frame only (cost / validation kernels).
+__device__ __forceinline__ void transform_point(const double* fc, double X, double Y, double Z,
+                                                double& px, double& py, double& pz) {
+    px = fc[FC_RC + 0] * X + fc[FC_RC + 1] * Y + fc[FC_RC + 2] * Z + fc[FC_TC + 0];
+    py = fc[FC_RC + 3] * X + fc[FC_RC + 4] * Y + fc[FC_RC + 5] * Z + fc[FC_TC + 1];
+    pz = fc[FC_RC + 6] * X + fc[FC_RC + 7] * Y + fc[FC_RC + 8] * Z + fc[FC_TC + 2];
+}
+
+// Huber weight as tiny-solver evaluates it: rho'(s) = 1 (s <= delta^2) else delta / sqrt(s).
+__device__ __forceinline__ double huber_weight(double s, double delta) {
+    return (delta > 0.0 && s > delta * delta) ? delta / sqrt(s) : 1.0;
+}
+
+}  // namespace ccal

@@ -1,0 +1,84 @@
+// Host-side structures shared by the API translation unit and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/ccal.h"
+#include "ccal_models.hpp"
+
+namespace ccal {
+
+constexpr int WAVES_PER_BLOCK = 4;     // 256 threads: one wavefront per observation frame
+constexpr int PF_STRIDE = 64;          // doubles kept per frame slot for back-substitution
+
+// Arguments of the per-camera kernels (everything device-resident).
+struct KArgs {
+    const float* x; const float* y; const float* z; const float* u; const float* v;
+    const int64_t* obs_off;        // [n_obs+1]
+    const int32_t* obs_slot;       // [n_obs]
+    const int64_t* joff;           // [n_obs] offset (doubles) of the frame's block Jacobians in J_out
+    const int32_t* list;           // observation frames of this camera
+    int32_t n_list;
+    int32_t cam;
+    const double* intr;            // [n_cams][CCAL_PMAX] full params
+    const double* poses;           // [n_slots][6]
+    const double* extr;            // [n_cams][6]
+    double huber_delta;
+    int32_t apply_loss;
+    double* r_out;                 // mode E
+    double* J_out;
+    double* err_out;               // reprojection errors
+};
+
+struct CamLayout {
+    int model = 0, P = 0, Peff = 0, D = 0;
+    int col_theta = 0, col_extr = -1;
+    double width = 0, height = 0;
+    std::vector<int32_t> obs;          // host copy of the camera's observation frames
+    int32_t* d_obs = nullptr;
+};
+
+}  // namespace ccal
+
+struct ccal_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+};
+
+struct ccal_problem {
+    ccal_ctx* ctx = nullptr;
+    int n_cams = 0, n_slots = 0, n_obs = 0, K = 0;
+    bool one_focal = false;
+    double huber_delta = 1.0;
+    int64_t n_corners = 0, j_len = 0;
+    std::vector<ccal::CamLayout> cams;
+    std::vector<int64_t> h_obs_off, h_joff;
+    std::vector<int32_t> h_obs_cam, h_obs_slot;
+    // device-resident inputs
+    float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_u = nullptr, *d_v = nullptr;
+    int64_t *d_obs_off = nullptr, *d_joff = nullptr;
+    int32_t *d_obs_cam = nullptr, *d_obs_slot = nullptr;
+    // device-resident parameters (current point and candidate)
+    double *d_intr = nullptr, *d_poses = nullptr, *d_extr = nullptr;
+    double *d_intr_c = nullptr, *d_poses_c = nullptr, *d_extr_c = nullptr;
+    // constraints in eff index space [n_cams][CCAL_PMAX]
+    std::vector<double> lo, hi;
+    std::vector<uint8_t> has_bound, fixed;
+    // mode N / solver workspaces (allocated lazily)
+    struct NormalWs* nws = nullptr;
+    // lazily sized scratch for host<->device staging of ccal_eval
+    double *d_r = nullptr, *d_J = nullptr, *d_err = nullptr;
+    ccal_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+};
+
+namespace ccal {
+// kernel launchers (ccal_kernels.hip)
+hipError_t launch_eval(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
+hipError_t launch_reproj_err(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
+}  // namespace ccal

@@ -1,0 +1,195 @@
+// Mode E: residual + Jacobian of every block, materialised in HBM (the reference's
+// Factor::residual_func evaluated with dual numbers per block, src/optimization/factors.rs:152-173,
+// 204-228), plus the residual-only reprojection-error kernel behind validation() (src/util.rs:733-745).
+//
+// Mapping: one wavefront per observation frame, 4 frames per 256-thread workgroup.  The frame's
+// pose-dependent constants are computed once per wave and staged in LDS; corner rows are read as
+// coalesced f32 SoA streams; every lane produces one block (r[2], J[2][D]).  The block Jacobians of
+// 64 consecutive corners form one contiguous 64*2*D*8-byte tile of J_out, so they are transposed
+// through LDS and written with full 16-B-per-lane coalesced stores.  HBM-write-bound by design.
+#include "ccal_device.hpp"
+#include "ccal_internal.hpp"
+
+namespace ccal {
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // producer and consumer are lanes of the same wavefront: LDS ops of one wave execute in order,
+    // this only has to stop the compiler from moving accesses across the hand-off.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : 40; }   // 39 used, keep 16-B alignment
+
+template <int MODEL, bool OF, bool OTHER>
+__global__ __launch_bounds__(256) void k_eval(const KArgs a) {
+    constexpr int D = block_dim(MODEL, OF, OTHER);
+    constexpr int TW = 2 * D;            // doubles per block Jacobian
+    constexpr int TS = TW + 2;           // padded LDS row stride (keeps 16-B alignment, spreads banks)
+    constexpr int FCN = fc_doubles<OTHER>();
+    constexpr int WS = FCN + 64 * TS;    // doubles of LDS per wave
+    extern __shared__ double smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int widx = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (widx >= a.n_list) return;        // whole wave exits; no workgroup barrier below
+    double* fc = smem + wave * WS;
+    double* tile = fc + FCN;
+
+    const int o = __builtin_amdgcn_readfirstlane(a.list[widx]);
+    const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[o]);
+    const int64_t start = a.obs_off[o];
+    const int n = (int)(a.obs_off[o + 1] - start);
+    const double* th_g = a.intr + a.cam * CCAL_PMAX;
+    double th[model_np(MODEL)];
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (OF) th[1] = th[0];
+
+    {   // frame constants -> LDS (every lane computes, lane 0 stores)
+        double pose[6], ex[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[(int64_t)slot * 6 + i];
+        if constexpr (OTHER) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ex[i] = a.extr[a.cam * 6 + i];
+        }
+        double fcr[OTHER ? FC_SIZE : 39];
+        frame_setup<OTHER>(pose, ex, fcr);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < (OTHER ? FC_SIZE : 39); ++i) fc[i] = fcr[i];
+        }
+    }
+    wave_lds_sync();
+
+    const int64_t jbase = a.joff[o];
+    for (int base = 0; base < n; base += 64) {
+        const int c = base + lane;
+        const bool valid = c < n;
+        const int64_t g = start + (valid ? c : 0);
+        const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
+        double ru, rv, J[TW];
+        double* Ju = J;
+        double* Jv = J + D;
+        corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, Ju, Jv);
+        if (a.apply_loss) {
+            const double sw = sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta));
+            ru *= sw; rv *= sw;
+#pragma unroll
+            for (int i = 0; i < D; ++i) { Ju[i] *= sw; Jv[i] *= sw; }
+        }
+        if (valid) *reinterpret_cast<double2*>(a.r_out + 2 * g) = make_double2(ru, rv);
+        // block Jacobian [Ju | Jv] -> LDS row of this lane
+        double* row = tile + lane * TS;
+#pragma unroll
+        for (int i = 0; i < D; ++i) *reinterpret_cast<double2*>(row + 2 * i) = make_double2(J[2 * i], J[2 * i + 1]);
+        wave_lds_sync();
+        // contiguous tile of J_out: 16 B per lane, 1 KiB per wave-instruction
+        const int nv = min(64, n - base);
+        const int tot = nv * TW;
+        double* dst = a.J_out + jbase + (int64_t)base * TW;
+        for (int e = lane * 2; e < tot; e += 128) {
+            const int cr = e / TW;
+            const int k = e - cr * TW;
+            const double2 val = *reinterpret_cast<const double2*>(tile + cr * TS + k);
+            __builtin_nontemporal_store(val.x, dst + e);
+            __builtin_nontemporal_store(val.y, dst + e + 1);
+        }
+        wave_lds_sync();
+    }
+}
+
+// Euclidean reprojection error per corner with the current parameters (no Jacobian).
+template <int MODEL, bool OF, bool OTHER>
+__global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
+    constexpr int FCN = fc_doubles<OTHER>();
+    __shared__ double smem[WAVES_PER_BLOCK * FCN];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int widx = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (widx >= a.n_list) return;
+    double* fc = smem + wave * FCN;
+    const int o = __builtin_amdgcn_readfirstlane(a.list[widx]);
+    const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[o]);
+    const int64_t start = a.obs_off[o];
+    const int n = (int)(a.obs_off[o + 1] - start);
+    const double* th_g = a.intr + a.cam * CCAL_PMAX;
+    double th[model_np(MODEL)];
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (OF) th[1] = th[0];
+    {
+        double pose[6], ex[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[(int64_t)slot * 6 + i];
+        if constexpr (OTHER) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ex[i] = a.extr[a.cam * 6 + i];
+        }
+        double fcr[OTHER ? FC_SIZE : 39];
+        frame_setup<OTHER>(pose, ex, fcr);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
+        }
+    }
+    wave_lds_sync();
+    for (int c = lane; c < n; c += 64) {
+        const int64_t g = start + c;
+        double px, py, pz, u, v;
+        transform_point(fc, a.x[g], a.y[g], a.z[g], px, py, pz);
+        project_uv<MODEL>(th, px, py, pz, u, v);
+        const double du = u - (double)a.u[g], dv = v - (double)a.v[g];
+        a.err_out[g] = sqrt(du * du + dv * dv);
+    }
+}
+
+template <int MODEL, bool OF, bool OTHER>
+static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
+    constexpr int D = block_dim(MODEL, OF, OTHER);
+    constexpr int WS = fc_doubles<OTHER>() + 64 * (2 * D + 2);
+    const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
+    const int blocks = (a.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER>), dim3(blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+template <int MODEL, bool OF, bool OTHER>
+static hipError_t launch_err_t(const KArgs& a, hipStream_t s) {
+    const int blocks = (a.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((k_reproj_err<MODEL, OF, OTHER>), dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+#define CCAL_DISPATCH(FN, model, of, other, ...)                                                     \
+    do {                                                                                             \
+        const int key_ = (model) * 4 + ((of) ? 2 : 0) + ((other) ? 1 : 0);                           \
+        switch (key_) {                                                                              \
+            case 0: return FN<kUCM, false, false>(__VA_ARGS__);   case 1: return FN<kUCM, false, true>(__VA_ARGS__);   \
+            case 2: return FN<kUCM, true, false>(__VA_ARGS__);    case 3: return FN<kUCM, true, true>(__VA_ARGS__);    \
+            case 4: return FN<kEUCM, false, false>(__VA_ARGS__);  case 5: return FN<kEUCM, false, true>(__VA_ARGS__);  \
+            case 6: return FN<kEUCM, true, false>(__VA_ARGS__);   case 7: return FN<kEUCM, true, true>(__VA_ARGS__);   \
+            case 8: return FN<kKB4, false, false>(__VA_ARGS__);   case 9: return FN<kKB4, false, true>(__VA_ARGS__);   \
+            case 10: return FN<kKB4, true, false>(__VA_ARGS__);   case 11: return FN<kKB4, true, true>(__VA_ARGS__);   \
+            case 12: return FN<kOCV5, false, false>(__VA_ARGS__); case 13: return FN<kOCV5, false, true>(__VA_ARGS__); \
+            case 14: return FN<kOCV5, true, false>(__VA_ARGS__);  case 15: return FN<kOCV5, true, true>(__VA_ARGS__);  \
+            default: return hipErrorInvalidValue;                                                    \
+        }                                                                                            \
+    } while (0)
+
+hipError_t launch_eval(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s) {
+    CCAL_DISPATCH(launch_eval_t, p->cams[cam].model, p->one_focal, cam > 0, a, s);
+}
+hipError_t launch_reproj_err(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s) {
+    CCAL_DISPATCH(launch_err_t, p->cams[cam].model, p->one_focal, cam > 0, a, s);
+}
+
+}  // namespace ccal

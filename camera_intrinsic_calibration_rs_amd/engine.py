@@ -1,0 +1,243 @@
+"""Thin object wrappers over the C ABI (include/ccal.h): Context and Problem.
+
+Nothing here computes; every method forwards to the HIP library through ctypes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import PMAX
+
+
+class CcalError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        name = _ffi.STATUS_NAMES[code] if 0 <= code < len(_ffi.STATUS_NAMES) else str(code)
+        super().__init__(f"{where}: {name}" + (f" ({detail})" if detail else ""))
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class Context:
+    """One GPU + one HIP stream (ccal_ctx)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = _ffi.load()
+        h = C.c_void_p()
+        rc = self.lib.ccal_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_ctx_create", "no usable HIP device" if rc == _ffi.ERR_HIP else "")
+        self.handle = h
+        self.device = device
+
+    def last_error(self) -> str:
+        return (self.lib.ccal_last_error(self.handle) or b"").decode()
+
+    def sync(self):
+        rc = self.lib.ccal_sync(self.handle)
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_sync", self.last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ccal_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def make_desc(n_cams, model, width, height, xy_same_focal, n_slots, obs_cam, obs_slot, obs_offsets,
+              x, y, z, u, v, huber_delta):
+    """Build a ccal_problem_desc and return (desc, keepalive-list-of-arrays)."""
+    keep = dict(
+        model=np.ascontiguousarray(model, dtype=np.int32), width=_f64(width), height=_f64(height),
+        obs_cam=np.ascontiguousarray(obs_cam, dtype=np.int32), obs_slot=np.ascontiguousarray(obs_slot, dtype=np.int32),
+        obs_offsets=np.ascontiguousarray(obs_offsets, dtype=np.int64),
+        x=np.ascontiguousarray(x, dtype=np.float32), y=np.ascontiguousarray(y, dtype=np.float32),
+        z=np.ascontiguousarray(z, dtype=np.float32), u=np.ascontiguousarray(u, dtype=np.float32),
+        v=np.ascontiguousarray(v, dtype=np.float32))
+    d = _ffi.ProblemDesc()
+    d.n_cams = int(n_cams)
+    d.model = keep["model"].ctypes.data_as(C.POINTER(C.c_int32))
+    d.width = _dp(keep["width"]); d.height = _dp(keep["height"])
+    d.xy_same_focal = 1 if xy_same_focal else 0
+    d.n_slots = int(n_slots); d.n_obs = int(len(keep["obs_cam"]))
+    d.obs_cam = keep["obs_cam"].ctypes.data_as(C.POINTER(C.c_int32))
+    d.obs_slot = keep["obs_slot"].ctypes.data_as(C.POINTER(C.c_int32))
+    d.obs_offsets = keep["obs_offsets"].ctypes.data_as(C.POINTER(C.c_int64))
+    for name, key in (("p3d_x", "x"), ("p3d_y", "y"), ("p3d_z", "z"), ("p2d_u", "u"), ("p2d_v", "v")):
+        setattr(d, name, keep[key].ctypes.data_as(C.POINTER(C.c_float)))
+    d.huber_delta = float(huber_delta)
+    return d, keep
+
+
+def desc_from_synth(sp):
+    x, y, z, u, v = sp.soa()
+    return make_desc(sp.n_cams, sp.model, sp.width, sp.height, sp.xy_same_focal, sp.n_slots,
+                     sp.obs_cam, sp.obs_slot, sp.obs_offsets, x, y, z, u, v, sp.huber_delta)
+
+
+def default_opts(method: int = _ffi.METHOD_GN, **kw) -> _ffi.SolverOpts:
+    o = _ffi.SolverOpts()
+    _ffi.load().ccal_set_defaults(C.byref(o))
+    o.method = method
+    for k, val in kw.items():
+        setattr(o, k, val)
+    return o
+
+
+class Problem:
+    """Calib-frame inputs resident in HBM (ccal_problem)."""
+
+    def __init__(self, ctx: Context, desc: _ffi.ProblemDesc, keep=None):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self._keep = keep
+        h = C.c_void_p()
+        rc = self.lib.ccal_problem_create(ctx.handle, C.byref(desc), C.byref(h))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_problem_create", ctx.last_error())
+        self.handle = h
+        self.n_cams = desc.n_cams
+        self.n_slots = desc.n_slots
+        self.n_corners = int(self.lib.ccal_num_corners(h))
+        self.K = int(self.lib.ccal_reduced_dim(h))
+        self.j_len = int(self.lib.ccal_jacobian_len(h))
+        self._cb = None
+
+    @classmethod
+    def from_synth(cls, ctx: Context, sp) -> "Problem":
+        d, keep = desc_from_synth(sp)
+        return cls(ctx, d, keep)
+
+    def _check(self, rc: int, where: str):
+        if rc != _ffi.OK:
+            raise CcalError(rc, where, self.ctx.last_error())
+
+    def block_dim(self, cam: int = 0) -> int:
+        return int(self.lib.ccal_block_dim(self.handle, cam))
+
+    def eff_num_params(self, cam: int = 0) -> int:
+        return int(self.lib.ccal_eff_num_params(self.handle, cam))
+
+    # -- constraints (tiny_solver::Problem::set_variable_bounds / fix_variable) -------------------
+    def set_bounds(self, cam, idx, lo, hi):
+        self._check(self.lib.ccal_set_bounds(self.handle, cam, idx, lo, hi), "ccal_set_bounds")
+
+    def fix_param(self, cam, idx):
+        self._check(self.lib.ccal_fix_param(self.handle, cam, idx), "ccal_fix_param")
+
+    def unfix_param(self, cam, idx):
+        self._check(self.lib.ccal_unfix_param(self.handle, cam, idx), "ccal_unfix_param")
+
+    def apply_reference_bounds(self):
+        self._check(self.lib.ccal_apply_reference_bounds(self.handle), "ccal_apply_reference_bounds")
+
+    def disable_distortions(self, n: int, intr: np.ndarray):
+        self._check(self.lib.ccal_disable_distortions(self.handle, n, _dp(intr)), "ccal_disable_distortions")
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, stream:int) -> int; kept alive on the object."""
+        if fn is None:
+            self._cb = None
+            self._check(self.lib.ccal_set_allreduce(self.handle, C.cast(None, _ffi.ALLREDUCE_FN), None), "ccal_set_allreduce")
+            return
+        def tramp(user, ptr, count, stream):
+            try:
+                return int(fn(ptr or 0, int(count), stream or 0) or 0)
+            except Exception:   # never unwind through C
+                import traceback; traceback.print_exc()
+                return 1
+        self._cb = _ffi.ALLREDUCE_FN(tramp)
+        self._check(self.lib.ccal_set_allreduce(self.handle, self._cb, None), "ccal_set_allreduce")
+
+    # -- mode E -----------------------------------------------------------------------------------
+    def _params(self, intr, poses, extr):
+        intr = _f64(intr, (self.n_cams, PMAX))
+        poses = _f64(poses, (self.n_slots, 6))
+        extr = _f64(np.zeros((self.n_cams, 6)) if extr is None else extr, (self.n_cams, 6))
+        return intr, poses, extr
+
+    def eval(self, intr, poses, extr=None, apply_loss=False):
+        intr, poses, extr = self._params(intr, poses, extr)
+        r = np.empty((self.n_corners, 2)); J = np.empty(self.j_len)
+        self._check(self.lib.ccal_eval(self.handle, _dp(intr), _dp(poses), _dp(extr), 1 if apply_loss else 0,
+                                       _dp(r), _dp(J)), "ccal_eval")
+        return r, J
+
+    def upload_params(self, intr, poses, extr=None):
+        intr, poses, extr = self._params(intr, poses, extr)
+        self._check(self.lib.ccal_upload_params(self.handle, _dp(intr), _dp(poses), _dp(extr)), "ccal_upload_params")
+
+    def download_params(self):
+        intr = np.zeros((self.n_cams, PMAX)); poses = np.zeros((self.n_slots, 6)); extr = np.zeros((self.n_cams, 6))
+        self._check(self.lib.ccal_download_params(self.handle, _dp(intr), _dp(poses), _dp(extr)), "ccal_download_params")
+        return intr, poses, extr
+
+    def eval_dev(self, r_dev_ptr: int, J_dev_ptr: int, apply_loss=False):
+        self._check(self.lib.ccal_eval_dev(self.handle, 1 if apply_loss else 0, C.c_void_p(r_dev_ptr), C.c_void_p(J_dev_ptr)),
+                    "ccal_eval_dev")
+
+    # -- mode N -----------------------------------------------------------------------------------
+    def build_normal(self, intr, poses, extr=None, lam=0.0):
+        intr, poses, extr = self._params(intr, poses, extr)
+        S = np.empty((self.K, self.K)); b = np.empty(self.K); cost = C.c_double()
+        self._check(self.lib.ccal_build_normal(self.handle, _dp(intr), _dp(poses), _dp(extr), float(lam),
+                                               _dp(S), _dp(b), C.byref(cost)), "ccal_build_normal")
+        return S, b, cost.value
+
+    def build_normal_dev(self, lam=0.0):
+        self._check(self.lib.ccal_build_normal_dev(self.handle, float(lam)), "ccal_build_normal_dev")
+
+    def solve(self, intr, poses, extr=None, opts: _ffi.SolverOpts | None = None, raise_on_error=True):
+        intr, poses, extr = self._params(intr, poses, extr)
+        intr, poses, extr = intr.copy(), poses.copy(), extr.copy()
+        opts = opts or default_opts()
+        rep = _ffi.Report()
+        rc = self.lib.ccal_solve(self.handle, C.byref(opts), _dp(intr), _dp(poses), _dp(extr), C.byref(rep))
+        if rc not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE) and raise_on_error:
+            raise CcalError(rc, "ccal_solve", self.ctx.last_error())
+        return intr, poses, extr, rep
+
+    # -- validation ---------------------------------------------------------------------------------
+    def reprojection_errors(self, intr, poses, extr=None):
+        intr, poses, extr = self._params(intr, poses, extr)
+        e = np.empty(self.n_corners)
+        self._check(self.lib.ccal_reprojection_errors(self.handle, _dp(intr), _dp(poses), _dp(extr), _dp(e)),
+                    "ccal_reprojection_errors")
+        return e
+
+    def validation(self, cam, intr, poses, extr=None):
+        intr, poses, extr = self._params(intr, poses, extr)
+        a = C.c_double(); m = C.c_double()
+        self._check(self.lib.ccal_validation(self.handle, cam, _dp(intr), _dp(poses), _dp(extr), C.byref(a), C.byref(m)),
+                    "ccal_validation")
+        return a.value, m.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ccal_problem_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,193 @@
+/*
+ * ccal.h -- C ABI of the MI355X-native reprojection residual + Jacobian engine
+ * and Gauss-Newton / Levenberg-Marquardt normal-equation builder.
+ *
+ * This is the drop-in boundary for the hot path of
+ * powei-lin/camera-intrinsic-calibration-rs (paths below are relative to the
+ * reference tree).  A Rust caller binds these symbols with `extern "C"`
+ * (INTEGRATION.md shows the stub); everything is plain pointers + sizes, no
+ * C++ types, no exceptions, no torch types.  All floating point is f64 except
+ * the detected-corner inputs, which are f32 exactly as the reference holds
+ * them (src/detected_points.rs:6-9, widened at src/optimization/factors.rs:141-143).
+ *
+ * What each entry point replaces:
+ *   ccal_problem_create      the `problem.add_residual_block(2, [...], ReprojectionFactor|
+ *                            OtherCamReprojectionFactor, HuberLoss(1.0))` loops
+ *                            src/util.rs:401-414 and src/util.rs:595-631
+ *   ccal_set_bounds          tiny_solver::Problem::set_variable_bounds   src/util.rs:36-47
+ *   ccal_fix_param           tiny_solver::Problem::fix_variable          src/util.rs:61,461,666
+ *   ccal_apply_reference_bounds / ccal_disable_distortions
+ *                            set_problem_parameter_bound / _disabled     src/util.rs:29-71
+ *   ccal_eval                Factor::residual_func evaluated with dual numbers for every
+ *                            block (src/optimization/factors.rs:152-173, 204-228)
+ *   ccal_build_normal        tiny-solver's J^T J / J^T r assembly (call sites src/util.rs:455,670),
+ *                            with the per-frame pose blocks eliminated exactly (Schur)
+ *   ccal_solve               GaussNewtonOptimizer::optimize(&problem, &initial_values, None)
+ *                            src/util.rs:443-463 and 668-670 (+ an LM mode)
+ *   ccal_reprojection_errors / ccal_validation
+ *                            validation()                                 src/util.rs:721-795
+ *
+ * Parameter layout.
+ *   intr   [n_cams][CCAL_PMAX]  FULL model parameters [fx,fy,cx,cy,dist...] per camera, like
+ *                               GenericModel::params().  With xy_same_focal the solver variable is
+ *                               f = intr[c][0] and fy is ignored on input / set to f on output
+ *                               (src/util.rs:391-395, 467-470).
+ *   poses  [n_slots][6]         rvec(3), tvec(3) of T_cam0_board per frame slot
+ *                               ("rvec{i}","tvec{i}" / "rvec_0_b_{f}","tvec_0_b_{f}").
+ *   extr   [n_cams][6]          rvec, tvec of T_cam_i_cam0 ("rvec_{c}_0","tvec_{c}_0"); row 0 unused.
+ * Solver-visible intrinsic index space ("eff" indices): full index with fy removed when
+ * xy_same_focal (the `shift` of src/util.rs:35).  Bounds / fixed flags use eff indices, exactly
+ * like the reference's set_variable_bounds / fix_variable calls.
+ *
+ * Jacobian column order of one block (ccal_eval): [theta_c (P_eff) | rvec_0_b | tvec_0_b] for
+ * camera 0 blocks and [theta_c | rvec_0_b | tvec_0_b | rvec_c_0 | tvec_c_0] for camera c>0
+ * (src/util.rs:411, 621-627).
+ * Reduced ("camera") system column order (ccal_build_normal): for c = 0..n_cams-1:
+ * theta_c (P_eff(c)), then for c>0 rvec_c_0, tvec_c_0.  K = sum P_eff + 6 (n_cams-1).
+ */
+#ifndef CCAL_H
+#define CCAL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCAL_PMAX 10          /* row stride of intr / bounds arrays (max model has 9 params) */
+#define CCAL_MAX_CAMS 8
+#define CCAL_KMAX 64          /* max size of the reduced camera system */
+
+typedef enum {
+    CCAL_OK = 0,
+    CCAL_ERR_INVALID_ARG = 1,
+    CCAL_ERR_HIP = 2,
+    CCAL_ERR_NONFINITE = 3,       /* NaN/Inf cost: tiny-solver returns None (src/util.rs:455-457) */
+    CCAL_ERR_NOT_PD = 4,          /* Cholesky of the normal equations failed: None */
+    CCAL_ERR_NO_CONVERGENCE = 5,  /* informational: max_iterations reached (reference still returns Some) */
+    CCAL_ERR_UNSUPPORTED = 6
+} ccal_status;
+
+typedef enum {                    /* camera-intrinsic-model GenericModel variants on the hot path */
+    CCAL_MODEL_UCM = 0,           /* [fx,fy,cx,cy,alpha]              tests/optimization_test.rs:41 */
+    CCAL_MODEL_EUCM = 1,          /* [fx,fy,cx,cy,alpha,beta]         data/eucm.json              */
+    CCAL_MODEL_KB4 = 2,           /* [fx,fy,cx,cy,k1,k2,k3,k4]                                     */
+    CCAL_MODEL_OPENCV5 = 3        /* [fx,fy,cx,cy,k1,k2,p1,p2,k3]                                  */
+} ccal_model;
+
+typedef struct ccal_ctx ccal_ctx;          /* one GPU + one HIP stream; single caller */
+typedef struct ccal_problem ccal_problem;  /* inputs resident in HBM + workspaces */
+
+/* Problem description = the reference's calib-frame inputs flattened.
+ * An "observation frame" is one (camera, frame slot) pair with its detected corners stored
+ * contiguously: corners [obs_offsets[i], obs_offsets[i+1]) of the SoA arrays.  Single camera:
+ * n_obs == n_slots, obs_cam[i] == 0, obs_slot[i] == i. */
+typedef struct {
+    int32_t n_cams;
+    const int32_t* model;          /* [n_cams] ccal_model */
+    const double* width;           /* [n_cams] image width  (bounds, src/util.rs:38) */
+    const double* height;          /* [n_cams] image height (bounds, src/util.rs:39) */
+    int32_t xy_same_focal;         /* ReprojectionFactor::xy_same_focal */
+    int32_t n_slots;               /* board-pose slots (frames) */
+    int32_t n_obs;                 /* observation frames */
+    const int32_t* obs_cam;        /* [n_obs] */
+    const int32_t* obs_slot;       /* [n_obs] */
+    const int64_t* obs_offsets;    /* [n_obs+1] */
+    const float* p3d_x;            /* [n_corners] board point (FeaturePoint::p3d), f32 */
+    const float* p3d_y;
+    const float* p3d_z;
+    const float* p2d_u;            /* [n_corners] detected pixel (FeaturePoint::p2d), f32 */
+    const float* p2d_v;
+    double huber_delta;            /* HuberLoss::new(1.0) in the reference; <= 0 disables the loss */
+} ccal_problem_desc;
+
+typedef enum { CCAL_METHOD_GN = 0, CCAL_METHOD_LM = 1 } ccal_method;
+
+typedef struct {
+    int32_t method;                /* CCAL_METHOD_GN is the reference's optimizer (parity mode) */
+    int32_t max_iterations;        /* tiny-solver default 100 */
+    double min_abs_error_decrease; /* 1e-5 */
+    double min_rel_error_decrease; /* 1e-5 */
+    double min_error;              /* 1e-10 */
+    double lm_initial_radius;      /* 1e4   (LM only; Ceres-style trust region, lambda = 1/radius) */
+    double lm_min_diagonal;        /* 1e-6 */
+    double lm_max_diagonal;        /* 1e32 */
+    int32_t verbose;
+    int32_t reserved;
+} ccal_solver_opts;
+
+typedef struct {
+    int32_t status;                /* ccal_status of the solve */
+    int32_t iterations;            /* linear solves performed */
+    int32_t lm_accepted;
+    int32_t lm_rejected;
+    double initial_cost;           /* sum over blocks of rho'(s) * s at the start (tiny-solver's "error") */
+    double final_cost;
+    double solve_ms;               /* wall time of the iteration loop */
+    double reserved;
+} ccal_report;
+
+/* Optional all-reduce hook for frame-sharded multi-GPU solves: called once per linear solve
+ * with a device pointer to `count` doubles ([S | b | cost | aux]) that must be summed in place
+ * over all ranks, ordered on `hip_stream`.  NULL = single GPU. */
+typedef int (*ccal_allreduce_fn)(void* user, double* device_buf, size_t count, void* hip_stream);
+
+/* ---- context ---------------------------------------------------------------------------- */
+int ccal_ctx_create(int device_id, void* hip_stream /* hipStream_t or NULL = own stream */, ccal_ctx** out);
+void ccal_ctx_destroy(ccal_ctx* ctx);
+const char* ccal_last_error(const ccal_ctx* ctx);
+const char* ccal_version(void);
+int ccal_model_num_params(int model);            /* 5 / 6 / 8 / 9, -1 if unknown */
+
+/* ---- problem ---------------------------------------------------------------------------- */
+int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* desc, ccal_problem** out);
+void ccal_problem_destroy(ccal_problem* p);
+int ccal_set_defaults(ccal_solver_opts* opts);   /* tiny-solver OptimizerOptions::default() */
+int ccal_set_bounds(ccal_problem* p, int cam, int eff_idx, double lo, double hi);
+int ccal_clear_bounds(ccal_problem* p, int cam, int eff_idx);
+int ccal_fix_param(ccal_problem* p, int cam, int eff_idx);
+int ccal_unfix_param(ccal_problem* p, int cam, int eff_idx);
+int ccal_apply_reference_bounds(ccal_problem* p);                 /* src/util.rs:29-49 for every camera */
+int ccal_disable_distortions(ccal_problem* p, int n_disabled, double* intr_io /* zeroed in place */);
+int ccal_set_allreduce(ccal_problem* p, ccal_allreduce_fn fn, void* user);
+
+int64_t ccal_num_corners(const ccal_problem* p);
+int ccal_reduced_dim(const ccal_problem* p);                      /* K */
+int ccal_block_dim(const ccal_problem* p, int cam);               /* D of that camera's blocks */
+int ccal_eff_num_params(const ccal_problem* p, int cam);          /* P_eff */
+int64_t ccal_jacobian_len(const ccal_problem* p);                 /* doubles in J_out of ccal_eval */
+
+/* ---- mode E: residual + Jacobian of every block ------------------------------------------
+ * r_out [n_corners][2]; J_out: per observation frame, [n_i][2][D_cam] row-major blocks, frames
+ * concatenated (offset of frame i = sum_{j<i} n_j * 2 * D_cam(j)).  apply_loss != 0 applies the
+ * Huber corrector (r and J scaled by sqrt(rho')) the way tiny-solver does before assembly.
+ * *_dev variants take device pointers and only enqueue work on the context stream. */
+int ccal_eval(ccal_problem* p, const double* intr, const double* poses, const double* extr,
+              int apply_loss, double* r_out, double* J_out);
+int ccal_upload_params(ccal_problem* p, const double* intr, const double* poses, const double* extr);
+int ccal_download_params(ccal_problem* p, double* intr, double* poses, double* extr);
+int ccal_eval_dev(ccal_problem* p, int apply_loss, double* r_out_dev, double* J_out_dev);
+int ccal_sync(ccal_ctx* ctx);
+
+/* ---- mode N: fused normal equations + exact per-frame Schur complement -------------------
+ * S [K][K] (row-major, symmetric, full), b [K] = reduced J^T r (so S dx = -b), cost = sum rho' s.
+ * lambda > 0 adds Marquardt damping lambda * clamp(diag) to every block before elimination. */
+int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, const double* extr,
+                      double lambda, double* S, double* b, double* cost);
+int ccal_build_normal_dev(ccal_problem* p, double lambda);   /* uses uploaded params; result stays on device */
+
+/* ---- the optimizer loop -------------------------------------------------------------------- */
+int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
+               double* intr_io, double* poses_io, double* extr_io, ccal_report* report);
+
+/* ---- reference validation() statistics (src/util.rs:721-795) ---------------------------- */
+int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr,
+                             double* err_out /* [n_corners] Euclidean px error */);
+int ccal_validation(ccal_problem* p, int cam, const double* intr, const double* poses, const double* extr,
+                    double* avg_99_percent, double* median);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCAL_H */

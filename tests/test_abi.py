@@ -1,0 +1,50 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/ccal.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+from camera_intrinsic_calibration_rs_amd import _ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ccal.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccal_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    declared = _declared()
+    bound = sorted(n for n, _, _ in _ffi.SYMBOLS)
+    assert declared == bound, (set(declared) ^ set(bound))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_ffi.LIB_PATH), "libccal_hip.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"missing export {name}"
+
+
+def test_host_only_entry_points():
+    lib = _ffi.load()
+    assert lib.ccal_version().startswith(b"ccal-mi355x")
+    assert [lib.ccal_model_num_params(m) for m in range(5)] == [5, 6, 8, 9, -1]
+    o = _ffi.SolverOpts()
+    assert lib.ccal_set_defaults(ctypes.byref(o)) == 0
+    # tiny-solver OptimizerOptions::default() as restated in SURVEY 3.3
+    assert (o.method, o.max_iterations) == (0, 100)
+    assert (o.min_abs_error_decrease, o.min_rel_error_decrease, o.min_error) == (1e-5, 1e-5, 1e-10)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    try:
+        _ffi.load()
+    except _ffi.CcalLibraryMissing as e:
+        assert "no CPU fallback" in str(e)
+    else:
+        raise AssertionError("load() must raise when the HIP library is missing")
