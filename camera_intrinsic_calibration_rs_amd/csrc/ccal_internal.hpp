@@ -33,6 +33,8 @@ struct KArgs {
     double* err_out;               // reprojection errors
 };
 
+struct NormalWs;
+
 struct CamLayout {
     int model = 0, P = 0, Peff = 0, D = 0;
     int col_theta = 0, col_extr = -1;
@@ -70,7 +72,7 @@ struct ccal_problem {
     std::vector<double> lo, hi;
     std::vector<uint8_t> has_bound, fixed;
     // mode N / solver workspaces (allocated lazily)
-    struct NormalWs* nws = nullptr;
+    ccal::NormalWs* nws = nullptr;
     // lazily sized scratch for host<->device staging of ccal_eval
     double *d_r = nullptr, *d_J = nullptr, *d_err = nullptr;
     ccal_allreduce_fn allreduce = nullptr;

@@ -1,0 +1,530 @@
+// Mode N kernels: weighted Gram of [J | r] per observation frame on the f64 matrix cores, per-slot
+// Schur complement, deterministic reductions, the small camera-system solve and the pose
+// back-substitution.  Replaces tiny-solver's sparse J^T J assembly + sparse Cholesky (call sites
+// src/util.rs:455, 670) by the exact arrow-structure elimination described in SURVEY 8(e).
+#include "ccal_device.hpp"
+#include "ccal_normal.hpp"
+
+namespace ccal {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct GramArgs {
+    KArgs k;
+    const int64_t* goff;
+    double* G;
+    double* cost_o;
+};
+
+// ---------------------------------------------------------------------------------------------
+// k_gram: one wavefront per observation frame.  Every lane evaluates one corner's two weighted
+// rows sqrt(w) [J | r] (NC = D + 1 columns), the wave stages them in LDS as a [rows][16 T] image and
+// v_mfma_f64_16x16x4_f64 accumulates G += rows^T rows, 4 rows (2 corners) per instruction: the
+// lane that feeds A[i][k] also feeds B[k][j] (same register), so a Gram tile costs one ds_read_b64
+// and one MFMA.  T = 1 (NC <= 16: every single-camera model) or 2 (other-camera blocks, NC <= 22).
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, bool OF, bool OTHER>
+__global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
+    const KArgs& a = ga.k;
+    constexpr int D = block_dim(MODEL, OF, OTHER);
+    constexpr int NC = D + 1;
+    constexpr int T = NC <= 16 ? 1 : 2;
+    constexpr int RS = T == 1 ? 16 : 24;      // doubles per staged row
+    constexpr int CS = 2 * RS + 2;            // doubles per corner (two rows + pad)
+    constexpr int NCP = 16 * T;
+    constexpr int FCN = OTHER ? FC_SIZE : 40;
+    constexpr int WS = FCN + 64 * CS;
+    extern __shared__ double smem[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int widx = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (widx >= a.n_list) return;
+    double* fc = smem + wave * WS;
+    double* tile = fc + FCN;
+
+    const int o = __builtin_amdgcn_readfirstlane(a.list[widx]);
+    const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[o]);
+    const int64_t start = a.obs_off[o];
+    const int n = (int)(a.obs_off[o + 1] - start);
+    const double* th_g = a.intr + a.cam * CCAL_PMAX;
+    double th[model_np(MODEL)];
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (OF) th[1] = th[0];
+    {
+        double pose[6], ex[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[(int64_t)slot * 6 + i];
+        if constexpr (OTHER) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ex[i] = a.extr[a.cam * 6 + i];
+        }
+        double fcr[OTHER ? FC_SIZE : 39];
+        frame_setup<OTHER>(pose, ex, fcr);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < (OTHER ? FC_SIZE : 39); ++i) fc[i] = fcr[i];
+        }
+    }
+    wave_sync_lds();
+
+    d4 acc00a = { 0, 0, 0, 0 }, acc00b = { 0, 0, 0, 0 }, acc01 = { 0, 0, 0, 0 }, acc11 = { 0, 0, 0, 0 };
+    // read position of this lane inside a corner pair: corner (lane >> 5), row (lane >> 4) & 1, column lane & 15
+    const int rd_off = (lane >> 5) * CS + ((lane >> 4) & 1) * RS + (lane & 15);
+    const bool hi_valid = (lane & 15) < (RS - 16);          // T == 2: columns 16..RS-1 exist, the rest are zero
+
+    for (int base = 0; base < n; base += 64) {
+        const int c = base + lane;
+        const bool valid = c < n;
+        const int64_t g = start + (valid ? c : 0);
+        const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
+        double ru, rv, J[2 * D];
+        corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        // Huber corrector: both rows scaled by sqrt(rho'); invalid lanes contribute zero rows
+        const double sw = valid ? sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta)) : 0.0;
+        double* row = tile + lane * CS;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < RS; i += 2) {
+                const double v0 = i < D ? sw * J[h * D + (i < D ? i : 0)] : (i == D ? sw * (h ? rv : ru) : 0.0);
+                const double v1 = (i + 1) < D ? sw * J[h * D + ((i + 1) < D ? (i + 1) : 0)] : ((i + 1) == D ? sw * (h ? rv : ru) : 0.0);
+                *reinterpret_cast<double2*>(row + h * RS + i) = make_double2(v0, v1);
+            }
+        }
+        wave_sync_lds();
+        const int npairs = (min(64, n - base) + 1) >> 1;
+        const double* rd = tile + rd_off;
+        if constexpr (T == 1) {
+            int m = 0;
+            for (; m + 1 < npairs; m += 2) {
+                const double p = rd[(2 * m) * CS];
+                const double q = rd[(2 * m + 2) * CS];
+                acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
+                acc00b = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc00b, 0, 0, 0);
+            }
+            if (m < npairs) {
+                const double p = rd[(2 * m) * CS];
+                acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
+            }
+        } else {
+            for (int m = 0; m < npairs; ++m) {
+                const double p = rd[(2 * m) * CS];
+                const double q = hi_valid ? rd[(2 * m) * CS + 16] : 0.0;
+                acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
+                acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, q, acc01, 0, 0, 0);
+                acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc11, 0, 0, 0);
+            }
+        }
+        wave_sync_lds();
+    }
+
+    // C/D layout of v_mfma_f64_16x16x4_f64: lane l, register v holds D[(l >> 4) + 4 v][l & 15]
+    double* Go = ga.G + ga.goff[o];
+    const int gi = lane >> 4, gj = lane & 15;
+    if constexpr (T == 1) {
+        const d4 acc = acc00a + acc00b;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Go[(gi + 4 * v) * NCP + gj] = acc[v];
+        if (gi + 4 * (D / 4) == D && gj == D) ga.cost_o[o] = acc[D / 4];
+    } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            Go[(gi + 4 * v) * NCP + gj] = acc00a[v];
+            Go[(gi + 4 * v) * NCP + 16 + gj] = acc01[v];
+            Go[(16 + gi + 4 * v) * NCP + 16 + gj] = acc11[v];
+        }
+        constexpr int dl = D - 16;   // residual column lives in tile (1,1)
+        if (gi + 4 * (dl / 4) == dl && gj == dl) ga.cost_o[o] = acc11[dl / 4];
+    }
+}
+
+template <int MODEL, bool OF, bool OTHER>
+static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
+    constexpr int D = block_dim(MODEL, OF, OTHER);
+    constexpr int T = (D + 1) <= 16 ? 1 : 2;
+    constexpr int RS = T == 1 ? 16 : 24;
+    constexpr int WS = (OTHER ? FC_SIZE : 40) + 64 * (2 * RS + 2);
+    const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
+    const int blocks = (ga.k.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    if (blocks == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram<MODEL, OF, OTHER>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gram<MODEL, OF, OTHER>), dim3(blocks), dim3(256), lds, s, ga);
+    return hipGetLastError();
+}
+
+#define CCAL_DISPATCH(FN, model, of, other, ...)                                                     \
+    do {                                                                                             \
+        const int key_ = (model) * 4 + ((of) ? 2 : 0) + ((other) ? 1 : 0);                           \
+        switch (key_) {                                                                              \
+            case 0: return FN<kUCM, false, false>(__VA_ARGS__);   case 1: return FN<kUCM, false, true>(__VA_ARGS__);   \
+            case 2: return FN<kUCM, true, false>(__VA_ARGS__);    case 3: return FN<kUCM, true, true>(__VA_ARGS__);    \
+            case 4: return FN<kEUCM, false, false>(__VA_ARGS__);  case 5: return FN<kEUCM, false, true>(__VA_ARGS__);  \
+            case 6: return FN<kEUCM, true, false>(__VA_ARGS__);   case 7: return FN<kEUCM, true, true>(__VA_ARGS__);   \
+            case 8: return FN<kKB4, false, false>(__VA_ARGS__);   case 9: return FN<kKB4, false, true>(__VA_ARGS__);   \
+            case 10: return FN<kKB4, true, false>(__VA_ARGS__);   case 11: return FN<kKB4, true, true>(__VA_ARGS__);   \
+            case 12: return FN<kOCV5, false, false>(__VA_ARGS__); case 13: return FN<kOCV5, false, true>(__VA_ARGS__); \
+            case 14: return FN<kOCV5, true, false>(__VA_ARGS__);  case 15: return FN<kOCV5, true, true>(__VA_ARGS__);  \
+            default: return hipErrorInvalidValue;                                                    \
+        }                                                                                            \
+    } while (0)
+
+hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    GramArgs ga = {};
+    KArgs& a = ga.k;
+    a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
+    a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
+    a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
+    a.intr = cand ? p->d_intr_c : p->d_intr; a.poses = cand ? p->d_poses_c : p->d_poses; a.extr = cand ? p->d_extr_c : p->d_extr;
+    a.huber_delta = p->huber_delta;
+    ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf];
+    CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_schur: persistent wavefronts, each walks frame slots with stride (number of waves) and keeps the
+// reduced system A[(K+1)^2] + extras in its own LDS accumulators (flushed once at the end).
+// ---------------------------------------------------------------------------------------------
+struct SchurArgs {
+    const double* G; const int64_t* goff;
+    const int32_t* slot_off; const int32_t* slot_obs; const int32_t* obs_cam; const int32_t* caminfo;
+    int32_t n_slots, K, RB, PF, n_pw;
+    double lambda, min_diag, max_diag;
+    double* partial; double* pf; int32_t* flags;
+};
+
+__device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+__global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
+    extern __shared__ double smem[];
+    const int K = a.K, K1 = a.K + 1, RB = a.RB;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    // per-wave LDS: acc[RB] | Baug[6][K1] | C[36] | Y[6][K1]
+    const int WS = ((RB + 12 * K1 + 36) + 1) & ~1;
+    double* acc = smem + wave * WS;
+    double* Baug = acc + RB;
+    double* Cm = Baug + 6 * K1;
+    double* Ym = Cm + 36;
+    double* hdiag = acc + K1 * K1;
+    double* gcv = hdiag + K;
+    for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
+    wave_sync_lds();
+    if (gw >= a.n_pw) return;
+
+    for (int s = gw; s < a.n_slots; s += a.n_pw) {
+        const int o0 = a.slot_off[s], o1 = a.slot_off[s + 1];
+        double* pf = a.pf + (int64_t)s * a.PF;
+        if (o0 == o1) {                                   // slot without observations
+            for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
+            continue;
+        }
+        for (int e = lane; e < 6 * K1 + 36; e += 64) Baug[e] = 0.0;
+        wave_sync_lds();
+        for (int oi = o0; oi < o1; ++oi) {
+            const int o = a.slot_obs[oi];
+            const int cam = a.obs_cam[o];
+            const int Pe = a.caminfo[cam * 4 + 0], ct = a.caminfo[cam * 4 + 1], ce = a.caminfo[cam * 4 + 2], NCP = a.caminfo[cam * 4 + 3];
+            const int D = Pe + (cam > 0 ? 12 : 6), NC = D + 1;
+            const double* Go = a.G + a.goff[o];
+            for (int e = lane; e < NC * NC; e += 64) {
+                const int i = e / NC, j = e - i * NC;
+                // local column -> (kind, index): kind 0 = camera-system column (r maps to K), 1 = pose
+                int ki, ii, kj, jj;
+                if (i < Pe) { ki = 0; ii = ct + i; } else if (i < Pe + 6) { ki = 1; ii = i - Pe; } else if (i < D) { ki = 0; ii = ce + (i - Pe - 6); } else { ki = 0; ii = K; }
+                if (j < Pe) { kj = 0; jj = ct + j; } else if (j < Pe + 6) { kj = 1; jj = j - Pe; } else if (j < D) { kj = 0; jj = ce + (j - Pe - 6); } else { kj = 0; jj = K; }
+                if (ki == 0 && kj == 1) continue;
+                const double g = Go[min(i, j) * NCP + max(i, j)];
+                if (ki == 0) {
+                    acc[ii * K1 + jj] += g;
+                    if (i == j && ii < K) hdiag[ii] += g;
+                    if (jj == K && ii < K) gcv[ii] += g;
+                    if (ii == K && jj == K) acc[RB - 1] += g;            // cost = sum rho' s
+                } else if (kj == 0) {
+                    Baug[ii * K1 + jj] += g;
+                } else {
+                    Cm[ii * 6 + jj] += g;
+                }
+            }
+            wave_sync_lds();
+        }
+        // Cholesky of C + lambda clamp(diag C): every lane runs the same 6x6 factorisation
+        double L[21], dC[6];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dC[i] = Cm[i * 6 + i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = Cm[i * 6 + j];
+                if (i == j && a.lambda > 0.0) t += a.lambda * clampd(dC[i], a.min_diag, a.max_diag);
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) {
+                    ok = ok && (t > 0.0) && (t < 1.7e308);
+                    L[i * (i + 1) / 2 + i] = ok ? 1.0 / sqrt(t) : 0.0;        // diagonal stored inverted
+                } else {
+                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
+                }
+            }
+        }
+        if (!ok) {
+            if (lane == 0) a.flags[0] = 1;
+            for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
+            wave_sync_lds();
+            continue;
+        }
+        // Y = L^-1 [B | g_p], one column per lane
+        for (int j = lane; j < K1; j += 64) {
+            double y[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double t = Baug[i * K1 + j];
+#pragma unroll
+                for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
+                y[i] = t * L[i * (i + 1) / 2 + i];
+                Ym[i * K1 + j] = y[i];
+                pf[21 + i * K1 + j] = y[i];
+            }
+        }
+        if (lane < 21) pf[lane] = L[lane];
+        if (lane < 6) { pf[21 + 6 * K1 + lane] = Baug[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dC[lane]; }
+        wave_sync_lds();
+        // A -= Y^T Y
+        for (int e = lane; e < K1 * K1; e += 64) {
+            const int i = e / K1, j = e - i * K1;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+            acc[e] -= t;
+        }
+        wave_sync_lds();
+    }
+    for (int e = lane; e < RB; e += 64) a.partial[(int64_t)e * a.n_pw + gw] = acc[e];
+}
+
+hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    SchurArgs a = {};
+    a.G = w->G[gbuf]; a.goff = w->d_goff; a.slot_off = w->d_slot_off; a.slot_obs = w->d_slot_obs;
+    a.obs_cam = w->d_obs_cam; a.caminfo = w->d_caminfo;
+    a.n_slots = p->n_slots; a.K = w->K; a.RB = w->RB; a.PF = w->PF; a.n_pw = w->n_pw;
+    a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
+    a.partial = w->partial; a.pf = w->pf; a.flags = w->flags;
+    const int K1 = w->K + 1;
+    const int WS = ((w->RB + 12 * K1 + 36) + 1) & ~1;
+    const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
+    static size_t attr_lds = 0;
+    if (lds > 48 * 1024 && lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_lds = lds;
+    }
+    const int blocks = (w->n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(k_schur, dim3(blocks), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reduce: red[e] = sum_w partial[e][w], one workgroup per element, fixed summation order.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw, double* red) {
+    __shared__ double sh[4];
+    const double* src = partial + (int64_t)blockIdx.x * n_pw;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n_pw; i += 256) v += src[i];
+    const double t = block_sum_256(v, sh);
+    if (threadIdx.x == 0) red[blockIdx.x] = t;
+}
+hipError_t launch_reduce(const ccal_problem* p, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw, w->red);
+    return hipGetLastError();
+}
+
+// scal[0] = sum_o cost_o, scal[1] = sum_s mc_slot   (block 0 / block 1)
+__global__ __launch_bounds__(256) void k_sum2(const double* a, int na, const double* b, int nb, double* out) {
+    __shared__ double sh[4];
+    const double* src = blockIdx.x == 0 ? a : b;
+    const int n = blockIdx.x == 0 ? na : nb;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) v += src[i];
+    const double t = block_sum_256(v, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_solve: one wavefront.  S = A[0:K,0:K] + lambda clamp(hdiag), rhs = -b, fixed columns -> identity,
+// in-LDS Cholesky, dc, candidate intrinsics/extrinsics = clamp(x + dc), model decrease of the camera block.
+// ---------------------------------------------------------------------------------------------
+struct SolveArgs {
+    const double* red; const ColInfo* cols; int32_t K;
+    double lambda, min_diag, max_diag;
+    const double* intr; const double* extr; double* intr_c; double* extr_c; int32_t n_intr, n_extr;
+    double* dc; double* scal; int32_t* flags;
+};
+__global__ __launch_bounds__(64) void k_solve(const SolveArgs a) {
+    __shared__ double S[CCAL_KMAX * (CCAL_KMAX + 1)];
+    __shared__ double x[CCAL_KMAX];
+    __shared__ int bad;
+    const int K = a.K, K1 = K + 1, lane = threadIdx.x;
+    const double* hdiag = a.red + K1 * K1;
+    const double* gc = hdiag + K;
+    if (lane == 0) bad = 0;
+    for (int e = lane; e < a.n_intr; e += 64) a.intr_c[e] = a.intr[e];
+    for (int e = lane; e < a.n_extr; e += 64) a.extr_c[e] = a.extr[e];
+    for (int e = lane; e < K * K; e += 64) {
+        const int i = e / K, j = e - i * K;
+        double v = a.red[i * K1 + j];
+        const bool fi = a.cols[i].fixed != 0, fj = a.cols[j].fixed != 0;
+        if (fi || fj) v = (i == j) ? 1.0 : 0.0;
+        else if (i == j && a.lambda > 0.0) v += a.lambda * clampd(hdiag[i], a.min_diag, a.max_diag);
+        S[i * (CCAL_KMAX + 1) + j] = v;
+    }
+    if (lane < K) x[lane] = a.cols[lane].fixed ? 0.0 : -a.red[lane * K1 + K];
+    __syncthreads();
+    // right-looking Cholesky, one lane per row
+    for (int j = 0; j < K; ++j) {
+        const double piv = S[j * (CCAL_KMAX + 1) + j];
+        if (!(piv > 0.0) || !(piv < 1.7e308)) { if (lane == 0) bad = 1; }
+        __syncthreads();
+        if (bad) break;
+        const double inv = 1.0 / sqrt(piv);
+        if (lane == j) S[j * (CCAL_KMAX + 1) + j] = sqrt(piv);
+        if (lane > j && lane < K) S[lane * (CCAL_KMAX + 1) + j] *= inv;
+        __syncthreads();
+        if (lane > j && lane < K) {
+            const double lij = S[lane * (CCAL_KMAX + 1) + j];
+            for (int k = j + 1; k <= lane; ++k) S[lane * (CCAL_KMAX + 1) + k] -= lij * S[k * (CCAL_KMAX + 1) + j];
+        }
+        __syncthreads();
+    }
+    if (bad) {
+        if (lane == 0) { a.flags[1] = 1; a.scal[2] = 0.0; }
+        if (lane < K) a.dc[lane] = 0.0;
+        return;
+    }
+    if (lane == 0) {       // two triangular solves, K <= 64
+        for (int i = 0; i < K; ++i) { double t = x[i]; for (int k = 0; k < i; ++k) t -= S[i * (CCAL_KMAX + 1) + k] * x[k]; x[i] = t / S[i * (CCAL_KMAX + 1) + i]; }
+        for (int i = K - 1; i >= 0; --i) { double t = x[i]; for (int k = i + 1; k < K; ++k) t -= S[k * (CCAL_KMAX + 1) + i] * x[k]; x[i] = t / S[i * (CCAL_KMAX + 1) + i]; }
+    }
+    __syncthreads();
+    double mc = 0.0;
+    if (lane < K) {
+        const ColInfo ci = a.cols[lane];
+        const double d = x[lane];
+        a.dc[lane] = d;
+        const double Dii = a.lambda > 0.0 ? a.lambda * clampd(hdiag[lane], a.min_diag, a.max_diag) : 0.0;
+        if (!ci.fixed) {
+            mc = d * (Dii * d - gc[lane]);
+            const double* src = ci.is_extr ? a.extr : a.intr;
+            double* dst = ci.is_extr ? a.extr_c : a.intr_c;
+            double v = src[ci.dst] + d;
+            if (ci.has_bound) v = fmin(fmax(v, ci.lo), ci.hi);     // tiny-solver: max(lo).min(hi)
+            dst[ci.dst] = v;
+            if (ci.dst2 >= 0) dst[ci.dst2] = v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
+    if (lane == 0) a.scal[2] = mc;
+}
+hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    SolveArgs a = {};
+    a.red = w->red; a.cols = w->cols; a.K = w->K; a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
+    a.intr = p->d_intr; a.extr = p->d_extr; a.intr_c = p->d_intr_c; a.extr_c = p->d_extr_c;
+    a.n_intr = p->n_cams * CCAL_PMAX; a.n_extr = p->n_cams * 6;
+    a.dc = w->dc; a.scal = w->scal; a.flags = w->flags;
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_backsub: one thread per frame slot.  dp = -L^-T (y_r + Y dc); poses_c = poses + dp;
+// mc_slot = dp^T (lambda D_p dp - g_p)
+// ---------------------------------------------------------------------------------------------
+struct BacksubArgs {
+    const double* pf; const double* dc; const double* poses; double* poses_c; double* mc_slot;
+    int32_t n_slots, K, PF; double lambda, min_diag, max_diag;
+};
+__global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a) {
+    __shared__ double dcs[CCAL_KMAX];
+    if (threadIdx.x < a.K) dcs[threadIdx.x] = a.dc[threadIdx.x];
+    __syncthreads();
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_slots) return;
+    const int K1 = a.K + 1;
+    const double* pf = a.pf + (int64_t)s * a.PF;
+    double L[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) L[i] = pf[i];
+    double dp[6];
+    if (L[0] == 0.0) {          // no observations / failed factorisation: pose unchanged
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.poses_c[(int64_t)s * 6 + i] = a.poses[(int64_t)s * 6 + i];
+        a.mc_slot[s] = 0.0;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double* yr = pf + 21 + i * K1;
+        double t = yr[a.K];
+        for (int j = 0; j < a.K; ++j) t += yr[j] * dcs[j];
+        dp[i] = -t;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {     // L^T x = rhs, diagonal stored inverted
+        double t = dp[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; ++k) t -= L[k * (k + 1) / 2 + i] * dp[k];
+        dp[i] = t * L[i * (i + 1) / 2 + i];
+    }
+    double mc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double gp = pf[21 + 6 * K1 + i], dC = pf[21 + 6 * K1 + 6 + i];
+        const double Dii = a.lambda > 0.0 ? a.lambda * clampd(dC, a.min_diag, a.max_diag) : 0.0;
+        mc += dp[i] * (Dii * dp[i] - gp);
+        a.poses_c[(int64_t)s * 6 + i] = a.poses[(int64_t)s * 6 + i] + dp[i];
+    }
+    a.mc_slot[s] = mc;
+}
+hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    if (p->n_slots == 0) return hipSuccess;
+    BacksubArgs a = {};
+    a.pf = w->pf; a.dc = w->dc; a.poses = p->d_poses; a.poses_c = p->d_poses_c; a.mc_slot = w->mc_slot;
+    a.n_slots = p->n_slots; a.K = w->K; a.PF = w->PF; a.lambda = lambda;
+    a.min_diag = min_diag; a.max_diag = max_diag;
+    hipLaunchKernelGGL(k_backsub, dim3((p->n_slots + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ccal

@@ -1,7 +1,62 @@
-// Mode N (fused normal equations + per-frame Schur complement) and solver-loop workspaces.
+// Mode N (normal equations + exact per-frame Schur complement) and solver-loop workspaces.
+//
+// Pipeline of one linear solve (all on the context stream, everything stays in HBM):
+//   k_gram    per observation frame: G_o = [J|r]^T W [J|r] with v_mfma_f64_16x16x4_f64   (heavy)
+//   k_schur   per frame slot: assemble C = H_pp, B = [H_pc | g_p], eliminate the pose block,
+//             accumulate the reduced system in per-wave LDS accumulators, keep L and Y = L^-1 B
+//   k_reduce  deterministic sum of the per-wave partials -> red[RB]      (the all-reduce buffer)
+//   k_solve   one workgroup: damping, fixed mask, Cholesky K x K, dc, clamp to bounds
+//   k_backsub per slot: dp = -L^-T (y_r + Y dc), candidate poses, model-decrease partials
 #pragma once
 #include "ccal_internal.hpp"
 
 namespace ccal {
+
+// layout of the reduced buffer red[RB]:  A[(K+1)*(K+1)] | hdiag[K] | gc[K] | cost
+//   A = [[S, b],[b^T, *]] undamped in the camera block (pose damping already inside the Schur terms)
+inline int red_size(int K) { return (K + 1) * (K + 1) + 2 * K + 1; }
+// per-slot record pf[PF]: L (21, row-major lower, diagonal stored inverted) | Y[6][K+1] | g_p[6] | dC[6]
+inline int pf_size(int K) { return (21 + 6 * (K + 1) + 12 + 1) & ~1; }
+
+struct ColInfo {          // one column of the reduced camera system
+    double lo, hi;
+    int32_t has_bound, fixed;
+    int32_t is_extr;      // 0: intrinsic (index into intr, full layout), 1: extrinsic (index into extr)
+    int32_t dst, dst2;    // element index in the destination array; dst2 >= 0 mirrors the value (fy = f)
+};
+
+struct NormalWs {
+    int K = 0, RB = 0, PF = 0, n_pw = 0;
+    double* G[2] = { nullptr, nullptr };       // per-observation-frame Gram blocks (current / candidate)
+    double* cost_o[2] = { nullptr, nullptr };  // per-observation-frame cost
+    int64_t* d_goff = nullptr;                 // [n_obs] offset of G_o
+    int32_t* d_slot_off = nullptr;             // [n_slots+1] CSR slot -> observation frames
+    int32_t* d_slot_obs = nullptr;
+    int32_t* d_obs_cam = nullptr;
+    int32_t* d_caminfo = nullptr;              // [n_cams][4]: Peff, col_theta, col_extr, NCP
+    double* partial = nullptr;                 // [RB][n_pw]
+    double* red = nullptr;                     // [RB]
+    double* pf = nullptr;                      // [n_slots][PF]
+    double* dc = nullptr;                      // [K]
+    double* mc_slot = nullptr;                 // [n_slots]
+    double* scal = nullptr;                    // [8]: 0 cost(cand) 1 mc_p 2 mc_c
+    int32_t* flags = nullptr;                  // [4]: 0 slot Cholesky failed, 1 camera Cholesky failed
+    ColInfo* cols = nullptr;                   // [K]
+    double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
+    int cur = 0;                               // which G buffer holds the current point
+    int64_t g_len = 0;
+};
+
 void normal_ws_destroy(ccal_problem* p);
+int normal_ws_ensure(ccal_problem* p);          // allocate on first use
+int normal_upload_cols(ccal_problem* p);        // bounds / fixed flags -> device
+
+// launchers (ccal_kernels_normal.hip); `cand` selects parameter set and G buffer
+hipError_t launch_gram(const ccal_problem* p, int cam, bool use_candidate_params, int gbuf, hipStream_t s);
+hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s);
+hipError_t launch_reduce(const ccal_problem* p, hipStream_t s);
+hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s);
+hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s);
+hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s);   // scal[0] = sum cost_o[gbuf], scal[1] = sum mc_slot
+
 }  // namespace ccal

@@ -1,8 +1,279 @@
-// placeholder until mode N lands (next commit)
+// Mode N host side: workspaces, ccal_build_normal and the optimizer loop (ccal_solve).
+//
+// The loop restates tiny_solver::GaussNewtonOptimizer::optimize as the reference calls it
+// (src/util.rs:443-463, 668-670; defaults in ccal_set_defaults) -- per iteration: Jacobian at x,
+// solve the normal equations, x <- clamp(x + dx), error(x), stop on min_error / |d error| thresholds --
+// and adds a Ceres-style Levenberg-Marquardt mode on the same kernels.  One host synchronisation per
+// iteration (two doubles + flags); everything else is stream-ordered device work.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
 #include "ccal_normal.hpp"
-namespace ccal { void normal_ws_destroy(ccal_problem*) {} }
-extern "C" {
-int ccal_build_normal(ccal_problem*, const double*, const double*, const double*, double, double*, double*, double*) { return CCAL_ERR_UNSUPPORTED; }
-int ccal_build_normal_dev(ccal_problem*, double) { return CCAL_ERR_UNSUPPORTED; }
-int ccal_solve(ccal_problem*, const ccal_solver_opts*, double*, double*, double*, ccal_report*) { return CCAL_ERR_UNSUPPORTED; }
+
+using namespace ccal;
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return CCAL_ERR_HIP;                                                                   \
+        }                                                                                          \
+    } while (0)
+
+namespace ccal {
+
+void normal_ws_destroy(ccal_problem* p) {
+    NormalWs* w = p->nws;
+    if (!w) return;
+    void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
+                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols };
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    if (w->h_pinned) (void)hipHostFree(w->h_pinned);
+    delete w;
+    p->nws = nullptr;
 }
+
+template <class T>
+static int dev_upload(ccal_ctx* ctx, T** dst, const std::vector<T>& src) {
+    HIP_TRY(ctx, hipMalloc((void**)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return CCAL_OK;
+}
+
+int normal_ws_ensure(ccal_problem* p) {
+    if (p->nws) return CCAL_OK;
+    ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    NormalWs* w = new NormalWs();
+    p->nws = w;
+    w->K = p->K; w->RB = red_size(p->K); w->PF = pf_size(p->K);
+    // persistent Schur waves: at most 2 workgroups per CU worth, never more than slots
+    int n_pw = std::min(std::max(p->n_slots, 1), 2048);
+    n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+    w->n_pw = n_pw;
+    std::vector<int64_t> goff(p->n_obs);
+    std::vector<int32_t> caminfo(p->n_cams * 4);
+    int64_t gl = 0;
+    for (int c = 0; c < p->n_cams; ++c) {
+        const int ncp = (p->cams[c].D + 1) <= 16 ? 16 : 32;
+        caminfo[c * 4 + 0] = p->cams[c].Peff; caminfo[c * 4 + 1] = p->cams[c].col_theta;
+        caminfo[c * 4 + 2] = p->cams[c].col_extr; caminfo[c * 4 + 3] = ncp;
+    }
+    for (int o = 0; o < p->n_obs; ++o) { goff[o] = gl; const int ncp = caminfo[p->h_obs_cam[o] * 4 + 3]; gl += (int64_t)ncp * ncp; }
+    w->g_len = gl;
+    std::vector<int32_t> slot_off(p->n_slots + 1, 0), slot_obs(p->n_obs);
+    for (int o = 0; o < p->n_obs; ++o) slot_off[p->h_obs_slot[o] + 1]++;
+    for (int s = 0; s < p->n_slots; ++s) slot_off[s + 1] += slot_off[s];
+    { std::vector<int32_t> cur(slot_off.begin(), slot_off.end() - 1);
+      for (int o = 0; o < p->n_obs; ++o) slot_obs[cur[p->h_obs_slot[o]]++] = o; }
+    int rc;
+    if ((rc = dev_upload(ctx, &w->d_goff, goff)) || (rc = dev_upload(ctx, &w->d_slot_off, slot_off)) ||
+        (rc = dev_upload(ctx, &w->d_slot_obs, slot_obs)) || (rc = dev_upload(ctx, &w->d_obs_cam, p->h_obs_cam)) ||
+        (rc = dev_upload(ctx, &w->d_caminfo, caminfo)))
+        return rc;
+    const size_t gbytes = std::max<int64_t>(gl, 1) * sizeof(double);
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipMalloc((void**)&w->G[i], gbytes));
+        HIP_TRY(ctx, hipMemset(w->G[i], 0, gbytes));     // tile (1,0) of two-tile blocks is never written
+        HIP_TRY(ctx, hipMalloc((void**)&w->cost_o[i], std::max(p->n_obs, 1) * sizeof(double)));
+        HIP_TRY(ctx, hipMemset(w->cost_o[i], 0, std::max(p->n_obs, 1) * sizeof(double)));
+    }
+    HIP_TRY(ctx, hipMalloc((void**)&w->partial, (size_t)w->RB * n_pw * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->red, (size_t)(w->RB + 8) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->mc_slot, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
+    HIP_TRY(ctx, hipMemset(w->mc_slot, 0, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->scal, 8 * sizeof(double)));
+    HIP_TRY(ctx, hipMemset(w->scal, 0, 8 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->flags, 4 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemset(w->flags, 0, 4 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&w->h_pinned, (size_t)(w->RB + 16) * sizeof(double), hipHostMallocDefault));
+    return normal_upload_cols(p);
+}
+
+int normal_upload_cols(ccal_problem* p) {
+    NormalWs* w = p->nws;
+    ccal_ctx* ctx = p->ctx;
+    std::vector<ColInfo> cols(CCAL_KMAX);
+    std::memset(cols.data(), 0, cols.size() * sizeof(ColInfo));
+    for (int c = 0; c < p->n_cams; ++c) {
+        const CamLayout& cl = p->cams[c];
+        for (int i = 0; i < cl.Peff; ++i) {
+            ColInfo& ci = cols[cl.col_theta + i];
+            const int q = c * CCAL_PMAX + i;
+            ci.lo = p->lo[q]; ci.hi = p->hi[q]; ci.has_bound = p->has_bound[q]; ci.fixed = p->fixed[q];
+            ci.is_extr = 0;
+            const int full = p->one_focal ? (i == 0 ? 0 : i + 1) : i;     // eff -> full index (fy re-inserted)
+            ci.dst = c * CCAL_PMAX + full;
+            ci.dst2 = (p->one_focal && i == 0) ? c * CCAL_PMAX + 1 : -1;
+        }
+        if (c > 0) for (int i = 0; i < 6; ++i) {
+            ColInfo& ci = cols[cl.col_extr + i];
+            ci.is_extr = 1; ci.dst = c * 6 + i; ci.dst2 = -1;
+        }
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(w->cols, cols.data(), CCAL_KMAX * sizeof(ColInfo), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CCAL_OK;
+}
+
+}  // namespace ccal
+
+// gram (all cameras) at the current or candidate parameters into G[gbuf]
+static int enqueue_gram(ccal_problem* p, bool cand, int gbuf) {
+    ccal_ctx* ctx = p->ctx;
+    for (int c = 0; c < p->n_cams; ++c) HIP_TRY(ctx, launch_gram(p, c, cand, gbuf, ctx->stream));
+    return CCAL_OK;
+}
+// schur + reduce (+ all-reduce) of G[gbuf] -> red
+static int enqueue_reduce_system(ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag) {
+    ccal_ctx* ctx = p->ctx;
+    NormalWs* w = p->nws;
+    HIP_TRY(ctx, launch_schur(p, gbuf, lambda, min_diag, max_diag, ctx->stream));
+    HIP_TRY(ctx, launch_reduce(p, ctx->stream));
+    if (p->allreduce) {
+        if (p->allreduce(p->allreduce_user, w->red, (size_t)w->RB, (void*)ctx->stream) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+    }
+    return CCAL_OK;
+}
+
+extern "C" {
+
+int ccal_build_normal_dev(ccal_problem* p, double lambda) {
+    if (!p) return CCAL_ERR_INVALID_ARG;
+    int rc = normal_ws_ensure(p);
+    if (rc != CCAL_OK) return rc;
+    NormalWs* w = p->nws;
+    if ((rc = enqueue_gram(p, false, w->cur)) != CCAL_OK) return rc;
+    return enqueue_reduce_system(p, w->cur, lambda, 1e-6, 1e32);
+}
+
+int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, const double* extr,
+                      double lambda, double* S, double* b, double* cost) {
+    if (!p || !intr || (!poses && p->n_slots)) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    int rc = ccal_upload_params(p, intr, poses, extr);
+    if (rc != CCAL_OK) return rc;
+    if ((rc = normal_ws_ensure(p)) != CCAL_OK) return rc;
+    NormalWs* w = p->nws;
+    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), ctx->stream));
+    if ((rc = ccal_build_normal_dev(p, lambda)) != CCAL_OK) return rc;
+    double* h = w->h_pinned;
+    HIP_TRY(ctx, hipMemcpyAsync(h, w->red, w->RB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    int32_t flags[4];
+    HIP_TRY(ctx, hipMemcpyAsync(flags, w->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int K = w->K, K1 = K + 1;
+    const double* hd = h + K1 * K1;
+    if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+        double v = h[i * K1 + j];
+        if (i == j && lambda > 0.0) v += lambda * std::min(std::max(hd[i], 1e-6), 1e32);
+        S[i * K + j] = v;
+    }
+    if (b) for (int i = 0; i < K; ++i) b[i] = h[i * K1 + K];
+    if (cost) *cost = h[w->RB - 1];
+    if (flags[0]) { ctx->err = "a frame's pose block is not positive definite"; return CCAL_ERR_NOT_PD; }
+    return CCAL_OK;
+}
+
+int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
+    if (!p || !o || !intr_io || (!poses_io && p->n_slots)) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    int rc = ccal_upload_params(p, intr_io, poses_io, extr_io);
+    if (rc != CCAL_OK) return rc;
+    if ((rc = normal_ws_ensure(p)) != CCAL_OK) return rc;
+    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
+    NormalWs* w = p->nws;
+    hipStream_t st = ctx->stream;
+    const bool lm = o->method == CCAL_METHOD_LM;
+    const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
+    ccal_report R = {};
+    double* h = w->h_pinned;
+    int32_t* hflags = reinterpret_cast<int32_t*>(h + 8);
+    const auto t0 = std::chrono::steady_clock::now();
+
+    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
+    // cost and Gram at the starting point
+    double radius = o->lm_initial_radius, dec = 2.0;
+    double lambda = lm ? 1.0 / radius : 0.0;
+    if ((rc = enqueue_gram(p, false, w->cur)) != CCAL_OK) return rc;
+    HIP_TRY(ctx, launch_sum_cost(p, w->cur, st));
+    if (p->allreduce && p->allreduce(p->allreduce_user, w->scal, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+    HIP_TRY(ctx, hipMemcpyAsync(h, w->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    double cur = h[0];
+    R.initial_cost = cur;
+    int status = CCAL_OK;
+    if (!std::isfinite(cur)) status = CCAL_ERR_NONFINITE;
+    bool need_system = true;      // red must be (re)built from G[cur] with the current lambda
+
+    for (int it = 0; status == CCAL_OK && it < o->max_iterations; ++it) {
+        if (need_system) {
+            if ((rc = enqueue_reduce_system(p, w->cur, lambda, min_d, max_d)) != CCAL_OK) return rc;
+            need_system = false;
+        }
+        HIP_TRY(ctx, launch_solve(p, lambda, min_d, max_d, st));
+        HIP_TRY(ctx, launch_backsub(p, lambda, min_d, max_d, st));
+        const int cand = w->cur ^ 1;
+        if ((rc = enqueue_gram(p, true, cand)) != CCAL_OK) return rc;
+        HIP_TRY(ctx, launch_sum_cost(p, cand, st));
+        if (p->allreduce && p->allreduce(p->allreduce_user, w->scal, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+        HIP_TRY(ctx, hipMemcpyAsync(h, w->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(hflags, w->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        R.iterations++;
+        const double cand_cost = h[0], mc = h[1] + h[2];
+        const bool lin_fail = hflags[0] || hflags[1];
+        if (!lm) {
+            if (lin_fail) { status = CCAL_ERR_NOT_PD; ctx->err = "normal equations are not positive definite"; break; }   // solve failed -> None
+            // accept unconditionally (Gauss-Newton): x <- candidate
+            std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+            w->cur = cand; need_system = true;
+            const double last = cur;
+            cur = cand_cost;
+            if (o->verbose) std::printf("[ccal GN] iter %d cost %.12g\n", it, cur);
+            if (cur < o->min_error) break;
+            if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
+            if (std::fabs(last - cur) < o->min_abs_error_decrease) break;
+            if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
+        } else {
+            const double rho = (cur - cand_cost) / mc;
+            if (!lin_fail && std::isfinite(cand_cost) && mc > 0.0 && rho > 0.0) {
+                std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+                w->cur = cand;
+                const double last = cur;
+                cur = cand_cost; R.lm_accepted++;
+                const double t = 2.0 * rho - 1.0;
+                radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
+                dec = 2.0;
+                if (o->verbose) std::printf("[ccal LM] iter %d accept cost %.12g rho %.3g radius %.3g\n", it, cur, rho, radius);
+                if (cur < o->min_error) break;
+                if (std::fabs(last - cur) < o->min_abs_error_decrease) break;
+                if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
+            } else {
+                R.lm_rejected++;
+                radius /= dec; dec *= 2.0;
+                if (lin_fail) HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
+                if (o->verbose) std::printf("[ccal LM] iter %d reject (cand %.12g) radius %.3g\n", it, cand_cost, radius);
+                if (radius < 1e-32) { status = CCAL_ERR_NO_CONVERGENCE; break; }
+            }
+            lambda = 1.0 / radius;
+            need_system = true;          // same or new G[cur], new lambda
+        }
+        if (it == o->max_iterations - 1) status = CCAL_ERR_NO_CONVERGENCE;
+    }
+    R.final_cost = cur; R.status = status;
+    rc = ccal_download_params(p, intr_io, poses_io, extr_io);
+    R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep) *rep = R;
+    if (rc != CCAL_OK) return rc;
+    return status;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+"""GPU parity, mode N: fused normal equations + per-frame Schur complement and the optimizer loop,
+through the C ABI, against the CPU oracle (dual-number Jacobians, dense host algebra).
+
+Tolerances (fp64): reduced system S, b: |d| <= 1e-9 * max|S| (resp. max|b|) -- the Schur terms cancel
+~3 digits of the raw sums; cost: 1e-12 relative; converged intrinsics: <= 1e-6 relative (north_star);
+final cost: 1e-9 relative."""
+import numpy as np
+import pytest
+
+from camera_intrinsic_calibration_rs_amd import _ffi, synth
+from camera_intrinsic_calibration_rs_amd.engine import CcalError, Problem, default_opts
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(gpu_ctx, oracle, sp):
+    return Problem.from_synth(gpu_ctx, sp), oracle.OracleProblem.from_synth(sp)
+
+
+@pytest.mark.parametrize("model", ["ucm", "eucm", "kb4", "opencv5"])
+@pytest.mark.parametrize("one_focal", [False, True])
+@pytest.mark.parametrize("n_cams", [1, 2])
+@pytest.mark.parametrize("lam", [0.0, 1e-3])
+def test_build_normal_matches_oracle(gpu_ctx, oracle, model, one_focal, n_cams, lam):
+    sp = synth.make_problem(23, model, n_cams=n_cams, xy_same_focal=one_focal, ragged=True, outlier_frac=0.02)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    S, b, cost = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+    So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+    assert abs(cost - costo) <= 1e-12 * costo
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max()
+    assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+    assert np.abs(S - S.T).max() <= 1e-12 * np.abs(S).max()
+    # the GN step itself (what the reference's Cholesky would return for the camera block)
+    dc, dco = np.linalg.solve(S, -b), np.linalg.solve(So, -bo)
+    assert np.abs(dc - dco).max() <= 1e-6 * np.abs(dco).max()
+
+
+@pytest.mark.parametrize("model,n_cams,one_focal", [("eucm", 1, False), ("kb4", 1, True), ("opencv5", 1, False),
+                                                    ("eucm", 2, False), ("ucm", 3, True)])
+@pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
+def test_solve_matches_oracle(gpu_ctx, oracle, model, n_cams, one_focal, method):
+    sp = synth.make_problem(30, model, n_cams=n_cams, xy_same_focal=one_focal, outlier_frac=0.01)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    gp.apply_reference_bounds(); op.apply_reference_bounds()
+    intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+    intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+    assert rep.status == rep_o.status == 0
+    assert rep.iterations == rep_o.iterations
+    assert abs(rep.initial_cost - rep_o.initial_cost) <= 1e-12 * rep_o.initial_cost
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+    P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+    scale = np.maximum(np.abs(intr_o[:, :P]), 1e-3)          # distortion terms near 0: absolute 1e-9
+    assert (np.abs(intr[:, :P] - intr_o[:, :P]) / scale).max() <= 1e-6
+    np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-7)
+    if one_focal:
+        assert (intr[:, 0] == intr[:, 1]).all()              # fy re-inserted (src/util.rs:467-470)
+    # and the answer is the right one: close to ground truth
+    assert np.abs(intr[:, :4] / sp.intr_gt[:, :4] - 1).max() < 5e-3
+
+
+def test_gn_and_lm_converge_to_same_intrinsics(gpu_ctx):
+    sp = synth.make_problem(200, "eucm")
+    gp = Problem.from_synth(gpu_ctx, sp)
+    tight = dict(min_abs_error_decrease=1e-11, min_rel_error_decrease=1e-13)
+    i_gn, _, _, r_gn = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN, **tight))
+    i_lm, _, _, r_lm = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM, **tight))
+    assert np.abs(i_gn[0, :6] / i_lm[0, :6] - 1).max() < 1e-6
+    assert abs(r_gn.final_cost / r_lm.final_cost - 1) < 1e-9
+
+
+def test_fixed_focal_disabled_distortion_and_bounds(gpu_ctx, oracle):
+    """set_problem_parameter_disabled (src/util.rs:50-71), fix_variable("params", 0) (src/util.rs:461),
+    bounds clamp after every step."""
+    sp = synth.make_problem(12, "opencv5", xy_same_focal=True)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    i0 = sp.intr0.copy(); i0o = sp.intr0.copy()
+    gp.disable_distortions(1, i0); op.disable_distortions(1, i0o)
+    np.testing.assert_array_equal(i0, i0o)
+    gp.fix_param(0, 0); op.fix_param(0, 0)
+    intr, poses, _, rep = gp.solve(i0, sp.poses0)
+    intr_o, poses_o, _, rep_o = op.solve(i0o, sp.poses0)
+    assert intr[0, 8] == 0.0 and intr[0, 0] == i0[0, 0] == intr[0, 1]
+    assert rep.iterations == rep_o.iterations
+    np.testing.assert_allclose(intr[0, :9], intr_o[0, :9], rtol=1e-6, atol=1e-9)
+
+    sp = synth.make_problem(8, "eucm")
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    gp.set_bounds(0, 4, 0.0, 0.5); op.set_bounds(0, 4, 0.0, 0.5)
+    i0 = sp.intr0.copy(); i0[0, 4] = 0.45
+    intr, _, _, rep = gp.solve(i0, sp.poses0)
+    intr_o, _, _, rep_o = op.solve(i0, sp.poses0)
+    assert intr[0, 4] <= 0.5
+    np.testing.assert_allclose(intr[0, :6], intr_o[0, :6], rtol=1e-6)
+
+
+def test_failure_is_a_status_not_a_crash(gpu_ctx):
+    """A degenerate problem (one corner per frame: rank-deficient pose blocks) returns CCAL_ERR_NOT_PD
+    (tiny-solver: None, src/util.rs:455-457), never aborts."""
+    from camera_intrinsic_calibration_rs_amd.engine import make_desc
+    sp = synth.make_problem(4, "eucm")
+    offs = np.arange(5, dtype=np.int64)
+    idx = sp.obs_offsets[:-1]
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, 4, [0] * 4, [0, 1, 2, 3], offs,
+                        sp.p3d[idx, 0], sp.p3d[idx, 1], sp.p3d[idx, 2], sp.p2d[idx, 0], sp.p2d[idx, 1], 1.0)
+    gp = Problem(gpu_ctx, d, keep)
+    with pytest.raises(CcalError) as ei:
+        gp.solve(sp.intr0, sp.poses0)
+    assert ei.value.code in (_ffi.ERR_NOT_PD, _ffi.ERR_NONFINITE)
+    # the context is still usable afterwards
+    sp2 = synth.make_problem(6, "eucm")
+    _, _, _, rep = Problem.from_synth(gpu_ctx, sp2).solve(sp2.intr0, sp2.poses0)
+    assert rep.status == 0
+
+
+def test_slot_without_observations_keeps_its_pose(gpu_ctx, oracle):
+    sp = synth.make_problem(6, "eucm")
+    keep = sp.obs_slot != 2
+    counts = np.diff(sp.obs_offsets)[keep]
+    offs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    rows = np.concatenate([np.arange(sp.obs_offsets[o], sp.obs_offsets[o + 1]) for o in np.nonzero(keep)[0]])
+    import dataclasses
+    sp2 = dataclasses.replace(sp, obs_cam=sp.obs_cam[keep], obs_slot=sp.obs_slot[keep], obs_offsets=offs,
+                              p3d=sp.p3d[rows], p2d=sp.p2d[rows])
+    gp, op = _pair(gpu_ctx, oracle, sp2)
+    intr, poses, _, rep = gp.solve(sp2.intr0, sp2.poses0)
+    intr_o, poses_o, _, _ = op.solve(sp2.intr0, sp2.poses0)
+    np.testing.assert_array_equal(poses[2], sp2.poses0[2])
+    np.testing.assert_allclose(intr[0, :6], intr_o[0, :6], rtol=1e-6)
+
+
+def test_full_size_solve_recovers_ground_truth(gpu_ctx):
+    """North-star size, 10 000 frames x 144 corners: GN and LM agree to 1e-6 and sit at the noise floor."""
+    sp = synth.make_problem(10000, "eucm")
+    gp = Problem.from_synth(gpu_ctx, sp)
+    i_gn, p_gn, _, r_gn = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
+    i_lm, _, _, r_lm = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    assert r_gn.status == 0 and r_lm.status == 0
+    assert np.abs(i_gn[0, :6] / i_lm[0, :6] - 1).max() < 1e-6
+    assert np.abs(i_gn[0, :6] / sp.intr_gt[0, :6] - 1).max() < 1e-4       # 1.44 M observations at 0.1 px
+    # cost at the optimum ~ 2 sigma^2 per corner (sigma = 0.1 px + f32 rounding)
+    assert 0.015 < r_gn.final_cost / gp.n_corners < 0.025
+    a, m = gp.validation(0, i_gn, p_gn)
+    assert 0.08 < m < 0.16
