@@ -46,6 +46,7 @@ def load():
         "oracle_pose_inverse": (C.c_int, [_dp, _dp]),
         "oracle_pose_apply": (C.c_int, [_dp, _dp, _dp]),
         "oracle_eval": (C.c_int, [D, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
+        "oracle_eval_timed": (C.c_double, [D, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
         "oracle_reduced_dim": (C.c_int, [D]),
         "oracle_build_normal": (C.c_int, [D, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp]),
         "oracle_cost": (C.c_double, [D, _dp, _dp, _dp]),
@@ -180,6 +181,14 @@ class OracleProblem:
         rc = self.lib.oracle_eval(C.byref(self.desc), _p(intr), _p(poses), _p(extr), int(apply_loss), threads, _p(r), _p(J))
         assert rc == 0
         return r, J
+
+    def eval_timed(self, intr, poses, extr=None, threads=1, reps=1):
+        """Wall seconds for `reps` full evaluations on `threads` threads (cpu_baseline leg of bench.py)."""
+        intr, poses, extr = self._params(intr, poses, extr)
+        if not hasattr(self, "_rbuf"):
+            self._rbuf = np.empty((self.n_corners, 2)); self._jbuf = np.empty(self.j_len)
+        return float(self.lib.oracle_eval_timed(C.byref(self.desc), _p(intr), _p(poses), _p(extr), threads, reps,
+                                                _p(self._rbuf), _p(self._jbuf)))
 
     def build_normal(self, intr, poses, extr=None, lam=0.0, min_diag=1e-6, max_diag=1e32, full=False):
         intr, poses, extr = self._params(intr, poses, extr)

@@ -307,14 +307,15 @@ int oracle_pose_apply(const double* a, const double* p, double* out) {
 // Mode E over a whole problem, the reference way: one dual-number factor evaluation per corner,
 // model and exp-map rebuilt per corner (src/optimization/factors.rs:152-173).  `threads` static
 // partition over observation frames (tiny-solver evaluates blocks from a rayon pool).
-int oracle_eval(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
-                int apply_loss, int threads, double* r_out, double* J_out) {
+static int oracle_eval_impl(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
+                            int apply_loss, int threads, int reps, double* r_out, double* J_out) {
     Layout L; if (!make_layout(d, L)) return CCAL_ERR_INVALID_ARG;
     double eff[CCAL_MAX_CAMS][9];
     for (int c = 0; c < L.n_cams; ++c) full_to_eff(L, c, intr + (size_t)c * CCAL_PMAX, eff[c]);
     std::vector<int64_t> joff(d->n_obs + 1, 0);
     for (int o = 0; o < d->n_obs; ++o) joff[o + 1] = joff[o] + (d->obs_offsets[o + 1] - d->obs_offsets[o]) * 2 * L.D[d->obs_cam[o]];
     auto work = [&](int o0, int o1) {
+        for (int rep = 0; rep < reps; ++rep)
         for (int o = o0; o < o1; ++o) {
             const int cam = d->obs_cam[o], slot = d->obs_slot[o], D = L.D[cam];
             for (int64_t k = d->obs_offsets[o]; k < d->obs_offsets[o + 1]; ++k) {
@@ -336,6 +337,19 @@ int oracle_eval(const ccal_problem_desc* d, const double* intr, const double* po
     }
     for (auto& th : pool) th.join();
     return CCAL_OK;
+}
+
+int oracle_eval(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
+                int apply_loss, int threads, double* r_out, double* J_out) {
+    return oracle_eval_impl(d, intr, poses, extr, apply_loss, threads, 1, r_out, J_out);
+}
+// CPU-baseline timing helper: every thread repeats its static share `reps` times (amortises thread
+// start-up the way a long-lived rayon pool would); returns wall seconds of the whole call.
+double oracle_eval_timed(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
+                         int threads, int reps, double* r_out, double* J_out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (oracle_eval_impl(d, intr, poses, extr, 0, threads, reps, r_out, J_out) != CCAL_OK) return -1.0;
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 int oracle_reduced_dim(const ccal_problem_desc* d) { Layout L; return make_layout(d, L) ? L.K : -1; }

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Produces the rocprofv3 summaries committed under profiles/ (run on the GPU box through gpurun):
+#   gpurun --timeout 1500 -- 'bash profiles/run_profile.sh r01'
+# Counters are collected in their own passes (kernel-trace only), as MI355X_MICROARCH.md prescribes.
+set -u
+TAG=${1:-r01}
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+python3 $REPO/bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH --no-extra > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH --no-extra > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
+ls -R $OUT | head -50
+find $OUT -name "*.csv" -size +20M -delete

@@ -137,7 +137,7 @@ def test_full_size_solve_recovers_ground_truth(gpu_ctx):
     i_lm, _, _, r_lm = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
     assert r_gn.status == 0 and r_lm.status == 0
     assert np.abs(i_gn[0, :6] / i_lm[0, :6] - 1).max() < 1e-6
-    assert np.abs(i_gn[0, :6] / sp.intr_gt[0, :6] - 1).max() < 1e-4       # 1.44 M observations at 0.1 px
+    assert np.abs(i_gn[0, :6] / sp.intr_gt[0, :6] - 1).max() < 5e-4       # 1.44 M observations at 0.1 px + f32 rounding
     # cost at the optimum ~ 2 sigma^2 per corner (sigma = 0.1 px + f32 rounding)
     assert 0.015 < r_gn.final_cost / gp.n_corners < 0.025
     a, m = gp.validation(0, i_gn, p_gn)
