@@ -102,6 +102,17 @@ def main():
         bytes_per_corner = 20 + 16 + 16 * D
         algo_bytes = n_corners * bytes_per_corner + sp.n_slots * 48
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command/workload
+        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/<round>/pmc_summary.json); null otherwise
+        traffic = None
+        try:
+            prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
+            with open(os.path.join(ROOT, "profiles", prof_dirs[-1], "pmc_summary.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("k_eval_algorithmic_bytes_per_launch") == algo_bytes:
+                traffic = pmc["k_eval_hbm_traffic_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
         out = {
             "metric": "corner residual+Jacobian evals/sec; LM iters/sec to converge (EUCM, TUM-VI cam0)",
             "value": total_corners * args.steps / elapsed,
@@ -115,7 +126,7 @@ def main():
                        "frames_per_gpu": args.frames, "corners_per_frame": 144, "model": args.model,
                        "block_jacobian_cols": D, "sharding": "frames" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "k_eval", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
         }
 
@@ -160,8 +171,8 @@ def main():
         t_single = op.eval_timed(sub.intr0, sub.poses0, threads=1, reps=1)
         single = op.n_corners / t_single
         # size the all-core run for ~10 s of wall time, every thread repeating its share of the sample
-        reps = max(2, int(10.0 * single * min(cores, sub.n_slots) / op.n_corners * 0.6))
-        op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=2)        # warm-up
+        t_cal = op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=8)        # warm-up + calibration
+        reps = int(min(max(8, 10.0 / max(t_cal / 8, 1e-6)), 1e6))
         t_all = op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=reps)
         out["cpu_baseline"] = {
             "value": op.n_corners * reps / t_all, "unit": "corner residual+Jacobian evals/s", "cores": cores,

@@ -50,7 +50,8 @@ def load():
         "oracle_reduced_dim": (C.c_int, [D]),
         "oracle_build_normal": (C.c_int, [D, _dp, _dp, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp, _dp, _dp, _dp]),
         "oracle_cost": (C.c_double, [D, _dp, _dp, _dp]),
-        "oracle_solve": (C.c_int, [D, _dp, _dp, _u8, _u8, C.POINTER(F.SolverOpts), _dp, _dp, _dp, C.POINTER(F.Report)]),
+        "oracle_solve": (C.c_int, [D, _dp, _dp, _u8, _u8, C.POINTER(F.SolverOpts), _dp, _dp, _dp, C.POINTER(F.Report),
+                                  F.ALLREDUCE_FN, C.c_void_p]),
         "oracle_gn_step_dense": (C.c_int, [D, _u8, _dp, _dp, _dp, _dp]),
         "oracle_reprojection_errors": (C.c_int, [D, _dp, _dp, _dp, _dp]),
         "oracle_validation_stats": (C.c_int, [_dp, C.c_int64, _dp, _dp]),
@@ -203,14 +204,26 @@ class OracleProblem:
         intr, poses, extr = self._params(intr, poses, extr)
         return float(self.lib.oracle_cost(C.byref(self.desc), _p(intr), _p(poses), _p(extr)))
 
-    def solve(self, intr, poses, extr=None, opts=None):
+    def solve(self, intr, poses, extr=None, opts=None, allreduce=None):
+        """allreduce: fn(ptr, count, stream) -> int on a HOST buffer (frame-sharded solves, gloo tests)."""
         from camera_intrinsic_calibration_rs_amd.engine import default_opts
+        if allreduce is None:
+            cb = C.cast(None, F.ALLREDUCE_FN)
+        else:
+            def tramp(user, ptr, count, stream):
+                try:
+                    return int(allreduce(ptr or 0, int(count), stream or 0) or 0)
+                except Exception:
+                    import traceback; traceback.print_exc()
+                    return 1
+            cb = F.ALLREDUCE_FN(tramp)
         intr, poses, extr = self._params(intr, poses, extr)
         intr, poses, extr = intr.copy(), poses.copy(), extr.copy()
         opts = opts or default_opts()
         rep = F.Report()
         rc = self.lib.oracle_solve(C.byref(self.desc), _p(self.lo), _p(self.hi), self.has_bound.ctypes.data_as(_u8),
-                                   self.fixed.ctypes.data_as(_u8), C.byref(opts), _p(intr), _p(poses), _p(extr), C.byref(rep))
+                                   self.fixed.ctypes.data_as(_u8), C.byref(opts), _p(intr), _p(poses), _p(extr), C.byref(rep),
+                                   cb, None)
         rep.status = rc
         if self.desc.xy_same_focal:
             intr[:, 1] = intr[:, 0]

@@ -145,8 +145,8 @@ static void build_normal(const ccal_problem_desc* d, const Layout& L, const doub
         }
     }
     // Schur complement of every pose block (Marquardt damping lambda * clamp(diag)).
+    // (the camera block's own damping lambda * clamp(diag Hcc) is added at solve time, after any all-reduce)
     N.S = N.Hcc; N.b = N.gc;
-    if (lambda > 0.0) for (int i = 0; i < K; ++i) N.S[(size_t)i * K + i] += lambda * clampd(N.Hcc[(size_t)i * K + i], min_diag, max_diag);
     std::vector<double> Y((size_t)6 * (K + 1));
     for (auto& sb : N.slots) {
         double Cl[36]; std::memcpy(Cl, sb.C, sizeof Cl);
@@ -200,9 +200,10 @@ struct Constraints { const double* lo; const double* hi; const uint8_t* has_boun
 // model_change with dx^T (lambda D dx - g) (the predicted decrease of sum w s).
 static int step(const ccal_problem_desc* d, const Layout& L, const Constraints& cs, const Normal& N, double lambda,
                 double min_diag, double max_diag, const double* intr, const double* poses, const double* extr,
-                double* intr_c, double* poses_c, double* extr_c, double* model_change) {
+                double* intr_c, double* poses_c, double* extr_c, double* mc_cam, double* mc_pose) {
     const int K = N.K;
     std::vector<double> S = N.S, dc(K);
+    if (lambda > 0.0) for (int i = 0; i < K; ++i) S[(size_t)i * K + i] += lambda * clampd(N.Hcc[(size_t)i * K + i], min_diag, max_diag);
     std::vector<uint8_t> fx(K, 0);
     for (int c = 0; c < L.n_cams; ++c) for (int i = 0; i < L.Peff[c]; ++i)
         if (cs.fixed && cs.fixed[c * CCAL_PMAX + i]) fx[L.col_theta[c] + i] = 1;
@@ -213,8 +214,9 @@ static int step(const ccal_problem_desc* d, const Layout& L, const Constraints& 
     double mc = 0.0;
     for (int i = 0; i < K; ++i) {
         const double Dii = lambda > 0.0 ? lambda * clampd(N.Hcc[(size_t)i * K + i], min_diag, max_diag) : 0.0;
-        mc += dc[i] * (Dii * dc[i] - N.gc[i]);
+        if (!fx[i]) mc += dc[i] * (Dii * dc[i] - N.gc[i]);
     }
+    *mc_cam = mc; mc = 0.0;
     // shared block update, clamp to bounds, keep fixed
     for (int c = 0; c < L.n_cams; ++c) {
         double eff[9]; full_to_eff(L, c, intr + (size_t)c * CCAL_PMAX, eff);
@@ -242,9 +244,34 @@ static int step(const ccal_problem_desc* d, const Layout& L, const Constraints& 
         chol_solve(Cl, 6, rhs);
         for (int i = 0; i < 6; ++i) { poses_c[(size_t)s * 6 + i] = poses[(size_t)s * 6 + i] + rhs[i]; mc += rhs[i] * (Dp[i] * rhs[i] - sb.g[i]); }
     }
-    *model_change = mc;
+    *mc_pose = mc;
     return CCAL_OK;
 }
+
+// Frame-sharded solves: the same hook signature as ccal_allreduce_fn, on a HOST buffer.
+typedef int (*allreduce_fn)(void* user, double* buf, size_t count, void* stream);
+static int allreduce_normal(Normal& N, allreduce_fn fn, void* user) {
+    if (!fn) return 0;
+    const int K = N.K;
+    std::vector<double> buf((size_t)K * K + 3 * K + 1);
+    double* q = buf.data();
+    std::memcpy(q, N.S.data(), sizeof(double) * K * K); q += (size_t)K * K;
+    std::memcpy(q, N.b.data(), sizeof(double) * K); q += K;
+    for (int i = 0; i < K; ++i) q[i] = N.Hcc[(size_t)i * K + i];
+    q += K;
+    std::memcpy(q, N.gc.data(), sizeof(double) * K); q += K;
+    *q = N.cost;
+    if (fn(user, buf.data(), buf.size(), nullptr) != 0) return 1;
+    q = buf.data();
+    std::memcpy(N.S.data(), q, sizeof(double) * K * K); q += (size_t)K * K;
+    std::memcpy(N.b.data(), q, sizeof(double) * K); q += K;
+    for (int i = 0; i < K; ++i) N.Hcc[(size_t)i * K + i] = q[i];
+    q += K;
+    std::memcpy(N.gc.data(), q, sizeof(double) * K); q += K;
+    N.cost = *q;
+    return 0;
+}
+static int allreduce_scalars(double* v, int n, allreduce_fn fn, void* user) { return fn ? fn(user, v, (size_t)n, nullptr) : 0; }
 
 }  // namespace oracle
 
@@ -359,7 +386,10 @@ int oracle_build_normal(const ccal_problem_desc* d, const double* intr, const do
                         double* S, double* b, double* cost, double* Hcc_diag, double* gc) {
     Layout L; if (!make_layout(d, L)) return CCAL_ERR_INVALID_ARG;
     Normal N; build_normal(d, L, intr, poses, extr, lambda, min_diag, max_diag, N);
-    if (S) std::memcpy(S, N.S.data(), sizeof(double) * N.S.size());
+    if (S) {
+        std::memcpy(S, N.S.data(), sizeof(double) * N.S.size());
+        if (lambda > 0.0) for (int i = 0; i < L.K; ++i) S[(size_t)i * L.K + i] += lambda * clampd(N.Hcc[(size_t)i * L.K + i], min_diag, max_diag);
+    }
     if (b) std::memcpy(b, N.b.data(), sizeof(double) * N.b.size());
     if (cost) *cost = N.cost;
     if (Hcc_diag) for (int i = 0; i < L.K; ++i) Hcc_diag[i] = N.Hcc[(size_t)i * L.K + i];
@@ -376,7 +406,8 @@ double oracle_cost(const ccal_problem_desc* d, const double* intr, const double*
 // lo/hi/has_bound/fixed: [n_cams][CCAL_PMAX] in eff index space (may be NULL).
 int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi, const uint8_t* has_bound,
                  const uint8_t* fixed, const ccal_solver_opts* o,
-                 double* intr, double* poses, double* extr, ccal_report* rep) {
+                 double* intr, double* poses, double* extr, ccal_report* rep,
+                 oracle::allreduce_fn ar, void* ar_user) {
     Layout L; if (!make_layout(d, L) || !o) return CCAL_ERR_INVALID_ARG;
     Constraints cs = { lo, hi, has_bound, fixed };
     const auto t0 = std::chrono::steady_clock::now();
@@ -386,20 +417,23 @@ int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi,
     Normal N;
     ccal_report R = {}; R.status = CCAL_OK;
     double cur = total_cost(d, L, intr, poses, extr);
+    if (allreduce_scalars(&cur, 1, ar, ar_user)) return CCAL_ERR_HIP;
     R.initial_cost = cur;
     int status = CCAL_OK;
     if (o->method == CCAL_METHOD_GN) {
         for (int it = 0; it < o->max_iterations; ++it) {
             const double last = cur;
             build_normal(d, L, intr, poses, extr, 0.0, 0.0, 0.0, N);
+            if (allreduce_normal(N, ar, ar_user)) return CCAL_ERR_HIP;
             if (!std::isfinite(N.cost)) { status = CCAL_ERR_NOT_PD; break; }
-            double mc;
-            status = step(d, L, cs, N, 0.0, 0.0, 0.0, intr, poses, extr, ic.data(), pc.data(), ec.data(), &mc);
+            double mcc, mcp;
+            status = step(d, L, cs, N, 0.0, 0.0, 0.0, intr, poses, extr, ic.data(), pc.data(), ec.data(), &mcc, &mcp);
             if (status != CCAL_OK) break;
             std::memcpy(intr, ic.data(), sizeof(double) * ic.size());
             std::memcpy(poses, pc.data(), sizeof(double) * pc.size());
             std::memcpy(extr == ex0.data() ? ex0.data() : extr, ec.data(), sizeof(double) * ec.size());
             cur = total_cost(d, L, intr, poses, extr);
+            if (allreduce_scalars(&cur, 1, ar, ar_user)) return CCAL_ERR_HIP;
             R.iterations++;
             if (o->verbose) std::printf("[oracle GN] iter %d cost %.12g\n", it, cur);
             if (cur < o->min_error) break;
@@ -416,12 +450,15 @@ int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi,
             // Gram at x is lambda-independent, but this oracle simply rebuilds.
             build_normal(d, L, intr, poses, extr, lambda, o->lm_min_diagonal, o->lm_max_diagonal, N);
             (void)have;
+            if (allreduce_normal(N, ar, ar_user)) return CCAL_ERR_HIP;
             if (!std::isfinite(N.cost)) { status = CCAL_ERR_NOT_PD; break; }
-            double mc;
-            int st = step(d, L, cs, N, lambda, o->lm_min_diagonal, o->lm_max_diagonal, intr, poses, extr, ic.data(), pc.data(), ec.data(), &mc);
+            double mcc = 0.0, mcp = 0.0;
+            int st = step(d, L, cs, N, lambda, o->lm_min_diagonal, o->lm_max_diagonal, intr, poses, extr, ic.data(), pc.data(), ec.data(), &mcc, &mcp);
             R.iterations++;
-            double cand = NAN, rho = -1.0;
-            if (st == CCAL_OK) { cand = total_cost(d, L, ic.data(), pc.data(), ec.data()); rho = (cur - cand) / mc; }
+            double cand = NAN, rho = -1.0, mc = 0.0;
+            double pair[2] = { st == CCAL_OK ? total_cost(d, L, ic.data(), pc.data(), ec.data()) : NAN, mcp };
+            if (allreduce_scalars(pair, 2, ar, ar_user)) return CCAL_ERR_HIP;
+            if (st == CCAL_OK) { cand = pair[0]; mc = mcc + pair[1]; rho = (cur - cand) / mc; }
             if (st == CCAL_OK && std::isfinite(cand) && mc > 0.0 && rho > 0.0) {
                 const double last = cur;
                 std::memcpy(intr, ic.data(), sizeof(double) * ic.size());

@@ -1,0 +1,84 @@
+"""CPU, world_size 2, gloo: the frame-sharded path -- shard by slot range, one all-reduce
+of the packed reduced system per linear solve through the SAME hook the GPU path registers
+(camera_intrinsic_calibration_rs_amd.dist.make_allreduce_hook), every rank solves the small camera
+system redundantly and back-substitutes its own poses.  The per-shard arithmetic here is the oracle's
+(there is no GPU in this container); on the GPU box the identical hook is driven by ccal_solve."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, model, n_cams, method, n_frames, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.dist import gather_poses, make_allreduce_hook
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    from oracle import binding as ob
+    sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+    shard = sp.shard(rank, world)
+    op = ob.OracleProblem.from_synth(shard)
+    op.apply_reference_bounds()
+    hook = make_allreduce_hook(device=None)
+    intr, poses, extr, rep = op.solve(shard.intr0, shard.poses0, shard.extr0, opts=default_opts(method), allreduce=hook)
+    poses_all = gather_poses(poses, sp.n_slots)
+    q.put((rank, intr, extr, poses_all, rep.iterations, rep.final_cost, rep.status))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,n_cams,method", [("eucm", 1, 0), ("eucm", 1, 1), ("kb4", 2, 0)])
+def test_two_rank_sharded_solve_equals_single_process(oracle, model, n_cams, method):
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    n_frames = 21                                      # odd: shards of 10 and 11 slots
+    sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+    op = oracle.OracleProblem.from_synth(sp)
+    op.apply_reference_bounds()
+    intr1, poses1, extr1, rep1 = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, model, n_cams, method, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, i0, e0, p0, it0, c0, s0), (_, i1, e1, p1, it1, c1, s1) = res
+    # every rank holds the same camera block, bit for bit (same all-reduced system, same solve)
+    np.testing.assert_array_equal(i0, i1); np.testing.assert_array_equal(e0, e1)
+    assert it0 == it1 == rep1.iterations and s0 == s1 == rep1.status == 0
+    # and it equals the single-process solve up to summation order
+    np.testing.assert_allclose(i0, intr1, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(e0, extr1, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(p0, poses1, rtol=0, atol=1e-9)
+    assert abs(c0 - rep1.final_cost) <= 1e-10 * rep1.final_cost
+
+
+def test_shard_partitions_every_observation_once():
+    from camera_intrinsic_calibration_rs_amd import synth
+    sp = synth.make_problem(13, "eucm", n_cams=2, ragged=True)
+    seen = 0
+    for r in range(4):
+        sh = sp.shard(r, 4)
+        seen += sh.n_corners
+        assert sh.obs_slot.min(initial=0) >= 0 and sh.obs_slot.max(initial=-1) < sh.n_slots
+        assert sh.poses0.shape[0] == sh.n_slots
+        # a slot's observations from all cameras stay on one rank
+        assert len(sh.obs_slot) == 2 * sh.n_slots
+    assert seen == sp.n_corners

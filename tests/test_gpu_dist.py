@@ -1,0 +1,51 @@
+"""GPU: the all-reduce hook path of ccal_solve with RCCL (backend "nccl") on a 1-rank group -- the
+device-pointer branch of dist.make_allreduce_hook, stream-ordered on the library's stream.  Multi-rank
+semantics are covered on CPU with gloo (tests/test_dist_cpu.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from camera_intrinsic_calibration_rs_amd import synth
+from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
+
+pytestmark = pytest.mark.gpu
+
+
+def test_solve_with_rccl_hook_single_rank():
+    import torch
+    import torch.distributed as dist
+    from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        stream = torch.cuda.Stream(device=dev)
+        ctx = Context(0, stream=stream.cuda_stream)
+        sp = synth.make_problem(50, "eucm", outlier_frac=0.01)
+        gp = Problem.from_synth(ctx, sp)
+        calls = []
+        hook = make_allreduce_hook(device=dev)
+
+        def counting(ptr, count, st):
+            calls.append(count)
+            return hook(ptr, count, st)
+
+        for method in (0, 1):
+            gp.set_allreduce(None)
+            ref = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+            gp.set_allreduce(counting)
+            calls.clear()
+            got = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+            np.testing.assert_array_equal(ref[0], got[0])
+            np.testing.assert_array_equal(ref[1], got[1])
+            assert ref[3].iterations == got[3].iterations
+            # one packed-system all-reduce per linear solve + one 2-double all-reduce per cost evaluation
+            K = gp.K
+            assert calls.count((K + 1) ** 2 + 2 * K + 1) >= got[3].iterations
+            assert calls.count(2) == got[3].iterations + 1
+    finally:
+        dist.destroy_process_group()
