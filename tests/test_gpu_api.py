@@ -1,0 +1,113 @@
+"""GPU: the reference-shaped API (api.py) end to end through the C ABI -- these read like the
+reference's own tests (tests/optimization_test.rs) and its call sites (src/util.rs)."""
+import numpy as np
+import pytest
+
+from camera_intrinsic_calibration_rs_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reprojection_factor(gpu_ctx):
+    """tests/optimization_test.rs:36-80, statement for statement."""
+    w, h = 640, 480
+    cam_params = np.array([500.0, 500.0, 320.0, 240.0, 0.5])
+    model = api.GenericModel("ucm", cam_params, w, h)
+    p3d = np.array([1.0, 2.0, 10.0], dtype=np.float32)
+    # project using the model: residual against p2d = 0 is the projection itself
+    probe = api.ReprojectionFactor.new(model, p3d, np.zeros(2, dtype=np.float32), False, gpu_ctx)
+    p2d_f64 = probe.residual_func([cam_params, np.zeros(3), np.zeros(3)])
+    np.testing.assert_allclose(p2d_f64, [369.3901531919198, 338.7803063838396], rtol=1e-14)
+    p2d = p2d_f64.astype(np.float32)
+    factor = api.ReprojectionFactor.new(model, p3d, p2d, False, gpu_ctx)
+    residual = factor.residual_func([cam_params, np.zeros(3), np.zeros(3)])
+    assert np.linalg.norm(residual) < 1e-4, "Residual should be zero at GT"
+    residual_bad = factor.residual_func([cam_params, np.zeros(3), np.array([0.1, 0.0, 0.0])])
+    assert np.linalg.norm(residual_bad) > 1e-3, "Residual should be non-zero for bad params"
+
+
+def test_factor_jacobian_matches_dual_numbers(gpu_ctx, oracle):
+    model = api.GenericModel("eucm", synth.GT_PARAMS[synth.MODEL_EUCM], 512, 512)
+    th = np.array(synth.GT_PARAMS[synth.MODEL_EUCM]); th_of = np.delete(th, 1)
+    pose = np.array([2.9, 0.1, -0.2, -0.3, 0.35, 0.9]); ext = np.array([0.01, -0.02, 0.005, -0.101, 0.002, 0.001])
+    p3d = [0.2, -0.3, 0.0]; p2d = [200.0, 260.0]
+    for of, p in ((False, th), (True, th_of)):
+        r, J = api.ReprojectionFactor.new(model, p3d, p2d, of, gpu_ctx).residual_func([p, pose[:3], pose[3:]], jacobian=True)
+        ro, Jo = oracle.factor(1, of, p, pose, p3d, p2d)
+        np.testing.assert_allclose(r, ro, atol=1e-10); np.testing.assert_allclose(J, Jo, rtol=1e-11, atol=1e-11)
+        r, J = api.OtherCamReprojectionFactor.new(model, p3d, p2d, of, gpu_ctx).residual_func(
+            [p, pose[:3], pose[3:], ext[:3], ext[3:]], jacobian=True)
+        ro, Jo = oracle.factor(1, of, p, pose, p3d, p2d, pose1=ext)
+        np.testing.assert_allclose(r, ro, atol=1e-10); np.testing.assert_allclose(J, Jo, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("one_focal,disabled,fixed_focal", [(False, 0, False), (True, 0, False), (True, 1, True)])
+def test_calib_camera(gpu_ctx, oracle, one_focal, disabled, fixed_focal):
+    """util::calib_camera on synthetic frames vs the oracle driven through the same steps
+    (bounds, disabled distortion, GN, optional fixed-focal second solve)."""
+    sp = synth.make_problem(24, "eucm", xy_same_focal=one_focal)
+    frames = api.frames_from_synth(sp)
+    frames[5] = None                                             # a frame without detections
+    cam0 = api.GenericModel("eucm", sp.intr0[0, :6], 512, 512)
+    init = {i: api.RvecTvec.from6(sp.poses0[i]) for i in range(sp.n_slots) if i != 5}
+    res = api.calib_camera(frames, cam0, one_focal, disabled, fixed_focal, init, ctx=gpu_ctx)
+    assert res is not None
+    model, poses = res
+    assert sorted(poses.keys()) == [i for i in range(24) if i != 5]
+    # oracle, same recipe
+    import dataclasses
+    keep = sp.obs_slot != 5
+    rows = np.concatenate([np.arange(sp.obs_offsets[o], sp.obs_offsets[o + 1]) for o in np.nonzero(keep)[0]])
+    sub = dataclasses.replace(sp, n_slots=23, obs_cam=sp.obs_cam[keep], obs_slot=np.arange(23, dtype=np.int32),
+                              obs_offsets=np.arange(24, dtype=np.int64) * 144, p3d=sp.p3d[rows], p2d=sp.p2d[rows])
+    op = oracle.OracleProblem.from_synth(sub)
+    op.apply_reference_bounds()
+    intr = sp.intr0.copy(); op.disable_distortions(disabled, intr)
+    p0 = np.delete(sp.poses0, 5, axis=0)
+    intr, p1, _, rep = op.solve(intr, p0)
+    if fixed_focal:
+        op.fix_param(0, 0); intr[0, 0] = sp.intr0[0, 0]; intr[0, 1] = intr[0, 0]
+        intr, p1, _, rep = op.solve(intr, p1)
+    got = model.params()
+    assert (np.abs(got - intr[0, :6]) / np.maximum(np.abs(intr[0, :6]), 1e-3)).max() < 1e-6
+    if one_focal:
+        assert got[0] == got[1]
+    if fixed_focal:
+        assert got[0] == sp.intr0[0, 0]
+    if disabled:
+        assert got[5] == 0.0
+    np.testing.assert_allclose(np.stack([poses[i].as6() for i in sorted(poses)]), p1, atol=1e-7)
+
+
+def test_calib_all_camera_with_extrinsics(gpu_ctx, oracle):
+    """util::calib_all_camera_with_extrinsics, 2 cameras; camera 1 misses some frames, camera 0 others."""
+    sp = synth.make_problem(16, "eucm", n_cams=2)
+    f0 = api.frames_from_synth(sp, 0); f1 = api.frames_from_synth(sp, 1)
+    cams = [api.GenericModel("eucm", sp.intr0[c, :6], 512, 512) for c in range(2)]
+    t_i_0 = [api.RvecTvec.from6(np.zeros(6)), api.RvecTvec.from6(sp.extr0[1])]
+    rt0 = {i: api.RvecTvec.from6(sp.poses0[i]) for i in range(16) if i not in (3, 4)}
+    rt1 = {i: t_i_0[1].compose(api.RvecTvec.from6(sp.poses0[i])) for i in range(16) if i not in (9,)}
+    res = api.calib_all_camera_with_extrinsics(cams, t_i_0, [rt0, rt1], [f0, f1], False, 0, False, ctx=gpu_ctx)
+    assert res is not None
+    models, t_out, board = res
+    assert sorted(board.keys()) == list(range(16))
+    assert t_out[0].as6().tolist() == [0.0] * 6
+    # ground truth is recovered within noise: baseline 101 mm to < 0.5 mm, focal to 0.5 %
+    assert np.abs(np.array(t_out[1].tvec) - sp.extr_gt[1, 3:]).max() < 5e-4
+    for c in range(2):
+        assert abs(models[c].params()[0] / sp.intr_gt[c, 0] - 1) < 5e-3
+    # reprojection statistics (validation) per camera with the saved-pose convention T_i_0 * T_0_b
+    for c, fr in ((0, f0), (1, f1)):
+        saved = {k: t_out[c].compose(v) for k, v in board.items() if fr[k] is not None and k in (rt0, rt1)[c]}
+        a, m = api.validation(c, models[c], saved, fr, ctx=gpu_ctx)
+        assert 0.05 < m < 0.25 and 0.05 < a < 0.25
+
+
+def test_validation_matches_oracle(gpu_ctx, oracle):
+    sp = synth.make_problem(10, "kb4")
+    frames = api.frames_from_synth(sp)
+    model = api.GenericModel("kb4", sp.intr_gt[0, :8], 512, 512)
+    poses = {i: api.RvecTvec.from6(sp.poses_gt[i]) for i in range(10)}
+    a, m = api.validation(0, model, poses, frames, ctx=gpu_ctx)
+    ao, mo = oracle.OracleProblem.from_synth(sp).validation(0, sp.intr_gt, sp.poses_gt)
+    assert abs(a - ao) < 1e-11 and abs(m - mo) < 1e-11
