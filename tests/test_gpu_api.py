@@ -41,14 +41,16 @@ def test_factor_jacobian_matches_dual_numbers(gpu_ctx, oracle):
         np.testing.assert_allclose(r, ro, atol=1e-10); np.testing.assert_allclose(J, Jo, rtol=1e-11, atol=1e-11)
 
 
-@pytest.mark.parametrize("one_focal,disabled,fixed_focal", [(False, 0, False), (True, 0, False), (True, 1, True)])
-def test_calib_camera(gpu_ctx, oracle, one_focal, disabled, fixed_focal):
+@pytest.mark.parametrize("model,one_focal,disabled,fixed_focal",
+                         [("eucm", False, 0, False), ("eucm", True, 0, False), ("opencv5", True, 1, True)])
+def test_calib_camera(gpu_ctx, oracle, model, one_focal, disabled, fixed_focal):
     """util::calib_camera on synthetic frames vs the oracle driven through the same steps
     (bounds, disabled distortion, GN, optional fixed-focal second solve)."""
-    sp = synth.make_problem(24, "eucm", xy_same_focal=one_focal)
+    sp = synth.make_problem(24, model, xy_same_focal=one_focal)
+    P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
     frames = api.frames_from_synth(sp)
     frames[5] = None                                             # a frame without detections
-    cam0 = api.GenericModel("eucm", sp.intr0[0, :6], 512, 512)
+    cam0 = api.GenericModel(model, sp.intr0[0, :P], 512, 512)
     init = {i: api.RvecTvec.from6(sp.poses0[i]) for i in range(sp.n_slots) if i != 5}
     res = api.calib_camera(frames, cam0, one_focal, disabled, fixed_focal, init, ctx=gpu_ctx)
     assert res is not None
@@ -69,13 +71,13 @@ def test_calib_camera(gpu_ctx, oracle, one_focal, disabled, fixed_focal):
         op.fix_param(0, 0); intr[0, 0] = sp.intr0[0, 0]; intr[0, 1] = intr[0, 0]
         intr, p1, _, rep = op.solve(intr, p1)
     got = model.params()
-    assert (np.abs(got - intr[0, :6]) / np.maximum(np.abs(intr[0, :6]), 1e-3)).max() < 1e-6
+    assert (np.abs(got - intr[0, :P]) / np.maximum(np.abs(intr[0, :P]), 1e-3)).max() < 1e-6
     if one_focal:
         assert got[0] == got[1]
     if fixed_focal:
         assert got[0] == sp.intr0[0, 0]
     if disabled:
-        assert got[5] == 0.0
+        assert got[P - 1] == 0.0
     np.testing.assert_allclose(np.stack([poses[i].as6() for i in sorted(poses)]), p1, atol=1e-7)
 
 
