@@ -50,7 +50,7 @@ class Report(C.Structure):
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libccal_hip.so")
+LIB_PATH = os.environ.get("CCAL_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libccal_hip.so")
 
 # every symbol include/ccal.h declares: (name, restype, argtypes)
 _vp = C.c_void_p

@@ -10,6 +10,8 @@
 #include "ccal_device.hpp"
 #include "ccal_internal.hpp"
 
+#include <algorithm>
+
 namespace ccal {
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -20,10 +22,26 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+#ifndef CCAL_EVAL_WPB
+#define CCAL_EVAL_WPB 2          // wavefronts (= observation frames in flight) per workgroup of k_eval
+#endif
+#ifndef CCAL_EVAL_NT
+#define CCAL_EVAL_NT 1           // non-temporal stores for the streamed J tile
+#endif
+#ifndef CCAL_EVAL_NTLOAD
+#define CCAL_EVAL_NTLOAD 0
+#endif
+#ifndef CCAL_EVAL_NTR
+#define CCAL_EVAL_NTR 0
+#endif
+#ifndef CCAL_EVAL_PERSIST
+#define CCAL_EVAL_PERSIST 0      // >0: that many workgroups per CU, each wave strides over frames
+#endif
+
 template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : 40; }   // 39 used, keep 16-B alignment
 
 template <int MODEL, bool OF, bool OTHER>
-__global__ __launch_bounds__(256) void k_eval(const KArgs a) {
+__global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int TW = 2 * D;            // doubles per block Jacobian
     constexpr int TS = TW + 2;           // padded LDS row stride (keeps 16-B alignment, spreads banks)
@@ -31,11 +49,10 @@ __global__ __launch_bounds__(256) void k_eval(const KArgs a) {
     constexpr int WS = FCN + 64 * TS;    // doubles of LDS per wave
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int widx = blockIdx.x * WAVES_PER_BLOCK + wave;
-    if (widx >= a.n_list) return;        // whole wave exits; no workgroup barrier below
     double* fc = smem + wave * WS;
     double* tile = fc + FCN;
-
+    const int wstride = CCAL_EVAL_PERSIST > 0 ? (int)gridDim.x * CCAL_EVAL_WPB : a.n_list;
+    for (int widx = blockIdx.x * CCAL_EVAL_WPB + wave; widx < a.n_list; widx += wstride) {   // no workgroup barrier inside
     const int o = __builtin_amdgcn_readfirstlane(a.list[widx]);
     const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[o]);
     const int64_t start = a.obs_off[o];
@@ -68,7 +85,13 @@ __global__ __launch_bounds__(256) void k_eval(const KArgs a) {
         const int c = base + lane;
         const bool valid = c < n;
         const int64_t g = start + (valid ? c : 0);
+#if CCAL_EVAL_NTLOAD
+        const double X = __builtin_nontemporal_load(a.x + g), Y = __builtin_nontemporal_load(a.y + g),
+                     Z = __builtin_nontemporal_load(a.z + g), uo = __builtin_nontemporal_load(a.u + g),
+                     vo = __builtin_nontemporal_load(a.v + g);
+#else
         const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
+#endif
         double ru, rv, J[TW];
         double* Ju = J;
         double* Jv = J + D;
@@ -79,7 +102,11 @@ __global__ __launch_bounds__(256) void k_eval(const KArgs a) {
 #pragma unroll
             for (int i = 0; i < D; ++i) { Ju[i] *= sw; Jv[i] *= sw; }
         }
+#if CCAL_EVAL_NTR
+        if (valid) { __builtin_nontemporal_store(ru, a.r_out + 2 * g); __builtin_nontemporal_store(rv, a.r_out + 2 * g + 1); }
+#else
         if (valid) *reinterpret_cast<double2*>(a.r_out + 2 * g) = make_double2(ru, rv);
+#endif
         // block Jacobian [Ju | Jv] -> LDS row of this lane
         double* row = tile + lane * TS;
 #pragma unroll
@@ -93,10 +120,15 @@ __global__ __launch_bounds__(256) void k_eval(const KArgs a) {
             const int cr = e / TW;
             const int k = e - cr * TW;
             const double2 val = *reinterpret_cast<const double2*>(tile + cr * TS + k);
+#if CCAL_EVAL_NT
             __builtin_nontemporal_store(val.x, dst + e);
             __builtin_nontemporal_store(val.y, dst + e + 1);
+#else
+            *reinterpret_cast<double2*>(dst + e) = val;
+#endif
         }
         wave_lds_sync();
+    }
     }
 }
 
@@ -148,9 +180,10 @@ template <int MODEL, bool OF, bool OTHER>
 static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int WS = fc_doubles<OTHER>() + 64 * (2 * D + 2);
-    const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
-    const int blocks = (a.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    const size_t lds = sizeof(double) * WS * CCAL_EVAL_WPB;
+    int blocks = (a.n_list + CCAL_EVAL_WPB - 1) / CCAL_EVAL_WPB;
     if (blocks == 0) return hipSuccess;
+    if (CCAL_EVAL_PERSIST > 0) blocks = std::min(blocks, 256 * CCAL_EVAL_PERSIST);
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER>),
@@ -158,7 +191,7 @@ static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER>), dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
     return hipGetLastError();
 }
 template <int MODEL, bool OF, bool OTHER>

@@ -1,0 +1,548 @@
+// Single-camera fast path of the optimizer: the whole Gauss-Newton / LM iteration is device-resident,
+// the host only enqueues kernels and watches a status word in pinned memory.
+//
+//   k_prep1      one thread per frame: candidate pose = pose + back-substitution of the previous solve,
+//                exp-map + dR/drvec (frame constants) -> fcbuf; the Gram kernel no longer repeats this
+//                in all 64 lanes
+//   k_gram1      one wavefront per frame: weighted rows sqrt(w) [J | r] -> LDS (32 corners at a time)
+//                -> v_mfma_f64_16x16x4_f64 Gram -> compact record per frame:
+//                C = H_pp (21) | [B | g_p] (6 x (K+1)) | A = [J_c | r]^T W [J_c | r] ((K+1)^2)
+//   k_schur1     persistent wavefronts over frame slots: 6x6 Cholesky (+ LM damping), Y = L^-1 [B|g],
+//                per-slot record for the next back-substitution, A_dir and Y^T Y accumulated in registers,
+//                one flush per wave (deterministic, no atomics).  An LM rejection re-runs only this kernel.
+//   k_reduce1    fixed-order sum over waves -> red (the all-reduce buffer of sharded solves)
+//   k_cost1      (LM) sum of per-frame costs and model decreases
+//   k_head       one wavefront: accept / reject / convergence tests (tiny-solver's rules or the Ceres-style
+//                trust region), K x K solve, candidate intrinsics, status to pinned host memory
+// Same arithmetic and decision sequence as the general loop in ccal_solver.hip (multi-camera problems,
+// sharded LM); parity tests cover both.
+#include <algorithm>
+
+#include "ccal_device.hpp"
+#include "ccal_fused.hpp"
+
+namespace ccal {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double clampd1(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
+
+// ---------------------------------------------------------------------------------------------
+// k_prep1
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep1(const FusedArgs a) {
+    const DevState* st = a.st;
+    if (st->done) return;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= a.n_obs) return;
+    const int K = a.K, K1 = K + 1;
+    const int cur = st->cur, first = st->first;
+    const int es = first ? cur : (cur ^ 1);
+    const int slot = a.obs_slot[f];
+    double pose[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+    double mc = 0.0;
+    if (!first) {
+        const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+        double L[21];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) L[i] = pf[i];
+        if (L[0] != 0.0) {
+            double dp[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double* yr = pf + 21 + i * K1;
+                double t = yr[K];
+                for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                dp[i] = -t;
+            }
+#pragma unroll
+            for (int i = 5; i >= 0; --i) {          // L^T x = rhs, diagonal stored inverted
+                double t = dp[i];
+#pragma unroll
+                for (int k = i + 1; k < 6; ++k) t -= L[k * (k + 1) / 2 + i] * dp[k];
+                dp[i] = t * L[i * (i + 1) / 2 + i];
+            }
+            const double lam = st->lambda_solve;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
+                const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
+                mc += dp[i] * (Dii * dp[i] - gp);
+                pose[i] += dp[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+    }
+    a.mc_f[f] = mc;
+    double fcr[39];
+    frame_setup<false>(pose, nullptr, fcr);
+    double* dst = a.fcbuf + (int64_t)f * 40;
+#pragma unroll
+    for (int i = 0; i < 39; ++i) dst[i] = fcr[i];
+}
+hipError_t launch_prep1(const FusedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_prep1, dim3((a.n_obs + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gram1
+// ---------------------------------------------------------------------------------------------
+template <int MODEL, bool OF>
+__global__ __launch_bounds__(256) void k_gram1(const FusedArgs a) {
+    constexpr int D = block_dim(MODEL, OF, false);
+    constexpr int K = D - 6, K1 = K + 1;
+    constexpr int RS = 16, CS = 2 * RS + 2;
+    constexpr int WS = 40 + GRAM_TILE_CORNERS * CS;
+    extern __shared__ double smem[];
+    const DevState* st = a.st;
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x * WAVES_PER_BLOCK + wave;
+    if (f >= a.n_obs) return;
+    double* fc = smem + wave * WS;
+    double* tile = fc + 40;
+    const int cur = st->cur, first = st->first;
+    const int es = first ? cur : (cur ^ 1);
+    const double* th_g = a.intr[es];
+    double th[model_np(MODEL)];
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (OF) th[1] = th[0];
+    if (lane < 39) fc[lane] = a.fcbuf[(int64_t)f * 40 + lane];
+    const int64_t start = a.obs_off[f];
+    const int n = (int)(a.obs_off[f + 1] - start);
+    wsync();
+
+    d4 acc0 = { 0, 0, 0, 0 }, acc1 = { 0, 0, 0, 0 };
+    const int rd_off = (lane >> 5) * CS + ((lane >> 4) & 1) * RS + (lane & 15);
+    for (int base = 0; base < n; base += 64) {
+        const int c = base + lane;
+        const bool valid = c < n;
+        const int64_t g = start + (valid ? c : 0);
+        const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
+        double ru, rv, J[2 * D];
+        corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        const double sw = valid ? sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta)) : 0.0;
+        const int nv = min(64, n - base);
+#pragma unroll
+        for (int half = 0; half < 64 / GRAM_TILE_CORNERS; ++half) {
+            if (half * GRAM_TILE_CORNERS >= nv) break;                    // wave-uniform
+            if ((lane / GRAM_TILE_CORNERS) == half) {
+                double* row = tile + (lane % GRAM_TILE_CORNERS) * CS;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < RS; i += 2) {
+                        const double v0 = i < D ? sw * J[h * D + (i < D ? i : 0)] : (i == D ? sw * (h ? rv : ru) : 0.0);
+                        const double v1 = (i + 1) < D ? sw * J[h * D + ((i + 1) < D ? (i + 1) : 0)] : ((i + 1) == D ? sw * (h ? rv : ru) : 0.0);
+                        *reinterpret_cast<double2*>(row + h * RS + i) = make_double2(v0, v1);
+                    }
+                }
+            }
+            wsync();
+            const int npairs = (min(GRAM_TILE_CORNERS, nv - half * GRAM_TILE_CORNERS) + 1) >> 1;
+            const double* rd = tile + rd_off;
+            int m = 0;
+            for (; m + 1 < npairs; m += 2) {
+                const double p = rd[(2 * m) * CS];
+                const double q = rd[(2 * m + 2) * CS];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc1, 0, 0, 0);
+            }
+            if (m < npairs) {
+                const double p = rd[(2 * m) * CS];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc0, 0, 0, 0);
+            }
+            wsync();
+        }
+    }
+    // Gram -> LDS (aliases the tile), then the compact record.  Columns: camera 0..K-1, pose K..K+5, r = D.
+    double* G = tile;
+    {
+        const d4 acc = acc0 + acc1;
+        const int gi = lane >> 4, gj = lane & 15;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) G[(gi + 4 * v) * 16 + gj] = acc[v];
+    }
+    wsync();
+    double* rec = a.praw[es] + (int64_t)f * a.PRAW;
+    if (lane < 21) {
+        int i = 0, r = lane;
+        while (r > i) { r -= i + 1; ++i; }          // lane -> (i, r) of the packed lower triangle
+        rec[lane] = G[(K + i) * 16 + (K + r)];
+    }
+    for (int e = lane; e < 6 * K1; e += 64) {
+        const int i = e / K1, j = e - i * K1;
+        rec[21 + e] = G[(K + i) * 16 + (j < K ? j : D)];
+    }
+    for (int e = lane; e < K1 * K1; e += 64) {
+        const int i = e / K1, j = e - i * K1;
+        rec[21 + 6 * K1 + e] = G[(i < K ? i : D) * 16 + (j < K ? j : D)];
+    }
+    if (lane == 0) a.cost_f[f] = G[D * 16 + D];
+}
+
+template <int MODEL, bool OF>
+static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
+    constexpr int WS = 40 + GRAM_TILE_CORNERS * 34;
+    const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram1<MODEL, OF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_gram1<MODEL, OF>), dim3((a.n_obs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
+    switch (model * 2 + (one_focal ? 1 : 0)) {
+        case 0: return launch_gram1_t<kUCM, false>(a, s);
+        case 1: return launch_gram1_t<kUCM, true>(a, s);
+        case 2: return launch_gram1_t<kEUCM, false>(a, s);
+        case 3: return launch_gram1_t<kEUCM, true>(a, s);
+        case 4: return launch_gram1_t<kKB4, false>(a, s);
+        case 5: return launch_gram1_t<kKB4, true>(a, s);
+        case 6: return launch_gram1_t<kOCV5, false>(a, s);
+        case 7: return launch_gram1_t<kOCV5, true>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_schur1: persistent wavefronts over frames.  set_sel 0: the set evaluated by the last k_gram1
+// (GN: eliminate right away); 1: the accepted set st->cur (LM: after the decision).
+// ---------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel) {
+    constexpr int K1 = K + 1;
+    constexpr int NQ = (K1 * K1 + 63) / 64;
+    constexpr int WSL = ((36 + 12 * K1) + 1) & ~1;      // C[36] | [B|g][6][K1] | Y[6][K1]
+    __shared__ double smem[WAVES_PER_BLOCK * WSL];
+    const DevState* st = a.st;
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    double* Cm = smem + wave * WSL;
+    double* Bm = Cm + 36;
+    double* Ym = Bm + 6 * K1;
+    const int cur = st->cur, first = st->first;
+    const int set = set_sel ? cur : (first ? cur : (cur ^ 1));
+    const double lambda = st->lambda;
+    double accA[NQ], accY[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
+    // packed-lower index of this lane (lanes 0..20)
+    int li = 0, lr = lane;
+    while (lr > li && li < 6) { lr -= li + 1; ++li; }
+
+    for (int f = gw; f < a.n_obs; f += a.n_pw) {
+        const int slot = a.obs_slot[f];
+        const double* rec = a.praw[set] + (int64_t)f * a.PRAW;
+        if (lane < 21) { const double v = rec[lane]; Cm[li * 6 + lr] = v; Cm[lr * 6 + li] = v; }
+        for (int e = lane; e < 6 * K1; e += 64) Bm[e] = rec[21 + e];
+        double adir[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) { const int e = lane + 64 * q; adir[q] = e < K1 * K1 ? rec[21 + 6 * K1 + e] : 0.0; }
+        wsync();
+        // 6x6 Cholesky of C + lambda clamp(diag C): every lane runs the same factorisation (diag inverted)
+        double L[21], dC[6];
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dC[i] = Cm[i * 6 + i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = Cm[i * 6 + j];
+                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) {
+                    ok = ok && (t > 0.0) && (t < 1.7e308);
+                    L[i * (i + 1) / 2 + i] = ok ? 1.0 / sqrt(t) : 0.0;
+                } else {
+                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
+                }
+            }
+        }
+        double* pf = a.pf[set] + (int64_t)slot * a.PF;
+        if (!ok) {
+            if (lane == 0) a.st_flags[0] = 1;
+            for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
+            for (int e = lane; e < 6 * K1; e += 64) Ym[e] = 0.0;
+        } else {
+            if (lane < K1) {
+                double y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double t = Bm[i * K1 + lane];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
+                    y[i] = t * L[i * (i + 1) / 2 + i];
+                    Ym[i * K1 + lane] = y[i];
+                    pf[21 + i * K1 + lane] = y[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 21; ++i) if (lane == i) pf[i] = L[i];        // static register indices: no scratch
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (lane == 32 + i) { pf[21 + 6 * K1 + i] = Bm[i * K1 + K]; pf[21 + 6 * K1 + 6 + i] = dC[i]; }
+        }
+        wsync();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * q;
+            if (e < K1 * K1) {
+                const int i = e / K1, j = e - i * K1;
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+                accY[q] += t;
+                accA[q] += adir[q];
+            }
+        }
+        wsync();
+    }
+    if (gw < a.n_pw) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = lane + 64 * q;
+            if (e < K1 * K1) {
+                a.partial[(int64_t)e * a.n_pw + gw] = accA[q];
+                a.partial[(int64_t)(K1 * K1 + e) * a.n_pw + gw] = accY[q];
+            }
+        }
+    }
+}
+hipError_t launch_schur1(const FusedArgs& a, int set_sel, hipStream_t s) {
+    const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
+    switch (a.K) {
+        case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a, set_sel); break;
+        case 5: hipLaunchKernelGGL(k_schur1<5>, grid, blk, 0, s, a, set_sel); break;
+        case 6: hipLaunchKernelGGL(k_schur1<6>, grid, blk, 0, s, a, set_sel); break;
+        case 7: hipLaunchKernelGGL(k_schur1<7>, grid, blk, 0, s, a, set_sel); break;
+        case 8: hipLaunchKernelGGL(k_schur1<8>, grid, blk, 0, s, a, set_sel); break;
+        case 9: hipLaunchKernelGGL(k_schur1<9>, grid, blk, 0, s, a, set_sel); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_reduce1: red[first + b] = sum_w partial[first + b][w];  k_cost1: red[2 K1^2 .. +1] = sum cost_f, sum mc_f
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+    return t;
+}
+__global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_pw, int first, double* red, const DevState* st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double* src = partial + (int64_t)(first + blockIdx.x) * n_pw;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 768 < n_pw; i += 1024) { v0 += src[i]; v1 += src[i + 256]; v2 += src[i + 512]; v3 += src[i + 768]; }
+    for (; i < n_pw; i += 256) v0 += src[i];
+    const double t = block_sum((v0 + v1) + (v2 + v3), sh);
+    if (threadIdx.x == 0) red[first + blockIdx.x] = t;
+}
+hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce1, dim3(count), dim3(256), 0, s, a.partial, a.n_pw, first, a.red, a.st);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const double* mc_f, int n, double* out, const DevState* st) {
+    if (st->done) return;
+    __shared__ double sh[16];
+    const double* src = blockIdx.x == 0 ? cost_f : mc_f;
+    double v0 = 0.0, v1 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 1024 < n; i += 2048) { v0 += src[i]; v1 += src[i + 1024]; }
+    if (i < n) v0 += src[i];
+    const double t = block_sum(v0 + v1, sh);
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+hipError_t launch_cost1(const FusedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_cost1, dim3(2), dim3(1024), 0, s, a.cost_f, a.mc_f, a.n_obs, a.red + 2 * (a.K + 1) * (a.K + 1), a.st);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_head: one wavefront.  phase bit 0 = decide (accept / reject / stop), bit 1 = solve.
+// red = [A_dir (K1*K1) | Y^T Y (K1*K1) | cost | mc_pose]
+// The optimizer state is staged in LDS once (the global copy is touched twice per launch).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
+    HostStatus* hs = a.hs;
+    hs->done = s->done; hs->iter = s->iter; hs->cur = s->cur;
+    hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
+    hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
+    __threadfence_system();
+    hs->seq = a.seq;
+    __threadfence_system();
+}
+
+__global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
+    __shared__ DevState S0;
+    __shared__ double red[2 * 100 + 2];
+    __shared__ double S[10 * 11];
+    __shared__ double x[10];
+    __shared__ int bad;
+    const int K = a.K, K1 = K + 1, lane = threadIdx.x;
+    {   // stage state + reduced sums
+        const double* src = reinterpret_cast<const double*>(a.st);
+        double* dst = reinterpret_cast<double*>(&S0);
+        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+        for (int e = lane; e < 2 * K1 * K1 + 2; e += 64) red[e] = a.red[e];
+    }
+    __syncthreads();
+    DevState* st = &S0;
+    if (st->done) { if (lane == 0) publish_status(a, st); return; }
+    const double* Ad = red;
+    const double* Yt = red + K1 * K1;
+    const bool lm = st->method == CCAL_METHOD_LM;
+    if (a.phase & 1) {
+        if (lane == 0) {
+            const double cost_e = lm ? red[2 * K1 * K1] : Ad[K * K1 + K];
+            int done = 0;
+            if (st->first) {
+                st->cur_cost = cost_e; st->initial_cost = cost_e; st->first = 0;
+                if (!(cost_e == cost_e) || !(fabs(cost_e) < 1.7e308)) done = CCAL_ERR_NONFINITE + 1;
+                st->accepted_now = 1;
+            } else if (!lm) {
+                // Gauss-Newton: the candidate is the new point (tiny-solver applies dx unconditionally)
+                st->cur ^= 1;
+                const double last = st->cur_cost, cur = cost_e;
+                st->last_cost = last; st->cur_cost = cur; st->iter += 1;
+                st->accepted_now = 1;
+                if (cur < st->min_error) done = CCAL_OK + 1;
+                else if (!(cur == cur)) done = CCAL_ERR_NONFINITE + 1;
+                else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
+                else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
+                else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
+            } else {
+                const double mc = st->mc_cam + red[2 * K1 * K1 + 1];
+                const double rho = (st->cur_cost - cost_e) / mc;
+                st->iter += 1;
+                const bool lin_fail = a.flags[0] || a.flags[1];
+                if (!lin_fail && fabs(cost_e) < 1.7e308 && mc > 0.0 && rho > 0.0) {
+                    st->cur ^= 1;
+                    const double last = st->cur_cost, cur = cost_e;
+                    st->last_cost = last; st->cur_cost = cur; st->lm_accepted += 1;
+                    const double t = 2.0 * rho - 1.0;
+                    st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                    st->dec = 2.0;
+                    st->accepted_now = 1;
+                    if (cur < st->min_error) done = CCAL_OK + 1;
+                    else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
+                    else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
+                } else {
+                    st->lm_rejected += 1;
+                    st->radius /= st->dec; st->dec *= 2.0;
+                    st->accepted_now = 0;
+                    if (lin_fail) { a.flags[0] = 0; a.flags[1] = 0; }
+                    if (st->radius < 1e-32) done = CCAL_ERR_NO_CONVERGENCE + 1;
+                }
+                if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
+                st->lambda = 1.0 / st->radius;
+            }
+            st->done = done;
+        }
+        __syncthreads();
+    }
+    if ((a.phase & 2) && !st->done) {
+        const double lambda = st->lambda;
+        const int cur = st->cur;
+        if (lane == 0) bad = (!lm && a.flags[0]) ? 1 : 0;     // GN: a frame's pose block failed at this point -> None
+        for (int e = lane; e < K * K; e += 64) {
+            const int i = e / K, j = e - i * K;
+            double v = Ad[i * K1 + j] - Yt[i * K1 + j];
+            const bool fi = a.cols[i].fixed != 0, fj = a.cols[j].fixed != 0;
+            if (fi || fj) v = (i == j) ? 1.0 : 0.0;
+            else if (i == j && lambda > 0.0) v += lambda * clampd1(Ad[i * K1 + i], a.min_diag, a.max_diag);
+            S[i * 11 + j] = v;
+        }
+        if (lane < K) x[lane] = a.cols[lane].fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
+        __syncthreads();
+        if (lane == 0 && !bad) {                     // K <= 9: serial Cholesky + two triangular solves
+            for (int j = 0; j < K && !bad; ++j) {
+                double s = S[j * 11 + j];
+                for (int k = 0; k < j; ++k) s -= S[j * 11 + k] * S[j * 11 + k];
+                if (!(s > 0.0) || !(s < 1.7e308)) { bad = 1; break; }
+                const double l = sqrt(s);
+                S[j * 11 + j] = l;
+                for (int i = j + 1; i < K; ++i) {
+                    double t = S[i * 11 + j];
+                    for (int k = 0; k < j; ++k) t -= S[i * 11 + k] * S[j * 11 + k];
+                    S[i * 11 + j] = t / l;
+                }
+            }
+            if (!bad) {
+                for (int i = 0; i < K; ++i) { double t = x[i]; for (int k = 0; k < i; ++k) t -= S[i * 11 + k] * x[k]; x[i] = t / S[i * 11 + i]; }
+                for (int i = K - 1; i >= 0; --i) { double t = x[i]; for (int k = i + 1; k < K; ++k) t -= S[k * 11 + i] * x[k]; x[i] = t / S[i * 11 + i]; }
+            }
+        }
+        __syncthreads();
+        if (bad) {
+            if (lane == 0) {
+                if (!lm) st->done = CCAL_ERR_NOT_PD + 1;
+                else a.flags[1] = 1;                 // LM: the next decision rejects and shrinks the radius
+                st->mc_cam = 0.0; st->lambda_solve = lambda;
+            }
+            if (lane < K) a.dc[lane] = 0.0;
+        }
+        if (!bad || lm) {
+            // candidate intrinsics = clamp(x + dc) into the other set; model decrease of the camera block
+            const double* src = a.intr[cur];
+            double* dst = a.intr[cur ^ 1];
+            double keep = lane < CCAL_PMAX ? src[lane] : 0.0;
+            if (lane < CCAL_PMAX) dst[lane] = keep;
+            __syncthreads();
+            double mc = 0.0;
+            if (lane < K && !bad) {
+                const ColInfo ci = a.cols[lane];
+                const double d = x[lane];
+                a.dc[lane] = d;
+                const double Dii = lambda > 0.0 ? lambda * clampd1(Ad[lane * K1 + lane], a.min_diag, a.max_diag) : 0.0;
+                if (!ci.fixed) {
+                    mc = d * (Dii * d - Ad[lane * K1 + K]);
+                    double v = src[ci.dst] + d;
+                    if (ci.has_bound) v = fmin(fmax(v, ci.lo), ci.hi);
+                    dst[ci.dst] = v;
+                    if (ci.dst2 >= 0) dst[ci.dst2] = v;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
+            if (lane == 0 && !bad) { st->mc_cam = mc; st->lambda_solve = lambda; }
+        }
+    }
+    __syncthreads();
+    {   // write the state back, then publish
+        const double* src = reinterpret_cast<const double*>(&S0);
+        double* dst = reinterpret_cast<double*>(a.st);
+        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+    }
+    __syncthreads();
+    if (lane == 0) publish_status(a, st);
+}
+hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ccal

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     constexpr int CS = 2 * RS + 2;            // doubles per corner (two rows + pad)
     constexpr int NCP = 16 * T;
     constexpr int FCN = OTHER ? FC_SIZE : 40;
-    constexpr int WS = FCN + 64 * CS;
+    constexpr int WS = FCN + GRAM_TILE_CORNERS * CS;   // rows are staged 32 corners at a time (LDS -> occupancy)
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int widx = blockIdx.x * WAVES_PER_BLOCK + wave;
@@ -87,41 +87,48 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
         corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
         // Huber corrector: both rows scaled by sqrt(rho'); invalid lanes contribute zero rows
         const double sw = valid ? sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta)) : 0.0;
-        double* row = tile + lane * CS;
+        const int nv = min(64, n - base);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int half = 0; half < 64 / GRAM_TILE_CORNERS; ++half) {
+            if (half * GRAM_TILE_CORNERS >= nv) break;                    // wave-uniform
+            if ((lane / GRAM_TILE_CORNERS) == half) {
+                double* row = tile + (lane % GRAM_TILE_CORNERS) * CS;
 #pragma unroll
-            for (int i = 0; i < RS; i += 2) {
-                const double v0 = i < D ? sw * J[h * D + (i < D ? i : 0)] : (i == D ? sw * (h ? rv : ru) : 0.0);
-                const double v1 = (i + 1) < D ? sw * J[h * D + ((i + 1) < D ? (i + 1) : 0)] : ((i + 1) == D ? sw * (h ? rv : ru) : 0.0);
-                *reinterpret_cast<double2*>(row + h * RS + i) = make_double2(v0, v1);
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int i = 0; i < RS; i += 2) {
+                        const double v0 = i < D ? sw * J[h * D + (i < D ? i : 0)] : (i == D ? sw * (h ? rv : ru) : 0.0);
+                        const double v1 = (i + 1) < D ? sw * J[h * D + ((i + 1) < D ? (i + 1) : 0)] : ((i + 1) == D ? sw * (h ? rv : ru) : 0.0);
+                        *reinterpret_cast<double2*>(row + h * RS + i) = make_double2(v0, v1);
+                    }
+                }
             }
+            wave_sync_lds();
+            const int npairs = (min(GRAM_TILE_CORNERS, nv - half * GRAM_TILE_CORNERS) + 1) >> 1;
+            const double* rd = tile + rd_off;
+            if constexpr (T == 1) {
+                int m = 0;
+                for (; m + 1 < npairs; m += 2) {
+                    const double p = rd[(2 * m) * CS];
+                    const double q = rd[(2 * m + 2) * CS];
+                    acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
+                    acc00b = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc00b, 0, 0, 0);
+                }
+                if (m < npairs) {
+                    const double p = rd[(2 * m) * CS];
+                    acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
+                }
+            } else {
+                for (int m = 0; m < npairs; ++m) {
+                    const double p = rd[(2 * m) * CS];
+                    const double q = hi_valid ? rd[(2 * m) * CS + 16] : 0.0;
+                    acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
+                    acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, q, acc01, 0, 0, 0);
+                    acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc11, 0, 0, 0);
+                }
+            }
+            wave_sync_lds();
         }
-        wave_sync_lds();
-        const int npairs = (min(64, n - base) + 1) >> 1;
-        const double* rd = tile + rd_off;
-        if constexpr (T == 1) {
-            int m = 0;
-            for (; m + 1 < npairs; m += 2) {
-                const double p = rd[(2 * m) * CS];
-                const double q = rd[(2 * m + 2) * CS];
-                acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
-                acc00b = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc00b, 0, 0, 0);
-            }
-            if (m < npairs) {
-                const double p = rd[(2 * m) * CS];
-                acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
-            }
-        } else {
-            for (int m = 0; m < npairs; ++m) {
-                const double p = rd[(2 * m) * CS];
-                const double q = hi_valid ? rd[(2 * m) * CS + 16] : 0.0;
-                acc00a = __builtin_amdgcn_mfma_f64_16x16x4f64(p, p, acc00a, 0, 0, 0);
-                acc01 = __builtin_amdgcn_mfma_f64_16x16x4f64(p, q, acc01, 0, 0, 0);
-                acc11 = __builtin_amdgcn_mfma_f64_16x16x4f64(q, q, acc11, 0, 0, 0);
-            }
-        }
-        wave_sync_lds();
     }
 
     // C/D layout of v_mfma_f64_16x16x4_f64: lane l, register v holds D[(l >> 4) + 4 v][l & 15]
@@ -149,7 +156,7 @@ static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int T = (D + 1) <= 16 ? 1 : 2;
     constexpr int RS = T == 1 ? 16 : 24;
-    constexpr int WS = (OTHER ? FC_SIZE : 40) + 64 * (2 * RS + 2);
+    constexpr int WS = (OTHER ? FC_SIZE : 40) + GRAM_TILE_CORNERS * (2 * RS + 2);
     const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
     const int blocks = (ga.k.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks == 0) return hipSuccess;

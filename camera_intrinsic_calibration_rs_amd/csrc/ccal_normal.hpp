@@ -10,7 +10,14 @@
 #pragma once
 #include "ccal_internal.hpp"
 
+#ifndef CCAL_GRAM_TILE
+#define CCAL_GRAM_TILE 32
+#endif
+
 namespace ccal {
+
+// corners whose weighted rows are staged in LDS at a time by the Gram kernels (32 or 64)
+constexpr int GRAM_TILE_CORNERS = CCAL_GRAM_TILE;
 
 // layout of the reduced buffer red[RB]:  A[(K+1)*(K+1)] | hdiag[K] | gc[K] | cost
 //   A = [[S, b],[b^T, *]] undamped in the camera block (pose damping already inside the Schur terms)
@@ -45,6 +52,20 @@ struct NormalWs {
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
     int64_t g_len = 0;
+    struct FusedWs* fws = nullptr;             // single-camera fused path (ccal_fused.hpp)
+};
+
+struct FusedWs {
+    int PRAW = 0, RB1 = 0, n_pw = 0;
+    double* pf[2] = { nullptr, nullptr };
+    double* praw[2] = { nullptr, nullptr };
+    double* partial = nullptr;
+    double* red = nullptr;
+    double* fcbuf = nullptr;                   // [n_obs][40] frame constants of the evaluated point
+    double* mc_f = nullptr;                    // [n_obs] model decrease of each pose block
+    double* cost_f = nullptr;                  // [n_obs] cost of each frame
+    struct DevState* d_state = nullptr;
+    struct HostStatus* h_status = nullptr;     // pinned, host-coherent
 };
 
 void normal_ws_destroy(ccal_problem* p);

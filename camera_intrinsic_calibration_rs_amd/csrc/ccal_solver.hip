@@ -11,9 +11,20 @@
 #include <cstdio>
 #include <cstring>
 
-#include "ccal_normal.hpp"
+#include <cstdlib>
+
+#include "ccal_fused.hpp"
 
 using namespace ccal;
+
+#define HIP_TRYN(ctx, expr)                                                                        \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+            return -CCAL_ERR_HIP;                                                                  \
+        }                                                                                          \
+    } while (0)
 
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \
@@ -33,8 +44,46 @@ void normal_ws_destroy(ccal_problem* p) {
                      w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
+    if (FusedWs* f = w->fws) {
+        void* fp[] = { f->pf[0], f->pf[1], f->praw[0], f->praw[1], f->partial, f->red, f->d_state, f->fcbuf, f->mc_f, f->cost_f };
+        for (void* q : fp) if (q) (void)hipFree(q);
+        if (f->h_status) (void)hipHostFree(f->h_status);
+        delete f;
+    }
     delete w;
     p->nws = nullptr;
+}
+
+static int fused_ws_ensure(ccal_problem* p) {
+    NormalWs* w = p->nws;
+    if (w->fws) return CCAL_OK;
+    ccal_ctx* ctx = p->ctx;
+    FusedWs* f = new FusedWs();
+    w->fws = f;
+    const int K1 = p->K + 1;
+    f->PRAW = (21 + 6 * K1 + K1 * K1 + 1) & ~1;
+    f->RB1 = 2 * K1 * K1 + 2;
+    const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
+    int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 4096);   // 4 workgroups of 4 waves per CU
+    f->n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+    const size_t ns = (size_t)std::max(p->n_slots, 1), no = (size_t)std::max(p->n_obs, 1);
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(ctx, hipMalloc((void**)&f->pf[i], ns * w->PF * sizeof(double)));
+        HIP_TRY(ctx, hipMemset(f->pf[i], 0, ns * w->PF * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc((void**)&f->praw[i], no * f->PRAW * sizeof(double)));
+        HIP_TRY(ctx, hipMemset(f->praw[i], 0, no * f->PRAW * sizeof(double)));
+    }
+    HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, no * 40 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&f->mc_f, no * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&f->cost_f, no * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&f->partial, (size_t)f->RB1 * f->n_pw * sizeof(double)));
+    HIP_TRY(ctx, hipMemset(f->partial, 0, (size_t)f->RB1 * f->n_pw * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&f->red, (size_t)(f->RB1 + 7) * sizeof(double)));
+    HIP_TRY(ctx, hipMemset(f->red, 0, (size_t)(f->RB1 + 7) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&f->d_state, sizeof(DevState)));
+    HIP_TRY(ctx, hipHostMalloc((void**)&f->h_status, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
+    std::memset((void*)f->h_status, 0, sizeof(HostStatus));
+    return CCAL_OK;
 }
 
 template <class T>
@@ -143,6 +192,130 @@ static int enqueue_reduce_system(ccal_problem* p, int gbuf, double lambda, doubl
     return CCAL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Single-camera fused path: the host only enqueues (k_normal1, k_reduce1, k_head) groups, two
+// iterations ahead, and watches a status word in pinned memory; accept/reject, damping, convergence
+// tests and the camera solve run on the device (ccal_kernels_fused.hip).  Same decisions and the same
+// arithmetic as the general loop in ccal_solve below.
+// ---------------------------------------------------------------------------------------------
+static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, ccal_report* rep) {
+    ccal_ctx* ctx = p->ctx;
+    NormalWs* w = p->nws;
+    int rc = fused_ws_ensure(p);
+    if (rc != CCAL_OK) return rc;
+    FusedWs* f = w->fws;
+    hipStream_t st = ctx->stream;
+    const bool lm = o->method == CCAL_METHOD_LM;
+    const int K = p->K, K1 = K + 1;
+    const auto t0 = std::chrono::steady_clock::now();
+
+    DevState hs0;
+    std::memset(&hs0, 0, sizeof hs0);
+    hs0.radius = o->lm_initial_radius; hs0.dec = 2.0;
+    hs0.lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
+    hs0.min_error = o->min_error; hs0.min_abs = o->min_abs_error_decrease; hs0.min_rel = o->min_rel_error_decrease;
+    hs0.cur = 0; hs0.first = 1; hs0.done = 0; hs0.iter = 0; hs0.max_iter = o->max_iterations; hs0.method = o->method;
+    HIP_TRY(ctx, hipMemcpyAsync(f->d_state, &hs0, sizeof hs0, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
+    // both parameter sets start from the caller's values (slots without observations never change)
+    HIP_TRY(ctx, hipMemcpyAsync(p->d_poses_c, p->d_poses, sizeof(double) * std::max(p->n_slots, 1) * 6, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(p->d_intr_c, p->d_intr, sizeof(double) * CCAL_PMAX, hipMemcpyDeviceToDevice, st));
+    HostStatus* hst = f->h_status;
+    hst->seq = 0; hst->done = 0;
+
+    FusedArgs fa = {};
+    fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
+    fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
+    fa.n_obs = p->n_obs; fa.K = K; fa.PF = w->PF; fa.PRAW = f->PRAW; fa.n_pw = f->n_pw;
+    fa.fcbuf = f->fcbuf; fa.mc_f = f->mc_f; fa.cost_f = f->cost_f;
+    fa.huber_delta = p->huber_delta; fa.min_diag = o->lm_min_diagonal; fa.max_diag = o->lm_max_diagonal;
+    fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
+    fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
+    fa.dc = w->dc; fa.st = f->d_state; fa.st_flags = w->flags; fa.partial = f->partial; fa.red = f->red;
+    HeadArgs ha = {};
+    ha.st = f->d_state; ha.hs = hst; ha.red = f->red; ha.cols = w->cols; ha.flags = w->flags;
+    ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
+    ha.min_diag = o->lm_min_diagonal; ha.max_diag = o->lm_max_diagonal;
+    const int model = p->cams[0].model;
+    int seq = 0;
+    auto enqueue = [&]() -> int {         // one evaluation + decision + solve; returns the seq that marks its end
+        HIP_TRYN(ctx, launch_prep1(fa, st));
+        HIP_TRYN(ctx, launch_gram1(model, p->one_focal, fa, st));
+        if (!lm) {
+            HIP_TRYN(ctx, launch_schur1(fa, 0, st));
+            HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
+            if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)f->RB1, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
+            ha.phase = 3; ha.seq = ++seq;
+            HIP_TRYN(ctx, launch_head(ha, st));
+        } else {
+            HIP_TRYN(ctx, launch_cost1(fa, st));
+            ha.phase = 1; ha.seq = ++seq;
+            HIP_TRYN(ctx, launch_head(ha, st));
+            HIP_TRYN(ctx, launch_schur1(fa, 1, st));
+            HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
+            ha.phase = 2; ha.seq = ++seq;
+            HIP_TRYN(ctx, launch_head(ha, st));
+        }
+        return seq;
+    };
+    auto wait_seq = [&](int target) -> int {
+        const auto tw = std::chrono::steady_clock::now();
+        long spins = 0;
+        while (hst->seq < target) {
+            if ((++spins & 0xFFF) == 0) {
+                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+                if (el > 0.002 && hipStreamQuery(st) == hipSuccess && hst->seq < target) {
+                    // stream drained but the word did not arrive: fall back to an explicit copy
+                    DevState ds;
+                    HIP_TRY(ctx, hipMemcpy(&ds, f->d_state, sizeof ds, hipMemcpyDeviceToHost));
+                    hst->done = ds.done; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
+                    hst->lm_rejected = ds.lm_rejected; hst->cur_cost = ds.cur_cost; hst->initial_cost = ds.initial_cost;
+                    hst->seq = target;
+                    break;
+                }
+                if (el > 30.0) { ctx->err = "fused solve timed out"; return CCAL_ERR_HIP; }
+            }
+        }
+        return CCAL_OK;
+    };
+
+    // keep two groups in flight: the GPU never waits for the host, the host wastes at most two
+    // early-exit groups after convergence
+    std::vector<int> pending;
+    int enq = 0;
+    const int max_groups = o->max_iterations + 1;
+    int status = CCAL_OK;
+    bool finished = false;
+    while (!finished) {
+        while ((int)pending.size() < 2 && enq < max_groups) {
+            const int s = enqueue();
+            if (s < 0) return -s;
+            pending.push_back(s); ++enq;
+        }
+        if (pending.empty()) break;
+        rc = wait_seq(pending.front());
+        if (rc != CCAL_OK) return rc;
+        pending.erase(pending.begin());
+        if (hst->done) { status = hst->done - 1; finished = true; }
+        else if (o->verbose) std::printf("[ccal fused %s] iter %d cost %.12g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    DevState ds;
+    HIP_TRY(ctx, hipMemcpy(&ds, f->d_state, sizeof ds, hipMemcpyDeviceToHost));
+    if (!ds.done) { status = CCAL_ERR_NO_CONVERGENCE; }
+    else status = ds.done - 1;
+    if (ds.cur == 1) { std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); }
+    ccal_report R = {};
+    R.status = status; R.iterations = ds.iter; R.lm_accepted = ds.lm_accepted; R.lm_rejected = ds.lm_rejected;
+    R.initial_cost = ds.initial_cost; R.final_cost = ds.cur_cost;
+    rc = ccal_download_params(p, intr_io, poses_io, nullptr);
+    R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep) *rep = R;
+    if (status == CCAL_ERR_NOT_PD) ctx->err = "normal equations are not positive definite";
+    if (rc != CCAL_OK) return rc;
+    return status;
+}
+
 extern "C" {
 
 int ccal_build_normal_dev(ccal_problem* p, double lambda) {
@@ -192,6 +365,9 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
     NormalWs* w = p->nws;
     hipStream_t st = ctx->stream;
     const bool lm = o->method == CCAL_METHOD_LM;
+    // single camera: device-resident loop (sharded LM needs a second all-reduce per iteration -> general loop)
+    if (p->n_cams == 1 && p->n_obs > 0 && !(p->allreduce && lm) && !std::getenv("CCAL_DISABLE_FUSED"))
+        return solve_fused(p, o, intr_io, poses_io, rep);
     const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
     ccal_report R = {};
     double* h = w->h_pinned;

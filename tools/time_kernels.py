@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Developer tool: time mode E / mode N device entry points for the library in $CCAL_LIB (variant A/B runs)."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from camera_intrinsic_calibration_rs_amd import synth
+from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=10000)
+ap.add_argument("--model", default="eucm")
+ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--what", default="eval,normal,solve")
+ap.add_argument("--tag", default=os.environ.get("CCAL_LIB", "default"))
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+stream = torch.cuda.Stream(device=dev)
+ctx = Context(0, stream=stream.cuda_stream)
+sp = synth.make_problem(args.frames, args.model)
+prob = Problem.from_synth(ctx, sp)
+prob.upload_params(sp.intr0, sp.poses0, sp.extr0)
+out = {"tag": os.path.basename(args.tag), "frames": args.frames}
+def timeit(fn, reps):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps): fn()
+    b.record(stream); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+if "eval" in args.what:
+    r = torch.empty(prob.n_corners * 2, dtype=torch.float64, device=dev); J = torch.empty(prob.j_len, dtype=torch.float64, device=dev)
+    us = min(timeit(lambda: prob.eval_dev(r.data_ptr(), J.data_ptr()), args.reps) for _ in range(3))
+    D = prob.block_dim(0)
+    out["eval_us"] = us; out["eval_GBps"] = (prob.n_corners * (36 + 16 * D) + sp.n_slots * 48) / us / 1e3
+if "normal" in args.what:
+    out["normal_us"] = min(timeit(lambda: prob.build_normal_dev(0.0), args.reps) for _ in range(3))
+if "solve" in args.what:
+    for name, m in (("gn", 0), ("lm", 1)):
+        best = None
+        for _ in range(3):
+            _, _, _, rep = prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(m))
+            if best is None or rep.solve_ms < best[0]: best = (rep.solve_ms, rep.iterations, rep.final_cost)
+        out[f"{name}_ms"], out[f"{name}_iters"], out[f"{name}_cost"] = best
+        out[f"{name}_it_per_s"] = best[1] / best[0] * 1e3
+print(json.dumps(out))
