@@ -23,6 +23,30 @@ namespace ccal {
 //   dp/dtvec_c_0    = I
 constexpr int FC_RC = 0, FC_TC = 9, FC_A = 12, FC_R1 = 39, FC_B = 48, FC_BK = 75, FC_SIZE = 84;
 
+// 1/x and (sqrt x, 1/sqrt x) from the hardware seeds (v_rcp_f64 / v_rsq_f64) plus two fused
+// Newton / Goldschmidt steps: <= 1-2 ulp, a third of the instructions of the IEEE division / sqrt
+// expansions (no div_scale / div_fmas / div_fixup).  Arguments on this path are finite, positive and
+// far from the denormal range (depths, radii, sums of squares of pixels).
+__device__ __forceinline__ double fast_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs) {
+    const double y0 = __builtin_amdgcn_rsq(x);
+    double g = x * y0, h = 0.5 * y0;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    // one final correction of the square root: g += h * 2 * (x - g^2) / 2
+    const double d = __builtin_fma(-g, g, x);
+    s = __builtin_fma(d, h, g);
+    rs = h + h;
+}
+
 // R = exp([w]x) and G_k = dR/dw_k (row-major 3x3 each), series below theta^2 < 0.04.
 // The reference's quaternion path (nalgebra from_scaled_axis) returns the identity as a constant at
 // exactly rvec == 0, i.e. a zero rvec-Jacobian there; we use the true limit dR/dw_k = [e_k]x instead
@@ -132,10 +156,10 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
         const double alpha = th[4];
         const double beta = (MODEL == kEUCM) ? th[5] : 1.0;
         const double r2 = x * x + y * y;
-        const double rho = sqrt(beta * r2 + z * z);
+        double rho, irho;
+        fast_sqrt_rsqrt(beta * r2 + z * z, rho, irho);
         const double n = alpha * rho + (1.0 - alpha) * z;
-        const double inv = 1.0 / n;
-        const double irho = 1.0 / rho;
+        const double inv = fast_rcp(n);
         mx = x * inv; my = y * inv;
         const double ab = alpha * beta * irho;
         const double nx = ab * x, ny = ab * y, nz = alpha * z * irho + (1.0 - alpha);
@@ -150,16 +174,16 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
         }
     } else if constexpr (MODEL == kKB4) {
         const double r2 = x * x + y * y;
-        const double r = sqrt(r2);
+        double r, ir;
+        fast_sqrt_rsqrt(r2, r, ir);          // r2 == 0 gives NaN here and falls into the pinhole branch below
         if (r > 1e-8) {
             const double t = atan2(r, z);
             const double t2 = t * t;
             const double k1 = th[4], k2 = th[5], k3 = th[6], k4 = th[7];
             const double td = t * (1.0 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4))));
             const double tdp = 1.0 + t2 * (3.0 * k1 + t2 * (5.0 * k2 + t2 * (7.0 * k3 + t2 * 9.0 * k4)));
-            const double ir = 1.0 / r;
             const double s = td * ir;
-            const double id2 = 1.0 / (r2 + z * z);
+            const double id2 = fast_rcp(r2 + z * z);
             const double tq = z * ir * id2;                 // theta_x = tq x, theta_y = tq y
             const double tz = -r * id2;
             const double g = ir * (tdp * tq - s * ir);      // s_x = g x, s_y = g y
@@ -172,7 +196,7 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
             ddx[0] = xr * t3; ddx[1] = xr * t5; ddx[2] = xr * t7; ddx[3] = xr * t9;
             ddy[0] = yr * t3; ddy[1] = yr * t5; ddy[2] = yr * t7; ddy[3] = yr * t9;
         } else {
-            const double iz = 1.0 / z;
+            const double iz = fast_rcp(z);
             mx = x * iz; my = y * iz;
             dmx[0] = iz; dmx[1] = 0.0; dmx[2] = -mx * iz;
             dmy[0] = 0.0; dmy[1] = iz; dmy[2] = -my * iz;
@@ -181,7 +205,7 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
         }
     } else {   // OPENCV5 [k1,k2,p1,p2,k3]
         const double k1 = th[4], k2 = th[5], p1 = th[6], p2 = th[7], k3 = th[8];
-        const double iz = 1.0 / z;
+        const double iz = fast_rcp(z);
         const double xn = x * iz, yn = y * iz;
         const double xx = xn * xn, yy = yn * yn, xy = xn * yn;
         const double r2 = xx + yy;
@@ -207,8 +231,10 @@ __device__ __forceinline__ void project_uv(const double* th, double x, double y,
     double mx, my;
     if constexpr (MODEL == kUCM || MODEL == kEUCM) {
         const double beta = (MODEL == kEUCM) ? th[5] : 1.0;
-        const double rho = sqrt(beta * (x * x + y * y) + z * z);
-        const double inv = 1.0 / (th[4] * rho + (1.0 - th[4]) * z);
+        double rho, irho;
+        fast_sqrt_rsqrt(beta * (x * x + y * y) + z * z, rho, irho);
+        (void)irho;
+        const double inv = fast_rcp(th[4] * rho + (1.0 - th[4]) * z);
         mx = x * inv; my = y * inv;
     } else if constexpr (MODEL == kKB4) {
         const double r = sqrt(x * x + y * y);
@@ -303,6 +329,13 @@ __device__ __forceinline__ void transform_point(const double* fc, double X, doub
 // Huber weight as tiny-solver evaluates it: rho'(s) = 1 (s <= delta^2) else delta / sqrt(s).
 __device__ __forceinline__ double huber_weight(double s, double delta) {
     return (delta > 0.0 && s > delta * delta) ? delta / sqrt(s) : 1.0;
+}
+// sqrt(rho') -- the factor tiny-solver's corrector applies to r and J.  1 for inliers; the outlier
+// branch is skipped by the whole wavefront when no lane needs it.
+__device__ __forceinline__ double huber_sqrt_weight(double s, double delta) {
+    double sw = 1.0;
+    if (delta > 0.0 && s > delta * delta) sw = sqrt(delta / sqrt(s));
+    return sw;
 }
 
 }  // namespace ccal

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         double* Jv = J + D;
         corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, Ju, Jv);
         if (a.apply_loss) {
-            const double sw = sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta));
+            const double sw = huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta);
             ru *= sw; rv *= sw;
 #pragma unroll
             for (int i = 0; i < D; ++i) { Ju[i] *= sw; Jv[i] *= sw; }

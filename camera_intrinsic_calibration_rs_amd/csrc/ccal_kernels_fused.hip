@@ -97,7 +97,7 @@ hipError_t launch_prep1(const FusedArgs& a, hipStream_t s) {
 // k_gram1
 // ---------------------------------------------------------------------------------------------
 template <int MODEL, bool OF>
-__global__ __launch_bounds__(256) void k_gram1(const FusedArgs a) {
+__global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a) {
     constexpr int D = block_dim(MODEL, OF, false);
     constexpr int K = D - 6, K1 = K + 1;
     constexpr int RS = 16, CS = 2 * RS + 2;
@@ -117,9 +117,55 @@ __global__ __launch_bounds__(256) void k_gram1(const FusedArgs a) {
 #pragma unroll
     for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
     if constexpr (OF) th[1] = th[0];
-    if (lane < 39) fc[lane] = a.fcbuf[(int64_t)f * 40 + lane];
     const int64_t start = a.obs_off[f];
     const int n = (int)(a.obs_off[f + 1] - start);
+    {
+        // candidate pose = accepted pose + back-substitution of the previous camera solve
+        // (dp = -L^-T (y_r + Y dc)), then the frame constants; wave-uniform, scalar loads
+        const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[f]);
+        double pose[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+        double mc = 0.0;
+        if (!first) {
+            const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+            if (pf[0] != 0.0) {
+                double dp[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double* yr = pf + 21 + i * K1;
+                    double t = yr[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                    dp[i] = -t;
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double t = dp[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+                    dp[i] = t * pf[i * (i + 1) / 2 + i];
+                }
+                const double lam = st->lambda_solve;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
+                    const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
+                    mc += dp[i] * (Dii * dp[i] - gp);
+                    pose[i] += dp[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (lane == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+        }
+        if (lane == 0) a.mc_f[f] = mc;
+        double fcr[39];
+        frame_setup<false>(pose, nullptr, fcr);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 39; ++i) fc[i] = fcr[i];
+        }
+    }
     wsync();
 
     d4 acc0 = { 0, 0, 0, 0 }, acc1 = { 0, 0, 0, 0 };
@@ -131,7 +177,7 @@ __global__ __launch_bounds__(256) void k_gram1(const FusedArgs a) {
         const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
         double ru, rv, J[2 * D];
         corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
-        const double sw = valid ? sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta)) : 0.0;
+        const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         const int nv = min(64, n - base);
 #pragma unroll
         for (int half = 0; half < 64 / GRAM_TILE_CORNERS; ++half) {
@@ -313,16 +359,17 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel) 
         }
         wsync();
     }
-    if (gw < a.n_pw) {
+    // the four waves of the workgroup combine in LDS (fixed order), one flush per workgroup
+    __shared__ double blk[WAVES_PER_BLOCK][2 * K1 * K1];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = lane + 64 * q;
-            if (e < K1 * K1) {
-                a.partial[(int64_t)e * a.n_pw + gw] = accA[q];
-                a.partial[(int64_t)(K1 * K1 + e) * a.n_pw + gw] = accY[q];
-            }
-        }
+    for (int q = 0; q < NQ; ++q) {
+        const int e = lane + 64 * q;
+        if (e < K1 * K1) { blk[wave][e] = accA[q]; blk[wave][K1 * K1 + e] = accY[q]; }
     }
+    __syncthreads();
+    const int nblk = a.n_pw / WAVES_PER_BLOCK;
+    for (int e = threadIdx.x; e < 2 * K1 * K1; e += 256)
+        a.partial[(int64_t)e * nblk + blockIdx.x] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
 }
 hipError_t launch_schur1(const FusedArgs& a, int set_sel, hipStream_t s) {
     const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
@@ -362,7 +409,7 @@ __global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_pw
     if (threadIdx.x == 0) red[first + blockIdx.x] = t;
 }
 hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce1, dim3(count), dim3(256), 0, s, a.partial, a.n_pw, first, a.red, a.st);
+    hipLaunchKernelGGL(k_reduce1, dim3(count), dim3(256), 0, s, a.partial, a.n_pw / WAVES_PER_BLOCK, first, a.red, a.st);
     return hipGetLastError();
 }
 __global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const double* mc_f, int n, double* out, const DevState* st) {
@@ -478,22 +525,34 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
         }
         if (lane < K) x[lane] = a.cols[lane].fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
         __syncthreads();
-        if (lane == 0 && !bad) {                     // K <= 9: serial Cholesky + two triangular solves
-            for (int j = 0; j < K && !bad; ++j) {
-                double s = S[j * 11 + j];
-                for (int k = 0; k < j; ++k) s -= S[j * 11 + k] * S[j * 11 + k];
-                if (!(s > 0.0) || !(s < 1.7e308)) { bad = 1; break; }
-                const double l = sqrt(s);
-                S[j * 11 + j] = l;
-                for (int i = j + 1; i < K; ++i) {
-                    double t = S[i * 11 + j];
-                    for (int k = 0; k < j; ++k) t -= S[i * 11 + k] * S[j * 11 + k];
-                    S[i * 11 + j] = t / l;
-                }
+        // K <= 9: right-looking Cholesky, one lane per row, then two lane-parallel triangular sweeps
+        for (int j = 0; j < K; ++j) {
+            const double piv = S[j * 11 + j];
+            if (lane == 0 && (!(piv > 0.0) || !(piv < 1.7e308))) bad = 1;
+            __syncthreads();
+            if (bad) break;
+            const double l = sqrt(piv), il = 1.0 / l;
+            if (lane == j) S[j * 11 + j] = l;
+            if (lane > j && lane < K) S[lane * 11 + j] *= il;
+            __syncthreads();
+            if (lane > j && lane < K) {
+                const double lij = S[lane * 11 + j];
+                for (int k = j + 1; k <= lane; ++k) S[lane * 11 + k] -= lij * S[k * 11 + j];
             }
-            if (!bad) {
-                for (int i = 0; i < K; ++i) { double t = x[i]; for (int k = 0; k < i; ++k) t -= S[i * 11 + k] * x[k]; x[i] = t / S[i * 11 + i]; }
-                for (int i = K - 1; i >= 0; --i) { double t = x[i]; for (int k = i + 1; k < K; ++k) t -= S[k * 11 + i] * x[k]; x[i] = t / S[i * 11 + i]; }
+            __syncthreads();
+        }
+        if (!bad) {
+            for (int j = 0; j < K; ++j) {            // L y = rhs
+                if (lane == j) x[j] /= S[j * 11 + j];
+                __syncthreads();
+                if (lane > j && lane < K) x[lane] -= S[lane * 11 + j] * x[j];
+                __syncthreads();
+            }
+            for (int j = K - 1; j >= 0; --j) {       // L^T x = y
+                if (lane == j) x[j] /= S[j * 11 + j];
+                __syncthreads();
+                if (lane < j) x[lane] -= S[j * 11 + lane] * x[j];
+                __syncthreads();
             }
         }
         __syncthreads();

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
         double ru, rv, J[2 * D];
         corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
         // Huber corrector: both rows scaled by sqrt(rho'); invalid lanes contribute zero rows
-        const double sw = valid ? sqrt(huber_weight(ru * ru + rv * rv, a.huber_delta)) : 0.0;
+        const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         const int nv = min(64, n - base);
 #pragma unroll
         for (int half = 0; half < 64 / GRAM_TILE_CORNERS; ++half) {

@@ -13,6 +13,9 @@
 #ifndef CCAL_GRAM_TILE
 #define CCAL_GRAM_TILE 32
 #endif
+#ifndef CCAL_GRAM_MINW
+#define CCAL_GRAM_MINW 1          // launch_bounds: minimum wavefronts per SIMD the Gram kernels are compiled for
+#endif
 
 namespace ccal {
 
@@ -66,6 +69,7 @@ struct FusedWs {
     double* cost_f = nullptr;                  // [n_obs] cost of each frame
     struct DevState* d_state = nullptr;
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
+    double* h_stage = nullptr;                 // pinned staging [poses | intr | state | cols]
 };
 
 void normal_ws_destroy(ccal_problem* p);

@@ -48,6 +48,7 @@ void normal_ws_destroy(ccal_problem* p) {
         void* fp[] = { f->pf[0], f->pf[1], f->praw[0], f->praw[1], f->partial, f->red, f->d_state, f->fcbuf, f->mc_f, f->cost_f };
         for (void* q : fp) if (q) (void)hipFree(q);
         if (f->h_status) (void)hipHostFree(f->h_status);
+        if (f->h_stage) (void)hipHostFree(f->h_stage);
         delete f;
     }
     delete w;
@@ -64,7 +65,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     f->PRAW = (21 + 6 * K1 + K1 * K1 + 1) & ~1;
     f->RB1 = 2 * K1 * K1 + 2;
     const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
-    int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 4096);   // 4 workgroups of 4 waves per CU
+    int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 16384);   // 4 workgroups of 4 waves per CU
     f->n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     const size_t ns = (size_t)std::max(p->n_slots, 1), no = (size_t)std::max(p->n_obs, 1);
     for (int i = 0; i < 2; ++i) {
@@ -82,6 +83,8 @@ static int fused_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMemset(f->red, 0, (size_t)(f->RB1 + 7) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->d_state, sizeof(DevState)));
     HIP_TRY(ctx, hipHostMalloc((void**)&f->h_status, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostMalloc((void**)&f->h_stage, ns * 6 * sizeof(double) + CCAL_PMAX * sizeof(double) + sizeof(DevState) +
+                                                      CCAL_KMAX * sizeof(ColInfo) + 64, hipHostMallocDefault));
     std::memset((void*)f->h_status, 0, sizeof(HostStatus));
     return CCAL_OK;
 }
@@ -146,11 +149,8 @@ int normal_ws_ensure(ccal_problem* p) {
     return normal_upload_cols(p);
 }
 
-int normal_upload_cols(ccal_problem* p) {
-    NormalWs* w = p->nws;
-    ccal_ctx* ctx = p->ctx;
-    std::vector<ColInfo> cols(CCAL_KMAX);
-    std::memset(cols.data(), 0, cols.size() * sizeof(ColInfo));
+static void build_cols(const ccal_problem* p, ColInfo* cols) {
+    std::memset(cols, 0, CCAL_KMAX * sizeof(ColInfo));
     for (int c = 0; c < p->n_cams; ++c) {
         const CamLayout& cl = p->cams[c];
         for (int i = 0; i < cl.Peff; ++i) {
@@ -167,6 +167,13 @@ int normal_upload_cols(ccal_problem* p) {
             ci.is_extr = 1; ci.dst = c * 6 + i; ci.dst2 = -1;
         }
     }
+}
+
+int normal_upload_cols(ccal_problem* p) {
+    NormalWs* w = p->nws;
+    ccal_ctx* ctx = p->ctx;
+    std::vector<ColInfo> cols(CCAL_KMAX);
+    build_cols(p, cols.data());
     HIP_TRY(ctx, hipMemcpyAsync(w->cols, cols.data(), CCAL_KMAX * sizeof(ColInfo), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CCAL_OK;
@@ -215,11 +222,26 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     hs0.lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
     hs0.min_error = o->min_error; hs0.min_abs = o->min_abs_error_decrease; hs0.min_rel = o->min_rel_error_decrease;
     hs0.cur = 0; hs0.first = 1; hs0.done = 0; hs0.iter = 0; hs0.max_iter = o->max_iterations; hs0.method = o->method;
-    HIP_TRY(ctx, hipMemcpyAsync(f->d_state, &hs0, sizeof hs0, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
+    // one pinned staging block [poses | intr | state | cols]: every upload is a true async copy, no host sync;
     // both parameter sets start from the caller's values (slots without observations never change)
-    HIP_TRY(ctx, hipMemcpyAsync(p->d_poses_c, p->d_poses, sizeof(double) * std::max(p->n_slots, 1) * 6, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(p->d_intr_c, p->d_intr, sizeof(double) * CCAL_PMAX, hipMemcpyDeviceToDevice, st));
+    const size_t np6 = (size_t)p->n_slots * 6;
+    double* h_poses = f->h_stage;
+    double* h_intr = h_poses + np6;
+    DevState* h_state = reinterpret_cast<DevState*>(h_intr + CCAL_PMAX);
+    ColInfo* h_cols = reinterpret_cast<ColInfo*>(h_state + 1);
+    std::memcpy(h_poses, poses_io, np6 * sizeof(double));
+    std::memcpy(h_intr, intr_io, CCAL_PMAX * sizeof(double));
+    *h_state = hs0;
+    build_cols(p, h_cols);
+    if (np6) {
+        HIP_TRY(ctx, hipMemcpyAsync(p->d_poses, h_poses, np6 * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(p->d_poses_c, h_poses, np6 * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(p->d_intr, h_intr, CCAL_PMAX * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(p->d_intr_c, h_intr, CCAL_PMAX * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->d_state, h_state, sizeof(DevState), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(w->cols, h_cols, CCAL_KMAX * sizeof(ColInfo), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
     HostStatus* hst = f->h_status;
     hst->seq = 0; hst->done = 0;
 
@@ -239,7 +261,6 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     const int model = p->cams[0].model;
     int seq = 0;
     auto enqueue = [&]() -> int {         // one evaluation + decision + solve; returns the seq that marks its end
-        HIP_TRYN(ctx, launch_prep1(fa, st));
         HIP_TRYN(ctx, launch_gram1(model, p->one_focal, fa, st));
         if (!lm) {
             HIP_TRYN(ctx, launch_schur1(fa, 0, st));
@@ -299,16 +320,22 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         if (hst->done) { status = hst->done - 1; finished = true; }
         else if (o->verbose) std::printf("[ccal fused %s] iter %d cost %.12g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost);
     }
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    DevState ds;
-    HIP_TRY(ctx, hipMemcpy(&ds, f->d_state, sizeof ds, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipStreamSynchronize(st));          // drains the speculative (early-exit) groups; the last k_head has published
+    struct { int done, iter, cur, acc, rej; double cur_cost, initial_cost; } ds =
+        { hst->done, hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->cur_cost, hst->initial_cost };
     if (!ds.done) { status = CCAL_ERR_NO_CONVERGENCE; }
     else status = ds.done - 1;
     if (ds.cur == 1) { std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); }
     ccal_report R = {};
-    R.status = status; R.iterations = ds.iter; R.lm_accepted = ds.lm_accepted; R.lm_rejected = ds.lm_rejected;
+    R.status = status; R.iterations = ds.iter; R.lm_accepted = ds.acc; R.lm_rejected = ds.rej;
     R.initial_cost = ds.initial_cost; R.final_cost = ds.cur_cost;
-    rc = ccal_download_params(p, intr_io, poses_io, nullptr);
+    if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    std::memcpy(poses_io, h_poses, np6 * sizeof(double));
+    std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
+    if (p->one_focal) intr_io[1] = intr_io[0];           // fy = f (src/util.rs:467-470)
+    rc = CCAL_OK;
     R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rep) *rep = R;
     if (status == CCAL_ERR_NOT_PD) ctx->err = "normal equations are not positive definite";
@@ -317,6 +344,15 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
 }
 
 extern "C" {
+
+// developer hook (not part of include/ccal.h): copy the per-frame scratch of the fast path to the host;
+// diagnostic builds (tools/) park in-kernel timestamps there
+int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
+    if (!p || !p->nws || !p->nws->fws || !out) return CCAL_ERR_INVALID_ARG;
+    const int64_t m = std::min<int64_t>(n, (int64_t)std::max(p->n_obs, 1) * 40);
+    if (hipMemcpy(out, p->nws->fws->fcbuf, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return CCAL_ERR_HIP;
+    return CCAL_OK;
+}
 
 int ccal_build_normal_dev(ccal_problem* p, double lambda) {
     if (!p) return CCAL_ERR_INVALID_ARG;
@@ -358,16 +394,16 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
 int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
     if (!p || !o || !intr_io || (!poses_io && p->n_slots)) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
-    int rc = ccal_upload_params(p, intr_io, poses_io, extr_io);
+    int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
-    if ((rc = normal_ws_ensure(p)) != CCAL_OK) return rc;
-    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
-    NormalWs* w = p->nws;
-    hipStream_t st = ctx->stream;
     const bool lm = o->method == CCAL_METHOD_LM;
     // single camera: device-resident loop (sharded LM needs a second all-reduce per iteration -> general loop)
     if (p->n_cams == 1 && p->n_obs > 0 && !(p->allreduce && lm) && !std::getenv("CCAL_DISABLE_FUSED"))
         return solve_fused(p, o, intr_io, poses_io, rep);
+    if ((rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
+    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
+    NormalWs* w = p->nws;
+    hipStream_t st = ctx->stream;
     const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
     ccal_report R = {};
     double* h = w->h_pinned;
