@@ -204,12 +204,34 @@ def _intr_matrix(cameras: Sequence[GenericModel]) -> np.ndarray:
     return intr
 
 
+def init_frame_poses(frame_feature_list: Sequence[Optional[FrameFeature]], generic_camera: GenericModel,
+                     min_points: int = 10, ctx: Optional[Context] = None) -> Dict[int, RvecTvec]:
+    """The pose initialisation inside calib_camera (src/util.rs:418-436): `unproject` the detections with
+    the current model, keep the valid ones, normalise by z, planar PnP -- one wavefront per frame."""
+    valid = [i for i, f in enumerate(frame_feature_list) if f is not None]
+    if not valid:
+        return {}
+    slots, obs_cam, obs_slot, offs, X, U = _flatten([frame_feature_list], [valid])
+    d, keep = make_desc(1, [generic_camera.model_id], [generic_camera.width()], [generic_camera.height()], False,
+                        len(slots), obs_cam, obs_slot, offs, X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
+    prob = Problem(_ctx(ctx), d, keep)
+    try:
+        poses, used = prob.init_poses(_intr_matrix([generic_camera]), min_points)
+    finally:
+        prob.close()
+    return {fi: RvecTvec.from6(poses[s]) for s, fi in enumerate(slots) if used[s] > 0}
+
+
 def calib_camera(frame_feature_list: Sequence[Optional[FrameFeature]], generic_camera: GenericModel,
                  xy_same_focal: bool, disabled_distortions: int, fixed_focal: bool,
-                 initial_poses: Dict[int, RvecTvec], ctx: Optional[Context] = None,
+                 initial_poses: Optional[Dict[int, RvecTvec]] = None, ctx: Optional[Context] = None,
                  opts: Optional[_ffi.SolverOpts] = None
                  ) -> Optional[Tuple[GenericModel, Dict[int, RvecTvec]]]:
-    """util::calib_camera (src/util.rs:384-490): single-camera bundle adjustment, Gauss-Newton."""
+    """util::calib_camera (src/util.rs:384-490): single-camera bundle adjustment, Gauss-Newton.
+    `initial_poses=None` reproduces the reference's in-function initialisation (unproject + planar PnP
+    per frame on the GPU, frames with fewer than 10 valid points are skipped, src/util.rs:418-436)."""
+    if initial_poses is None:
+        initial_poses = init_frame_poses(frame_feature_list, generic_camera, ctx=ctx)
     valid = [i for i, f in enumerate(frame_feature_list) if f is not None and i in initial_poses]
     if not valid:
         return None

@@ -297,6 +297,28 @@ int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* 
     return CCAL_OK;
 }
 
+// Pose initialisation of every observation frame (src/util.rs:418-436), see ccal_kernels_init.hip.
+int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double* poses_obs, int32_t* n_used) {
+    if (!p || !intr || !poses_obs || !n_used) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    int rc = ccal_upload_params(p, intr, nullptr, nullptr);
+    if (rc != CCAL_OK) return rc;
+    const size_t no = (size_t)std::max(p->n_obs, 1);
+    double* d_po = nullptr; int32_t* d_va = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**)&d_po, no * 6 * sizeof(double)));
+    if (hipMalloc((void**)&d_va, no * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_po); return fail(ctx, CCAL_ERR_HIP, "hipMalloc failed"); }
+    hipError_t e = hipMemsetAsync(d_va, 0, no * sizeof(int32_t), ctx->stream);
+    for (int c = 0; c < p->n_cams && e == hipSuccess; ++c) e = launch_pose_init(p, c, p->d_intr, d_po, d_va, min_points, ctx->stream);
+    if (e == hipSuccess && p->n_obs) {
+        e = hipMemcpyAsync(poses_obs, d_po, (size_t)p->n_obs * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(n_used, d_va, (size_t)p->n_obs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_po); (void)hipFree(d_va);
+    if (e != hipSuccess) { ctx->err = std::string("ccal_init_poses: ") + hipGetErrorString(e); return CCAL_ERR_HIP; }
+    return CCAL_OK;
+}
+
 // validation() statistics of one camera (src/util.rs:778-795): errors of that camera's corners,
 // sorted; median = e[len/2]; avg_99 = sum_{i < len*99/100} e_i / (len*99/100).
 int ccal_validation(ccal_problem* p, int cam, const double* intr, const double* poses, const double* extr,

@@ -216,6 +216,16 @@ class Problem:
             raise CcalError(rc, "ccal_solve", self.ctx.last_error())
         return intr, poses, extr, rep
 
+    # -- pose initialisation (src/util.rs:418-436) ---------------------------------------------------
+    def init_poses(self, intr, min_points: int = 10):
+        """T_cam_board per observation frame [n_obs, 6] and the number of corners used (0 = no pose)."""
+        intr = _f64(intr, (self.n_cams, PMAX))
+        n_obs = len(self._keep["obs_cam"]) if self._keep is not None else 0
+        poses = np.zeros((max(n_obs, 1), 6)); used = np.zeros(max(n_obs, 1), dtype=np.int32)
+        self._check(self.lib.ccal_init_poses(self.handle, _dp(intr), int(min_points), _dp(poses),
+                                             used.ctypes.data_as(C.POINTER(C.c_int32))), "ccal_init_poses")
+        return poses[:n_obs], used[:n_obs]
+
     # -- validation ---------------------------------------------------------------------------------
     def reprojection_errors(self, intr, poses, extr=None):
         intr, poses, extr = self._params(intr, poses, extr)

@@ -24,6 +24,7 @@
  *                            with the per-frame pose blocks eliminated exactly (Schur)
  *   ccal_solve               GaussNewtonOptimizer::optimize(&problem, &initial_values, None)
  *                            src/util.rs:443-463 and 668-670 (+ an LM mode)
+ *   ccal_init_poses          the unproject + sqpnp pose initialisation inside calib_camera  src/util.rs:418-436
  *   ccal_reprojection_errors / ccal_validation
  *                            validation()                                 src/util.rs:721-795
  *
@@ -180,6 +181,14 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda);   /* uses uploaded pa
 /* ---- the optimizer loop -------------------------------------------------------------------- */
 int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
                double* intr_io, double* poses_io, double* extr_io, ccal_report* report);
+
+/* ---- per-frame pose initialisation (src/util.rs:418-436) ---------------------------------
+ * What calib_camera does before it builds the problem: unproject the detections with the current model,
+ * keep the valid ones, divide by z, planar PnP (the reference calls sqpnp_simple; here a plane-induced
+ * homography -- same basin, the joint solve refines it).  poses_obs [n_obs][6] = T_cam_board of every
+ * observation frame; n_used [n_obs] = corners that entered the estimate, 0 = no pose (the reference skips
+ * frames with fewer than 10 valid unprojections: pass min_points = 10). */
+int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double* poses_obs, int32_t* n_used);
 
 /* ---- reference validation() statistics (src/util.rs:721-795) ---------------------------- */
 int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr,
