@@ -308,6 +308,70 @@ def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0:
         prob.close()
 
 
+def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]]) -> List[RvecTvec]:
+    """util::init_camera_extrinsic (src/util.rs:511-561): T_i_0 of every camera from the frames both it and
+    camera 0 have a board pose for (SE3Factor + HuberLoss(0.5) + Gauss-Newton, in the library's host code)."""
+    import ctypes as C
+    lib = _ffi.load()
+    out = [RvecTvec((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))]
+    for cam_i in range(1, len(cam_rtvecs)):
+        keys = sorted(set(cam_rtvecs[0].keys()) & set(cam_rtvecs[cam_i].keys()))
+        if not keys:
+            raise ValueError(f"camera {cam_i} shares no frame with camera 0")       # the reference indexes [0] and panics
+        p0 = np.ascontiguousarray(np.stack([cam_rtvecs[0][k].as6() for k in keys]))
+        pi = np.ascontiguousarray(np.stack([cam_rtvecs[cam_i][k].as6() for k in keys]))
+        x = np.zeros(6)
+        rep = _ffi.Report()
+        rc = lib.ccal_init_camera_extrinsic(p0.ctypes.data_as(C.POINTER(C.c_double)), pi.ctypes.data_as(C.POINTER(C.c_double)),
+                                            len(keys), x.ctypes.data_as(C.POINTER(C.c_double)), 0, C.byref(rep))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_init_camera_extrinsic")                        # `.unwrap()` in the reference
+        out.append(RvecTvec.from6(x))
+    return out
+
+
+def convert_model(source_model: GenericModel, target_model: GenericModel) -> GenericModel:
+    """util::convert_model, the closed-form branch (src/util.rs:230-235): UCM -> EUCM copies the parameters
+    and sets beta = 1 (pinned by tests/util_test.rs:77-110).  The optimisation branch (ModelConvertFactor over
+    a pixel grid) belongs to the initialisation pipeline and is not part of this build."""
+    if source_model.kind == "ucm" and target_model.kind == "eucm":
+        return GenericModel("eucm", list(source_model.params()) + [1.0], source_model.width(), source_model.height())
+    if source_model.kind == target_model.kind:
+        return source_model.copy()
+    raise NotImplementedError("only the closed-form UCM -> EUCM conversion is provided (SURVEY 8(f) rank 4)")
+
+
+def init_ucm(frame_feature0: FrameFeature, frame_feature1: FrameFeature, rtvec0: RvecTvec, rtvec1: RvecTvec,
+             init_f: float, init_alpha: float, fixed_focal: bool, ctx: Optional[Context] = None) -> Optional[GenericModel]:
+    """util::init_ucm (src/util.rs:287-378).  UCMInitFocalAlphaFactor (factors.rs:82-120) is the reprojection
+    factor of a UCM whose only free intrinsics are f = fx = fy and alpha with the principal point pinned at the
+    image centre, i.e. the engine's UCM + xy_same_focal problem with cx, cy fixed; bounds f in [f0/3, 3 f0],
+    alpha in [1e-6, 1] (:345-346).  Then calib_camera on the two frames with xy_same_focal = true (:365-371)."""
+    w, h = frame_feature0.img_w_h
+    ucm0 = GenericModel("ucm", [init_f, init_f, w / 2.0, h / 2.0, init_alpha], w, h)
+    frames = [frame_feature0, frame_feature1]
+    slots, obs_cam, obs_slot, offs, X, U = _flatten([frames], [[0, 1]])
+    d, keep = make_desc(1, [ucm0.model_id], [w], [h], True, 2, obs_cam, obs_slot, offs, X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
+    prob = Problem(_ctx(ctx), d, keep)
+    try:
+        prob.fix_param(0, 1); prob.fix_param(0, 2)                      # cx, cy (eff indices with fy removed)
+        if fixed_focal:
+            prob.fix_param(0, 0)
+        prob.set_bounds(0, 0, init_f / 3.0, init_f * 3.0)
+        prob.set_bounds(0, 3, 1e-6, 1.0)
+        try:
+            intr, _, _, _ = prob.solve(_intr_matrix([ucm0]), np.stack([rtvec0.as6(), rtvec1.as6()]), None, default_opts())
+        except CcalError:
+            return None
+    finally:
+        prob.close()
+    ucm1 = GenericModel("ucm", [intr[0, 0], intr[0, 0], w / 2.0, h / 2.0, intr[0, 4]], w, h)
+    res = calib_camera(frames, ucm1, True, 0, fixed_focal, None, ctx=ctx)
+    if res is None:
+        raise RuntimeError("The initial UCM model fitting failed. Might be wrong board configuration.")   # .expect(...)
+    return res[0]
+
+
 def validation(cam_idx: int, final_result: GenericModel, rtvec_list: Dict[int, RvecTvec],
                detected_feature_frames: Sequence[Optional[FrameFeature]], ctx: Optional[Context] = None
                ) -> Tuple[float, float]:

@@ -190,6 +190,14 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
  * frames with fewer than 10 valid unprojections: pass min_points = 10). */
 int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double* poses_obs, int32_t* n_used);
 
+/* ---- init_camera_extrinsic (src/util.rs:511-561) ------------------------------------------
+ * T_i_0 of camera i from the board poses camera 0 and camera i estimated for the same n_common frames:
+ * one SE3Factor (src/optimization/factors.rs:234-272) per frame, HuberLoss(0.5), Gauss-Newton from
+ * T_i_b[0] * T_0_b[0]^-1 (or from t_i_0_io when use_initial != 0).  A 6-unknown problem: host code of the
+ * library, needs no context.  poses_* are [n_common][6] rvec,tvec. */
+int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common,
+                               double* t_i_0_io, int use_initial, ccal_report* report);
+
 /* ---- reference validation() statistics (src/util.rs:721-795) ---------------------------- */
 int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr,
                              double* err_out /* [n_corners] Euclidean px error */);

@@ -55,6 +55,7 @@ def load():
         "oracle_gn_step_dense": (C.c_int, [D, _u8, _dp, _dp, _dp, _dp]),
         "oracle_reprojection_errors": (C.c_int, [D, _dp, _dp, _dp, _dp]),
         "oracle_validation_stats": (C.c_int, [_dp, C.c_int64, _dp, _dp]),
+        "oracle_init_camera_extrinsic": (C.c_int, [_dp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]),
         "oracle_hardware_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -250,6 +251,15 @@ class OracleProblem:
         sel = np.ascontiguousarray(sel)
         assert self.lib.oracle_validation_stats(_p(sel), len(sel), C.byref(a), C.byref(m)) == 0
         return a.value, m.value
+
+
+def init_camera_extrinsic(poses0, posesi):
+    """SE3Factor Gauss-Newton with dual-number Jacobians (src/util.rs:511-561); returns (T_i_0 as 6-vector, iterations)."""
+    p0 = _f64(poses0, (-1, 6)); pi = _f64(posesi, (-1, 6))
+    out = np.empty(6); it = C.c_int()
+    rc = load().oracle_init_camera_extrinsic(_p(p0), _p(pi), p0.shape[0], _p(out), C.byref(it))
+    assert rc == 0, rc
+    return out, it.value
 
 
 def hardware_threads() -> int:

@@ -556,6 +556,55 @@ int oracle_validation_stats(const double* err, int64_t n, double* avg_99, double
     return CCAL_OK;
 }
 
+// init_camera_extrinsic (src/util.rs:511-561): SE3Factor per common frame, HuberLoss(0.5), Gauss-Newton
+// with dual-number Jacobians and tiny-solver's default thresholds, from t_i_b[0] * t_0_b[0]^-1.
+int oracle_init_camera_extrinsic(const double* poses0, const double* posesi, int n, double* out6, int* iters) {
+    if (n < 1) return CCAL_ERR_INVALID_ARG;
+    using DT = Dual<6>;
+    const double delta = 0.5;
+    Iso3<double> a = iso_new<double>({ poses0[3], poses0[4], poses0[5] }, { poses0[0], poses0[1], poses0[2] });
+    Iso3<double> b = iso_new<double>({ posesi[3], posesi[4], posesi[5] }, { posesi[0], posesi[1], posesi[2] });
+    Iso3<double> init = iso_mul(b, iso_inverse(a));
+    double x[6]; quat_scaled_axis(init.q, x); x[3] = init.t.x; x[4] = init.t.y; x[5] = init.t.z;
+    auto total = [&](const double* xx) {
+        double c = 0;
+        for (int k = 0; k < n; ++k) {
+            double r[6]; se3_factor<double>(poses0 + 6 * k, posesi + 6 * k, xx, xx + 3, r);
+            double s = 0; for (int i = 0; i < 6; ++i) s += r[i] * r[i];
+            c += huber_weight(s, delta) * s;
+        }
+        return c;
+    };
+    double cur = total(x);
+    int it_done = 0, status = CCAL_OK;
+    for (int it = 0; it < 100; ++it) {
+        const double last = cur;
+        double H[36] = { 0 }, g[6] = { 0 };
+        DT xv[6]; for (int i = 0; i < 6; ++i) xv[i] = DT::seed(x[i], i);
+        for (int k = 0; k < n; ++k) {
+            DT r[6]; se3_factor<DT>(poses0 + 6 * k, posesi + 6 * k, xv, xv + 3, r);
+            double s = 0; for (int i = 0; i < 6; ++i) s += r[i].re * r[i].re;
+            const double w = huber_weight(s, delta);
+            for (int i = 0; i < 6; ++i) for (int c = 0; c < 6; ++c) {
+                g[c] += w * r[i].eps[c] * r[i].re;
+                for (int e = 0; e < 6; ++e) H[c * 6 + e] += w * r[i].eps[c] * r[i].eps[e];
+            }
+        }
+        if (!cholesky(H, 6)) { status = CCAL_ERR_NOT_PD; break; }
+        double dx[6]; for (int i = 0; i < 6; ++i) dx[i] = -g[i];
+        chol_solve(H, 6, dx);
+        for (int i = 0; i < 6; ++i) x[i] += dx[i];
+        cur = total(x); ++it_done;
+        if (cur < 1e-10) break;
+        if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
+        if (std::fabs(last - cur) < 1e-5) break;
+        if (std::fabs(last - cur) / last < 1e-5) break;
+    }
+    if (iters) *iters = it_done;
+    std::memcpy(out6, x, sizeof x);
+    return status;
+}
+
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
 }  // extern "C"

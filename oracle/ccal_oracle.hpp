@@ -286,6 +286,28 @@ void factor_jacobian_dyn(int D, int model, bool xy_same_focal, bool other_cam, i
                          const double* params, const double* pose0, const double* pose1,
                          const float p3d[3], const float p2d[2], double r[2], double* J);
 
+// UnitQuaternion::scaled_axis generic over the scalar (needed with duals by SE3Factor).
+template <class T> inline void quat_scaled_axis_t(const Quat<T>& q, T out[3]) {
+    const double sgn = real(q.w) >= 0.0 ? 1.0 : -1.0;
+    const T vx = q.i * sgn, vy = q.j * sgn, vz = q.k * sgn;
+    const T n = sqrt(vx * vx + vy * vy + vz * vz);
+    if (real(n) <= 2.220446049250313e-16) { out[0] = T(0.0); out[1] = T(0.0); out[2] = T(0.0); return; }
+    const T ang = atan2(n, q.w * sgn) * 2.0;
+    out[0] = vx / n * ang; out[1] = vy / n * ang; out[2] = vz / n * ang;
+}
+
+// SE3Factor::residual_func (src/optimization/factors.rs:248-271):
+// t_diff = t_i_b^-1 * Isometry3::new(tvec, rvec) * t_0_b ; [scaled_axis(rotation), translation]
+template <class T>
+inline void se3_factor(const double* pose_0_b, const double* pose_i_b, const T* rvec, const T* tvec, T r[6]) {
+    const Iso3<T> t_0_b = iso_new<T>({ T(pose_0_b[3]), T(pose_0_b[4]), T(pose_0_b[5]) }, { T(pose_0_b[0]), T(pose_0_b[1]), T(pose_0_b[2]) });
+    const Iso3<T> t_i_b = iso_new<T>({ T(pose_i_b[3]), T(pose_i_b[4]), T(pose_i_b[5]) }, { T(pose_i_b[0]), T(pose_i_b[1]), T(pose_i_b[2]) });
+    const Iso3<T> t_i_0 = iso_new<T>({ tvec[0], tvec[1], tvec[2] }, { rvec[0], rvec[1], rvec[2] });
+    const Iso3<T> d = iso_mul(iso_mul(iso_inverse(t_i_b), t_i_0), t_0_b);
+    quat_scaled_axis_t(d.q, r);
+    r[3] = d.t.x; r[4] = d.t.y; r[5] = d.t.z;
+}
+
 // Huber loss as tiny-solver evaluates it (HuberLoss::new(1.0), src/util.rs:413):
 // rho'(s) = 1 for s <= delta^2, delta / sqrt(s) otherwise; corrector scales r and J by sqrt(rho').
 inline double huber_weight(double s, double delta) {

@@ -47,3 +47,35 @@ def test_rvec_tvec_algebra_matches_oracle(oracle):
     np.testing.assert_allclose(a.compose(b).as6(), oracle.pose_compose(a.as6(), b.as6()), atol=1e-13)
     np.testing.assert_allclose(a.inverse().as6(), oracle.pose_inverse(a.as6()), atol=1e-13)
     np.testing.assert_allclose(a.inverse().inverse().as6(), a.as6(), atol=1e-13)
+
+
+def test_init_camera_extrinsic_matches_oracle_and_truth(oracle):
+    """util::init_camera_extrinsic (src/util.rs:511-561) -- SE3Factor + HuberLoss(0.5) + GN.  The library's
+    host implementation (central-difference Jacobian) against the oracle's dual-number one and against the
+    transform the poses were generated with; one gross outlier frame is absorbed by the Huber loss."""
+    rng = np.random.default_rng(3)
+    t_i_0 = api.RvecTvec((0.01, -0.02, 0.005), (-0.101, 0.002, 0.001))
+    cam0, cam1 = {}, {}
+    for k in range(40):
+        t_0_b = api.RvecTvec(tuple(np.array([3.0, 0.1, -0.2]) + rng.normal(0, 0.2, 3)), tuple(np.array([-0.3, 0.3, 0.9]) + rng.normal(0, 0.1, 3)))
+        noisy = api.RvecTvec.from6(t_i_0.compose(t_0_b).as6() + rng.normal(0, 1e-3, 6))
+        cam0[k * 3] = t_0_b
+        cam1[k * 3] = noisy
+    cam1[6] = api.RvecTvec.from6(cam1[6].as6() + np.array([0.4, 0.0, 0.0, 0.3, 0.0, 0.0]))     # outlier frame
+    cam0[1000] = api.RvecTvec((0.0, 0.0, 0.0), (0.0, 0.0, 1.0))                                   # not shared
+    out = api.init_camera_extrinsic([cam0, cam1])
+    assert out[0].as6().tolist() == [0.0] * 6
+    keys = sorted(set(cam0) & set(cam1))
+    ref, iters = oracle.init_camera_extrinsic([cam0[k].as6() for k in keys], [cam1[k].as6() for k in keys])
+    np.testing.assert_allclose(out[1].as6(), ref, rtol=0, atol=1e-6)       # both stop on the 1e-5 cost thresholds
+    # Huber bounds the outlier's pull to ~delta / n = 0.5 / 40 per component
+    np.testing.assert_allclose(out[1].as6(), t_i_0.as6(), rtol=0, atol=1.5e-2)
+    assert 1 <= iters <= 20
+
+
+def test_convert_model_closed_form():
+    """tests/util_test.rs:77-110: UCM -> EUCM copies the parameters and sets beta = 1."""
+    ucm = api.GenericModel("ucm", [500.0, 500.0, 320.0, 240.0, 0.5], 640, 480)
+    eucm = api.GenericModel("eucm", [400.0, 400.0, 320.0, 240.0, 0.0, 1.0], 640, 480)
+    p = api.convert_model(ucm, eucm).params()
+    assert abs(p[0] - 500.0) < 1e-6 and abs(p[4] - 0.5) < 1e-6 and abs(p[5] - 1.0) < 1e-6

@@ -113,3 +113,40 @@ def test_validation_matches_oracle(gpu_ctx, oracle):
     a, m = api.validation(0, model, poses, frames, ctx=gpu_ctx)
     ao, mo = oracle.OracleProblem.from_synth(sp).validation(0, sp.intr_gt, sp.poses_gt)
     assert abs(a - ao) < 1e-11 and abs(m - mo) < 1e-11
+
+
+def test_init_ucm_two_frames(gpu_ctx):
+    """util::init_ucm (src/util.rs:287-378): [f, alpha] + two poses from two frames, principal point pinned at
+    the image centre, then calib_camera(xy_same_focal = true) on the same two frames."""
+    sp = synth.make_problem(2, "ucm", seed=77)
+    frames = api.frames_from_synth(sp)
+    gt = sp.intr_gt[0]
+    m = api.init_ucm(frames[0], frames[1], api.RvecTvec.from6(sp.poses0[0]), api.RvecTvec.from6(sp.poses0[1]),
+                     init_f=gt[0] * 1.3, init_alpha=0.4, fixed_focal=False, ctx=gpu_ctx)
+    assert m is not None and m.kind == "ucm"
+    p = m.params()
+    assert p[0] == p[1]
+    assert abs(p[0] / gt[0] - 1) < 0.03 and abs(p[4] - gt[4]) < 0.05         # two frames only: a few percent
+    assert abs(p[2] - gt[2]) < 5 and abs(p[3] - gt[3]) < 5
+
+
+def test_multi_camera_pipeline_from_detections(gpu_ctx):
+    """The reference's flow for two cameras, end to end on the GPU engine: per-camera calib_camera (poses
+    initialised inside), init_camera_extrinsic, calib_all_camera_with_extrinsics, validation."""
+    sp = synth.make_problem(20, "eucm", n_cams=2)
+    frames = [api.frames_from_synth(sp, c) for c in range(2)]
+    cams0 = [api.GenericModel("eucm", sp.intr0[c, :6], 512, 512) for c in range(2)]
+    per_cam = [api.calib_camera(frames[c], cams0[c], False, 0, False, None, ctx=gpu_ctx) for c in range(2)]
+    assert all(r is not None for r in per_cam)
+    t_i_0 = api.init_camera_extrinsic([r[1] for r in per_cam])
+    assert np.abs(np.array(t_i_0[1].tvec) - sp.extr_gt[1, 3:]).max() < 3e-3
+    res = api.calib_all_camera_with_extrinsics([r[0] for r in per_cam], t_i_0, [r[1] for r in per_cam], frames,
+                                               False, 0, False, ctx=gpu_ctx)
+    assert res is not None
+    models, t_out, board = res
+    assert np.abs(np.array(t_out[1].tvec) - sp.extr_gt[1, 3:]).max() < 5e-4
+    assert np.abs(np.array(t_out[1].rvec) - sp.extr_gt[1, :3]).max() < 2e-3
+    for c in range(2):
+        saved = {k: t_out[c].compose(v) for k, v in board.items()}
+        a, m = api.validation(c, models[c], saved, frames[c], ctx=gpu_ctx)
+        assert 0.05 < m < 0.25
