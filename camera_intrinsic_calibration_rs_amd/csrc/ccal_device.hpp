@@ -47,6 +47,26 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double& s, double& rs)
     rs = h + h;
 }
 
+// sin and cos for rotation angles (|x| < ~1e5): two-term Cody-Waite reduction by pi/2 and the fdlibm
+// kernel polynomials (< 1 ulp on [-pi/4, pi/4]).  A fraction of the instructions of the general-purpose
+// library sincos (no Payne-Hanek path, no branches).
+__device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
+    const double kd = __builtin_rint(x * 6.36619772367581382433e-01);
+    const int k = (int)kd;
+    double r = __builtin_fma(-kd, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                      z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double sr = __builtin_fma(r * z, ps, r);
+    const double cr = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
+    const double s1 = (k & 1) ? cr : sr, c1 = (k & 1) ? sr : cr;
+    s = (k & 2) ? -s1 : s1;
+    c = ((k + 1) & 2) ? -c1 : c1;
+}
+
 // R = exp([w]x) and G_k = dR/dw_k (row-major 3x3 each), series below theta^2 < 0.04.
 // The reference's quaternion path (nalgebra from_scaled_axis) returns the identity as a constant at
 // exactly rvec == 0, i.e. a zero rvec-Jacobian there; we use the true limit dR/dw_k = [e_k]x instead
@@ -61,12 +81,14 @@ __device__ inline void so3_exp_jac(const double w[3], double R[9], double G[27])
         c = -1.0 / 3 + t2 * (1.0 / 30 + t2 * (-1.0 / 840 + t2 * (1.0 / 45360 + t2 * (-1.0 / 3991680 + t2 * (1.0 / 518918400.0)))));
         d = -1.0 / 12 + t2 * (1.0 / 180 + t2 * (-1.0 / 6720 + t2 * (1.0 / 453600 + t2 * (-1.0 / 47900160 + t2 * (1.0 / 7264857600.0)))));
     } else {
-        const double t = sqrt(t2);
-        double s, co;
-        sincos(t, &s, &co);
-        const double it2 = 1.0 / t2;
-        a = s / t;
-        const double sh = sin(0.5 * t);
+        double t, it;
+        fast_sqrt_rsqrt(t2, t, it);
+        double s, co, sh, ch;
+        fast_sincos(t, s, co);
+        fast_sincos(0.5 * t, sh, ch);
+        (void)ch;
+        const double it2 = it * it;
+        a = s * it;
         b = 2.0 * sh * sh * it2;          // (1 - cos t) / t^2 without cancellation
         c = (co - a) * it2;
         d = (a - 2.0 * b) * it2;

@@ -45,7 +45,8 @@ struct HeadArgs {
 };
 
 hipError_t launch_prep1(const FusedArgs& a, hipStream_t s);
-hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);
+hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
+hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // VALU Gram (<= 105 triangle entries)
 hipError_t launch_schur1(const FusedArgs& a, int set_sel, hipStream_t s);
 hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s);
 hipError_t launch_cost1(const FusedArgs& a, hipStream_t s);

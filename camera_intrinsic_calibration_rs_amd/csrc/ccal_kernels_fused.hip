@@ -119,6 +119,13 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     if constexpr (OF) th[1] = th[0];
     const int64_t start = a.obs_off[f];
     const int n = (int)(a.obs_off[f + 1] - start);
+    // software prefetch: the first pass's corner rows are requested before the (long, latency-bound)
+    // back-substitution + exp-map below; every later pass is requested one pass ahead
+    float pX, pY, pZ, pU, pV;
+    {
+        const int64_t g0 = start + (lane < n ? lane : 0);
+        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+    }
     {
         // candidate pose = accepted pose + back-substitution of the previous camera solve
         // (dp = -L^-T (y_r + Y dc)), then the frame constants; wave-uniform, scalar loads
@@ -173,8 +180,12 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     for (int base = 0; base < n; base += 64) {
         const int c = base + lane;
         const bool valid = c < n;
-        const int64_t g = start + (valid ? c : 0);
-        const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
+        const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
+        if (base + 64 < n) {                                              // wave-uniform: next pass in flight
+            const int cn = base + 64 + lane;
+            const int64_t gn = start + (cn < n ? cn : 0);
+            pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+        }
         double ru, rv, J[2 * D];
         corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
@@ -235,6 +246,223 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
         rec[21 + 6 * K1 + e] = G[(i < K ? i : D) * 16 + (j < K ? j : D)];
     }
     if (lane == 0) a.cost_f[f] = G[D * 16 + D];
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gram1v: the same per-frame record as k_gram1, without the LDS transposition the matrix cores need.
+// Measured (profiles/r01, ablations in DESIGN.md): staging sqrt(w)[J|r] rows through LDS in MFMA operand
+// order costs ~45 us of k_gram1's 69 us at 10 000 frames, and f64 MFMA shares the FP64 datapath with the
+// VALU on gfx950 (no overlap).  Here 16 lanes own one frame (4 frames per wavefront; 144 corners = 9 x 16,
+// no idle lanes), every lane keeps the upper triangle of [J|r]^T W [J|r] in registers (structural zeros of
+// the intrinsic columns skipped at compile time) and the 16 partial Grams of a frame meet once in LDS.
+// ---------------------------------------------------------------------------------------------
+#ifndef CCAL_GRAMV_WPB
+#define CCAL_GRAMV_WPB 2          // wavefronts per workgroup (4 frames each)
+#endif
+// structural zeros of the block Jacobian rows (u row: no fy, cy; v row: no fx, cx); f feeds both rows
+template <bool OF> __device__ constexpr bool nz_u(int i) { return OF ? (i != 2) : (i != 1 && i != 3); }
+template <bool OF> __device__ constexpr bool nz_v(int i) { return OF ? (i != 1) : (i != 0 && i != 2); }
+
+template <int MODEL, bool OF>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedArgs a) {
+    constexpr int D = block_dim(MODEL, OF, false);
+    constexpr int K = D - 6, K1 = K + 1;
+    constexpr int NC = D + 1;                       // columns of [J | r]
+    constexpr int NE = NC * (NC + 1) / 2;           // upper triangle
+    constexpr int HALF = (NE + 1) / 2;              // entries reduced per LDS round
+    constexpr int LS = HALF | 1;                    // odd row stride (doubles): conflict-free column sums
+    constexpr int WSL = 4 * 40 + 64 * LS;           // per wave: 4 frames' constants | reduction buffer
+    constexpr int NQ = (4 * HALF + 63) / 64;        // (frame, entry) sums per lane and round
+    extern __shared__ double smem[];
+    const DevState* st = a.st;
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, gl = lane & 15;
+    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * 4 + grp;
+    const bool active = f < a.n_obs;
+    const int fa_ = active ? f : 0;
+    double* fcw = smem + wave * WSL;
+    double* fc = fcw + grp * 40;
+    double* red = fcw + 160;
+    const int cur = st->cur, first = st->first;
+    const int es = first ? cur : (cur ^ 1);
+    const double* th_g = a.intr[es];
+    double th[model_np(MODEL)];
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (OF) th[1] = th[0];
+    const int64_t start = a.obs_off[fa_];
+    const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
+    float pX, pY, pZ, pU, pV;
+    {
+        const int64_t g0 = start + (gl < n ? gl : 0);
+        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+    }
+    {
+        // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants;
+        // the 16 lanes of a group compute the same values, the 4 groups work on 4 frames at once
+        const int slot = a.obs_slot[fa_];
+        double pose[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+        double mc = 0.0;
+        if (!first) {
+            const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+            if (pf[0] != 0.0) {
+                double dp[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double* yr = pf + 21 + i * K1;
+                    double t = yr[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                    dp[i] = -t;
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double t = dp[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+                    dp[i] = t * pf[i * (i + 1) / 2 + i];
+                }
+                const double lam = st->lambda_solve;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
+                    const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
+                    mc += dp[i] * (Dii * dp[i] - gp);
+                    pose[i] += dp[i];
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+            }
+        }
+        if (active && gl == 0) a.mc_f[f] = mc;
+        double fcr[39];
+        frame_setup<false>(pose, nullptr, fcr);
+        if (gl == 0) {
+#pragma unroll
+            for (int i = 0; i < 39; ++i) fc[i] = fcr[i];
+        }
+    }
+    wsync();
+
+    double acc[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) acc[e] = 0.0;
+    // same trip count for the whole wave: the largest frame of the four
+    int nmax = n;
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    for (int base = 0; base < nmax; base += 16) {
+        const int c = base + gl;
+        const bool valid = c < n;
+        const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
+        if (base + 16 < nmax) {
+            const int cn = base + 16 + gl;
+            const int64_t gn = start + (cn < n ? cn : 0);
+            pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+        }
+        double ru, rv, J[2 * D];
+        corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
+        // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
+        double su[NC], sv[NC];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { su[i] = sw * J[i]; sv[i] = sw * J[D + i]; }
+        su[D] = sw * ru; sv[D] = sw * rv;
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int j = i; j < NC; ++j) {
+                const bool bu = (i >= K || nz_u<OF>(i)) && (j >= K || nz_u<OF>(j));
+                const bool bv = (i >= K || nz_v<OF>(i)) && (j >= K || nz_v<OF>(j));
+                if (bu) acc[e] = __builtin_fma(su[i], su[j], acc[e]);
+                if (bv) acc[e] = __builtin_fma(sv[i], sv[j], acc[e]);
+                ++e;
+            }
+        }
+    }
+
+    // 16 partial Grams per frame -> one, through LDS, in two halves of the triangle
+    double res[2][NQ];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        wsync();
+#pragma unroll
+        for (int t = 0; t < HALF; ++t) { const int e = h * HALF + t; if (e < NE) red[lane * LS + t] = acc[e < NE ? e : 0]; }
+        wsync();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = lane + 64 * q;                      // (group, entry) pairs
+            double sum = 0.0;
+            if (idx < 4 * HALF) {
+                const int g = idx / HALF, t = idx - g * HALF;
+                const double* src = red + (g * 16) * LS + t;
+#pragma unroll
+                for (int l = 0; l < 16; ++l) sum += src[l * LS];
+            }
+            res[h][q] = sum;
+        }
+    }
+    // scatter the upper triangle into the compact record  C (21) | [B|g] (6 x K1) | A (K1 x K1)
+    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = lane + 64 * q;
+            if (idx >= 4 * HALF) continue;
+            const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
+            const int ff = fbase + g;
+            if (e >= NE || ff >= a.n_obs) continue;
+            int i = 0, rem = e;
+            while (rem >= NC - i) { rem -= NC - i; ++i; }
+            const int j = i + rem;
+            const double v = res[h][q];
+            double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
+            const bool ip = i >= K && i < D, jp = j >= K && j < D;      // pose columns
+            const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
+            if (ip && jp) rec[(j - K) * (j - K + 1) / 2 + (i - K)] = v;
+            else if (!ip && jp) rec[21 + (j - K) * K1 + ci] = v;                         // i camera, j pose
+            else if (ip && !jp) rec[21 + (i - K) * K1 + K] = v;                          // i pose, j = r
+            else { rec[21 + 6 * K1 + ci * K1 + cj] = v; rec[21 + 6 * K1 + cj * K1 + ci] = v; if (i == D) a.cost_f[ff] = v; }
+        }
+    }
+}
+
+template <int MODEL, bool OF>
+static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
+    constexpr int NC = block_dim(MODEL, OF, false) + 1;
+    constexpr int HALF = (NC * (NC + 1) / 2 + 1) / 2;
+    constexpr int WSL = 4 * 40 + 64 * (HALF | 1);
+    const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram1v<MODEL, OF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int fpb = 4 * CCAL_GRAMV_WPB;
+    hipLaunchKernelGGL((k_gram1v<MODEL, OF>), dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
+    switch (model * 2 + (one_focal ? 1 : 0)) {
+        case 0: return launch_gram1v_t<kUCM, false>(a, s);
+        case 1: return launch_gram1v_t<kUCM, true>(a, s);
+        case 2: return launch_gram1v_t<kEUCM, false>(a, s);
+        case 3: return launch_gram1v_t<kEUCM, true>(a, s);
+        case 4: return launch_gram1v_t<kKB4, false>(a, s);
+        case 5: return launch_gram1v_t<kKB4, true>(a, s);
+        case 6: return launch_gram1v_t<kOCV5, false>(a, s);
+        case 7: return launch_gram1v_t<kOCV5, true>(a, s);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 template <int MODEL, bool OF>
@@ -315,7 +543,9 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel) 
                 for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
                 if (i == j) {
                     ok = ok && (t > 0.0) && (t < 1.7e308);
-                    L[i * (i + 1) / 2 + i] = ok ? 1.0 / sqrt(t) : 0.0;
+                    double sq, rsq;
+                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
+                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;
                 } else {
                     L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
                 }

@@ -281,7 +281,9 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
                 if (i == j) {
                     ok = ok && (t > 0.0) && (t < 1.7e308);
-                    L[i * (i + 1) / 2 + i] = ok ? 1.0 / sqrt(t) : 0.0;        // diagonal stored inverted
+                    double sq, rsq;
+                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
+                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;                  // diagonal stored inverted
                 } else {
                     L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
                 }

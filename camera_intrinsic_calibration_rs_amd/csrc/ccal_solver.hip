@@ -259,9 +259,15 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
     ha.min_diag = o->lm_min_diagonal; ha.max_diag = o->lm_max_diagonal;
     const int model = p->cams[0].model;
+    // register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR file next to the row math
+    // (UCM / EUCM, one-focal KB4); matrix-core Gram otherwise.  CCAL_GRAM=mfma|valu overrides.
+    const int ncols = p->cams[0].D + 1;
+    bool use_valu_gram = ncols * (ncols + 1) / 2 <= 105;
+    if (const char* g = std::getenv("CCAL_GRAM")) use_valu_gram = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 120;
     int seq = 0;
     auto enqueue = [&]() -> int {         // one evaluation + decision + solve; returns the seq that marks its end
-        HIP_TRYN(ctx, launch_gram1(model, p->one_focal, fa, st));
+        if (use_valu_gram) HIP_TRYN(ctx, launch_gram1v(model, p->one_focal, fa, st));
+        else HIP_TRYN(ctx, launch_gram1(model, p->one_focal, fa, st));
         if (!lm) {
             HIP_TRYN(ctx, launch_schur1(fa, 0, st));
             HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));

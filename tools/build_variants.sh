@@ -4,9 +4,9 @@ set -e
 cd "$(dirname "$0")/../camera_intrinsic_calibration_rs_amd/csrc"
 mkdir -p ../lib/variants build/var
 build() { name=$1; shift
-  for f in ccal_api ccal_kernels_eval ccal_kernels_normal ccal_kernels_fused ccal_solver; do
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $f.hip -o build/var/${name}_$f.o &
+  for f in ccal_*.hip; do b=${f%.hip}
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $f -o build/var/${name}_$b.o &
   done; wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libccal_$name.so build/var/${name}_*.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libccal_$name.so build/var/${name}_ccal_*.o
 }
 for spec in "$@"; do name=${spec%%:*}; flags=${spec#*:}; build $name $flags; echo built $name; done
