@@ -106,7 +106,8 @@ def main():
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/<round>/pmc_summary.json); null otherwise
         traffic = None
         try:
-            prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if d.startswith("r"))
+            import re
+            prof_dirs = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if re.fullmatch(r"r\d+", d))
             with open(os.path.join(ROOT, "profiles", prof_dirs[-1], "pmc_summary.json")) as f:
                 pmc = json.load(f)
             if pmc.get("k_eval_algorithmic_bytes_per_launch") == algo_bytes:
@@ -148,8 +149,14 @@ def main():
             ms = a.elapsed_time(b) / nb
             extra["mode_N_build_ms"] = ms
             extra["mode_N_evals_per_s"] = n_corners / (ms * 1e-3)
+            extra["mode_N_note"] = "general path (k_gram MFMA + k_schur + k_reduce), what ccal_build_normal runs"
             for name, method in (("gn", 0), ("lm", 1)):
-                intr, poses, _, rep = prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+                best = None
+                for _ in range(3):                      # wall time of the whole ccal_solve call, best of 3
+                    intr, poses, _, rep = prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+                    if best is None or rep.solve_ms < best.solve_ms:
+                        best = rep
+                rep = best
                 extra[f"{name}_iterations"] = rep.iterations
                 extra[f"{name}_solve_ms"] = rep.solve_ms
                 extra[f"{name}_iters_per_s"] = rep.iterations / (rep.solve_ms * 1e-3) if rep.solve_ms > 0 else None
@@ -171,8 +178,9 @@ def main():
         t_single = op.eval_timed(sub.intr0, sub.poses0, threads=1, reps=1)
         single = op.n_corners / t_single
         # size the all-core run for ~10 s of wall time, every thread repeating its share of the sample
-        t_cal = op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=8)        # warm-up + calibration
-        reps = int(min(max(8, 10.0 / max(t_cal / 8, 1e-6)), 1e6))
+        op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=8)                # warm-up
+        t_cal = op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=64)       # calibration (~0.5 s)
+        reps = int(min(max(8, 10.0 / max(t_cal / 64, 1e-6)), 1e6))
         t_all = op.eval_timed(sub.intr0, sub.poses0, threads=cores, reps=reps)
         out["cpu_baseline"] = {
             "value": op.n_corners * reps / t_all, "unit": "corner residual+Jacobian evals/s", "cores": cores,
@@ -185,6 +193,17 @@ def main():
                     "than tiny-solver's heap-backed duals, so GPU/CPU ratios are conservative",
         }
         out["gpu_over_cpu"] = out["value"] / world / out["cpu_baseline"]["value"]
+        if not args.no_extra and "extra" in out:
+            # the oracle's Gauss-Newton (reference algorithm, one thread) on a small sample, for the iterations/s line
+            try:
+                small = sp.shard(0, max(1, args.frames // 200)) if args.frames > 200 else sp
+                ops = ob.OracleProblem.from_synth(small)
+                _, _, _, orep = ops.solve(small.intr0, small.poses0, small.extr0, opts=default_opts(0))
+                out["extra"]["cpu_oracle_gn"] = {"frames": small.n_slots, "iterations": orep.iterations,
+                                                 "solve_ms": orep.solve_ms, "threads": 1,
+                                                 "iters_per_s": orep.iterations / (orep.solve_ms * 1e-3)}
+            except Exception as e:  # noqa: BLE001
+                out["extra"]["cpu_oracle_gn"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(out), flush=True)
