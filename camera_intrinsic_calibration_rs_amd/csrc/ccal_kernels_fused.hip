@@ -663,6 +663,55 @@ hipError_t launch_cost1(const FusedArgs& a, hipStream_t s) {
 // red = [A_dir (K1*K1) | Y^T Y (K1*K1) | cost | mc_pose]
 // The optimizer state is staged in LDS once (the global copy is touched twice per launch).
 // ---------------------------------------------------------------------------------------------
+// S (LDS, row stride 11) x = rhs (LDS) by Cholesky, entirely in registers of every lane; lane 0 writes x back.
+template <int K>
+__device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
+    double M[K * K], v[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        v[i] = x[i];
+#pragma unroll
+        for (int j = 0; j <= i; ++j) M[i * K + j] = S[i * 11 + j];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        double d = M[j * K + j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) d -= M[j * K + k] * M[j * K + k];
+        ok = ok && (d > 0.0) && (d < 1.7e308);
+        double sq, rs;
+        fast_sqrt_rsqrt(ok ? d : 1.0, sq, rs);
+        M[j * K + j] = rs;                               // inverted diagonal
+#pragma unroll
+        for (int i = j + 1; i < K; ++i) {
+            double t = M[i * K + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= M[i * K + k] * M[j * K + k];
+            M[i * K + j] = t * rs;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        double t = v[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) t -= M[i * K + k] * v[k];
+        v[i] = t * M[i * K + i];
+    }
+#pragma unroll
+    for (int i = K - 1; i >= 0; --i) {
+        double t = v[i];
+#pragma unroll
+        for (int k = i + 1; k < K; ++k) t -= M[k * K + i] * v[k];
+        v[i] = t * M[i * K + i];
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) x[i] = v[i];
+    }
+    return ok;
+}
+
 __device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
     HostStatus* hs = a.hs;
     hs->done = s->done; hs->iter = s->iter; hs->cur = s->cur;
@@ -755,35 +804,19 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
         }
         if (lane < K) x[lane] = a.cols[lane].fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
         __syncthreads();
-        // K <= 9: right-looking Cholesky, one lane per row, then two lane-parallel triangular sweeps
-        for (int j = 0; j < K; ++j) {
-            const double piv = S[j * 11 + j];
-            if (lane == 0 && (!(piv > 0.0) || !(piv < 1.7e308))) bad = 1;
-            __syncthreads();
-            if (bad) break;
-            const double l = sqrt(piv), il = 1.0 / l;
-            if (lane == j) S[j * 11 + j] = l;
-            if (lane > j && lane < K) S[lane * 11 + j] *= il;
-            __syncthreads();
-            if (lane > j && lane < K) {
-                const double lij = S[lane * 11 + j];
-                for (int k = j + 1; k <= lane; ++k) S[lane * 11 + k] -= lij * S[k * 11 + j];
+        // K <= 9: Cholesky + both triangular solves in registers (every lane the same wave-uniform work, no
+        // LDS round trips or barriers inside the factorisation)
+        {
+            bool okc = true;
+            switch (K) {
+                case 4: okc = chol_solve_reg<4>(S, x); break;
+                case 5: okc = chol_solve_reg<5>(S, x); break;
+                case 6: okc = chol_solve_reg<6>(S, x); break;
+                case 7: okc = chol_solve_reg<7>(S, x); break;
+                case 8: okc = chol_solve_reg<8>(S, x); break;
+                default: okc = chol_solve_reg<9>(S, x); break;
             }
-            __syncthreads();
-        }
-        if (!bad) {
-            for (int j = 0; j < K; ++j) {            // L y = rhs
-                if (lane == j) x[j] /= S[j * 11 + j];
-                __syncthreads();
-                if (lane > j && lane < K) x[lane] -= S[lane * 11 + j] * x[j];
-                __syncthreads();
-            }
-            for (int j = K - 1; j >= 0; --j) {       // L^T x = y
-                if (lane == j) x[j] /= S[j * 11 + j];
-                __syncthreads();
-                if (lane < j) x[lane] -= S[j * 11 + lane] * x[j];
-                __syncthreads();
-            }
+            if (lane == 0 && !okc) bad = 1;
         }
         __syncthreads();
         if (bad) {

@@ -314,7 +314,11 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     int status = CCAL_OK;
     bool finished = false;
     while (!finished) {
-        while ((int)pending.size() < 2 && enq < max_groups) {
+        // Sharded solves (all-reduce hook set) must issue the SAME sequence of collectives on every rank:
+        // no speculative group there -- the next group is enqueued only after this one's status is known
+        // (identical on all ranks, it is computed from the all-reduced sums).
+        const int depth = p->allreduce ? 1 : 2;
+        while ((int)pending.size() < depth && enq < max_groups) {
             const int s = enqueue();
             if (s < 0) return -s;
             pending.push_back(s); ++enq;
