@@ -1,0 +1,309 @@
+// ccal.hpp -- header-only C++17 mirror of the reference's calib-frame API on top of the C ABI (ccal.h).
+//
+// The reference is Rust (no toolchain in this image), so the host side a Rust maintainer would write
+// is given here in C++ with the reference's names, argument meaning and error behaviour:
+//
+//   reference (Rust)                                               here (namespace ccal)
+//   -----------------------------------------------------------   ----------------------------------------
+//   detected_points::FeaturePoint / FrameFeature                   FeaturePoint / FrameFeature
+//   types::RvecTvec, to_na_isometry3, ToRvecTvec                    RvecTvec (+ compose / inverse)
+//   camera_intrinsic_model::GenericModel<f64>                       GenericModel
+//   factors::ReprojectionFactor / OtherCamReprojectionFactor        ReprojectionFactor / OtherCamReprojectionFactor
+//   util::calib_camera                  src/util.rs:384-490         calib_camera            -> std::optional
+//   util::calib_all_camera_with_extrinsics   src/util.rs:567-715    calib_all_camera_with_extrinsics
+//   util::init_camera_extrinsic         src/util.rs:511-561         init_camera_extrinsic
+//   util::validation                    src/util.rs:721-795         validation
+//
+// `None` of the reference == std::nullopt here; nothing falls back to a CPU implementation: every
+// numeric call goes through libccal_hip.so.  Corner order inside a frame is by corner id (std::map), the
+// reference iterates a HashMap (order is random per process there; results agree at the optimum).
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <map>
+#include <optional>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ccal.h"
+
+namespace ccal {
+
+struct FeaturePoint { std::array<float, 2> p2d; std::array<float, 3> p3d; };                    // src/detected_points.rs:6-9
+struct FrameFeature { int64_t time_ns = 0; std::pair<uint32_t, uint32_t> img_w_h{0, 0}; std::map<uint32_t, FeaturePoint> features; };
+
+struct RvecTvec {                                                                                // src/types.rs:13-36
+    std::array<double, 3> rvec{0, 0, 0}, tvec{0, 0, 0};
+    std::array<double, 6> as6() const { return {rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2]}; }
+    static RvecTvec from6(const double* v) { RvecTvec r; for (int i = 0; i < 3; ++i) { r.rvec[i] = v[i]; r.tvec[i] = v[3 + i]; } return r; }
+    // unit quaternion (w, x, y, z) of the rotation, as nalgebra's UnitQuaternion::from_scaled_axis
+    std::array<double, 4> quat() const {
+        const double hx = 0.5 * rvec[0], hy = 0.5 * rvec[1], hz = 0.5 * rvec[2], nn = hx * hx + hy * hy + hz * hz;
+        if (nn <= 4.930380657631324e-32) return {1, 0, 0, 0};
+        const double n = std::sqrt(nn), s = std::sin(n) / n;
+        return {std::cos(n), hx * s, hy * s, hz * s};
+    }
+    static std::array<double, 3> rotate(const std::array<double, 4>& q, const std::array<double, 3>& p) {
+        const double tx = 2 * (q[2] * p[2] - q[3] * p[1]), ty = 2 * (q[3] * p[0] - q[1] * p[2]), tz = 2 * (q[1] * p[1] - q[2] * p[0]);
+        return {p[0] + q[0] * tx + (q[2] * tz - q[3] * ty), p[1] + q[0] * ty + (q[3] * tx - q[1] * tz), p[2] + q[0] * tz + (q[1] * ty - q[2] * tx)};
+    }
+    static RvecTvec from_quat(const std::array<double, 4>& q, const std::array<double, 3>& t) {   // ToRvecTvec, src/types.rs:55-64
+        RvecTvec r; r.tvec = t;
+        const double sg = q[0] >= 0 ? 1.0 : -1.0, vx = q[1] * sg, vy = q[2] * sg, vz = q[3] * sg, n = std::sqrt(vx * vx + vy * vy + vz * vz);
+        if (n > 2.220446049250313e-16) { const double a = 2.0 * std::atan2(n, std::fabs(q[0])) / n; r.rvec = {vx * a, vy * a, vz * a}; }
+        return r;
+    }
+    RvecTvec compose(const RvecTvec& o) const {                                                   // self * o
+        const auto a = quat(), b = o.quat();
+        const std::array<double, 4> q = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+        auto t = rotate(a, o.tvec); for (int i = 0; i < 3; ++i) t[i] += tvec[i];
+        return from_quat(q, t);
+    }
+    RvecTvec inverse() const {
+        const auto a = quat(); const std::array<double, 4> qi = {a[0], -a[1], -a[2], -a[3]};
+        auto t = rotate(qi, tvec); for (auto& v : t) v = -v;
+        return from_quat(qi, t);
+    }
+};
+
+class GenericModel {                                                                             // camera_intrinsic_model::GenericModel<f64>
+public:
+    GenericModel(int model, std::vector<double> params, double width, double height) : model_(model), p_(std::move(params)), w_(width), h_(height) {
+        if (ccal_model_num_params(model) != (int)p_.size()) throw std::invalid_argument("wrong number of parameters");
+    }
+    int model_id() const { return model_; }
+    const std::vector<double>& params() const { return p_; }
+    void set_params(const std::vector<double>& p) { p_ = p; }
+    double width() const { return w_; }
+    double height() const { return h_; }
+private:
+    int model_; std::vector<double> p_; double w_, h_;
+};
+
+namespace detail {
+
+struct Ctx {     // RAII over ccal_ctx
+    ccal_ctx* h = nullptr;
+    explicit Ctx(int device = 0) { if (ccal_ctx_create(device, nullptr, &h) != CCAL_OK) throw std::runtime_error("ccal_ctx_create failed: no usable HIP device / library"); }
+    ~Ctx() { ccal_ctx_destroy(h); }
+    Ctx(const Ctx&) = delete; Ctx& operator=(const Ctx&) = delete;
+};
+struct Prob {
+    ccal_problem* h = nullptr;
+    ~Prob() { ccal_problem_destroy(h); }
+};
+
+// (camera, frame index) observation frames -> CSR + SoA; slots = sorted union of the frame indices
+struct Flat {
+    std::vector<size_t> slots; std::vector<int32_t> obs_cam, obs_slot; std::vector<int64_t> offs{0};
+    std::vector<float> x, y, z, u, v;
+};
+inline Flat flatten(const std::vector<const std::vector<std::optional<FrameFeature>>*>& cams, const std::vector<std::set<size_t>>& use) {
+    Flat f; std::set<size_t> all;
+    for (auto& s : use) all.insert(s.begin(), s.end());
+    f.slots.assign(all.begin(), all.end());
+    for (size_t s = 0; s < f.slots.size(); ++s) {
+        const size_t fi = f.slots[s];
+        for (size_t c = 0; c < cams.size(); ++c) {
+            if (!use[c].count(fi)) continue;
+            const FrameFeature& ff = *(*cams[c])[fi];
+            for (auto& kv : ff.features) {
+                f.x.push_back(kv.second.p3d[0]); f.y.push_back(kv.second.p3d[1]); f.z.push_back(kv.second.p3d[2]);
+                f.u.push_back(kv.second.p2d[0]); f.v.push_back(kv.second.p2d[1]);
+            }
+            f.obs_cam.push_back((int32_t)c); f.obs_slot.push_back((int32_t)s); f.offs.push_back((int64_t)f.x.size());
+        }
+    }
+    return f;
+}
+inline int make_problem(Ctx& ctx, const Flat& f, const std::vector<GenericModel>& cams, bool xy_same_focal, Prob& out) {
+    std::vector<int32_t> model; std::vector<double> w, h;
+    for (auto& m : cams) { model.push_back(m.model_id()); w.push_back(m.width()); h.push_back(m.height()); }
+    ccal_problem_desc d{};
+    d.n_cams = (int32_t)cams.size(); d.model = model.data(); d.width = w.data(); d.height = h.data();
+    d.xy_same_focal = xy_same_focal; d.n_slots = (int32_t)f.slots.size(); d.n_obs = (int32_t)f.obs_cam.size();
+    d.obs_cam = f.obs_cam.data(); d.obs_slot = f.obs_slot.data(); d.obs_offsets = f.offs.data();
+    d.p3d_x = f.x.data(); d.p3d_y = f.y.data(); d.p3d_z = f.z.data(); d.p2d_u = f.u.data(); d.p2d_v = f.v.data();
+    d.huber_delta = 1.0;                                             // HuberLoss::new(1.0), src/util.rs:413
+    return ccal_problem_create(ctx.h, &d, &out.h);
+}
+inline std::vector<double> intr_matrix(const std::vector<GenericModel>& cams) {
+    std::vector<double> intr(cams.size() * CCAL_PMAX, 0.0);
+    for (size_t c = 0; c < cams.size(); ++c) for (size_t i = 0; i < cams[c].params().size(); ++i) intr[c * CCAL_PMAX + i] = cams[c].params()[i];
+    return intr;
+}
+
+}  // namespace detail
+
+// The pose initialisation inside calib_camera (src/util.rs:418-436): unproject, keep valid, planar PnP.
+inline std::map<size_t, RvecTvec> init_frame_poses(const std::vector<std::optional<FrameFeature>>& frames, const GenericModel& cam, int min_points = 10, int device = 0) {
+    std::set<size_t> valid;
+    for (size_t i = 0; i < frames.size(); ++i) if (frames[i]) valid.insert(i);
+    std::map<size_t, RvecTvec> out;
+    if (valid.empty()) return out;
+    detail::Ctx ctx(device); detail::Prob p;
+    const auto f = detail::flatten({&frames}, {valid});
+    if (detail::make_problem(ctx, f, {cam}, false, p) != CCAL_OK) return out;
+    std::vector<double> poses(f.slots.size() * 6); std::vector<int32_t> used(f.slots.size());
+    const auto intr = detail::intr_matrix({cam});
+    if (ccal_init_poses(p.h, intr.data(), min_points, poses.data(), used.data()) != CCAL_OK) return out;
+    for (size_t s = 0; s < f.slots.size(); ++s) if (used[s] > 0) out[f.slots[s]] = RvecTvec::from6(&poses[6 * s]);
+    return out;
+}
+
+// util::calib_camera (src/util.rs:384-490).  `initial_poses == nullptr` initialises the poses inside, as the reference does.
+inline std::optional<std::pair<GenericModel, std::map<size_t, RvecTvec>>>
+calib_camera(const std::vector<std::optional<FrameFeature>>& frame_feature_list, const GenericModel& generic_camera,
+             bool xy_same_focal, size_t disabled_distortions, bool fixed_focal,
+             const std::map<size_t, RvecTvec>* initial_poses = nullptr, int device = 0) {
+    std::map<size_t, RvecTvec> init_local;
+    if (!initial_poses) { init_local = init_frame_poses(frame_feature_list, generic_camera, 10, device); initial_poses = &init_local; }
+    std::set<size_t> valid;
+    for (size_t i = 0; i < frame_feature_list.size(); ++i) if (frame_feature_list[i] && initial_poses->count(i)) valid.insert(i);
+    if (valid.empty()) return std::nullopt;
+    detail::Ctx ctx(device); detail::Prob p;
+    const auto f = detail::flatten({&frame_feature_list}, {valid});
+    if (detail::make_problem(ctx, f, {generic_camera}, xy_same_focal, p) != CCAL_OK) return std::nullopt;
+    auto intr = detail::intr_matrix({generic_camera});
+    std::vector<double> poses;
+    for (size_t fi : f.slots) { const auto v = initial_poses->at(fi).as6(); poses.insert(poses.end(), v.begin(), v.end()); }
+    ccal_apply_reference_bounds(p.h);                                               // src/util.rs:446
+    ccal_disable_distortions(p.h, (int)disabled_distortions, intr.data());          // src/util.rs:447-454
+    ccal_solver_opts o; ccal_set_defaults(&o);                                      // GaussNewtonOptimizer::default()
+    ccal_report rep{};
+    int rc = ccal_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);         // :455
+    if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;        // result_option.as_ref()?
+    if (fixed_focal) {                                                              // :459-464
+        ccal_fix_param(p.h, 0, 0);
+        intr[0] = generic_camera.params()[0]; if (xy_same_focal) intr[1] = intr[0];
+        rc = ccal_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);
+        if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) throw std::runtime_error("second solve failed");   // .unwrap()
+    }
+    GenericModel out = generic_camera;
+    out.set_params(std::vector<double>(intr.begin(), intr.begin() + generic_camera.params().size()));
+    std::map<size_t, RvecTvec> rt;
+    for (size_t s = 0; s < f.slots.size(); ++s) rt[f.slots[s]] = RvecTvec::from6(&poses[6 * s]);
+    return std::make_pair(out, rt);
+}
+
+struct AllCameraResult { std::vector<GenericModel> intrinsics; std::vector<RvecTvec> t_i_0; std::map<size_t, RvecTvec> board_poses; };
+
+// util::calib_all_camera_with_extrinsics (src/util.rs:567-715)
+inline std::optional<AllCameraResult>
+calib_all_camera_with_extrinsics(const std::vector<GenericModel>& cameras, const std::vector<RvecTvec>& t_cam_i_0,
+                                 const std::vector<std::map<size_t, RvecTvec>>& cam_rtvecs,
+                                 const std::vector<std::vector<std::optional<FrameFeature>>>& cams_detected_feature_frames,
+                                 bool xy_same_focal, size_t disabled_distortions, bool cam0_fixed_focal, int device = 0) {
+    const size_t n = cameras.size();
+    std::vector<std::set<size_t>> use(n);
+    std::vector<const std::vector<std::optional<FrameFeature>>*> fr;
+    for (size_t c = 0; c < n; ++c) { for (auto& kv : cam_rtvecs[c]) use[c].insert(kv.first); fr.push_back(&cams_detected_feature_frames[c]); }
+    const auto f = detail::flatten(fr, use);
+    if (f.slots.empty()) return std::nullopt;
+    detail::Ctx ctx(device); detail::Prob p;
+    if (detail::make_problem(ctx, f, cameras, xy_same_focal, p) != CCAL_OK) return std::nullopt;
+    auto intr = detail::intr_matrix(cameras);
+    std::vector<double> extr(n * 6, 0.0), poses(f.slots.size() * 6, 0.0);
+    for (size_t c = 1; c < n; ++c) { const auto v = t_cam_i_0[c].as6(); for (int i = 0; i < 6; ++i) extr[c * 6 + i] = v[i]; }
+    for (size_t s = 0; s < f.slots.size(); ++s)                                      // `.entry().or_insert()` in camera order, :633-651
+        for (size_t c = 0; c < n; ++c) {
+            auto it = cam_rtvecs[c].find(f.slots[s]);
+            if (it == cam_rtvecs[c].end()) continue;
+            const auto v = (c == 0 ? it->second : t_cam_i_0[c].inverse().compose(it->second)).as6();
+            for (int i = 0; i < 6; ++i) poses[6 * s + i] = v[i];
+            break;
+        }
+    ccal_apply_reference_bounds(p.h);
+    ccal_disable_distortions(p.h, (int)disabled_distortions, intr.data());
+    if (cam0_fixed_focal) ccal_fix_param(p.h, 0, 0);                                 // :664-667
+    ccal_solver_opts o; ccal_set_defaults(&o);
+    ccal_report rep{};
+    const int rc = ccal_solve(p.h, &o, intr.data(), poses.data(), extr.data(), &rep);
+    if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;
+    AllCameraResult r;
+    for (size_t c = 0; c < n; ++c) {
+        GenericModel m = cameras[c];
+        m.set_params(std::vector<double>(intr.begin() + c * CCAL_PMAX, intr.begin() + c * CCAL_PMAX + cameras[c].params().size()));
+        r.intrinsics.push_back(m);
+        r.t_i_0.push_back(c == 0 ? RvecTvec{} : RvecTvec::from6(&extr[c * 6]));
+    }
+    for (size_t s = 0; s < f.slots.size(); ++s) r.board_poses[f.slots[s]] = RvecTvec::from6(&poses[6 * s]);
+    return r;
+}
+
+// util::init_camera_extrinsic (src/util.rs:511-561)
+inline std::vector<RvecTvec> init_camera_extrinsic(const std::vector<std::map<size_t, RvecTvec>>& cam_rtvecs) {
+    std::vector<RvecTvec> out(1);
+    for (size_t ci = 1; ci < cam_rtvecs.size(); ++ci) {
+        std::vector<double> p0, pi;
+        for (auto& kv : cam_rtvecs[0]) {
+            auto it = cam_rtvecs[ci].find(kv.first);
+            if (it == cam_rtvecs[ci].end()) continue;
+            const auto a = kv.second.as6(), b = it->second.as6();
+            p0.insert(p0.end(), a.begin(), a.end()); pi.insert(pi.end(), b.begin(), b.end());
+        }
+        if (p0.empty()) throw std::runtime_error("camera shares no frame with camera 0");
+        double x[6] = {0, 0, 0, 0, 0, 0};
+        if (ccal_init_camera_extrinsic(p0.data(), pi.data(), (int)(p0.size() / 6), x, 0, nullptr) != CCAL_OK) throw std::runtime_error("init_camera_extrinsic failed");
+        out.push_back(RvecTvec::from6(x));
+    }
+    return out;
+}
+
+// util::validation (src/util.rs:721-795): (avg of the lowest 99 %, median)
+inline std::pair<double, double> validation(size_t /*cam_idx*/, const GenericModel& final_result, const std::map<size_t, RvecTvec>& rtvec_list,
+                                            const std::vector<std::optional<FrameFeature>>& detected_feature_frames, int device = 0) {
+    std::set<size_t> valid;
+    for (auto& kv : rtvec_list) if (kv.first < detected_feature_frames.size() && detected_feature_frames[kv.first]) valid.insert(kv.first);
+    detail::Ctx ctx(device); detail::Prob p;
+    const auto f = detail::flatten({&detected_feature_frames}, {valid});
+    if (detail::make_problem(ctx, f, {final_result}, false, p) != CCAL_OK) throw std::runtime_error("problem creation failed");
+    std::vector<double> poses;
+    for (size_t fi : f.slots) { const auto v = rtvec_list.at(fi).as6(); poses.insert(poses.end(), v.begin(), v.end()); }
+    const auto intr = detail::intr_matrix({final_result});
+    double avg = 0, med = 0;
+    if (ccal_validation(p.h, 0, intr.data(), poses.data(), nullptr, &avg, &med) != CCAL_OK) throw std::runtime_error("validation failed");
+    return {avg, med};
+}
+
+// factors::ReprojectionFactor (src/optimization/factors.rs:126-173): residual_func(params) with
+// params = [intrinsics (P_eff), rvec, tvec]; `J` (2 x D, row-major) optionally receives what tiny-solver gets with duals.
+class ReprojectionFactor {
+public:
+    ReprojectionFactor(const GenericModel& target, std::array<float, 3> p3d, std::array<float, 2> p2d, bool xy_same_focal)
+        : target_(target), p3d_(p3d), p2d_(p2d), xy_(xy_same_focal) {}
+    std::array<double, 2> residual_func(const std::vector<std::vector<double>>& params, std::vector<double>* J = nullptr) const { return eval(params, false, J); }
+protected:
+    std::array<double, 2> eval(const std::vector<std::vector<double>>& params, bool other, std::vector<double>* J) const {
+        const int n = other ? 2 : 1;
+        std::vector<double> full = params[0];
+        if (xy_) full.insert(full.begin() + 1, full[0]);                           // factors.rs:155-158
+        std::vector<GenericModel> cams(n, GenericModel(target_.model_id(), full, target_.width(), target_.height()));
+        detail::Ctx ctx; detail::Prob p; detail::Flat f;
+        f.slots = {0}; f.obs_cam = {n - 1}; f.obs_slot = {0}; f.offs = {0, 1};
+        f.x = {p3d_[0]}; f.y = {p3d_[1]}; f.z = {p3d_[2]}; f.u = {p2d_[0]}; f.v = {p2d_[1]};
+        if (detail::make_problem(ctx, f, cams, xy_, p) != CCAL_OK) throw std::runtime_error("problem creation failed");
+        const auto intr = detail::intr_matrix(cams);
+        double pose[6], extr[12] = {0};
+        for (int i = 0; i < 3; ++i) { pose[i] = params[1][i]; pose[3 + i] = params[2][i]; if (other) { extr[6 + i] = params[3][i]; extr[9 + i] = params[4][i]; } }
+        std::array<double, 2> r{};
+        std::vector<double> Jl((size_t)ccal_jacobian_len(p.h));
+        if (ccal_eval(p.h, intr.data(), pose, extr, 0, r.data(), Jl.data()) != CCAL_OK) throw std::runtime_error(ccal_last_error(ctx.h));
+        if (J) *J = Jl;
+        return r;
+    }
+    GenericModel target_; std::array<float, 3> p3d_; std::array<float, 2> p2d_; bool xy_;
+};
+// factors::OtherCamReprojectionFactor (factors.rs:179-228): params = [intrinsics, rvec_0_b, tvec_0_b, rvec_i_0, tvec_i_0]
+class OtherCamReprojectionFactor : public ReprojectionFactor {
+public:
+    using ReprojectionFactor::ReprojectionFactor;
+    std::array<double, 2> residual_func(const std::vector<std::vector<double>>& params, std::vector<double>* J = nullptr) const { return eval(params, true, J); }
+};
+
+}  // namespace ccal
