@@ -323,20 +323,16 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
 // sorted; median = e[len/2]; avg_99 = sum_{i < len*99/100} e_i / (len*99/100).
 int ccal_validation(ccal_problem* p, int cam, const double* intr, const double* poses, const double* extr,
                     double* avg_99, double* median) {
-    if (!p || cam < 0 || cam >= p->n_cams || !avg_99 || !median) return CCAL_ERR_INVALID_ARG;
-    std::vector<double> all((size_t)std::max<int64_t>(p->n_corners, 1));
-    int rc = ccal_reprojection_errors(p, intr, poses, extr, all.data());
+    if (!p || cam < 0 || cam >= p->n_cams || !avg_99 || !median || !intr || (!poses && p->n_slots)) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    if (p->cams[cam].obs.empty()) return fail(ctx, CCAL_ERR_INVALID_ARG, "camera has no observations");
+    int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
-    std::vector<double> e;
-    for (int o : p->cams[cam].obs)
-        e.insert(e.end(), all.begin() + p->h_obs_off[o], all.begin() + p->h_obs_off[o + 1]);
-    if (e.empty()) return fail(p->ctx, CCAL_ERR_INVALID_ARG, "camera has no observations");
-    std::sort(e.begin(), e.end());
-    *median = e[e.size() / 2];
-    const size_t n99 = e.size() * 99 / 100;
-    double s = 0.0;
-    for (size_t i = 0; i < n99; ++i) s += e[i] / (double)n99;
-    *avg_99 = s;
+    if (!p->d_err) HIP_TRY(ctx, hipMalloc((void**)&p->d_err, sizeof(double) * std::max<int64_t>(p->n_corners, 1)));
+    KArgs a = make_args(p, cam);
+    a.err_out = p->d_err;
+    HIP_TRY(ctx, launch_reproj_err(p, cam, a, ctx->stream));
+    HIP_TRY(ctx, validation_stats_device(p, cam, p->d_err, avg_99, median, ctx->stream));     // gather + radix sort + sums on the device
     return CCAL_OK;
 }
 

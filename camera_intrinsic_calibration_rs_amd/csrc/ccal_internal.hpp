@@ -83,6 +83,8 @@ namespace ccal {
 // kernel launchers (ccal_kernels.hip)
 hipError_t launch_eval(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
 hipError_t launch_reproj_err(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
+// ccal_kernels_stats.hip
+hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
 // ccal_kernels_init.hip
 hipError_t launch_pose_init(const ccal_problem* p, int cam, const double* d_intr, double* d_poses_obs, int32_t* d_valid,
                             int min_points, hipStream_t s);

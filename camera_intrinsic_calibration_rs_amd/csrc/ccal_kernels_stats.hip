@@ -1,0 +1,67 @@
+// validation() statistics on the device (src/util.rs:778-795): gather one camera's reprojection errors,
+// radix-sort them (hipCUB/rocPRIM header-only device primitives), median = e[len/2],
+// avg_99 = sum_{i < len*99/100} e_i / (len*99/100).
+#include <hipcub/hipcub.hpp>
+
+#include "ccal_internal.hpp"
+
+namespace ccal {
+
+__global__ __launch_bounds__(256) void k_gather_err(const double* err, const int64_t* obs_off, const int32_t* list, int n_list,
+                                                    const int64_t* dst_off, double* out) {
+    // one workgroup per observation frame of the camera: contiguous copy
+    const int o = list[blockIdx.x];
+    const int64_t s = obs_off[o], n = obs_off[o + 1] - s, d = dst_off[blockIdx.x];
+    for (int64_t i = threadIdx.x; i < n; i += 256) out[d + i] = err[s + i];
+}
+__global__ __launch_bounds__(256) void k_scale(double* v, int64_t n, double inv) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] *= inv;
+}
+
+// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`.
+hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
+    const CamLayout& cl = p->cams[cam];
+    const int n_list = (int)cl.obs.size();
+    std::vector<int64_t> dst(n_list + 1, 0);
+    for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
+    const int64_t n = dst[n_list];
+    if (n <= 0) return hipErrorInvalidValue;
+    int64_t* d_dst = nullptr; double *d_a = nullptr, *d_b = nullptr, *d_sum = nullptr; void* d_tmp = nullptr;
+    hipError_t e;
+#define TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
+    size_t tmp_sort = 0, tmp_red = 0, tmp_bytes = 0;
+    const int64_t n99 = n * 99 / 100;
+    double h[2] = { 0.0, 0.0 };
+    TRY(hipMalloc((void**)&d_dst, (n_list + 1) * sizeof(int64_t)));
+    TRY(hipMalloc((void**)&d_a, n * sizeof(double)));
+    TRY(hipMalloc((void**)&d_b, n * sizeof(double)));
+    TRY(hipMalloc((void**)&d_sum, sizeof(double)));
+    TRY(hipMemcpyAsync(d_dst, dst.data(), (n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a);
+    TRY(hipGetLastError());
+    TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, d_a, d_b, (int)n, 0, 64, s));
+    TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_red, d_b, d_sum, (int)std::max<int64_t>(n99, 1), s));
+    tmp_bytes = std::max(tmp_sort, tmp_red);
+    TRY(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
+    TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_a, d_b, (int)n, 0, 64, s));       // errors are >= 0: bit order == value order
+    TRY(hipMemcpyAsync(&h[0], d_b + n / 2, sizeof(double), hipMemcpyDeviceToHost, s));          // median = e[len / 2]
+    if (n99 > 0) {
+        hipLaunchKernelGGL(k_scale, dim3((unsigned)((n99 + 255) / 256)), dim3(256), 0, s, d_b, n99, 1.0 / (double)n99);   // e_i / len_99, then sum
+        TRY(hipGetLastError());
+        TRY(hipcub::DeviceReduce::Sum(d_tmp, tmp_bytes, d_b, d_sum, (int)n99, s));
+        TRY(hipMemcpyAsync(&h[1], d_sum, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    TRY(hipStreamSynchronize(s));
+    *median = h[0]; *avg_99 = h[1];
+done:
+#undef TRY
+    if (d_dst) (void)hipFree(d_dst);
+    if (d_a) (void)hipFree(d_a);
+    if (d_b) (void)hipFree(d_b);
+    if (d_sum) (void)hipFree(d_sum);
+    if (d_tmp) (void)hipFree(d_tmp);
+    return e;
+}
+
+}  // namespace ccal
