@@ -765,7 +765,12 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
                 const double rho = (st->cur_cost - cost_e) / mc;
                 st->iter += 1;
                 const bool lin_fail = a.flags[0] || a.flags[1];
-                if (!lin_fail && fabs(cost_e) < 1.7e308 && mc > 0.0 && rho > 0.0) {
+                if (!lin_fail && fabs(cost_e) < 1.7e308 && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * st->cur_cost)) {
+                    // predicted decrease below the thresholds: converged (see ccal_solver.hip)
+                    if (cost_e < st->cur_cost) { st->cur ^= 1; st->last_cost = st->cur_cost; st->cur_cost = cost_e; st->lm_accepted += 1; }
+                    st->accepted_now = 0;
+                    done = CCAL_OK + 1;
+                } else if (!lin_fail && fabs(cost_e) < 1.7e308 && mc > 0.0 && rho > 0.0) {
                     st->cur ^= 1;
                     const double last = st->cur_cost, cur = cost_e;
                     st->last_cost = last; st->cur_cost = cur; st->lm_accepted += 1;

@@ -466,6 +466,16 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
             if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
         } else {
             const double rho = (cur - cand_cost) / mc;
+            // predicted decrease below the thresholds: converged (the re-weighted cost is not monotone under
+            // exact steps at the optimum, so waiting for an accepted tiny decrease would only shrink the radius)
+            if (!lin_fail && std::isfinite(cand_cost) && mc >= 0.0 &&
+                (mc < o->min_abs_error_decrease || mc < o->min_rel_error_decrease * cur)) {
+                if (cand_cost < cur) {
+                    std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+                    w->cur = cand; cur = cand_cost; R.lm_accepted++;
+                }
+                break;
+            }
             if (!lin_fail && std::isfinite(cand_cost) && mc > 0.0 && rho > 0.0) {
                 std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
                 w->cur = cand;

@@ -459,6 +459,17 @@ int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi,
             double pair[2] = { st == CCAL_OK ? total_cost(d, L, ic.data(), pc.data(), ec.data()) : NAN, mcp };
             if (allreduce_scalars(pair, 2, ar, ar_user)) return CCAL_ERR_HIP;
             if (st == CCAL_OK) { cand = pair[0]; mc = mcc + pair[1]; rho = (cur - cand) / mc; }
+            if (st == CCAL_OK && std::isfinite(cand) && mc >= 0.0 &&
+                (mc < o->min_abs_error_decrease || mc < o->min_rel_error_decrease * cur)) {
+                // predicted decrease below the thresholds: converged
+                if (cand < cur) {
+                    std::memcpy(intr, ic.data(), sizeof(double) * ic.size());
+                    std::memcpy(poses, pc.data(), sizeof(double) * pc.size());
+                    std::memcpy(extr == ex0.data() ? ex0.data() : extr, ec.data(), sizeof(double) * ec.size());
+                    cur = cand; R.lm_accepted++;
+                }
+                break;
+            }
             if (st == CCAL_OK && std::isfinite(cand) && mc > 0.0 && rho > 0.0) {
                 const double last = cur;
                 std::memcpy(intr, ic.data(), sizeof(double) * ic.size());

@@ -142,3 +142,37 @@ def test_full_size_solve_recovers_ground_truth(gpu_ctx):
     assert 0.015 < r_gn.final_cost / gp.n_corners < 0.025
     a, m = gp.validation(0, i_gn, p_gn)
     assert 0.08 < m < 0.16
+
+
+def test_lm_with_rejected_steps_matches_oracle(gpu_ctx, oracle):
+    """A poor starting point (intrinsics off by up to 80 %, 5 % gross outliers): the LM path takes a rejected
+    step (radius shrink, re-elimination of the pose blocks from the stored records with the new damping, no
+    Jacobian re-evaluation) and must walk the same accept / reject sequence as the oracle -- in the
+    device-resident loop and in the general loop."""
+    import os
+    sp = synth.make_problem(8, "eucm", init_perturb=0.8, outlier_frac=0.05, seed=1)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    gp.apply_reference_bounds(); op.apply_reference_bounds()
+    intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    assert rep_o.lm_rejected >= 1 and rep_o.status == 0
+    for disable_fused in ("", "1"):
+        if disable_fused:
+            os.environ["CCAL_DISABLE_FUSED"] = "1"
+        try:
+            intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+        finally:
+            os.environ.pop("CCAL_DISABLE_FUSED", None)
+        assert (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected) == \
+               (rep_o.status, rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected), disable_fused
+        assert abs(rep.final_cost - rep_o.final_cost) <= 1e-8 * rep_o.final_cost
+        assert (np.abs(intr[0, :6] - intr_o[0, :6]) / np.abs(intr_o[0, :6])).max() <= 1e-6
+
+
+def test_lm_hard_start_never_crashes(gpu_ctx):
+    """Intrinsics off by up to 200 %: whatever happens (convergence, max_iterations, not-PD) is a status."""
+    sp = synth.make_problem(8, "kb4", init_perturb=2.0, outlier_frac=0.05, seed=2)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    gp.apply_reference_bounds()
+    intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM), raise_on_error=False)
+    assert rep.status in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE, _ffi.ERR_NOT_PD, _ffi.ERR_NONFINITE)
+    assert rep.lm_accepted + rep.lm_rejected == rep.iterations or rep.status != _ffi.OK
