@@ -35,6 +35,7 @@ struct FusedArgs {
     double* fcbuf; double* mc_f; double* cost_f;
     const double* dc; const DevState* st; int32_t* st_flags;
     double* partial; double* red;
+    int32_t* ticket;               // arrival counter of the fused reduce + head tail of k_schur1
 };
 
 struct HeadArgs {
@@ -47,7 +48,7 @@ struct HeadArgs {
 hipError_t launch_prep1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // VALU Gram (<= 105 triangle entries)
-hipError_t launch_schur1(const FusedArgs& a, int set_sel, hipStream_t s);
+hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* fused_head, hipStream_t s);   // fused_head != NULL: last workgroup reduces + decides + solves
 hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s);
 hipError_t launch_cost1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);

@@ -263,27 +263,29 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
 template <bool OF> __device__ constexpr bool nz_u(int i) { return OF ? (i != 2) : (i != 1 && i != 3); }
 template <bool OF> __device__ constexpr bool nz_v(int i) { return OF ? (i != 1) : (i != 0 && i != 2); }
 
-template <int MODEL, bool OF>
+// LPF = lanes per frame (16, 32 or 64): small problems spread a frame over more lanes so that the chip still fills.
+template <int MODEL, bool OF, int LPF>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedArgs a) {
+    constexpr int G = 64 / LPF;                     // frames per wavefront
     constexpr int D = block_dim(MODEL, OF, false);
     constexpr int K = D - 6, K1 = K + 1;
     constexpr int NC = D + 1;                       // columns of [J | r]
     constexpr int NE = NC * (NC + 1) / 2;           // upper triangle
     constexpr int HALF = (NE + 1) / 2;              // entries reduced per LDS round
     constexpr int LS = HALF | 1;                    // odd row stride (doubles): conflict-free column sums
-    constexpr int WSL = 4 * 40 + 64 * LS;           // per wave: 4 frames' constants | reduction buffer
-    constexpr int NQ = (4 * HALF + 63) / 64;        // (frame, entry) sums per lane and round
+    constexpr int WSL = G * 40 + 64 * LS;           // per wave: G frames' constants | reduction buffer
+    constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
     extern __shared__ double smem[];
     const DevState* st = a.st;
     if (st->done) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int grp = lane >> 4, gl = lane & 15;
-    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * 4 + grp;
+    const int grp = lane / LPF, gl = lane % LPF;
+    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
     const bool active = f < a.n_obs;
     const int fa_ = active ? f : 0;
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * 40;
-    double* red = fcw + 160;
+    double* red = fcw + G * 40;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
@@ -355,13 +357,13 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     // same trip count for the whole wave: the largest frame of the four
     int nmax = n;
 #pragma unroll
-    for (int off = 16; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
-    for (int base = 0; base < nmax; base += 16) {
+    for (int off = LPF; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    for (int base = 0; base < nmax; base += LPF) {
         const int c = base + gl;
         const bool valid = c < n;
         const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
-        if (base + 16 < nmax) {
-            const int cn = base + 16 + gl;
+        if (base + LPF < nmax) {
+            const int cn = base + LPF + gl;
             const int64_t gn = start + (cn < n ? cn : 0);
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
@@ -399,23 +401,23 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         for (int q = 0; q < NQ; ++q) {
             const int idx = lane + 64 * q;                      // (group, entry) pairs
             double sum = 0.0;
-            if (idx < 4 * HALF) {
+            if (idx < G * HALF) {
                 const int g = idx / HALF, t = idx - g * HALF;
-                const double* src = red + (g * 16) * LS + t;
+                const double* src = red + (g * LPF) * LS + t;
 #pragma unroll
-                for (int l = 0; l < 16; ++l) sum += src[l * LS];
+                for (int l = 0; l < LPF; ++l) sum += src[l * LS];
             }
             res[h][q] = sum;
         }
     }
     // scatter the upper triangle into the compact record  C (21) | [B|g] (6 x K1) | A (K1 x K1)
-    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * 4;
+    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int idx = lane + 64 * q;
-            if (idx >= 4 * HALF) continue;
+            if (idx >= G * HALF) continue;
             const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
             const int ff = fbase + g;
             if (e >= NE || ff >= a.n_obs) continue;
@@ -434,22 +436,31 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     }
 }
 
-template <int MODEL, bool OF>
-static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
+template <int MODEL, bool OF, int LPF>
+static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
+    constexpr int G = 64 / LPF;
     constexpr int NC = block_dim(MODEL, OF, false) + 1;
     constexpr int HALF = (NC * (NC + 1) / 2 + 1) / 2;
-    constexpr int WSL = 4 * 40 + 64 * (HALF | 1);
+    constexpr int WSL = G * 40 + 64 * (HALF | 1);
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram1v<MODEL, OF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram1v<MODEL, OF, LPF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int fpb = 4 * CCAL_GRAMV_WPB;
-    hipLaunchKernelGGL((k_gram1v<MODEL, OF>), dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
+    const int fpb = G * CCAL_GRAMV_WPB;
+    hipLaunchKernelGGL((k_gram1v<MODEL, OF, LPF>), dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
+}
+template <int MODEL, bool OF>
+static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
+    // enough wavefronts to fill 1024 SIMDs: 16 lanes per frame from ~4000 frames up, a whole wave per frame
+    // for TUM-VI-sized problems (a few hundred frames)
+    if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16>(a, s);
+    if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32>(a, s);
+    return launch_gram1v_l<MODEL, OF, 64>(a, s);
 }
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
@@ -497,14 +508,36 @@ hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream
 // k_schur1: persistent wavefronts over frames.  set_sel 0: the set evaluated by the last k_gram1
 // (GN: eliminate right away); 1: the accepted set st->cur (LM: after the decision).
 // ---------------------------------------------------------------------------------------------
+struct HeadShared {               // LDS of the decision / solve step
+    DevState S0;
+    double red[2 * 100 + 2];
+    double S[10 * 11];
+    double x[10];
+    int bad;
+};
+__device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
+    HostStatus* hs = a.hs;
+    hs->done = s->done; hs->iter = s->iter; hs->cur = s->cur;
+    hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
+    hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
+    __threadfence_system();
+    hs->seq = a.seq;
+    __threadfence_system();
+}
+
+__device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red);
+
 template <int K>
-__global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel) {
+__global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, const HeadArgs ha, int fuse_head) {
     constexpr int K1 = K + 1;
     constexpr int NQ = (K1 * K1 + 63) / 64;
     constexpr int WSL = ((36 + 12 * K1) + 1) & ~1;      // C[36] | [B|g][6][K1] | Y[6][K1]
     __shared__ double smem[WAVES_PER_BLOCK * WSL];
     const DevState* st = a.st;
-    if (st->done) return;
+    if (st->done) {                  // finished earlier: the host still waits for this group's sequence number
+        if (fuse_head && blockIdx.x == 0 && threadIdx.x == 0) publish_status(ha, st);
+        return;
+    }
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     double* Cm = smem + wave * WSL;
@@ -598,18 +631,61 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel) 
     }
     __syncthreads();
     const int nblk = a.n_pw / WAVES_PER_BLOCK;
-    for (int e = threadIdx.x; e < 2 * K1 * K1; e += 256)
-        a.partial[(int64_t)e * nblk + blockIdx.x] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
+    if (!fuse_head) {                // [entry][workgroup]: k_reduce1 sums one entry per workgroup
+        for (int e = threadIdx.x; e < 2 * K1 * K1; e += 256)
+            a.partial[(int64_t)e * nblk + blockIdx.x] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
+        return;
+    }
+    // Fused tail: partials as [workgroup][entry]; the last workgroup to arrive sums them in workgroup order
+    // (deterministic whichever workgroup that is) and runs the decision / camera solve - no separate
+    // reduce and head launches.  The per-XCD L2s are not coherent with each other, and an agent-scope
+    // release fence per workgroup means a whole-L2 writeback per workgroup (measured: +75 us per iteration).
+    // Instead the partials travel as agent-scope relaxed atomics (sc1: write-through stores, L2-bypassing
+    // loads), ordered against the ticket by waiting for the stores' acknowledgements.
+    constexpr int RB1 = 2 * K1 * K1;
+    for (int e = threadIdx.x; e < RB1; e += 256)
+        __hip_atomic_store(&a.partial[(int64_t)blockIdx.x * RB1 + e], (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ int is_last;
+    __shared__ HeadShared hs;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (t == (int)gridDim.x - 1);
+        if (is_last) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (int e = threadIdx.x; e < RB1; e += 256) {
+        const double* src = a.partial + e;
+        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+        int i = 0;
+#pragma unroll 4
+        for (; i + 3 < nblk; i += 4) {
+            v0 += __hip_atomic_load(src + (int64_t)i * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v1 += __hip_atomic_load(src + (int64_t)(i + 1) * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v2 += __hip_atomic_load(src + (int64_t)(i + 2) * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v3 += __hip_atomic_load(src + (int64_t)(i + 3) * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        for (; i < nblk; ++i) v0 += __hip_atomic_load(src + (int64_t)i * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hs.red[e] = (v0 + v1) + (v2 + v3);
+    }
+    if (threadIdx.x < 2) hs.red[2 * K1 * K1 + threadIdx.x] = a.red[2 * K1 * K1 + threadIdx.x];    // cost / mc of k_cost1 (LM)
+    __syncthreads();
+    head_body(ha, hs, false);
 }
-hipError_t launch_schur1(const FusedArgs& a, int set_sel, hipStream_t s) {
+hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* ha, hipStream_t s) {
     const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
+    const HeadArgs h = ha ? *ha : HeadArgs{};
+    const int fuse = ha ? 1 : 0;
     switch (a.K) {
-        case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a, set_sel); break;
-        case 5: hipLaunchKernelGGL(k_schur1<5>, grid, blk, 0, s, a, set_sel); break;
-        case 6: hipLaunchKernelGGL(k_schur1<6>, grid, blk, 0, s, a, set_sel); break;
-        case 7: hipLaunchKernelGGL(k_schur1<7>, grid, blk, 0, s, a, set_sel); break;
-        case 8: hipLaunchKernelGGL(k_schur1<8>, grid, blk, 0, s, a, set_sel); break;
-        case 9: hipLaunchKernelGGL(k_schur1<9>, grid, blk, 0, s, a, set_sel); break;
+        case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a, set_sel, h, fuse); break;
+        case 5: hipLaunchKernelGGL(k_schur1<5>, grid, blk, 0, s, a, set_sel, h, fuse); break;
+        case 6: hipLaunchKernelGGL(k_schur1<6>, grid, blk, 0, s, a, set_sel, h, fuse); break;
+        case 7: hipLaunchKernelGGL(k_schur1<7>, grid, blk, 0, s, a, set_sel, h, fuse); break;
+        case 8: hipLaunchKernelGGL(k_schur1<8>, grid, blk, 0, s, a, set_sel, h, fuse); break;
+        case 9: hipLaunchKernelGGL(k_schur1<9>, grid, blk, 0, s, a, set_sel, h, fuse); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -712,28 +788,19 @@ __device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
     return ok;
 }
 
-__device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
-    HostStatus* hs = a.hs;
-    hs->done = s->done; hs->iter = s->iter; hs->cur = s->cur;
-    hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
-    hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
-    __threadfence_system();
-    hs->seq = a.seq;
-    __threadfence_system();
-}
-
-__global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
-    __shared__ DevState S0;
-    __shared__ double red[2 * 100 + 2];
-    __shared__ double S[10 * 11];
-    __shared__ double x[10];
-    __shared__ int bad;
-    const int K = a.K, K1 = K + 1, lane = threadIdx.x;
-    {   // stage state + reduced sums
+// Runs on the first wavefront of the calling workgroup (all threads must call it: it contains workgroup
+// barriers).  stage_red: copy the reduced sums from global memory (standalone k_head); otherwise the caller
+// has already put A_dir | Y^T Y | cost | mc into hs.red (fused tail of k_schur1).
+__device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
+    DevState& S0 = hs.S0;
+    double* red = hs.red; double* S = hs.S; double* x = hs.x; int& bad = hs.bad;
+    const int K = a.K, K1 = K + 1;
+    const int lane = threadIdx.x < 64 ? (int)threadIdx.x : (1 << 28);      // other waves only keep the barriers company
+    {   // stage state (+ reduced sums)
         const double* src = reinterpret_cast<const double*>(a.st);
         double* dst = reinterpret_cast<double*>(&S0);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
-        for (int e = lane; e < 2 * K1 * K1 + 2; e += 64) red[e] = a.red[e];
+        if (stage_red) for (int e = lane; e < 2 * K1 * K1 + 2; e += 64) red[e] = a.red[e];
     }
     __syncthreads();
     DevState* st = &S0;
@@ -866,6 +933,10 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
     }
     __syncthreads();
     if (lane == 0) publish_status(a, st);
+}
+__global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
+    __shared__ HeadShared hs;
+    head_body(a, hs, true);
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, s, a);

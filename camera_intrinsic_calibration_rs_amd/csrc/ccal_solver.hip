@@ -254,6 +254,15 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
     fa.dc = w->dc; fa.st = f->d_state; fa.st_flags = w->flags; fa.partial = f->partial; fa.red = f->red;
+    fa.ticket = w->flags + 2;
+    // CCAL_FUSE_TAIL=1: the last Schur workgroup reduces and decides itself (two launches per GN iteration
+    // instead of four).  Off by default: measured 10 us per iteration SLOWER than the split launches on
+    // MI355X (10k frames 0.51 vs 0.46 ms, 1k frames 0.23 vs 0.20 ms for 3 GN iterations) - the ticket round
+    // trip, the L2-bypassing reduction and the serial decision on one CU cost more than two launches do.
+    const char* env_ft = std::getenv("CCAL_FUSE_TAIL");
+    const char* env_tw = std::getenv("CCAL_FUSED_TAIL_WAVES");
+    const bool fuse_tail = !p->allreduce && env_ft && env_ft[0] == '1';
+    if (fuse_tail) fa.n_pw = std::min(f->n_pw, std::max(4, (env_tw ? std::atoi(env_tw) : 2048) / 4 * 4));
     HeadArgs ha = {};
     ha.st = f->d_state; ha.hs = hst; ha.red = f->red; ha.cols = w->cols; ha.flags = w->flags;
     ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
@@ -269,19 +278,28 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         if (use_valu_gram) HIP_TRYN(ctx, launch_gram1v(model, p->one_focal, fa, st));
         else HIP_TRYN(ctx, launch_gram1(model, p->one_focal, fa, st));
         if (!lm) {
-            HIP_TRYN(ctx, launch_schur1(fa, 0, st));
-            HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
-            if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)f->RB1, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
-            ha.phase = 3; ha.seq = ++seq;
-            HIP_TRYN(ctx, launch_head(ha, st));
+            if (fuse_tail) {
+                ha.phase = 3; ha.seq = ++seq;
+                HIP_TRYN(ctx, launch_schur1(fa, 0, &ha, st));
+            } else {
+                HIP_TRYN(ctx, launch_schur1(fa, 0, nullptr, st));
+                HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
+                if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)f->RB1, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
+                ha.phase = 3; ha.seq = ++seq;
+                HIP_TRYN(ctx, launch_head(ha, st));
+            }
         } else {
             HIP_TRYN(ctx, launch_cost1(fa, st));
             ha.phase = 1; ha.seq = ++seq;
             HIP_TRYN(ctx, launch_head(ha, st));
-            HIP_TRYN(ctx, launch_schur1(fa, 1, st));
-            HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
             ha.phase = 2; ha.seq = ++seq;
-            HIP_TRYN(ctx, launch_head(ha, st));
+            if (fuse_tail) {
+                HIP_TRYN(ctx, launch_schur1(fa, 1, &ha, st));
+            } else {
+                HIP_TRYN(ctx, launch_schur1(fa, 1, nullptr, st));
+                HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
+                HIP_TRYN(ctx, launch_head(ha, st));
+            }
         }
         return seq;
     };

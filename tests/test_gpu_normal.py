@@ -176,3 +176,32 @@ def test_lm_hard_start_never_crashes(gpu_ctx):
     intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM), raise_on_error=False)
     assert rep.status in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE, _ffi.ERR_NOT_PD, _ffi.ERR_NONFINITE)
     assert rep.lm_accepted + rep.lm_rejected == rep.iterations or rep.status != _ffi.OK
+
+
+@pytest.mark.parametrize("n_frames", [700, 2500, 4100])
+def test_solve_all_lane_mappings(gpu_ctx, oracle, n_frames):
+    """The register-Gram kernel maps 64 / 32 / 16 lanes to a frame depending on the problem size
+    (< 2000, < 4000, >= 4000 frames): every mapping against the oracle, ragged frames included."""
+    sp = synth.make_problem(n_frames, "eucm", ragged=True, outlier_frac=0.01)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
+    intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
+    assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations)
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+    assert (np.abs(intr[0, :6] - intr_o[0, :6]) / np.abs(intr_o[0, :6])).max() <= 1e-6
+    np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
+def test_solve_fused_tail_opt_in(gpu_ctx, oracle, method, monkeypatch):
+    """CCAL_FUSE_TAIL=1 (last Schur workgroup reduces + decides, opt-in because it measured slower) must
+    follow the same iterates as the split launches."""
+    sp = synth.make_problem(300, "eucm", ragged=True)
+    gp, _ = _pair(gpu_ctx, oracle, sp)
+    ref = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+    monkeypatch.setenv("CCAL_FUSE_TAIL", "1")
+    out = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+    assert (out[3].status, out[3].iterations) == (ref[3].status, ref[3].iterations)
+    assert abs(out[3].final_cost - ref[3].final_cost) <= 1e-10 * ref[3].final_cost
+    np.testing.assert_allclose(out[0], ref[0], rtol=1e-9, atol=0)
+    np.testing.assert_allclose(out[1], ref[1], rtol=0, atol=1e-9)
