@@ -23,6 +23,7 @@ SURVEY 0.5); results agree at the converged optimum.  `None` is returned where t
 """
 from __future__ import annotations
 
+import ctypes as C
 import dataclasses
 import json
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -311,7 +312,6 @@ def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0:
 def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]]) -> List[RvecTvec]:
     """util::init_camera_extrinsic (src/util.rs:511-561): T_i_0 of every camera from the frames both it and
     camera 0 have a board pose for (SE3Factor + HuberLoss(0.5) + Gauss-Newton, in the library's host code)."""
-    import ctypes as C
     lib = _ffi.load()
     out = [RvecTvec((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))]
     for cam_i in range(1, len(cam_rtvecs)):
@@ -330,15 +330,32 @@ def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]]) -> List[Rve
     return out
 
 
-def convert_model(source_model: GenericModel, target_model: GenericModel) -> GenericModel:
-    """util::convert_model, the closed-form branch (src/util.rs:230-235): UCM -> EUCM copies the parameters
-    and sets beta = 1 (pinned by tests/util_test.rs:77-110).  The optimisation branch (ModelConvertFactor over
-    a pixel grid) belongs to the initialisation pipeline and is not part of this build."""
-    if source_model.kind == "ucm" and target_model.kind == "eucm":
-        return GenericModel("eucm", list(source_model.params()) + [1.0], source_model.width(), source_model.height())
-    if source_model.kind == target_model.kind:
-        return source_model.copy()
-    raise NotImplementedError("only the closed-form UCM -> EUCM conversion is provided (SURVEY 8(f) rank 4)")
+def convert_model(source_model: GenericModel, target_model: GenericModel, disabled_distortions: int = 0,
+                  ctx: Optional[Context] = None) -> GenericModel:
+    """util::convert_model (src/util.rs:224-282).  UCM -> EUCM is the closed form beta = 1 (:229-235, pinned by
+    tests/util_test.rs:77-110); everything else fits the target over the reference's pixel grid with
+    ModelConvertFactor (src/optimization/factors.rs:10-76) through `ccal_convert_model` on the device.  The
+    reference mutates `target_model`; here the fitted model is also returned."""
+    if round(source_model.width()) != round(target_model.width()):
+        raise ValueError("source width and target width are not the same.")          # factors.rs:29-33: panic!
+    if round(source_model.height()) != round(target_model.height()):
+        raise ValueError("source height and target height are not the same.")
+    if source_model.kind == "ucm" and target_model.kind == "eucm":                   # closed form: no device needed
+        target_model.set_params(list(source_model.params()) + [1.0])
+        return target_model
+    lib = _ffi.load()
+    c = _ctx(ctx)
+    src = np.ascontiguousarray(source_model.params(), dtype=np.float64)
+    tgt = np.ascontiguousarray(target_model.params(), dtype=np.float64).copy()
+    rep = _ffi.Report()
+    rc = lib.ccal_convert_model(c.handle, source_model.model_id, src.ctypes.data_as(C.POINTER(C.c_double)),
+                                target_model.model_id, tgt.ctypes.data_as(C.POINTER(C.c_double)),
+                                float(source_model.width()), float(source_model.height()), int(disabled_distortions),
+                                None, C.byref(rep))
+    if rc != _ffi.OK:
+        raise CcalError(rc, "ccal_convert_model: " + c.last_error())                 # `.unwrap()` in the reference (:276)
+    target_model.set_params(tgt)
+    return target_model
 
 
 def init_ucm(frame_feature0: FrameFeature, frame_feature1: FrameFeature, rtvec0: RvecTvec, rtvec1: RvecTvec,

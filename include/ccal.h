@@ -198,6 +198,20 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
 int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common,
                                double* t_i_0_io, int use_initial, ccal_report* report);
 
+/* ---- convert_model (src/util.rs:224-282) -----------------------------------------------------
+ * Fit the target model to the source model over the reference's pixel grid: ModelConvertFactor
+ * (src/optimization/factors.rs:10-76) = ONE residual block source.project(ray) - target.project(ray) over the
+ * rays the source model unprojects from rows/cols edge = max(w,h)/100 .. in steps of max(w,h)/30, 10000 where a
+ * projection is undefined, HuberLoss(1.0) on the whole block; Gauss-Newton on all target intrinsics with the
+ * reference's parameter bounds, the last `disabled_distortions` parameters fixed at 0; UCM -> EUCM is the closed
+ * form beta = 1 (util.rs:229-235).  tgt_params_io: in = the target's current parameters (its first four are
+ * replaced by the source's fx, fy, cx, cy: util.rs:256-258), out = the fitted parameters.  opts NULL = the
+ * reference's Gauss-Newton defaults.  Rays and the per-iteration Gram run on the device; the <= 9 x 9 solve
+ * on the host. */
+int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* src_params, int tgt_model,
+                       double* tgt_params_io, double width, double height, int disabled_distortions,
+                       const ccal_solver_opts* opts, ccal_report* report);
+
 /* ---- reference validation() statistics (src/util.rs:721-795) ---------------------------- */
 int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr,
                              double* err_out /* [n_corners] Euclidean px error */);

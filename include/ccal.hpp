@@ -13,6 +13,7 @@
 //   util::calib_all_camera_with_extrinsics   src/util.rs:567-715    calib_all_camera_with_extrinsics
 //   util::init_camera_extrinsic         src/util.rs:511-561         init_camera_extrinsic
 //   util::validation                    src/util.rs:721-795         validation
+//   util::convert_model                 src/util.rs:224-282         convert_model
 //
 // `None` of the reference == std::nullopt here; nothing falls back to a CPU implementation: every
 // numeric call goes through libccal_hip.so.  Corner order inside a frame is by corner id (std::map), the
@@ -253,6 +254,18 @@ inline std::vector<RvecTvec> init_camera_extrinsic(const std::vector<std::map<si
         out.push_back(RvecTvec::from6(x));
     }
     return out;
+}
+
+// util::convert_model (src/util.rs:224-282): fits `target_model` in place, like the reference's &mut argument
+inline void convert_model(const GenericModel& source_model, GenericModel& target_model, size_t disabled_distortions, int device = 0) {
+    if ((uint32_t)std::lround(source_model.width()) != (uint32_t)std::lround(target_model.width())) throw std::invalid_argument("source width and target width are not the same.");      // factors.rs:29-33: panic!
+    if ((uint32_t)std::lround(source_model.height()) != (uint32_t)std::lround(target_model.height())) throw std::invalid_argument("source height and target height are not the same.");
+    detail::Ctx ctx(device);
+    std::vector<double> t = target_model.params();
+    const int rc = ccal_convert_model(ctx.h, source_model.model_id(), source_model.params().data(), target_model.model_id(), t.data(),
+                                      source_model.width(), source_model.height(), (int)disabled_distortions, nullptr, nullptr);
+    if (rc != CCAL_OK) throw std::runtime_error(std::string("convert_model failed: ") + ccal_last_error(ctx.h));       // `.unwrap()` (util.rs:276)
+    target_model.set_params(t);
 }
 
 // util::validation (src/util.rs:721-795): (avg of the lowest 99 %, median)

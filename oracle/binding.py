@@ -56,6 +56,8 @@ def load():
         "oracle_reprojection_errors": (C.c_int, [D, _dp, _dp, _dp, _dp]),
         "oracle_validation_stats": (C.c_int, [_dp, C.c_int64, _dp, _dp]),
         "oracle_init_camera_extrinsic": (C.c_int, [_dp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]),
+        "oracle_convert_model": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, _u8,
+                                           C.POINTER(C.c_int), C.c_void_p]),
         "oracle_hardware_threads": (C.c_int, []),
     }
     for name, (res, args) in sig.items():
@@ -260,6 +262,21 @@ def init_camera_extrinsic(poses0, posesi):
     rc = load().oracle_init_camera_extrinsic(_p(p0), _p(pi), p0.shape[0], _p(out), C.byref(it))
     assert rc == 0, rc
     return out, it.value
+
+
+def convert_model(src_model: int, src_params, tgt_model: int, tgt_params, width: float, height: float,
+                  disabled: int = 0, lo=None, hi=None):
+    """util::convert_model with ModelConvertFactor (src/util.rs:224-282); returns (params, n_grid_points, status)."""
+    src = _f64(src_params); tgt = _f64(tgt_params).copy()
+    n = C.c_int()
+    if lo is None:
+        lo_a = hi_a = hb = None
+    else:
+        lo_a = _f64(lo); hi_a = _f64(hi); hb = np.ones(len(lo_a), dtype=np.uint8)
+    rc = load().oracle_convert_model(src_model, _p(src), tgt_model, _p(tgt), float(width), float(height), int(disabled),
+                                     _p(lo_a) if lo is not None else None, _p(hi_a) if lo is not None else None,
+                                     hb.ctypes.data_as(_u8) if lo is not None else None, C.byref(n), None)
+    return tgt, n.value, rc
 
 
 def hardware_threads() -> int:

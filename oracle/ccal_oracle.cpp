@@ -277,6 +277,37 @@ static int allreduce_scalars(double* v, int n, allreduce_fn fn, void* user) { re
 
 using namespace oracle;
 
+// ModelConvertFactor evaluation (see oracle_convert_model below)
+namespace {
+template <int P>
+void convert_eval(int src_model, const double* src, int tgt_model, const double* th, const std::vector<double>& rays,
+                  double* H, double* g, double* s_out) {
+    using DT = Dual<P>;
+    DT tv[P]; for (int i = 0; i < P; ++i) tv[i] = DT::seed(th[i], i);
+    for (int i = 0; i < P * P; ++i) H[i] = 0.0;
+    for (int i = 0; i < P; ++i) g[i] = 0.0;
+    double s = 0.0;
+    const size_t M = rays.size() / 3;
+    for (size_t k = 0; k < M; ++k) {
+        const double* q = &rays[3 * k];
+        const bool ok = project_valid(src_model, src, q[0], q[1], q[2]) && project_valid(tgt_model, th, q[0], q[1], q[2]);
+        if (!ok) { s += 2.0 * 10000.0 * 10000.0; continue; }              // factors.rs:71: constant, no Jacobian
+        double u0, v0; project_one<double>(src_model, src, { q[0], q[1], q[2] }, u0, v0);
+        DT u1, v1; project_one<DT>(tgt_model, tv, { DT(q[0]), DT(q[1]), DT(q[2]) }, u1, v1);
+        const DT r[2] = { DT(u0) - u1, DT(v0) - v1 };
+        for (int a = 0; a < 2; ++a) {
+            s += r[a].re * r[a].re;
+            for (int i = 0; i < P; ++i) {
+                g[i] += r[a].eps[i] * r[a].re;
+                for (int j = 0; j < P; ++j) H[i * P + j] += r[a].eps[i] * r[a].eps[j];
+            }
+        }
+    }
+    *s_out = s;
+}
+typedef void (*convert_eval_fn)(int, const double*, int, const double*, const std::vector<double>&, double*, double*, double*);
+}  // namespace
+
 extern "C" {
 
 int oracle_model_num_params(int model) { return model_nparams(model); }
@@ -613,6 +644,78 @@ int oracle_init_camera_extrinsic(const double* poses0, const double* posesi, int
     }
     if (iters) *iters = it_done;
     std::memcpy(out6, x, sizeof x);
+    return status;
+}
+
+// util::convert_model (src/util.rs:224-282) with ModelConvertFactor (src/optimization/factors.rs:10-76).
+// ONE residual block of dimension 2 M over the M grid points the source model can unproject, HuberLoss(1.0) on
+// the whole block, variable "params" = all target intrinsics, Gauss-Newton with the reference's bounds
+// (lo/hi/has_bound, [CCAL_PMAX]) and the last `disabled` distortion parameters fixed at 0.
+// n_points_out: M.  Returns the solver status.
+
+int oracle_convert_model(int src_model, const double* src, int tgt_model, double* tgt_io, double width, double height,
+                         int disabled, const double* lo, const double* hi, const uint8_t* has_bound,
+                         int* n_points_out, ccal_report* rep) {
+    const int P = model_nparams(tgt_model);
+    if (P < 0 || model_nparams(src_model) < 0 || disabled < 0 || disabled > P - 4) return CCAL_ERR_INVALID_ARG;
+    ccal_report R = {};
+    if (src_model == UCM && tgt_model == EUCM) {                              // src/util.rs:229-235
+        for (int i = 0; i < 5; ++i) tgt_io[i] = src[i];
+        tgt_io[5] = 1.0;
+        if (n_points_out) *n_points_out = 0;
+        if (rep) *rep = R;
+        return CCAL_OK;
+    }
+    const double big = std::max(width, height);
+    const uint32_t edge = (uint32_t)big / 100u;                               // src/util.rs:245
+    const size_t steps = (size_t)(big / 30.0);                                // :246
+    if (steps == 0 || (uint32_t)height <= edge || (uint32_t)width <= edge) return CCAL_ERR_INVALID_ARG;
+    std::vector<double> rays;
+    for (uint32_t r = edge; r < (uint32_t)height - edge; r += (uint32_t)steps)          // factors.rs:35-39
+        for (uint32_t c = edge; c < (uint32_t)width - edge; c += (uint32_t)steps) {
+            double q[3];
+            if (unproject_one(src_model, src, (double)c, (double)r, q)) { rays.push_back(q[0]); rays.push_back(q[1]); rays.push_back(q[2]); }
+        }
+    if (n_points_out) *n_points_out = (int)(rays.size() / 3);
+    double th[9];
+    for (int i = 0; i < P; ++i) th[i] = tgt_io[i];
+    for (int i = 0; i < 4; ++i) th[i] = src[i];                               // src/util.rs:256-258
+    std::vector<uint8_t> fx(P, 0);
+    for (int i = 0; i < disabled; ++i) { fx[P - 1 - i] = 1; th[P - 1 - i] = 0.0; }   // src/util.rs:58-70
+    const convert_eval_fn ev = P == 5 ? convert_eval<5> : P == 6 ? convert_eval<6> : P == 8 ? convert_eval<8> : convert_eval<9>;
+    double H[81], g[9], s;
+    ev(src_model, src, tgt_model, th, rays, H, g, &s);
+    double cur = huber_weight(s, 1.0) * s;
+    R.initial_cost = cur;
+    int status = CCAL_OK;
+    for (int it = 0; it < 100; ++it) {
+        const double last = cur;
+        // the corrector multiplies J and r by sqrt(rho'): one block => one common factor on H and g
+        const double w = huber_weight(s, 1.0);
+        double S[81], dx[9];
+        for (int i = 0; i < P * P; ++i) S[i] = w * H[i];
+        for (int i = 0; i < P; ++i) dx[i] = fx[i] ? 0.0 : -w * g[i];
+        for (int i = 0; i < P; ++i) if (fx[i]) { for (int j = 0; j < P; ++j) { S[i * P + j] = 0.0; S[j * P + i] = 0.0; } S[i * P + i] = 1.0; }
+        if (!cholesky(S, P)) { status = CCAL_ERR_NOT_PD; break; }
+        chol_solve(S, P, dx);
+        for (int i = 0; i < P; ++i) {
+            if (fx[i]) continue;
+            double v = th[i] + dx[i];
+            if (has_bound && has_bound[i]) v = std::min(std::max(v, lo[i]), hi[i]);
+            th[i] = v;
+        }
+        ev(src_model, src, tgt_model, th, rays, H, g, &s);
+        cur = huber_weight(s, 1.0) * s;
+        R.iterations++;
+        if (cur < 1e-10) break;
+        if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
+        if (std::fabs(last - cur) < 1e-5) break;
+        if (std::fabs(last - cur) / last < 1e-5) break;
+        if (it == 99) status = CCAL_ERR_NO_CONVERGENCE;
+    }
+    R.final_cost = cur; R.status = status;
+    if (rep) *rep = R;
+    for (int i = 0; i < P; ++i) tgt_io[i] = th[i];
     return status;
 }
 

@@ -217,6 +217,75 @@ template <class T> inline void project_one(int model, const T* p, const V3<T>& p
 }
 
 // ---------------------------------------------------------------------------
+// GenericModel::unproject / project validity (camera-intrinsic-model, not under /root/reference: restated from
+// the models' published definitions - UCM/EUCM: Usenko et al. 2018, "The Double Sphere Camera Model", sec. II;
+// KB4: Kannala-Brandt 2006 with Newton on theta; OPENCV5: fixed-point undistortion).  Used only by the
+// ModelConvertFactor restatement (src/optimization/factors.rs:23-54).  Parity unpinned for the crate's
+// exact validity thresholds and iteration counts.
+// ---------------------------------------------------------------------------
+inline bool unproject_one(int model, const double* p, double u, double v, double ray[3]) {
+    const double mx = (u - p[2]) / p[0], my = (v - p[3]) / p[1];
+    const double r2 = mx * mx + my * my;
+    if (model == UCM || model == EUCM) {
+        const double alpha = p[4], beta = model == EUCM ? p[5] : 1.0;
+        if (alpha > 0.5 && r2 > 1.0 / (beta * (2.0 * alpha - 1.0))) return false;
+        const double t1 = 1.0 - (2.0 * alpha - 1.0) * beta * r2;
+        if (t1 < 0.0) return false;
+        const double mz = (1.0 - beta * alpha * alpha * r2) / (alpha * std::sqrt(t1) + (1.0 - alpha));
+        const double n = std::sqrt(r2 + mz * mz);
+        ray[0] = mx / n; ray[1] = my / n; ray[2] = mz / n;
+        return true;
+    }
+    if (model == KB4) {
+        const double r = std::sqrt(r2);
+        if (r < 1e-8) { ray[0] = mx; ray[1] = my; ray[2] = 1.0; return true; }
+        double t = r;
+        for (int it = 0; it < 20; ++it) {
+            const double t2 = t * t;
+            const double f = t * (1.0 + t2 * (p[4] + t2 * (p[5] + t2 * (p[6] + t2 * p[7])))) - r;
+            const double fp = 1.0 + t2 * (3.0 * p[4] + t2 * (5.0 * p[5] + t2 * (7.0 * p[6] + t2 * 9.0 * p[7])));
+            const double dt = f / fp;
+            t -= dt;
+            if (std::fabs(dt) < 1e-14) break;
+        }
+        if (!(t > 0.0) || !(t < 3.141592653589793)) return false;
+        const double s = std::sin(t) / r;
+        ray[0] = mx * s; ray[1] = my * s; ray[2] = std::cos(t);
+        return true;
+    }
+    if (model == OPENCV5) {
+        const double k1 = p[4], k2 = p[5], p1 = p[6], p2 = p[7], k3 = p[8];
+        double x = mx, y = my;
+        for (int it = 0; it < 50; ++it) {
+            const double q = x * x + y * y;
+            const double rad = 1.0 + q * (k1 + q * (k2 + q * k3));
+            const double dx = 2.0 * p1 * x * y + p2 * (q + 2.0 * x * x);
+            const double dy = p1 * (q + 2.0 * y * y) + 2.0 * p2 * x * y;
+            x = (mx - dx) / rad; y = (my - dy) / rad;
+        }
+        const double q = x * x + y * y, rad = 1.0 + q * (k1 + q * (k2 + q * k3));
+        const double ex = x * rad + 2.0 * p1 * x * y + p2 * (q + 2.0 * x * x) - mx;
+        const double ey = y * rad + p1 * (q + 2.0 * y * y) + 2.0 * p2 * x * y - my;
+        if (!(std::fabs(ex) + std::fabs(ey) < 1e-9)) return false;
+        const double n = std::sqrt(q + 1.0);
+        ray[0] = x / n; ray[1] = y / n; ray[2] = 1.0 / n;
+        return true;
+    }
+    return false;
+}
+// Is `project` defined for this camera-frame point?  (The `Option` of GenericModel::project.)
+inline bool project_valid(int model, const double* p, double x, double y, double z) {
+    if (model == UCM || model == EUCM) {
+        const double alpha = p[4], beta = model == EUCM ? p[5] : 1.0;
+        const double d = std::sqrt(beta * (x * x + y * y) + z * z);
+        const double w = alpha <= 0.5 ? alpha / (1.0 - alpha) : (1.0 - alpha) / alpha;
+        return z > -w * d;
+    }
+    if (model == KB4) return x * x + y * y + z * z > 0.0;
+    return z > 1e-9;
+}
+
+// ---------------------------------------------------------------------------
 // The two factors, line for line.  `params` is the solver-visible intrinsic
 // block (P_eff entries: fy removed when xy_same_focal), then rvec, tvec
 // (and rvec_i_0, tvec_i_0 for the other-camera factor).

@@ -71,6 +71,11 @@ int main(int argc, char** argv) {
     std::printf("], \"n_poses\": %zu, \"avg99\": %.17g, \"median\": %.17g, \"pose0\": [", res->second.size(), val.first, val.second);
     const auto p0 = res->second.begin()->second.as6();
     for (int i = 0; i < 6; ++i) std::printf("%s%.17g", i ? ", " : "", p0[i]);
+    // convert_model: the calibrated model refitted as KB4 over the reference's pixel grid
+    GenericModel kb4(2, std::vector<double>(8, 0.0), w, h);
+    convert_model(res->first, kb4, 0);
+    std::printf("], \"kb4\": [");
+    for (size_t i = 0; i < kb4.params().size(); ++i) std::printf("%s%.17g", i ? ", " : "", kb4.params()[i]);
     std::printf("]}\n");
     return 0;
 }

@@ -48,3 +48,5 @@ def test_cpp_calib_camera_matches_python_binding(tmp_path, gpu_ctx):
     assert got["n_poses"] == len(poses) == 17
     assert abs(got["avg99"] - a) < 1e-12 and abs(got["median"] - m) < 1e-12
     np.testing.assert_allclose(got["pose0"], poses[min(poses)].as6(), atol=1e-12)
+    kb4 = api.convert_model(model, api.GenericModel("kb4", [0.0] * 8, 512, 512), 0, ctx=gpu_ctx)
+    np.testing.assert_allclose(got["kb4"], kb4.params(), rtol=1e-12, atol=1e-14)

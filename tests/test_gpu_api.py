@@ -150,3 +150,50 @@ def test_multi_camera_pipeline_from_detections(gpu_ctx):
         saved = {k: t_out[c].compose(v) for k, v in board.items()}
         a, m = api.validation(c, models[c], saved, frames[c], ctx=gpu_ctx)
         assert 0.05 < m < 0.25
+
+
+# ---- convert_model (src/util.rs:224-282) ------------------------------------------------------------------
+_EUCM_GT = [190.89618687183938, 190.87022285882367, 254.9375370481962, 256.86414483060787, 0.6283550447635853, 1.0458678747533083]
+_KB4_GT = [190.9, 190.9, 255.0, 257.0, 0.003, 0.0007, -0.002, 0.0002]
+_CV5_GT = [380.0, 380.0, 255.0, 257.0, -0.28, 0.07, 0.0002, 0.00002, 0.0]
+_REF_BOUNDS = {
+    "ucm": ([0, 0, 0, 0, 1e-6], [1e4, 1e4, 512, 512, 1.0]),
+    "eucm": ([0, 0, 0, 0, 1e-6, 1e-6], [1e4, 1e4, 512, 512, 1.0, 100.0]),
+    "kb4": ([0, 0, 0, 0, -1, -1, -1, -1], [1e4, 1e4, 512, 512, 1, 1, 1, 1]),
+    "opencv5": ([0, 0, 0, 0, -1, -1, -1, -1, -1], [1e4, 1e4, 512, 512, 1, 1, 1, 1, 1]),
+}
+
+
+@pytest.mark.parametrize("src,src_p,tgt,tgt_p,disabled", [
+    ("eucm", _EUCM_GT, "kb4", [0.0] * 8, 0),
+    ("eucm", _EUCM_GT, "kb4", [0.0] * 8, 2),
+    ("eucm", _EUCM_GT, "ucm", [0, 0, 0, 0, 0.6], 0),
+    ("kb4", _KB4_GT, "eucm", [0, 0, 0, 0, 0.5, 1.0], 0),
+    ("opencv5", _CV5_GT, "kb4", [0.0] * 8, 0),
+    ("kb4", _KB4_GT, "opencv5", [0.0] * 9, 0),
+    ("ucm", _EUCM_GT[:5], "kb4", [0.0] * 8, 0),
+])
+def test_convert_model_vs_oracle(gpu_ctx, oracle, src, src_p, tgt, tgt_p, disabled):
+    """Device ModelConvertFactor fit against the oracle's dual-number restatement: same iteration count, same
+    parameters (f64 tolerance 1e-8 relative / 1e-10 absolute: the sums run in a different order)."""
+    s = api.GenericModel(src, src_p, 512, 512)
+    t = api.GenericModel(tgt, tgt_p, 512, 512)
+    lo, hi = _REF_BOUNDS[tgt]
+    p_o, n, rc = oracle.convert_model(s.model_id, src_p, t.model_id, tgt_p, 512, 512, disabled, lo, hi)
+    assert rc == 0 and n > 0
+    out = api.convert_model(s, t, disabled, ctx=gpu_ctx)
+    np.testing.assert_allclose(out.params(), p_o, rtol=1e-8, atol=1e-10)
+    if disabled:
+        assert (np.asarray(out.params())[-disabled:] == 0.0).all()
+
+
+def test_convert_model_roundtrip_identity(gpu_ctx):
+    """EUCM -> EUCM from a different start recovers the source exactly (size-independent property)."""
+    s = api.GenericModel("eucm", _EUCM_GT, 512, 512)
+    t = api.GenericModel("eucm", [1, 1, 1, 1, 0.5, 1.0], 512, 512)
+    np.testing.assert_allclose(api.convert_model(s, t, ctx=gpu_ctx).params(), _EUCM_GT, rtol=1e-9)
+
+
+def test_convert_model_size_mismatch():
+    with pytest.raises(ValueError):
+        api.convert_model(api.GenericModel("eucm", _EUCM_GT, 512, 512), api.GenericModel("kb4", [0.0] * 8, 640, 480))

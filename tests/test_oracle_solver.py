@@ -82,3 +82,70 @@ def test_validation_statistics(oracle):
     assert m == e[len(e) // 2]
     assert np.isclose(a, e[:n99].sum() / n99, rtol=1e-13)
     assert 0.05 < m < 0.25                     # 0.1 px noise per axis
+
+
+# ---- convert_model / ModelConvertFactor (src/util.rs:224-282, src/optimization/factors.rs:10-76) -------------
+EUCM_GT = [190.89618687183938, 190.87022285882367, 254.9375370481962, 256.86414483060787, 0.6283550447635853, 1.0458678747533083]
+
+
+def _grid_rays(oracle, model, params, w, h):
+    big = max(w, h)
+    edge, steps = int(big) // 100, int(big / 30.0)
+    px = np.array([[c, r] for r in range(edge, int(h) - edge, steps) for c in range(edge, int(w) - edge, steps)], dtype=float)
+    return px
+
+
+def test_convert_model_closed_form_oracle(oracle):
+    p, n, rc = oracle.convert_model(synth.MODEL_UCM, [500.0, 500.0, 320.0, 240.0, 0.5], synth.MODEL_EUCM,
+                                    [400.0, 400.0, 320.0, 240.0, 0.0, 1.0], 640, 480)
+    assert rc == 0 and n == 0
+    np.testing.assert_allclose(p, [500.0, 500.0, 320.0, 240.0, 0.5, 1.0], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("tgt,init", [(synth.MODEL_KB4, [0, 0, 0, 0, 0, 0, 0, 0]),
+                                      (synth.MODEL_UCM, [0, 0, 0, 0, 0.6]),
+                                      (synth.MODEL_EUCM, [0, 0, 0, 0, 0.5, 1.0])])
+def test_convert_model_fits_the_source(oracle, tgt, init):
+    """The fitted target reproduces the source over the grid: exactly for EUCM -> EUCM, to a fraction of a
+    pixel for EUCM -> KB4 (both fisheye models), UCM only roughly (it has no beta)."""
+    lo = [0, 0, 0, 0] + ([1e-6] if tgt == synth.MODEL_UCM else [1e-6, 1e-6] if tgt == synth.MODEL_EUCM else [-1.0] * 4)
+    hi = [1e4, 1e4, 512, 512] + ([1.0] if tgt == synth.MODEL_UCM else [1.0, 100.0] if tgt == synth.MODEL_EUCM else [1.0] * 4)
+    p, n, rc = oracle.convert_model(synth.MODEL_EUCM, EUCM_GT, tgt, init, 512, 512, 0, lo, hi)
+    assert rc == 0 and n == 30 * 30
+    # rays of the grid through the source, reprojected by both
+    px = _grid_rays(oracle, synth.MODEL_EUCM, EUCM_GT, 512, 512)
+    mx = (px[:, 0] - EUCM_GT[2]) / EUCM_GT[0]; my = (px[:, 1] - EUCM_GT[3]) / EUCM_GT[1]
+    a, b = EUCM_GT[4], EUCM_GT[5]
+    r2 = mx * mx + my * my
+    mz = (1 - b * a * a * r2) / (a * np.sqrt(1 - (2 * a - 1) * b * r2) + (1 - a))
+    rays = np.stack([mx, my, mz], axis=1)
+    np.testing.assert_allclose(oracle.project(synth.MODEL_EUCM, EUCM_GT, rays), px, rtol=0, atol=1e-9)   # unproject o project = id
+    err = np.linalg.norm(oracle.project(tgt, p, rays) - px, axis=1)
+    tol = {synth.MODEL_EUCM: 1e-6, synth.MODEL_KB4: 0.05, synth.MODEL_UCM: 5.0}[tgt]
+    assert err.max() < tol, err.max()
+    if tgt == synth.MODEL_EUCM:
+        np.testing.assert_allclose(p, EUCM_GT, rtol=1e-8)
+
+
+def test_convert_model_matches_scipy(oracle):
+    """Independent optimum: scipy least_squares on the same residual (one Huber block = a common factor, so the
+    stationary point is the plain least-squares one)."""
+    from scipy.optimize import least_squares
+    init = [0, 0, 0, 0, 0, 0, 0, 0]
+    p, n, rc = oracle.convert_model(synth.MODEL_EUCM, EUCM_GT, synth.MODEL_KB4, init, 512, 512, 0, None, None)
+    assert rc == 0
+    px = _grid_rays(oracle, synth.MODEL_EUCM, EUCM_GT, 512, 512)
+    mx = (px[:, 0] - EUCM_GT[2]) / EUCM_GT[0]; my = (px[:, 1] - EUCM_GT[3]) / EUCM_GT[1]
+    a, b = EUCM_GT[4], EUCM_GT[5]
+    r2 = mx * mx + my * my
+    mz = (1 - b * a * a * r2) / (a * np.sqrt(1 - (2 * a - 1) * b * r2) + (1 - a))
+    rays = np.stack([mx, my, mz], axis=1)
+    f = lambda t: (oracle.project(synth.MODEL_KB4, t, rays) - px).ravel()
+    sol = least_squares(f, p, method="lm", xtol=1e-14, ftol=1e-14, gtol=1e-14)
+    assert abs(np.sum(f(p) ** 2) - np.sum(sol.fun ** 2)) <= 1e-4 * np.sum(sol.fun ** 2) + 1e-10
+    np.testing.assert_allclose(p[:4], sol.x[:4], rtol=1e-4)
+
+
+def test_convert_model_disabled_distortions(oracle):
+    p, n, rc = oracle.convert_model(synth.MODEL_EUCM, EUCM_GT, synth.MODEL_KB4, [0, 0, 0, 0, 0.1, 0.1, 0.1, 0.1], 512, 512, 2, None, None)
+    assert rc == 0 and p[6] == 0.0 and p[7] == 0.0 and p[4] != 0.0

@@ -11,16 +11,18 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=10000)
 ap.add_argument("--model", default="eucm")
 ap.add_argument("--reps", type=int, default=100)
+ap.add_argument("--cams", type=int, default=1)
+ap.add_argument("--one-focal", action="store_true")
 ap.add_argument("--what", default="eval,normal,solve")
 ap.add_argument("--tag", default=os.environ.get("CCAL_LIB", "default"))
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
 ctx = Context(0, stream=stream.cuda_stream)
-sp = synth.make_problem(args.frames, args.model)
+sp = synth.make_problem(args.frames, args.model, n_cams=args.cams, xy_same_focal=args.one_focal)
 prob = Problem.from_synth(ctx, sp)
 prob.upload_params(sp.intr0, sp.poses0, sp.extr0)
-out = {"tag": os.path.basename(args.tag), "frames": args.frames}
+out = {"tag": os.path.basename(args.tag), "frames": args.frames, "model": args.model, "cams": args.cams}
 def timeit(fn, reps):
     for _ in range(5): fn()
     torch.cuda.synchronize()
