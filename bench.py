@@ -176,13 +176,18 @@ def main():
         from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
         result = {}
 
+        # one shared camera: every rank starts from rank 0's initial intrinsics (each rank's frames are its own)
+        intr_shared = torch.from_numpy(np.ascontiguousarray(sp.intr0)).to(dev)
+        dist.broadcast(intr_shared, src=0)
+        intr_start = intr_shared.cpu().numpy()
+
         def sharded():
             try:
                 prob.set_allreduce(make_allreduce_hook(device=dev))
                 with torch.cuda.stream(stream):
                     best = None
                     for _ in range(3):
-                        i2, p2, _, rep = prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(0))
+                        i2, p2, _, rep = prob.solve(intr_start, sp.poses0, sp.extr0, opts=default_opts(0))
                         if best is None or rep.solve_ms < best.solve_ms:
                             best = rep
                 result.update(iterations=best.iterations, solve_ms=best.solve_ms, status=best.status,

@@ -617,7 +617,9 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
 #pragma unroll
                 for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
                 accY[q] += t;
-                accA[q] += adir[q];
+                // a pose block that is not positive definite poisons the cost entry: in a sharded solve the NaN
+                // reaches every rank through the all-reduce, so all of them stop in the same group
+                accA[q] += (ok || e != K * K1 + K) ? adir[q] : __builtin_nan("");
             }
         }
         wsync();
@@ -858,6 +860,9 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
                 if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
                 st->lambda = 1.0 / st->radius;
             }
+            // GN: a pose block of this rank failed at the evaluated point (its NaN cost is what the other ranks of a
+            // sharded solve see): None, like the failed linear solve of the reference
+            if (!lm && a.flags[0] && (done == 0 || done == CCAL_ERR_NONFINITE + 1)) done = CCAL_ERR_NOT_PD + 1;
             st->done = done;
         }
         __syncthreads();

@@ -20,6 +20,7 @@ struct GramArgs {
     const int64_t* goff;
     double* G;
     double* cost_o;
+    const int32_t* stop;     // != 0: the Gauss-Newton loop has converged, an iteration enqueued ahead does nothing
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -32,6 +33,7 @@ struct GramArgs {
 template <int MODEL, bool OF, bool OTHER>
 __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const KArgs& a = ga.k;
+    if (*ga.stop) return;
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int NC = D + 1;
     constexpr int T = NC <= 16 ? 1 : 2;
@@ -196,7 +198,7 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = cand ? p->d_intr_c : p->d_intr; a.poses = cand ? p->d_poses_c : p->d_poses; a.extr = cand ? p->d_extr_c : p->d_extr;
     a.huber_delta = p->huber_delta;
-    ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf];
+    ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf]; ga.stop = w->flags + 3;
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
 }
 
@@ -225,11 +227,9 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
     double* Baug = acc + RB;
     double* Cm = Baug + 6 * K1;
     double* Ym = Cm + 36;
-    double* hdiag = acc + K1 * K1;
-    double* gcv = hdiag + K;
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
     wave_sync_lds();
-    if (gw >= a.n_pw) return;
+    if (gw >= a.n_pw || a.flags[3]) return;
 
     for (int s = gw; s < a.n_slots; s += a.n_pw) {
         const int o0 = a.slot_off[s], o1 = a.slot_off[s + 1];
@@ -246,24 +246,46 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
             const int Pe = a.caminfo[cam * 4 + 0], ct = a.caminfo[cam * 4 + 1], ce = a.caminfo[cam * 4 + 2], NCP = a.caminfo[cam * 4 + 3];
             const int D = Pe + (cam > 0 ? 12 : 6), NC = D + 1;
             const double* Go = a.G + a.goff[o];
-            for (int e = lane; e < NC * NC; e += 64) {
-                const int i = e / NC, j = e - i * NC;
+            // all of this lane's Gram entries first (NC <= 22: at most 8 per lane), one memory latency per frame
+            constexpr int GV = (22 * 22 + 63) / 64;
+            double gv[GV];
+            const float rnc = 1.0f / (float)NC;          // e / NC for e < 4096 without the integer-division sequence
+#pragma unroll
+            for (int t = 0; t < GV; ++t) {
+                const int e = lane + 64 * t;
+                const int i = (int)(((float)e + 0.5f) * rnc), j = e - i * NC;
+                // k_gram leaves the whole 16 x 16 tile (T = 1) or the block-upper three tiles (T = 2, NCP = 32):
+                // read along rows (coalesced) except in the missing lower-left tile
+                gv[t] = e < NC * NC ? ((i >= 16 && j < 16) ? Go[j * NCP + i] : Go[i * NCP + j]) : 0.0;
+            }
+#pragma unroll
+            for (int t = 0; t < GV; ++t) {
+                const int e = lane + 64 * t;
+                if (e >= NC * NC) continue;
+                const int i = (int)(((float)e + 0.5f) * rnc), j = e - i * NC;
                 // local column -> (kind, index): kind 0 = camera-system column (r maps to K), 1 = pose
                 int ki, ii, kj, jj;
                 if (i < Pe) { ki = 0; ii = ct + i; } else if (i < Pe + 6) { ki = 1; ii = i - Pe; } else if (i < D) { ki = 0; ii = ce + (i - Pe - 6); } else { ki = 0; ii = K; }
                 if (j < Pe) { kj = 0; jj = ct + j; } else if (j < Pe + 6) { kj = 1; jj = j - Pe; } else if (j < D) { kj = 0; jj = ce + (j - Pe - 6); } else { kj = 0; jj = K; }
-                if (ki == 0 && kj == 1) continue;
-                const double g = Go[min(i, j) * NCP + max(i, j)];
+                // one destination (+ at most one extra) per entry, added with LDS atomics (ds_add_f64, nothing to wait
+                // for): the branchy read-modify-write version serialised three divergent LDS round trips per entry.
+                // Within one observation frame every address receives exactly one addend, so the sums stay ordered.
+                int off = -1, xoff = -1;
                 if (ki == 0) {
-                    acc[ii * K1 + jj] += g;
-                    if (i == j && ii < K) hdiag[ii] += g;
-                    if (jj == K && ii < K) gcv[ii] += g;
-                    if (ii == K && jj == K) acc[RB - 1] += g;            // cost = sum rho' s
+                    if (kj == 0) {
+                        off = ii * K1 + jj;
+                        if (i == j && ii < K) xoff = K1 * K1 + ii;                    // hdiag
+                        else if (jj == K && ii < K) xoff = K1 * K1 + K + ii;           // g_c
+                        else if (ii == K && jj == K) xoff = RB - 1;                    // cost = sum rho' s
+                    }
                 } else if (kj == 0) {
-                    Baug[ii * K1 + jj] += g;
+                    off = RB + ii * K1 + jj;                                           // Baug
                 } else {
-                    Cm[ii * 6 + jj] += g;
+                    off = RB + 6 * K1 + ii * 6 + jj;                                   // Cm
                 }
+                const double g = gv[t];
+                if (off >= 0) __hip_atomic_fetch_add(acc + off, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (xoff >= 0) __hip_atomic_fetch_add(acc + xoff, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_sync_lds();
         }
@@ -312,12 +334,13 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
         if (lane < 6) { pf[21 + 6 * K1 + lane] = Baug[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dC[lane]; }
         wave_sync_lds();
         // A -= Y^T Y
+        const float rk1 = 1.0f / (float)K1;
         for (int e = lane; e < K1 * K1; e += 64) {
-            const int i = e / K1, j = e - i * K1;
+            const int i = (int)(((float)e + 0.5f) * rk1), j = e - i * K1;
             double t = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
-            acc[e] -= t;
+            __hip_atomic_fetch_add(acc + e, -t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         wave_sync_lds();
     }
@@ -358,8 +381,9 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw, double* red) {
+__global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw, double* red, const int32_t* stop) {
     __shared__ double sh[4];
+    if (*stop) return;
     const double* src = partial + (int64_t)blockIdx.x * n_pw;
     double v = 0.0;
     for (int i = threadIdx.x; i < n_pw; i += 256) v += src[i];
@@ -368,23 +392,49 @@ __global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw,
 }
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw, w->red);
+    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw, w->red, w->flags + 3);
     return hipGetLastError();
 }
 
 // scal[0] = sum_o cost_o, scal[1] = sum_s mc_slot   (block 0 / block 1)
-__global__ __launch_bounds__(256) void k_sum2(const double* a, int na, const double* b, int nb, double* out) {
+__global__ __launch_bounds__(256) void k_sum2(const double* a, int na, const double* b, int nb, double* out, const int32_t* flags) {
     __shared__ double sh[4];
+    if (flags[3]) return;
     const double* src = blockIdx.x == 0 ? a : b;
     const int n = blockIdx.x == 0 ? na : nb;
-    double v = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) v += src[i];
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {          // eight loads in flight per thread; fixed order
+        v0 += src[i];           v1 += src[i + 256];     v2 += src[i + 2 * 256]; v3 += src[i + 3 * 256];
+        v4 += src[i + 4 * 256]; v5 += src[i + 5 * 256]; v6 += src[i + 6 * 256]; v7 += src[i + 7 * 256];
+    }
+    for (; i < n; i += 256) v0 += src[i];
+    const double v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
     const double t = block_sum_256(v, sh);
-    if (threadIdx.x == 0) out[blockIdx.x] = t;
+    // a failed linear solve on this rank poisons the cost: the all-reduce of a sharded solve carries the NaN to
+    // every rank, so all of them reject (LM) or stop (GN) at the same iteration
+    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x == 0 && (flags[0] | flags[1])) ? __builtin_nan("") : t;
 }
 hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal);
+    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal, w->flags);
+    return hipGetLastError();
+}
+
+// Gauss-Newton stop test on the device, mirroring the host's (tiny-solver's rules): it only makes the iteration
+// that was enqueued ahead of the host's decision free.  scal[4] keeps the previous cost.
+__global__ void k_gn_decide(double* scal, int32_t* flags, int init, double min_error, double min_abs, double min_rel) {
+    if (flags[3]) return;
+    const double cur = scal[0];
+    if (init) { scal[4] = cur; if (!(fabs(cur) <= 1.7976931348623157e308)) flags[3] = 1; return; }
+    if (flags[0] || flags[1]) { flags[3] = 1; return; }
+    const double last = scal[4];
+    scal[4] = cur;
+    if (cur < min_error || cur != cur || fabs(last - cur) < min_abs || fabs(last - cur) / last < min_rel) flags[3] = 1;
+}
+hipError_t launch_gn_decide(const ccal_problem* p, bool init, double min_error, double min_abs, double min_rel, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    hipLaunchKernelGGL(k_gn_decide, dim3(1), dim3(1), 0, s, w->scal, w->flags, init ? 1 : 0, min_error, min_abs, min_rel);
     return hipGetLastError();
 }
 
@@ -405,56 +455,76 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a) {
     const int K = a.K, K1 = K + 1, lane = threadIdx.x;
     const double* hdiag = a.red + K1 * K1;
     const double* gc = hdiag + K;
+    if (a.flags[3]) return;
+    __shared__ int fxs[CCAL_KMAX];
+    ColInfo ci = {};
+    if (lane < K) { ci = a.cols[lane]; fxs[lane] = ci.fixed; }
     if (lane == 0) bad = 0;
     for (int e = lane; e < a.n_intr; e += 64) a.intr_c[e] = a.intr[e];
     for (int e = lane; e < a.n_extr; e += 64) a.extr_c[e] = a.extr[e];
+    const double rhs = lane < K ? a.red[lane * K1 + K] : 0.0;
+    const double hd = lane < K ? hdiag[lane] : 0.0, gcl = lane < K ? gc[lane] : 0.0;
+    const double xsrc = lane < K ? (ci.is_extr ? a.extr : a.intr)[ci.dst] : 0.0;
+    __syncthreads();
+#pragma unroll 4
     for (int e = lane; e < K * K; e += 64) {
         const int i = e / K, j = e - i * K;
         double v = a.red[i * K1 + j];
-        const bool fi = a.cols[i].fixed != 0, fj = a.cols[j].fixed != 0;
-        if (fi || fj) v = (i == j) ? 1.0 : 0.0;
-        else if (i == j && a.lambda > 0.0) v += a.lambda * clampd(hdiag[i], a.min_diag, a.max_diag);
+        if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
         S[i * (CCAL_KMAX + 1) + j] = v;
     }
-    if (lane < K) x[lane] = a.cols[lane].fixed ? 0.0 : -a.red[lane * K1 + K];
     __syncthreads();
-    // right-looking Cholesky, one lane per row
+    if (lane < K && !ci.fixed && a.lambda > 0.0) S[lane * (CCAL_KMAX + 1) + lane] += a.lambda * clampd(hd, a.min_diag, a.max_diag);
+    if (lane < K) x[lane] = ci.fixed ? 0.0 : -rhs;
+    __syncthreads();
+    // left-looking Cholesky, lane i owns row i: t = S[i][j] - sum_{k<j} L[i][k] L[j][k] (no stores inside the sum,
+    // so the LDS reads pipeline), the pivot travels by shuffle; one barrier per column.  Same operation order as
+    // the right-looking form.
+    constexpr int LD = CCAL_KMAX + 1;
     for (int j = 0; j < K; ++j) {
-        const double piv = S[j * (CCAL_KMAX + 1) + j];
-        if (!(piv > 0.0) || !(piv < 1.7e308)) { if (lane == 0) bad = 1; }
-        __syncthreads();
-        if (bad) break;
-        const double inv = 1.0 / sqrt(piv);
-        if (lane == j) S[j * (CCAL_KMAX + 1) + j] = sqrt(piv);
-        if (lane > j && lane < K) S[lane * (CCAL_KMAX + 1) + j] *= inv;
-        __syncthreads();
-        if (lane > j && lane < K) {
-            const double lij = S[lane * (CCAL_KMAX + 1) + j];
-            for (int k = j + 1; k <= lane; ++k) S[lane * (CCAL_KMAX + 1) + k] -= lij * S[k * (CCAL_KMAX + 1) + j];
+        double t = 0.0;
+        if (lane >= j && lane < K) {
+            t = S[lane * LD + j];
+#pragma unroll 4
+            for (int k = 0; k < j; ++k) t -= S[lane * LD + k] * S[j * LD + k];
         }
+        const double piv = __shfl(t, j, 64);
+        if (!(piv > 0.0) || !(piv < 1.7e308)) { if (lane == 0) bad = 1; break; }      // uniform
+        const double sq = sqrt(piv), inv = 1.0 / sq;
+        if (lane == j) S[j * LD + j] = sq;
+        else if (lane > j && lane < K) S[lane * LD + j] = t * inv;
         __syncthreads();
     }
+    __syncthreads();
     if (bad) {
         if (lane == 0) { a.flags[1] = 1; a.scal[2] = 0.0; }
         if (lane < K) a.dc[lane] = 0.0;
         return;
     }
-    if (lane == 0) {       // two triangular solves, K <= 64
-        for (int i = 0; i < K; ++i) { double t = x[i]; for (int k = 0; k < i; ++k) t -= S[i * (CCAL_KMAX + 1) + k] * x[k]; x[i] = t / S[i * (CCAL_KMAX + 1) + i]; }
-        for (int i = K - 1; i >= 0; --i) { double t = x[i]; for (int k = i + 1; k < K; ++k) t -= S[k * (CCAL_KMAX + 1) + i] * x[k]; x[i] = t / S[i * (CCAL_KMAX + 1) + i]; }
+    {   // two triangular solves: lane i owns x_i, the finished component travels by shuffle
+        double xi = lane < K ? x[lane] : 0.0;
+        for (int j = 0; j < K; ++j) {
+            if (lane == j) xi = xi / S[j * LD + j];
+            const double xj = __shfl(xi, j, 64);
+            if (lane > j && lane < K) xi -= S[lane * LD + j] * xj;
+        }
+        for (int j = K - 1; j >= 0; --j) {
+            if (lane == j) xi = xi / S[j * LD + j];
+            const double xj = __shfl(xi, j, 64);
+            if (lane < j) xi -= S[j * LD + lane] * xj;
+        }
+        if (lane < K) x[lane] = xi;
     }
     __syncthreads();
     double mc = 0.0;
     if (lane < K) {
-        const ColInfo ci = a.cols[lane];
         const double d = x[lane];
         a.dc[lane] = d;
-        const double Dii = a.lambda > 0.0 ? a.lambda * clampd(hdiag[lane], a.min_diag, a.max_diag) : 0.0;
+        const double Dii = a.lambda > 0.0 ? a.lambda * clampd(hd, a.min_diag, a.max_diag) : 0.0;
         if (!ci.fixed) {
-            mc = d * (Dii * d - gc[lane]);
-            const double* src = ci.is_extr ? a.extr : a.intr;
+            mc = d * (Dii * d - gcl);
             double* dst = ci.is_extr ? a.extr_c : a.intr_c;
-            double v = src[ci.dst] + d;
+            double v = xsrc + d;
             if (ci.has_bound) v = fmin(fmax(v, ci.lo), ci.hi);     // tiny-solver: max(lo).min(hi)
             dst[ci.dst] = v;
             if (ci.dst2 >= 0) dst[ci.dst2] = v;
@@ -482,9 +552,11 @@ hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, d
 struct BacksubArgs {
     const double* pf; const double* dc; const double* poses; double* poses_c; double* mc_slot;
     int32_t n_slots, K, PF; double lambda, min_diag, max_diag;
+    const int32_t* stop;
 };
 __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a) {
     __shared__ double dcs[CCAL_KMAX];
+    if (*a.stop) return;
     if (threadIdx.x < a.K) dcs[threadIdx.x] = a.dc[threadIdx.x];
     __syncthreads();
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -531,7 +603,7 @@ hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag,
     BacksubArgs a = {};
     a.pf = w->pf; a.dc = w->dc; a.poses = p->d_poses; a.poses_c = p->d_poses_c; a.mc_slot = w->mc_slot;
     a.n_slots = p->n_slots; a.K = w->K; a.PF = w->PF; a.lambda = lambda;
-    a.min_diag = min_diag; a.max_diag = max_diag;
+    a.min_diag = min_diag; a.max_diag = max_diag; a.stop = w->flags + 3;
     hipLaunchKernelGGL(k_backsub, dim3((p->n_slots + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -49,8 +49,8 @@ struct NormalWs {
     double* pf = nullptr;                      // [n_slots][PF]
     double* dc = nullptr;                      // [K]
     double* mc_slot = nullptr;                 // [n_slots]
-    double* scal = nullptr;                    // [8]: 0 cost(cand) 1 mc_p 2 mc_c
-    int32_t* flags = nullptr;                  // [4]: 0 slot Cholesky failed, 1 camera Cholesky failed
+    double* scal = nullptr;                    // [8]: 0 cost(cand) 1 mc_p 2 mc_c 4 previous cost (k_gn_decide)
+    int32_t* flags = nullptr;                  // [4]: 0 slot Cholesky failed, 1 camera Cholesky failed, 2 ticket, 3 GN loop stopped
     ColInfo* cols = nullptr;                   // [K]
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
@@ -82,6 +82,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s);
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s);
 hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s);
+hipError_t launch_gn_decide(const ccal_problem* p, bool init, double min_error, double min_abs, double min_rel, hipStream_t s);
 hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s);   // scal[0] = sum cost_o[gbuf], scal[1] = sum mc_slot
 
 }  // namespace ccal

@@ -104,7 +104,8 @@ int normal_ws_ensure(ccal_problem* p) {
     p->nws = w;
     w->K = p->K; w->RB = red_size(p->K); w->PF = pf_size(p->K);
     // persistent Schur waves: at most 2 workgroups per CU worth, never more than slots
-    int n_pw = std::min(std::max(p->n_slots, 1), 2048);
+    const char* env_sw = std::getenv("CCAL_SCHUR_WAVES");
+    int n_pw = std::min(std::max(p->n_slots, 1), env_sw ? std::max(4, std::atoi(env_sw)) : 2048);
     n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     w->n_pw = n_pw;
     std::vector<int64_t> goff(p->n_obs);
@@ -453,7 +454,66 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
     if (!std::isfinite(cur)) status = CCAL_ERR_NONFINITE;
     bool need_system = true;      // red must be (re)built from G[cur] with the current lambda
 
-    for (int it = 0; status == CCAL_OK && it < o->max_iterations; ++it) {
+    if (!lm && status == CCAL_OK) {
+        // Gauss-Newton accepts every step, so iteration i+1 can be enqueued before the host has seen the cost of
+        // iteration i: the GPU never waits for the host, which only decides when to stop.  Exactly one iteration
+        // is enqueued ahead (a fixed rule: sharded ranks issue identical collective sequences); its candidate
+        // goes to the buffers of x_{i-1}, so stopping at iteration i leaves x_{i+1} of that iteration intact.
+        hipEvent_t ev[2];
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
+        struct EvGuard { hipEvent_t* e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } evg{ ev };
+        auto enqueue_iter = [&](int slot) -> int {
+            int r = enqueue_reduce_system(p, w->cur, 0.0, min_d, max_d);
+            if (r != CCAL_OK) return r;
+            HIP_TRY(ctx, launch_solve(p, 0.0, min_d, max_d, st));
+            HIP_TRY(ctx, launch_backsub(p, 0.0, min_d, max_d, st));
+            const int cand = w->cur ^ 1;
+            if ((r = enqueue_gram(p, true, cand)) != CCAL_OK) return r;
+            HIP_TRY(ctx, launch_sum_cost(p, cand, st));
+            if (p->allreduce && p->allreduce(p->allreduce_user, w->scal, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+            HIP_TRY(ctx, launch_gn_decide(p, false, o->min_error, o->min_abs_error_decrease, o->min_rel_error_decrease, st));
+            HIP_TRY(ctx, hipMemcpyAsync(h + 8 * slot, w->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(h + 8 * slot + 4, w->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipEventRecord(ev[slot], st));
+            std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+            w->cur = cand;
+            return CCAL_OK;
+        };
+        auto undo_last = [&]() {
+            std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+            w->cur ^= 1;
+        };
+        HIP_TRY(ctx, launch_gn_decide(p, true, 0.0, 0.0, 0.0, st));
+        if ((rc = enqueue_iter(0)) != CCAL_OK) return rc;
+        for (int it = 0; it < o->max_iterations; ++it) {
+            const bool ahead = it + 1 < o->max_iterations;
+            if (ahead && (rc = enqueue_iter((it + 1) & 1)) != CCAL_OK) return rc;
+            HIP_TRY(ctx, hipEventSynchronize(ev[it & 1]));
+            const double* hs = h + 8 * (it & 1);
+            const int32_t* hf = reinterpret_cast<const int32_t*>(hs + 4);
+            R.iterations++;
+            bool stop = false;
+            if (hf[0] || hf[1]) {            // solve failed -> None; the step of this iteration is not applied
+                status = CCAL_ERR_NOT_PD; ctx->err = "normal equations are not positive definite";
+                undo_last();
+                stop = true;
+            } else {
+                const double last = cur;
+                cur = hs[0];
+                if (o->verbose) std::printf("[ccal GN] iter %d cost %.12g\n", it, cur);
+                if (cur < o->min_error) stop = true;
+                else if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; stop = true; }
+                else if (std::fabs(last - cur) < o->min_abs_error_decrease) stop = true;
+                else if (std::fabs(last - cur) / last < o->min_rel_error_decrease) stop = true;
+                else if (it == o->max_iterations - 1) status = CCAL_ERR_NO_CONVERGENCE;
+            }
+            if (stop) { if (ahead) undo_last(); break; }
+        }
+        HIP_TRY(ctx, hipMemsetAsync(w->flags + 3, 0, sizeof(int32_t), st));     // behind the (skipped) iteration enqueued ahead
+    }
+
+    for (int it = 0; lm && status == CCAL_OK && it < o->max_iterations; ++it) {
         if (need_system) {
             if ((rc = enqueue_reduce_system(p, w->cur, lambda, min_d, max_d)) != CCAL_OK) return rc;
             need_system = false;

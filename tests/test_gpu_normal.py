@@ -205,3 +205,26 @@ def test_solve_fused_tail_opt_in(gpu_ctx, oracle, method, monkeypatch):
     assert abs(out[3].final_cost - ref[3].final_cost) <= 1e-10 * ref[3].final_cost
     np.testing.assert_allclose(out[0], ref[0], rtol=1e-9, atol=0)
     np.testing.assert_allclose(out[1], ref[1], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_one_degenerate_frame_gn_not_pd_lm_recovers(gpu_ctx, fused, monkeypatch):
+    """One frame with a single corner (rank-deficient 6 x 6 pose block) among good frames: Gauss-Newton reports
+    CCAL_ERR_NOT_PD on both loops (the failed block also poisons the all-reduced cost, so every rank of a sharded
+    solve stops in the same iteration); Levenberg-Marquardt damps the block and converges."""
+    from camera_intrinsic_calibration_rs_amd.engine import make_desc
+    if not fused:
+        monkeypatch.setenv("CCAL_DISABLE_FUSED", "1")
+    sp = synth.make_problem(12, "eucm")
+    offs = sp.obs_offsets.copy()
+    keep_idx = np.concatenate([np.arange(offs[0], offs[5]), [offs[5]], np.arange(offs[6], offs[-1])])
+    new_offs = np.concatenate([offs[:6], offs[6:] - (offs[6] - offs[5] - 1)]).astype(np.int64)
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, 12, [0] * 12, list(range(12)), new_offs,
+                        sp.p3d[keep_idx, 0], sp.p3d[keep_idx, 1], sp.p3d[keep_idx, 2], sp.p2d[keep_idx, 0], sp.p2d[keep_idx, 1], 1.0)
+    gp = Problem(gpu_ctx, d, keep)
+    with pytest.raises(CcalError) as ei:
+        gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
+    assert ei.value.code == _ffi.ERR_NOT_PD
+    intr, _, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    assert rep.status == _ffi.OK
+    assert (np.abs(intr[0, :4] / sp.intr_gt[0, :4] - 1)).max() < 5e-3
