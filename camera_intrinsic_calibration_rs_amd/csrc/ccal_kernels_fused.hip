@@ -17,6 +17,7 @@
 // Same arithmetic and decision sequence as the general loop in ccal_solver.hip (multi-camera problems,
 // sharded LM); parity tests cover both.
 #include <algorithm>
+#include <cstdlib>
 
 #include "ccal_device.hpp"
 #include "ccal_fused.hpp"
@@ -436,31 +437,263 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     }
 }
 
+// k_gram1w: k_gram1v with two wavefronts per SIMD.  k_gram1v needs 256 VGPRs + 66 AGPRs (91 accumulators and the
+// hoisted frame constants), i.e. one wavefront per SIMD and nothing to hide the f64 dependency stalls behind.
+// Here the 6 K camera x pose accumulators of every lane live in LDS ([entry][lane], stride 65: conflict-free both
+// for the lane-private ds_add_f64 of the corner loop - fire and forget, nothing waits on it - and for the column
+// sums afterwards), and the frame constants are re-read from LDS every corner instead of being hoisted.
 template <int MODEL, bool OF, int LPF>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedArgs a) {
+    constexpr int G = 64 / LPF;                     // frames per wavefront
+    constexpr int D = block_dim(MODEL, OF, false);
+    constexpr int K = D - 6, K1 = K + 1;
+    constexpr int NC = D + 1;                       // columns of [J | r]
+    constexpr int NE = NC * (NC + 1) / 2;           // upper triangle
+    constexpr int NL = 6 * K;                       // camera x pose entries: LDS accumulators
+    constexpr int NR = NE - NL;                     // the rest: registers
+    constexpr int LSA = 65;                         // lane stride of an LDS accumulator row
+    constexpr int HALF = (NR + 1) / 2;              // register entries reduced per LDS round
+    constexpr int LS = HALF | 1;                    // odd row stride (doubles): conflict-free column sums
+    constexpr int RED = NL * LSA > 64 * LS ? NL * LSA : 64 * LS;
+    constexpr int WSL = G * 40 + RED;               // per wave: G frames' constants | accumulators / reduction buffer
+    constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
+    constexpr int NQA = (G * NL + 63) / 64;
+    extern __shared__ double smem[];
+    const DevState* st = a.st;
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane / LPF, gl = lane % LPF;
+    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
+    const bool active = f < a.n_obs;
+    const int fa_ = active ? f : 0;
+    double* fcw = smem + wave * WSL;
+    double* fc = fcw + grp * 40;
+    double* red = fcw + G * 40;
+    const int cur = st->cur, first = st->first;
+    const int es = first ? cur : (cur ^ 1);
+    const double* th_g = a.intr[es];
+    double th[model_np(MODEL)];
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (OF) th[1] = th[0];
+    const int64_t start = a.obs_off[fa_];
+    const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
+    float pX, pY, pZ, pU, pV;
+    {
+        const int64_t g0 = start + (gl < n ? gl : 0);
+        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+    }
+    {
+        // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants;
+        // the 16 lanes of a group compute the same values, the 4 groups work on 4 frames at once
+        const int slot = a.obs_slot[fa_];
+        double pose[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+        double mc = 0.0;
+        if (!first) {
+            const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+            if (pf[0] != 0.0) {
+                double dp[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double* yr = pf + 21 + i * K1;
+                    double t = yr[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                    dp[i] = -t;
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double t = dp[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+                    dp[i] = t * pf[i * (i + 1) / 2 + i];
+                }
+                const double lam = st->lambda_solve;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
+                    const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
+                    mc += dp[i] * (Dii * dp[i] - gp);
+                    pose[i] += dp[i];
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+            }
+        }
+        if (active && gl == 0) a.mc_f[f] = mc;
+        double fcr[39];
+        frame_setup<false>(pose, nullptr, fcr);
+        if (gl == 0) {
+#pragma unroll
+            for (int i = 0; i < 39; ++i) fc[i] = fcr[i];
+        }
+    }
+    wsync();
+
+    double acc[NR];
+#pragma unroll
+    for (int e = 0; e < NR; ++e) acc[e] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NL; ++t) red[t * LSA + lane] = 0.0;
+    // same trip count for the whole wave: the largest frame of the four
+    int nmax = n;
+#pragma unroll
+    for (int off = LPF; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    for (int base = 0; base < nmax; base += LPF) {
+        asm volatile("" ::: "memory");      // frame constants stay in LDS: no 78 registers of hoisted copies
+        const int c = base + gl;
+        const bool valid = c < n;
+        const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
+        if (base + LPF < nmax) {
+            const int cn = base + LPF + gl;
+            const int64_t gn = start + (cn < n ? cn : 0);
+            pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+        }
+        double ru, rv, J[2 * D];
+        corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
+        // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
+        double su[NC], sv[NC];
+#pragma unroll
+        for (int i = 0; i < D; ++i) { su[i] = sw * J[i]; sv[i] = sw * J[D + i]; }
+        su[D] = sw * ru; sv[D] = sw * rv;
+        int e = 0, el = 0;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+#pragma unroll
+            for (int j = i; j < NC; ++j) {
+                const bool bu = (i >= K || nz_u<OF>(i)) && (j >= K || nz_u<OF>(j));
+                const bool bv = (i >= K || nz_v<OF>(i)) && (j >= K || nz_v<OF>(j));
+                if (i < K && j >= K && j < D) {          // camera x pose: LDS accumulator of this lane
+                    double t = bu ? su[i] * su[j] : 0.0;
+                    if (bv) t = __builtin_fma(sv[i], sv[j], t);
+                    __hip_atomic_fetch_add(red + el * LSA + lane, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    ++el;
+                } else {
+                    if (bu) acc[e] = __builtin_fma(su[i], su[j], acc[e]);
+                    if (bv) acc[e] = __builtin_fma(sv[i], sv[j], acc[e]);
+                    ++e;
+                }
+            }
+        }
+    }
+    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
+    // camera x pose: LPF lane-private LDS sums per frame -> record  [B|g][pose j][camera i]
+    wsync();
+    {
+        double resa[NQA];
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
+            const int idx = lane + 64 * q;
+            double sum = 0.0;
+            if (idx < G * NL) {
+                const int g = idx / NL, t = idx - g * NL;
+                const double* src = red + t * LSA + g * LPF;
+#pragma unroll
+                for (int l = 0; l < LPF; ++l) sum += src[l];
+            }
+            resa[q] = sum;
+        }
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
+            const int idx = lane + 64 * q;
+            if (idx >= G * NL) continue;
+            const int g = idx / NL, t = idx - g * NL;
+            const int ff = fbase + g;
+            if (ff >= a.n_obs) continue;
+            const int i = t / 6, jp = t - 6 * i;
+            a.praw[es][(int64_t)ff * a.PRAW + 21 + jp * K1 + i] = resa[q];
+        }
+    }
+
+    // 16 partial Grams per frame -> one, through LDS, in two halves of the triangle
+    double res[2][NQ];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        wsync();
+#pragma unroll
+        for (int t = 0; t < HALF; ++t) { const int e = h * HALF + t; if (e < NR) red[lane * LS + t] = acc[e < NR ? e : 0]; }
+        wsync();
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = lane + 64 * q;                      // (group, entry) pairs
+            double sum = 0.0;
+            if (idx < G * HALF) {
+                const int g = idx / HALF, t = idx - g * HALF;
+                const double* src = red + (g * LPF) * LS + t;
+#pragma unroll
+                for (int l = 0; l < LPF; ++l) sum += src[l * LS];
+            }
+            res[h][q] = sum;
+        }
+    }
+    // scatter the upper triangle into the compact record  C (21) | [B|g] (6 x K1) | A (K1 x K1)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = lane + 64 * q;
+            if (idx >= G * HALF) continue;
+            const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
+            const int ff = fbase + g;
+            if (e >= NR || ff >= a.n_obs) continue;
+            // register entry -> (i, j): camera rows hold j = i..K-1 and j = D (their pose columns are in LDS)
+            int i = 0, rem = e;
+            while (rem >= (i < K ? K - i + 1 : NC - i)) { rem -= (i < K ? K - i + 1 : NC - i); ++i; }
+            const int j = i < K ? (rem < K - i ? i + rem : D) : i + rem;
+            const double v = res[h][q];
+            double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
+            const bool ip = i >= K && i < D, jp = j >= K && j < D;      // pose columns
+            const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
+            if (ip && jp) rec[(j - K) * (j - K + 1) / 2 + (i - K)] = v;
+            else if (!ip && jp) rec[21 + (j - K) * K1 + ci] = v;                         // i camera, j pose
+            else if (ip && !jp) rec[21 + (i - K) * K1 + K] = v;                          // i pose, j = r
+            else { rec[21 + 6 * K1 + ci * K1 + cj] = v; rec[21 + 6 * K1 + cj * K1 + ci] = v; if (i == D) a.cost_f[ff] = v; }
+        }
+    }
+}
+
+template <int MODEL, bool OF, int LPF, bool W>
 static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int G = 64 / LPF;
     constexpr int NC = block_dim(MODEL, OF, false) + 1;
-    constexpr int HALF = (NC * (NC + 1) / 2 + 1) / 2;
-    constexpr int WSL = G * 40 + 64 * (HALF | 1);
+    constexpr int NE = NC * (NC + 1) / 2, NL = 6 * (NC - 7);
+    constexpr int HALF = ((W ? NE - NL : NE) + 1) / 2;
+    constexpr int RED = (W && NL * 65 > 64 * (HALF | 1)) ? NL * 65 : 64 * (HALF | 1);
+    constexpr int WSL = G * 40 + RED;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
+    auto kern = W ? k_gram1w<MODEL, OF, LPF> : k_gram1v<MODEL, OF, LPF>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram1v<MODEL, OF, LPF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int fpb = G * CCAL_GRAMV_WPB;
-    hipLaunchKernelGGL((k_gram1v<MODEL, OF, LPF>), dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
 template <int MODEL, bool OF>
 static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // enough wavefronts to fill 1024 SIMDs: 16 lanes per frame from ~4000 frames up, a whole wave per frame
     // for TUM-VI-sized problems (a few hundred frames)
-    if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16>(a, s);
-    if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32>(a, s);
-    return launch_gram1v_l<MODEL, OF, 64>(a, s);
+    // More wavefronts than SIMDs (>= 2000 frames): k_gram1w, two wavefronts per SIMD (10 000 frames: 40 vs 53 us).
+    // Below that every wavefront has a SIMD to itself and k_gram1v's all-register accumulators are a little faster.
+    // CCAL_GRAMV_LDSACC=0|1 forces one or the other.
+    static const int force = [] { const char* e = std::getenv("CCAL_GRAMV_LDSACC"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool w = force >= 0 ? force == 1 : a.n_obs >= 2000;
+    if (w) {
+        if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16, true>(a, s);
+        if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32, true>(a, s);
+        return launch_gram1v_l<MODEL, OF, 64, true>(a, s);
+    }
+    if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16, false>(a, s);
+    if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32, false>(a, s);
+    return launch_gram1v_l<MODEL, OF, 64, false>(a, s);
 }
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
     switch (model * 2 + (one_focal ? 1 : 0)) {

@@ -12,6 +12,8 @@ ap.add_argument("--frames", type=int, default=10000)
 ap.add_argument("--model", default="eucm")
 ap.add_argument("--reps", type=int, default=100)
 ap.add_argument("--cams", type=int, default=1)
+ap.add_argument("--joff-mb", type=int, default=0, help="place J this many MiB into a larger allocation")
+ap.add_argument("--pad-mb", type=int, default=0, help="allocate (and keep) this much before the outputs")
 ap.add_argument("--one-focal", action="store_true")
 ap.add_argument("--what", default="eval,normal,solve")
 ap.add_argument("--tag", default=os.environ.get("CCAL_LIB", "default"))
@@ -32,8 +34,12 @@ def timeit(fn, reps):
     b.record(stream); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 if "eval" in args.what:
-    r = torch.empty(prob.n_corners * 2, dtype=torch.float64, device=dev); J = torch.empty(prob.j_len, dtype=torch.float64, device=dev)
-    us = min(timeit(lambda: prob.eval_dev(r.data_ptr(), J.data_ptr()), args.reps) for _ in range(3))
+    pad = torch.empty(args.pad_mb << 20, dtype=torch.uint8, device=dev) if args.pad_mb else None
+    off = (args.joff_mb << 20) // 8
+    r = torch.empty(prob.n_corners * 2, dtype=torch.float64, device=dev); J = torch.empty(prob.j_len + off, dtype=torch.float64, device=dev)
+    jp = J.data_ptr() + off * 8
+    out["J_ptr"] = hex(jp); out["r_ptr"] = hex(r.data_ptr())
+    us = min(timeit(lambda: prob.eval_dev(r.data_ptr(), jp), args.reps) for _ in range(3))
     D = prob.block_dim(0)
     out["eval_us"] = us; out["eval_GBps"] = (prob.n_corners * (36 + 16 * D) + sp.n_slots * 48) / us / 1e3
 if "normal" in args.what:
