@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of profiles/run_profile.sh (gpurun_out/prof_<tag>/) into the small files
+committed under profiles/<tag>/:
+
+  kernel_stats_bench_steps50.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --steps 50 --warmup 5`
+  pmc_summary.json                 per-kernel means of the --pmc passes + the HBM bytes per k_eval launch that
+                                   bench.py reports as roofline.traffic
+  bench_full.json                  the default `python bench.py` line of the same box
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE come from separate passes, are
+in KiB, and on gfx950 FETCH_SIZE under-reports streaming reads by 2x.
+
+    python profiles/summarize.py r01
+"""
+import csv
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name: str) -> str:
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def main() -> None:
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles", tag)
+    os.makedirs(dst, exist_ok=True)
+    shutil.copyfile(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, "kernel_stats_bench_steps50.csv"))
+    line = [l for l in open(os.path.join(src, "bench_full.json")) if l.startswith("{")][-1]
+    with open(os.path.join(dst, "bench_full.json"), "w") as f:
+        f.write(line)
+    bench = json.loads(line)
+
+    counters = defaultdict(lambda: defaultdict(list))
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+        path = os.path.join(src, sub, "pmc_counter_collection.csv")
+        if not os.path.exists(path):
+            continue
+        per_dispatch = defaultdict(float)        # a counter is reported once per XCD/instance: sum them per dispatch
+        names = {}
+        for r in csv.DictReader(open(path)):
+            if not r["Kernel_Name"].startswith(("ccal::", "void ccal::")):
+                continue
+            key = (r["Dispatch_Id"], r["Counter_Name"])
+            per_dispatch[key] += float(r["Counter_Value"])
+            names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+        for (disp, cname), v in per_dispatch.items():
+            counters[names[disp]][cname].append(v)
+
+    out_c = {}
+    for k, cs in counters.items():
+        out_c[k] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in sorted(cs.items())}
+    ev = next((k for k in out_c if k.startswith("ccal::k_eval")), None)
+    summary = {
+        "note": "rocprofv3 --pmc passes of `bench.py --steps 50 --warmup 5 --no-cpu-baseline` "
+                f"({bench['config']['workload']}); per-dispatch means. FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 "
+                "FETCH_SIZE under-reports streaming reads by 2x (MI355X_MICROARCH.md, HBM) so read bytes = "
+                "2 * FETCH_SIZE * 1024.",
+    }
+    if ev and "FETCH_SIZE" in out_c[ev] and "WRITE_SIZE" in out_c[ev]:
+        rd = 2.0 * out_c[ev]["FETCH_SIZE"]["mean"] * 1024.0
+        wr = out_c[ev]["WRITE_SIZE"]["mean"] * 1024.0
+        summary.update(k_eval_hbm_traffic_bytes_per_launch=rd + wr, k_eval_read_bytes=rd, k_eval_write_bytes=wr,
+                       k_eval_algorithmic_bytes_per_launch=bench["roofline"]["algorithmic_bytes_per_launch"])
+    summary["counters"] = out_c
+    with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print("wrote", dst, "traffic", summary.get("k_eval_hbm_traffic_bytes_per_launch"))
+
+
+if __name__ == "__main__":
+    main()
