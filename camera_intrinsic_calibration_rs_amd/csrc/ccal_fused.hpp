@@ -45,7 +45,12 @@ struct HeadArgs {
     double min_diag, max_diag;
 };
 
-hipError_t launch_prep1(const FusedArgs& a, hipStream_t s);
+struct UnpackArgs {               // staging block (doubles): [intr CCAL_PMAX | DevState | ColInfo x CCAL_KMAX | poses np6]
+    const double* stage; int64_t small_doubles, np6;
+    double* intr0; double* intr1; double* poses0; double* poses1;
+    DevState* st; ColInfo* cols; int32_t* flags;
+};
+hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // VALU Gram (<= 105 triangle entries)
 hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* fused_head, hipStream_t s);   // fused_head != NULL: last workgroup reduces + decides + solves

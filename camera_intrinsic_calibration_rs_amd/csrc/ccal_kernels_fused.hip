@@ -1,9 +1,8 @@
 // Single-camera fast path of the optimizer: the whole Gauss-Newton / LM iteration is device-resident,
 // the host only enqueues kernels and watches a status word in pinned memory.
 //
-//   k_prep1      one thread per frame: candidate pose = pose + back-substitution of the previous solve,
-//                exp-map + dR/drvec (frame constants) -> fcbuf; the Gram kernel no longer repeats this
-//                in all 64 lanes
+//   k_unpack1    distributes the one-copy staging block of a solve's starting point
+//   k_gram1v/w   16-64 lanes per frame, register (+ LDS) Gram accumulators: the default Gram kernels (see below)
 //   k_gram1      one wavefront per frame: weighted rows sqrt(w) [J | r] -> LDS (32 corners at a time)
 //                -> v_mfma_f64_16x16x4_f64 Gram -> compact record per frame:
 //                C = H_pp (21) | [B | g_p] (6 x (K+1)) | A = [J_c | r]^T W [J_c | r] ((K+1)^2)
@@ -34,63 +33,27 @@ __device__ __forceinline__ void wsync() {
 __device__ __forceinline__ double clampd1(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 // ---------------------------------------------------------------------------------------------
-// k_prep1
+// k_unpack1: the whole starting point arrives as ONE host-to-device copy of the staging block
+// [intr | DevState | ColInfo x KMAX | poses]; this kernel distributes it (both parameter sets start from the
+// caller's values, slots without observations never change) and clears the flags.  Seven stream operations
+// (five of them tiny copies at ~5 us each) became two.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prep1(const FusedArgs a) {
-    const DevState* st = a.st;
-    if (st->done) return;
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= a.n_obs) return;
-    const int K = a.K, K1 = K + 1;
-    const int cur = st->cur, first = st->first;
-    const int es = first ? cur : (cur ^ 1);
-    const int slot = a.obs_slot[f];
-    double pose[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
-    double mc = 0.0;
-    if (!first) {
-        const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
-        double L[21];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) L[i] = pf[i];
-        if (L[0] != 0.0) {
-            double dp[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double* yr = pf + 21 + i * K1;
-                double t = yr[K];
-                for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
-                dp[i] = -t;
-            }
-#pragma unroll
-            for (int i = 5; i >= 0; --i) {          // L^T x = rhs, diagonal stored inverted
-                double t = dp[i];
-#pragma unroll
-                for (int k = i + 1; k < 6; ++k) t -= L[k * (k + 1) / 2 + i] * dp[k];
-                dp[i] = t * L[i * (i + 1) / 2 + i];
-            }
-            const double lam = st->lambda_solve;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
-                const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
-                mc += dp[i] * (Dii * dp[i] - gp);
-                pose[i] += dp[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+__global__ __launch_bounds__(256) void k_unpack1(const UnpackArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
+    const double* small = a.stage;
+    const double* poses = a.stage + a.small_doubles;
+    for (int64_t e = t; e < a.np6; e += nt) { const double v = poses[e]; a.poses0[e] = v; a.poses1[e] = v; }
+    if (blockIdx.x == 0) {
+        constexpr int NS = (int)(sizeof(DevState) / sizeof(double)), NCOL = (int)(CCAL_KMAX * sizeof(ColInfo) / sizeof(double));
+        for (int e = threadIdx.x; e < CCAL_PMAX; e += 256) { a.intr0[e] = small[e]; a.intr1[e] = small[e]; }
+        for (int e = threadIdx.x; e < NS; e += 256) reinterpret_cast<double*>(a.st)[e] = small[CCAL_PMAX + e];
+        for (int e = threadIdx.x; e < NCOL; e += 256) reinterpret_cast<double*>(a.cols)[e] = small[CCAL_PMAX + NS + e];
+        if (threadIdx.x < 4) a.flags[threadIdx.x] = 0;
     }
-    a.mc_f[f] = mc;
-    double fcr[39];
-    frame_setup<false>(pose, nullptr, fcr);
-    double* dst = a.fcbuf + (int64_t)f * 40;
-#pragma unroll
-    for (int i = 0; i < 39; ++i) dst[i] = fcr[i];
 }
-hipError_t launch_prep1(const FusedArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_prep1, dim3((a.n_obs + 255) / 256), dim3(256), 0, s, a);
+hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s) {
+    const int blocks = (int)std::min<int64_t>(std::max<int64_t>((a.np6 + 255) / 256, 1), 1024);
+    hipLaunchKernelGGL(k_unpack1, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -685,7 +648,9 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // Below that every wavefront has a SIMD to itself and k_gram1v's all-register accumulators are a little faster.
     // CCAL_GRAMV_LDSACC=0|1 forces one or the other.
     static const int force = [] { const char* e = std::getenv("CCAL_GRAMV_LDSACC"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
-    const bool w = force >= 0 ? force == 1 : a.n_obs >= 2000;
+    constexpr int NCt = block_dim(MODEL, OF, false) + 1;
+    // larger triangles (KB4) do not fit two wavefronts per SIMD without scratch: k_gram1v there
+    const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 105);
     if (w) {
         if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16, true>(a, s);
         if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32, true>(a, s);

@@ -69,7 +69,10 @@ struct FusedWs {
     double* cost_f = nullptr;                  // [n_obs] cost of each frame
     struct DevState* d_state = nullptr;
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
-    double* h_stage = nullptr;                 // pinned staging [poses | intr | state | cols]
+    double* h_stage = nullptr;                 // pinned staging [intr | state | cols | poses]
+    double* d_stage = nullptr;                 // its device image (one copy per solve, k_unpack1 distributes it)
+    hipStream_t side = nullptr;                // result download: does not queue behind the early-exit groups
+    bool tail_pending = false;                 // early-exit groups of the previous solve may still be in flight
 };
 
 void normal_ws_destroy(ccal_problem* p);

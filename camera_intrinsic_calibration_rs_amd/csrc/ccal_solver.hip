@@ -49,6 +49,8 @@ void normal_ws_destroy(ccal_problem* p) {
         for (void* q : fp) if (q) (void)hipFree(q);
         if (f->h_status) (void)hipHostFree(f->h_status);
         if (f->h_stage) (void)hipHostFree(f->h_stage);
+        if (f->d_stage) (void)hipFree(f->d_stage);
+        if (f->side) (void)hipStreamDestroy(f->side);
         delete f;
     }
     delete w;
@@ -83,8 +85,10 @@ static int fused_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMemset(f->red, 0, (size_t)(f->RB1 + 7) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->d_state, sizeof(DevState)));
     HIP_TRY(ctx, hipHostMalloc((void**)&f->h_status, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
-    HIP_TRY(ctx, hipHostMalloc((void**)&f->h_stage, ns * 6 * sizeof(double) + CCAL_PMAX * sizeof(double) + sizeof(DevState) +
-                                                      CCAL_KMAX * sizeof(ColInfo) + 64, hipHostMallocDefault));
+    const size_t stage_bytes = ns * 6 * sizeof(double) + CCAL_PMAX * sizeof(double) + sizeof(DevState) + CCAL_KMAX * sizeof(ColInfo) + 64;
+    HIP_TRY(ctx, hipHostMalloc((void**)&f->h_stage, stage_bytes, hipHostMallocDefault));
+    HIP_TRY(ctx, hipMalloc((void**)&f->d_stage, stage_bytes));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
     std::memset((void*)f->h_status, 0, sizeof(HostStatus));
     return CCAL_OK;
 }
@@ -223,26 +227,26 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     hs0.lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
     hs0.min_error = o->min_error; hs0.min_abs = o->min_abs_error_decrease; hs0.min_rel = o->min_rel_error_decrease;
     hs0.cur = 0; hs0.first = 1; hs0.done = 0; hs0.iter = 0; hs0.max_iter = o->max_iterations; hs0.method = o->method;
-    // one pinned staging block [poses | intr | state | cols]: every upload is a true async copy, no host sync;
-    // both parameter sets start from the caller's values (slots without observations never change)
+    // one pinned staging block [intr | state | cols | poses] -> ONE async copy -> k_unpack1 (both parameter sets start
+    // from the caller's values; slots without observations never change)
+    static_assert(sizeof(ColInfo) % 8 == 0, "ColInfo is staged as doubles");
+    if (f->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); f->tail_pending = false; }   // stale k_head must not publish into this solve
     const size_t np6 = (size_t)p->n_slots * 6;
-    double* h_poses = f->h_stage;
-    double* h_intr = h_poses + np6;
+    const size_t small_doubles = CCAL_PMAX + sizeof(DevState) / sizeof(double) + CCAL_KMAX * sizeof(ColInfo) / sizeof(double);
+    double* h_intr = f->h_stage;
     DevState* h_state = reinterpret_cast<DevState*>(h_intr + CCAL_PMAX);
     ColInfo* h_cols = reinterpret_cast<ColInfo*>(h_state + 1);
+    double* h_poses = f->h_stage + small_doubles;
     std::memcpy(h_poses, poses_io, np6 * sizeof(double));
     std::memcpy(h_intr, intr_io, CCAL_PMAX * sizeof(double));
     *h_state = hs0;
     build_cols(p, h_cols);
-    if (np6) {
-        HIP_TRY(ctx, hipMemcpyAsync(p->d_poses, h_poses, np6 * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(ctx, hipMemcpyAsync(p->d_poses_c, h_poses, np6 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->d_stage, f->h_stage, (small_doubles + np6) * sizeof(double), hipMemcpyHostToDevice, st));
+    {
+        UnpackArgs ua = { f->d_stage, (int64_t)small_doubles, (int64_t)np6, p->d_intr, p->d_intr_c, p->d_poses, p->d_poses_c,
+                          f->d_state, w->cols, w->flags };
+        HIP_TRY(ctx, launch_unpack1(ua, st));
     }
-    HIP_TRY(ctx, hipMemcpyAsync(p->d_intr, h_intr, CCAL_PMAX * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(p->d_intr_c, h_intr, CCAL_PMAX * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(f->d_state, h_state, sizeof(DevState), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(w->cols, h_cols, CCAL_KMAX * sizeof(ColInfo), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
     HostStatus* hst = f->h_status;
     hst->seq = 0; hst->done = 0;
 
@@ -269,11 +273,12 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
     ha.min_diag = o->lm_min_diagonal; ha.max_diag = o->lm_max_diagonal;
     const int model = p->cams[0].model;
-    // register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR file next to the row math
-    // (UCM / EUCM, one-focal KB4); matrix-core Gram otherwise.  CCAL_GRAM=mfma|valu overrides.
+    // register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR/AGPR file next to the row math
+    // (measured at 10 000 frames, GN solve: KB4 0.58 vs 0.60 ms, OPENCV5 0.59 vs 0.55 ms); matrix-core Gram
+    // otherwise.  CCAL_GRAM=mfma|valu overrides.
     const int ncols = p->cams[0].D + 1;
-    bool use_valu_gram = ncols * (ncols + 1) / 2 <= 105;
-    if (const char* g = std::getenv("CCAL_GRAM")) use_valu_gram = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 120;
+    bool use_valu_gram = ncols * (ncols + 1) / 2 <= 120;      // UCM, EUCM, KB4; OPENCV5 (136 entries) is faster on the matrix cores
+    if (const char* g = std::getenv("CCAL_GRAM")) use_valu_gram = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 136;
     int seq = 0;
     auto enqueue = [&]() -> int {         // one evaluation + decision + solve; returns the seq that marks its end
         if (use_valu_gram) HIP_TRYN(ctx, launch_gram1v(model, p->one_focal, fa, st));
@@ -349,7 +354,12 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         if (hst->done) { status = hst->done - 1; finished = true; }
         else if (o->verbose) std::printf("[ccal fused %s] iter %d cost %.12g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost);
     }
-    HIP_TRY(ctx, hipStreamSynchronize(st));          // drains the speculative (early-exit) groups; the last k_head has published
+    // hst->done was published by the last instruction of the deciding k_head (after a system-scope fence): everything
+    // the result depends on is complete.  The download goes through a side stream so that it does not queue behind
+    // the (at most two) early-exit groups still in the main stream; the next solve drains those before it starts.
+    hipStream_t dl = st;
+    if (hst->done && !pending.empty()) { dl = f->side; f->tail_pending = true; }
+    else HIP_TRY(ctx, hipStreamSynchronize(st));
     struct { int done, iter, cur, acc, rej; double cur_cost, initial_cost; } ds =
         { hst->done, hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->cur_cost, hst->initial_cost };
     if (!ds.done) { status = CCAL_ERR_NO_CONVERGENCE; }
@@ -358,9 +368,9 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     ccal_report R = {};
     R.status = status; R.iterations = ds.iter; R.lm_accepted = ds.acc; R.lm_rejected = ds.rej;
     R.initial_cost = ds.initial_cost; R.final_cost = ds.cur_cost;
-    if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));
+    HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, dl));
+    HIP_TRY(ctx, hipStreamSynchronize(dl));
     std::memcpy(poses_io, h_poses, np6 * sizeof(double));
     std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
     if (p->one_focal) intr_io[1] = intr_io[0];           // fy = f (src/util.rs:467-470)
