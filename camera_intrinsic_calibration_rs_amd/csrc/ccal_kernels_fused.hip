@@ -711,6 +711,8 @@ struct HeadShared {               // LDS of the decision / solve step
     double red[2 * 100 + 2];
     double S[10 * 11];
     double x[10];
+    double cur_intr[CCAL_PMAX];   // current intrinsics (full layout)
+    int fx[10];                   // fixed flags of the camera columns
     int bad;
 };
 __device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
@@ -719,8 +721,7 @@ __device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState
     hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
     hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
     __threadfence_system();
-    hs->seq = a.seq;
-    __threadfence_system();
+    hs->seq = a.seq;                 // the host polls this word; kernel completion flushes it at the latest
 }
 
 __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red);
@@ -935,7 +936,7 @@ hipError_t launch_cost1(const FusedArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_head: one wavefront.  phase bit 0 = decide (accept / reject / stop), bit 1 = solve.
+// k_head: one wavefront.  phase bit 0 = decide (accept / reject / stop), bit 1 = solve, bit 2 = do not publish.
 // red = [A_dir (K1*K1) | Y^T Y (K1*K1) | cost | mc_pose]
 // The optimizer state is staged in LDS once (the global copy is touched twice per launch).
 // ---------------------------------------------------------------------------------------------
@@ -996,11 +997,20 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
     double* red = hs.red; double* S = hs.S; double* x = hs.x; int& bad = hs.bad;
     const int K = a.K, K1 = K + 1;
     const int lane = threadIdx.x < 64 ? (int)threadIdx.x : (1 << 28);      // other waves only keep the barriers company
+    // everything the solve phase needs from global memory is requested up front, next to the state: one memory
+    // latency instead of a chain of three (state -> column info -> intrinsics)
+    ColInfo ci = {};
+    double intr_a = 0.0, intr_b = 0.0;
+    if (a.phase & 2) {
+        if (lane < K) ci = a.cols[lane];
+        if (lane < CCAL_PMAX) { intr_a = a.intr[0][lane]; intr_b = a.intr[1][lane]; }
+    }
     {   // stage state (+ reduced sums)
         const double* src = reinterpret_cast<const double*>(a.st);
         double* dst = reinterpret_cast<double*>(&S0);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
         if (stage_red) for (int e = lane; e < 2 * K1 * K1 + 2; e += 64) red[e] = a.red[e];
+        if (lane < K) hs.fx[lane] = ci.fixed;
     }
     __syncthreads();
     DevState* st = &S0;
@@ -1072,12 +1082,12 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
         for (int e = lane; e < K * K; e += 64) {
             const int i = e / K, j = e - i * K;
             double v = Ad[i * K1 + j] - Yt[i * K1 + j];
-            const bool fi = a.cols[i].fixed != 0, fj = a.cols[j].fixed != 0;
+            const bool fi = hs.fx[i] != 0, fj = hs.fx[j] != 0;
             if (fi || fj) v = (i == j) ? 1.0 : 0.0;
             else if (i == j && lambda > 0.0) v += lambda * clampd1(Ad[i * K1 + i], a.min_diag, a.max_diag);
             S[i * 11 + j] = v;
         }
-        if (lane < K) x[lane] = a.cols[lane].fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
+        if (lane < K) x[lane] = ci.fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
         __syncthreads();
         // K <= 9: Cholesky + both triangular solves in registers (every lane the same wave-uniform work, no
         // LDS round trips or barriers inside the factorisation)
@@ -1104,20 +1114,18 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
         }
         if (!bad || lm) {
             // candidate intrinsics = clamp(x + dc) into the other set; model decrease of the camera block
-            const double* src = a.intr[cur];
             double* dst = a.intr[cur ^ 1];
-            double keep = lane < CCAL_PMAX ? src[lane] : 0.0;
-            if (lane < CCAL_PMAX) dst[lane] = keep;
+            const double keep = cur ? intr_b : intr_a;          // current intrinsics, full layout, element `lane`
+            if (lane < CCAL_PMAX) { dst[lane] = keep; hs.cur_intr[lane] = keep; }
             __syncthreads();
             double mc = 0.0;
             if (lane < K && !bad) {
-                const ColInfo ci = a.cols[lane];
                 const double d = x[lane];
                 a.dc[lane] = d;
                 const double Dii = lambda > 0.0 ? lambda * clampd1(Ad[lane * K1 + lane], a.min_diag, a.max_diag) : 0.0;
                 if (!ci.fixed) {
                     mc = d * (Dii * d - Ad[lane * K1 + K]);
-                    double v = src[ci.dst] + d;
+                    double v = hs.cur_intr[ci.dst] + d;
                     if (ci.has_bound) v = fmin(fmax(v, ci.lo), ci.hi);
                     dst[ci.dst] = v;
                     if (ci.dst2 >= 0) dst[ci.dst2] = v;
@@ -1135,7 +1143,9 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
     }
     __syncthreads();
-    if (lane == 0) publish_status(a, st);
+    // phase bit 2: an intermediate step of a group (LM's decision before its elimination) - the host waits for the
+    // group's last sequence number only, so nothing is published unless the solve just finished
+    if (lane == 0 && (!(a.phase & 4) || st->done)) publish_status(a, st);
 }
 __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
     __shared__ HeadShared hs;

@@ -296,7 +296,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
             }
         } else {
             HIP_TRYN(ctx, launch_cost1(fa, st));
-            ha.phase = 1; ha.seq = ++seq;
+            ha.phase = 1 | 4; ha.seq = ++seq;       // decide; the group's status is published by its last step
             HIP_TRYN(ctx, launch_head(ha, st));
             ha.phase = 2; ha.seq = ++seq;
             if (fuse_tail) {
