@@ -341,7 +341,8 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         // Sharded solves (all-reduce hook set) must issue the SAME sequence of collectives on every rank:
         // no speculative group there -- the next group is enqueued only after this one's status is known
         // (identical on all ranks, it is computed from the all-reduced sums).
-        const int depth = p->allreduce ? 1 : 2;
+        static const int env_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH"); return e ? std::max(1, std::atoi(e)) : 2; }();
+        const int depth = p->allreduce ? 1 : env_depth;
         while ((int)pending.size() < depth && enq < max_groups) {
             const int s = enqueue();
             if (s < 0) return -s;
