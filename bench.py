@@ -76,15 +76,17 @@ def main():
         for _ in range(args.warmup):
             step()
         barrier()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        # HIP events on the launch stream around the K launches of the timed region: average launch duration of
+        # the kernel (one pair for the whole region - an event between launches would add its own gap)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        for a, b in evs:
-            a.record(stream)
+        ev0.record(stream)
+        for _ in range(args.steps):
             step()
-            b.record(stream)
+        ev1.record(stream)
         barrier()
         elapsed = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kernel_ms = float(ev0.elapsed_time(ev1)) / args.steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
