@@ -35,7 +35,14 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const KArgs& a = ga.k;
     if (*ga.stop) return;
     constexpr int D = block_dim(MODEL, OF, OTHER);
-    constexpr int NC = D + 1;
+    // Other-camera blocks: d r / d tvec_0_b = (d r / d tvec_c_0) R_c0, so those three columns are linear combinations
+    // of three others with per-camera constant coefficients.  When the remaining D - 3 + 1 columns fit ONE 16 x 16
+    // matrix-core tile (UCM / EUCM rigs) the Gram is built without them (one MFMA per corner pair instead of
+    // three) and k_schur expands it with R_c0, which is stored behind the tile.
+    constexpr bool CMP = gram_compact(MODEL, OF, OTHER);
+    constexpr int PE = D - (OTHER ? 12 : 6);
+    constexpr int NC = CMP ? D - 2 : D + 1;   // staged columns (the last one is the residual)
+    constexpr int RC = NC - 1;                // index of the residual column
     constexpr int T = NC <= 16 ? 1 : 2;
     constexpr int RS = T == 1 ? 16 : 24;      // doubles per staged row
     constexpr int CS = 2 * RS + 2;            // doubles per corner (two rows + pad)
@@ -99,8 +106,10 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
                     for (int i = 0; i < RS; i += 2) {
-                        const double v0 = i < D ? sw * J[h * D + (i < D ? i : 0)] : (i == D ? sw * (h ? rv : ru) : 0.0);
-                        const double v1 = (i + 1) < D ? sw * J[h * D + ((i + 1) < D ? (i + 1) : 0)] : ((i + 1) == D ? sw * (h ? rv : ru) : 0.0);
+                        // staged column -> Jacobian column (compact form skips tvec_0_b: PE+3 .. PE+5)
+                        const int s0 = (CMP && i >= PE + 3) ? i + 3 : i, s1 = (CMP && i + 1 >= PE + 3) ? i + 4 : i + 1;
+                        const double v0 = i < RC ? sw * J[h * D + (i < RC ? s0 : 0)] : (i == RC ? sw * (h ? rv : ru) : 0.0);
+                        const double v1 = (i + 1) < RC ? sw * J[h * D + ((i + 1) < RC ? s1 : 0)] : ((i + 1) == RC ? sw * (h ? rv : ru) : 0.0);
                         *reinterpret_cast<double2*>(row + h * RS + i) = make_double2(v0, v1);
                     }
                 }
@@ -140,7 +149,8 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
         const d4 acc = acc00a + acc00b;
 #pragma unroll
         for (int v = 0; v < 4; ++v) Go[(gi + 4 * v) * NCP + gj] = acc[v];
-        if (gi + 4 * (D / 4) == D && gj == D) ga.cost_o[o] = acc[D / 4];
+        if (gi + 4 * (RC / 4) == RC && gj == RC) ga.cost_o[o] = acc[RC / 4];
+        if constexpr (CMP) { if (lane < 9) Go[256 + lane] = fc[FC_R1 + lane]; }
     } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
             Go[(gi + 4 * v) * NCP + 16 + gj] = acc01[v];
             Go[(16 + gi + 4 * v) * NCP + 16 + gj] = acc11[v];
         }
-        constexpr int dl = D - 16;   // residual column lives in tile (1,1)
+        constexpr int dl = RC - 16;  // residual column lives in tile (1,1)
         if (gi + 4 * (dl / 4) == dl && gj == dl) ga.cost_o[o] = acc11[dl / 4];
     }
 }
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
 template <int MODEL, bool OF, bool OTHER>
 static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
-    constexpr int T = (D + 1) <= 16 ? 1 : 2;
+    constexpr int T = (gram_compact(MODEL, OF, OTHER) ? D - 2 : D + 1) <= 16 ? 1 : 2;
     constexpr int RS = T == 1 ? 16 : 24;
     constexpr int WS = (OTHER ? FC_SIZE : 40) + GRAM_TILE_CORNERS * (2 * RS + 2);
     const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
@@ -246,6 +256,10 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
             const int Pe = a.caminfo[cam * 4 + 0], ct = a.caminfo[cam * 4 + 1], ce = a.caminfo[cam * 4 + 2], NCP = a.caminfo[cam * 4 + 3];
             const int D = Pe + (cam > 0 ? 12 : 6), NC = D + 1;
             const double* Go = a.G + a.goff[o];
+            const bool compact = cam > 0 && NCP == 16;        // Gram without the tvec_0_b columns + R_c0 behind the tile
+            double R1[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) R1[q] = compact ? Go[256 + q] : 0.0;
             // all of this lane's Gram entries first (NC <= 22: at most 8 per lane), one memory latency per frame
             constexpr int GV = (22 * 22 + 63) / 64;
             double gv[GV];
@@ -256,7 +270,30 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 const int i = (int)(((float)e + 0.5f) * rnc), j = e - i * NC;
                 // k_gram leaves the whole 16 x 16 tile (T = 1) or the block-upper three tiles (T = 2, NCP = 32):
                 // read along rows (coalesced) except in the missing lower-left tile
-                gv[t] = e < NC * NC ? ((i >= 16 && j < 16) ? Go[j * NCP + i] : Go[i * NCP + j]) : 0.0;
+                double val = 0.0;
+                if (e < NC * NC) {
+                    if (!compact) {
+                        val = (i >= 16 && j < 16) ? Go[j * NCP + i] : Go[i * NCP + j];
+                    } else {
+                        // virtual column -> compact column, or -(a + 1) for tvec_0_b component a = sum_m R_c0[m][a] tvec_c_0[m]
+                        const int ci = i < Pe + 3 ? i : (i < Pe + 6 ? -(i - Pe - 3) - 1 : i - 3);
+                        const int cj = j < Pe + 3 ? j : (j < Pe + 6 ? -(j - Pe - 3) - 1 : j - 3);
+                        const int tc = Pe + 6;                // first tvec_c_0 column of the compact tile
+                        if (ci >= 0 && cj >= 0) val = Go[ci * 16 + cj];
+                        else if (ci < 0 && cj >= 0) { const int aa = -ci - 1;
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) val += R1[m * 3 + aa] * Go[(tc + m) * 16 + cj]; }
+                        else if (ci >= 0) { const int ab = -cj - 1;
+#pragma unroll
+                            for (int m = 0; m < 3; ++m) val += R1[m * 3 + ab] * Go[ci * 16 + tc + m]; }
+                        else { const int aa = -ci - 1, ab = -cj - 1;
+#pragma unroll
+                            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                                for (int n2 = 0; n2 < 3; ++n2) val += R1[m * 3 + aa] * R1[n2 * 3 + ab] * Go[(tc + m) * 16 + tc + n2]; }
+                    }
+                }
+                gv[t] = val;
             }
 #pragma unroll
             for (int t = 0; t < GV; ++t) {

@@ -12,4 +12,10 @@ __host__ __device__ constexpr int block_dim(int model, bool one_focal, bool othe
     return model_np(model) - (one_focal ? 1 : 0) + (other ? 12 : 6);
 }
 
+// Other-camera Gram blocks that fit one 16 x 16 matrix-core tile once the tvec_0_b columns (linear combinations of
+// the tvec_c_0 columns) are left out: block_dim - 3 Jacobian columns + the residual <= 16.
+__host__ __device__ constexpr bool gram_compact(int model, bool one_focal, bool other) {
+    return other && block_dim(model, one_focal, true) - 2 <= 16;
+}
+
 }  // namespace ccal
