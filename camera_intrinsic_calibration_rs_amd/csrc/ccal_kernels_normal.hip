@@ -145,12 +145,43 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     // C/D layout of v_mfma_f64_16x16x4_f64: lane l, register v holds D[(l >> 4) + 4 v][l & 15]
     double* Go = ga.G + ga.goff[o];
     const int gi = lane >> 4, gj = lane & 15;
-    if constexpr (T == 1) {
+    if constexpr (CMP) {
+        // compact tile -> LDS -> the block-upper-triangular 32-stride layout k_schur reads (rows 0..15 x all columns,
+        // rows 16.. x columns 16..), with the tvec_0_b rows / columns restored: column a = sum_m R_c0[m][a] tvec_c_0[m]
+        const d4 acc = acc00a + acc00b;
+        wave_sync_lds();
+#pragma unroll
+        for (int v = 0; v < 4; ++v) tile[(gi + 4 * v) * 17 + gj] = acc[v];
+        wave_sync_lds();
+        constexpr int NV = D + 1, TC = PE + 6;            // virtual columns; first tvec_c_0 column of the compact tile
+        const double* R1 = fc + FC_R1;
+        for (int e = lane; e < NV * NV; e += 64) {
+            const int i = e / NV, j = e - i * NV;
+            if (i >= 16 && j < 16) continue;                // lower-left tile is never read
+            const int ci = i < PE + 3 ? i : (i < PE + 6 ? -(i - PE - 3) - 1 : i - 3);
+            const int cj = j < PE + 3 ? j : (j < PE + 6 ? -(j - PE - 3) - 1 : j - 3);
+            double val = 0.0;
+            if (ci >= 0 && cj >= 0) val = tile[ci * 17 + cj];
+            else if (ci < 0 && cj >= 0) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) val += R1[m * 3 + (-ci - 1)] * tile[(TC + m) * 17 + cj];
+            } else if (ci >= 0) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) val += R1[m * 3 + (-cj - 1)] * tile[ci * 17 + TC + m];
+            } else {
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int n2 = 0; n2 < 3; ++n2) val += R1[m * 3 + (-ci - 1)] * R1[n2 * 3 + (-cj - 1)] * tile[(TC + m) * 17 + TC + n2];
+            }
+            Go[i * 32 + j] = val;
+            if (i == D && j == D) ga.cost_o[o] = val;
+        }
+    } else if constexpr (T == 1) {
         const d4 acc = acc00a + acc00b;
 #pragma unroll
         for (int v = 0; v < 4; ++v) Go[(gi + 4 * v) * NCP + gj] = acc[v];
         if (gi + 4 * (RC / 4) == RC && gj == RC) ga.cost_o[o] = acc[RC / 4];
-        if constexpr (CMP) { if (lane < 9) Go[256 + lane] = fc[FC_R1 + lane]; }
     } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -256,10 +287,6 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
             const int Pe = a.caminfo[cam * 4 + 0], ct = a.caminfo[cam * 4 + 1], ce = a.caminfo[cam * 4 + 2], NCP = a.caminfo[cam * 4 + 3];
             const int D = Pe + (cam > 0 ? 12 : 6), NC = D + 1;
             const double* Go = a.G + a.goff[o];
-            const bool compact = cam > 0 && NCP == 16;        // Gram without the tvec_0_b columns + R_c0 behind the tile
-            double R1[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) R1[q] = compact ? Go[256 + q] : 0.0;
             // all of this lane's Gram entries first (NC <= 22: at most 8 per lane), one memory latency per frame
             constexpr int GV = (22 * 22 + 63) / 64;
             double gv[GV];
@@ -270,30 +297,7 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 const int i = (int)(((float)e + 0.5f) * rnc), j = e - i * NC;
                 // k_gram leaves the whole 16 x 16 tile (T = 1) or the block-upper three tiles (T = 2, NCP = 32):
                 // read along rows (coalesced) except in the missing lower-left tile
-                double val = 0.0;
-                if (e < NC * NC) {
-                    if (!compact) {
-                        val = (i >= 16 && j < 16) ? Go[j * NCP + i] : Go[i * NCP + j];
-                    } else {
-                        // virtual column -> compact column, or -(a + 1) for tvec_0_b component a = sum_m R_c0[m][a] tvec_c_0[m]
-                        const int ci = i < Pe + 3 ? i : (i < Pe + 6 ? -(i - Pe - 3) - 1 : i - 3);
-                        const int cj = j < Pe + 3 ? j : (j < Pe + 6 ? -(j - Pe - 3) - 1 : j - 3);
-                        const int tc = Pe + 6;                // first tvec_c_0 column of the compact tile
-                        if (ci >= 0 && cj >= 0) val = Go[ci * 16 + cj];
-                        else if (ci < 0 && cj >= 0) { const int aa = -ci - 1;
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) val += R1[m * 3 + aa] * Go[(tc + m) * 16 + cj]; }
-                        else if (ci >= 0) { const int ab = -cj - 1;
-#pragma unroll
-                            for (int m = 0; m < 3; ++m) val += R1[m * 3 + ab] * Go[ci * 16 + tc + m]; }
-                        else { const int aa = -ci - 1, ab = -cj - 1;
-#pragma unroll
-                            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                                for (int n2 = 0; n2 < 3; ++n2) val += R1[m * 3 + aa] * R1[n2 * 3 + ab] * Go[(tc + m) * 16 + tc + n2]; }
-                    }
-                }
-                gv[t] = val;
+                gv[t] = e < NC * NC ? ((i >= 16 && j < 16) ? Go[j * NCP + i] : Go[i * NCP + j]) : 0.0;
             }
 #pragma unroll
             for (int t = 0; t < GV; ++t) {

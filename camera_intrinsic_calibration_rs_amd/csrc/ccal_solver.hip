@@ -116,15 +116,11 @@ int normal_ws_ensure(ccal_problem* p) {
     std::vector<int32_t> caminfo(p->n_cams * 4);
     int64_t gl = 0;
     for (int c = 0; c < p->n_cams; ++c) {
-        const int ncp = (p->cams[c].D + 1) <= 16 || gram_compact(p->cams[c].model, p->one_focal, c > 0) ? 16 : 32;
+        const int ncp = (p->cams[c].D + 1) <= 16 ? 16 : 32;
         caminfo[c * 4 + 0] = p->cams[c].Peff; caminfo[c * 4 + 1] = p->cams[c].col_theta;
         caminfo[c * 4 + 2] = p->cams[c].col_extr; caminfo[c * 4 + 3] = ncp;
     }
-    for (int o = 0; o < p->n_obs; ++o) {       // compact other-camera blocks carry R_c0 (9 doubles, padded) behind the tile
-        goff[o] = gl;
-        const int cam = p->h_obs_cam[o], ncp = caminfo[cam * 4 + 3];
-        gl += (int64_t)ncp * ncp + ((cam > 0 && ncp == 16) ? 16 : 0);
-    }
+    for (int o = 0; o < p->n_obs; ++o) { goff[o] = gl; const int ncp = caminfo[p->h_obs_cam[o] * 4 + 3]; gl += (int64_t)ncp * ncp; }
     w->g_len = gl;
     std::vector<int32_t> slot_off(p->n_slots + 1, 0), slot_obs(p->n_obs);
     for (int o = 0; o < p->n_obs; ++o) slot_off[p->h_obs_slot[o] + 1]++;
