@@ -248,8 +248,9 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
 // reduced system A[(K+1)^2] + extras in its own LDS accumulators (flushed once at the end).
 // ---------------------------------------------------------------------------------------------
 struct SchurArgs {
-    const double* G; const int64_t* goff;
-    const int32_t* slot_off; const int32_t* slot_obs; const int32_t* obs_cam; const int32_t* caminfo;
+    const double* G;
+    const int64_t* slot_desc;      // per (slot, observation) in slot order: goff * 8 + camera - one load instead of three
+    const int32_t* slot_off; const int32_t* caminfo; int32_t n_cams;
     int32_t n_slots, K, RB, PF, n_pw;
     double lambda, min_diag, max_diag;
     double* partial; double* pf; int32_t* flags;
@@ -268,12 +269,16 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
     double* Baug = acc + RB;
     double* Cm = Baug + 6 * K1;
     double* Ym = Cm + 36;
+    __shared__ int32_t cinfo[CCAL_MAX_CAMS * 4];
+    if (threadIdx.x < a.n_cams * 4) cinfo[threadIdx.x] = a.caminfo[threadIdx.x];
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
-    wave_sync_lds();
+    __syncthreads();
     if (gw >= a.n_pw || a.flags[3]) return;
 
+    int o0n = gw < a.n_slots ? a.slot_off[gw] : 0, o1n = gw < a.n_slots ? a.slot_off[gw + 1] : 0;
     for (int s = gw; s < a.n_slots; s += a.n_pw) {
-        const int o0 = a.slot_off[s], o1 = a.slot_off[s + 1];
+        const int o0 = o0n, o1 = o1n;
+        if (s + a.n_pw < a.n_slots) { o0n = a.slot_off[s + a.n_pw]; o1n = a.slot_off[s + a.n_pw + 1]; }   // next slot's range: off the critical path
         double* pf = a.pf + (int64_t)s * a.PF;
         if (o0 == o1) {                                   // slot without observations
             for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
@@ -282,11 +287,11 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
         for (int e = lane; e < 6 * K1 + 36; e += 64) Baug[e] = 0.0;
         wave_sync_lds();
         for (int oi = o0; oi < o1; ++oi) {
-            const int o = a.slot_obs[oi];
-            const int cam = a.obs_cam[o];
-            const int Pe = a.caminfo[cam * 4 + 0], ct = a.caminfo[cam * 4 + 1], ce = a.caminfo[cam * 4 + 2], NCP = a.caminfo[cam * 4 + 3];
+            const int64_t desc = a.slot_desc[oi];
+            const int cam = (int)(desc & 7);
+            const int Pe = cinfo[cam * 4 + 0], ct = cinfo[cam * 4 + 1], ce = cinfo[cam * 4 + 2], NCP = cinfo[cam * 4 + 3];
             const int D = Pe + (cam > 0 ? 12 : 6), NC = D + 1;
-            const double* Go = a.G + a.goff[o];
+            const double* Go = a.G + (desc >> 3);
             // all of this lane's Gram entries first (NC <= 22: at most 8 per lane), one memory latency per frame
             constexpr int GV = (22 * 22 + 63) / 64;
             double gv[GV];
@@ -371,8 +376,10 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 pf[21 + i * K1 + j] = y[i];
             }
         }
-        if (lane < 21) pf[lane] = L[lane];
-        if (lane < 6) { pf[21 + 6 * K1 + lane] = Baug[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dC[lane]; }
+#pragma unroll
+        for (int i = 0; i < 21; ++i) if (lane == i) pf[i] = L[i];          // static register indices: no scratch
+#pragma unroll
+        for (int i = 0; i < 6; ++i) if (lane == 32 + i) { pf[21 + 6 * K1 + i] = Baug[i * K1 + K]; pf[21 + 6 * K1 + 6 + i] = dC[i]; }
         wave_sync_lds();
         // A -= Y^T Y
         const float rk1 = 1.0f / (float)K1;
@@ -391,8 +398,8 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s) {
     const NormalWs* w = p->nws;
     SchurArgs a = {};
-    a.G = w->G[gbuf]; a.goff = w->d_goff; a.slot_off = w->d_slot_off; a.slot_obs = w->d_slot_obs;
-    a.obs_cam = w->d_obs_cam; a.caminfo = w->d_caminfo;
+    a.G = w->G[gbuf]; a.slot_desc = w->d_slot_desc; a.slot_off = w->d_slot_off;
+    a.caminfo = w->d_caminfo; a.n_cams = p->n_cams;
     a.n_slots = p->n_slots; a.K = w->K; a.RB = w->RB; a.PF = w->PF; a.n_pw = w->n_pw;
     a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
     a.partial = w->partial; a.pf = w->pf; a.flags = w->flags;

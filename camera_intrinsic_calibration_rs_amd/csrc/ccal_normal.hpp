@@ -42,6 +42,7 @@ struct NormalWs {
     int64_t* d_goff = nullptr;                 // [n_obs] offset of G_o
     int32_t* d_slot_off = nullptr;             // [n_slots+1] CSR slot -> observation frames
     int32_t* d_slot_obs = nullptr;
+    int64_t* d_slot_desc = nullptr;            // [n_obs] in slot order: goff * 8 + camera
     int32_t* d_obs_cam = nullptr;
     int32_t* d_caminfo = nullptr;              // [n_cams][4]: Peff, col_theta, col_extr, NCP
     double* partial = nullptr;                 // [RB][n_pw]

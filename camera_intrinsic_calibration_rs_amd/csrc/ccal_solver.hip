@@ -41,7 +41,7 @@ void normal_ws_destroy(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (!w) return;
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
-                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols };
+                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
     if (FusedWs* f = w->fws) {
@@ -127,7 +127,10 @@ int normal_ws_ensure(ccal_problem* p) {
     for (int s = 0; s < p->n_slots; ++s) slot_off[s + 1] += slot_off[s];
     { std::vector<int32_t> cur(slot_off.begin(), slot_off.end() - 1);
       for (int o = 0; o < p->n_obs; ++o) slot_obs[cur[p->h_obs_slot[o]]++] = o; }
+    std::vector<int64_t> slot_desc(p->n_obs);
+    for (int i = 0; i < p->n_obs; ++i) slot_desc[i] = goff[slot_obs[i]] * 8 + p->h_obs_cam[slot_obs[i]];
     int rc;
+    if ((rc = dev_upload(ctx, &w->d_slot_desc, slot_desc))) return rc;
     if ((rc = dev_upload(ctx, &w->d_goff, goff)) || (rc = dev_upload(ctx, &w->d_slot_off, slot_off)) ||
         (rc = dev_upload(ctx, &w->d_slot_obs, slot_obs)) || (rc = dev_upload(ctx, &w->d_obs_cam, p->h_obs_cam)) ||
         (rc = dev_upload(ctx, &w->d_caminfo, caminfo)))
