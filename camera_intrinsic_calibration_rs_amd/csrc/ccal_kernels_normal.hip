@@ -269,8 +269,44 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
     double* Baug = acc + RB;
     double* Cm = Baug + 6 * K1;
     double* Ym = Cm + 36;
-    __shared__ int32_t cinfo[CCAL_MAX_CAMS * 4];
-    if (threadIdx.x < a.n_cams * 4) cinfo[threadIdx.x] = a.caminfo[threadIdx.x];
+    // Scatter table, built once per workgroup: for every entry e of a camera's (D+1) x (D+1) Gram block where it is
+    // read from (k_gram leaves the whole 16 x 16 tile or the block-upper three tiles of a 32-stride block) and which
+    // LDS accumulator(s) receive it - packed src | (dst + 1) << 16 | (extra + 1) << 32.  The per-slot loop is then
+    // load, load, ds_add: the index arithmetic and its divergent branches cost as many scalar as vector
+    // instructions before (SQ_INSTS_SALU = SQ_INSTS_VALU = 5 k per wavefront).
+    __shared__ int32_t cbase[CCAL_MAX_CAMS + 1], cnc2[CCAL_MAX_CAMS];
+    int64_t* tab = reinterpret_cast<int64_t*>(smem + WAVES_PER_BLOCK * WS);
+    {
+        int base = 0;
+        for (int c = 0; c < a.n_cams; ++c) {
+            const int Pe = a.caminfo[c * 4 + 0], ct = a.caminfo[c * 4 + 1], ce = a.caminfo[c * 4 + 2], NCP = a.caminfo[c * 4 + 3];
+            const int D = Pe + (c > 0 ? 12 : 6), NC = D + 1;
+            if (threadIdx.x == 0) { cbase[c] = base; cnc2[c] = NC * NC; }
+            for (int e = threadIdx.x; e < NC * NC; e += 256) {
+                const int i = e / NC, j = e - i * NC;
+                // local column -> (kind, index): kind 0 = camera-system column (r maps to K), 1 = pose
+                int ki, ii, kj, jj;
+                if (i < Pe) { ki = 0; ii = ct + i; } else if (i < Pe + 6) { ki = 1; ii = i - Pe; } else if (i < D) { ki = 0; ii = ce + (i - Pe - 6); } else { ki = 0; ii = K; }
+                if (j < Pe) { kj = 0; jj = ct + j; } else if (j < Pe + 6) { kj = 1; jj = j - Pe; } else if (j < D) { kj = 0; jj = ce + (j - Pe - 6); } else { kj = 0; jj = K; }
+                int off = -1, xoff = -1;
+                if (ki == 0) {
+                    if (kj == 0) {
+                        off = ii * K1 + jj;
+                        if (i == j && ii < K) xoff = K1 * K1 + ii;                    // hdiag
+                        else if (jj == K && ii < K) xoff = K1 * K1 + K + ii;           // g_c
+                        else if (ii == K && jj == K) xoff = RB - 1;                    // cost = sum rho' s
+                    }                                                                  // camera row x pose column: its transpose is taken
+                } else if (kj == 0) {
+                    off = RB + ii * K1 + jj;                                           // Baug
+                } else {
+                    off = RB + 6 * K1 + ii * 6 + jj;                                   // Cm
+                }
+                const int src = (i >= 16 && j < 16) ? j * NCP + i : i * NCP + j;
+                tab[base + e] = (int64_t)src | ((int64_t)(off + 1) << 16) | ((int64_t)(xoff + 1) << 32);
+            }
+            base += NC * NC;
+        }
+    }
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
     __syncthreads();
     if (gw >= a.n_pw || a.flags[3]) return;
@@ -289,49 +325,24 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
         for (int oi = o0; oi < o1; ++oi) {
             const int64_t desc = a.slot_desc[oi];
             const int cam = (int)(desc & 7);
-            const int Pe = cinfo[cam * 4 + 0], ct = cinfo[cam * 4 + 1], ce = cinfo[cam * 4 + 2], NCP = cinfo[cam * 4 + 3];
-            const int D = Pe + (cam > 0 ? 12 : 6), NC = D + 1;
             const double* Go = a.G + (desc >> 3);
-            // all of this lane's Gram entries first (NC <= 22: at most 8 per lane), one memory latency per frame
+            const int64_t* tb = tab + cbase[cam];
+            const int nc2 = cnc2[cam];
+            // table entries, then all of this lane's Gram entries (NC <= 22: at most 8 per lane; one memory latency per
+            // frame), then the adds: LDS atomics (ds_add_f64, nothing waits on them); within one observation frame
+            // every accumulator receives exactly one addend, so the sums stay ordered
             constexpr int GV = (22 * 22 + 63) / 64;
+            int64_t ent[GV];
             double gv[GV];
-            const float rnc = 1.0f / (float)NC;          // e / NC for e < 4096 without the integer-division sequence
+#pragma unroll
+            for (int t = 0; t < GV; ++t) { const int e = lane + 64 * t; ent[t] = e < nc2 ? tb[e] : 0; }
+#pragma unroll
+            for (int t = 0; t < GV; ++t) gv[t] = (lane + 64 * t) < nc2 ? Go[ent[t] & 0xffff] : 0.0;
 #pragma unroll
             for (int t = 0; t < GV; ++t) {
-                const int e = lane + 64 * t;
-                const int i = (int)(((float)e + 0.5f) * rnc), j = e - i * NC;
-                // k_gram leaves the whole 16 x 16 tile (T = 1) or the block-upper three tiles (T = 2, NCP = 32):
-                // read along rows (coalesced) except in the missing lower-left tile
-                gv[t] = e < NC * NC ? ((i >= 16 && j < 16) ? Go[j * NCP + i] : Go[i * NCP + j]) : 0.0;
-            }
-#pragma unroll
-            for (int t = 0; t < GV; ++t) {
-                const int e = lane + 64 * t;
-                if (e >= NC * NC) continue;
-                const int i = (int)(((float)e + 0.5f) * rnc), j = e - i * NC;
-                // local column -> (kind, index): kind 0 = camera-system column (r maps to K), 1 = pose
-                int ki, ii, kj, jj;
-                if (i < Pe) { ki = 0; ii = ct + i; } else if (i < Pe + 6) { ki = 1; ii = i - Pe; } else if (i < D) { ki = 0; ii = ce + (i - Pe - 6); } else { ki = 0; ii = K; }
-                if (j < Pe) { kj = 0; jj = ct + j; } else if (j < Pe + 6) { kj = 1; jj = j - Pe; } else if (j < D) { kj = 0; jj = ce + (j - Pe - 6); } else { kj = 0; jj = K; }
-                // one destination (+ at most one extra) per entry, added with LDS atomics (ds_add_f64, nothing to wait
-                // for): the branchy read-modify-write version serialised three divergent LDS round trips per entry.
-                // Within one observation frame every address receives exactly one addend, so the sums stay ordered.
-                int off = -1, xoff = -1;
-                if (ki == 0) {
-                    if (kj == 0) {
-                        off = ii * K1 + jj;
-                        if (i == j && ii < K) xoff = K1 * K1 + ii;                    // hdiag
-                        else if (jj == K && ii < K) xoff = K1 * K1 + K + ii;           // g_c
-                        else if (ii == K && jj == K) xoff = RB - 1;                    // cost = sum rho' s
-                    }
-                } else if (kj == 0) {
-                    off = RB + ii * K1 + jj;                                           // Baug
-                } else {
-                    off = RB + 6 * K1 + ii * 6 + jj;                                   // Cm
-                }
-                const double g = gv[t];
-                if (off >= 0) __hip_atomic_fetch_add(acc + off, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (xoff >= 0) __hip_atomic_fetch_add(acc + xoff, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const int off = (int)((ent[t] >> 16) & 0xffff) - 1, xoff = (int)((ent[t] >> 32) & 0xffff) - 1;
+                if (off >= 0) __hip_atomic_fetch_add(acc + off, gv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (xoff >= 0) __hip_atomic_fetch_add(acc + xoff, gv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_sync_lds();
         }
@@ -405,7 +416,9 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     a.partial = w->partial; a.pf = w->pf; a.flags = w->flags;
     const int K1 = w->K + 1;
     const int WS = ((w->RB + 12 * K1 + 36) + 1) & ~1;
-    const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
+    int tab_entries = 0;
+    for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
+    const size_t lds = sizeof(double) * ((size_t)WS * WAVES_PER_BLOCK + tab_entries);
     static size_t attr_lds = 0;
     if (lds > 48 * 1024 && lds > attr_lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
