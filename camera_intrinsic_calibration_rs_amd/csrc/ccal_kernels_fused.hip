@@ -220,6 +220,32 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
 // no idle lanes), every lane keeps the upper triangle of [J|r]^T W [J|r] in registers (structural zeros of
 // the intrinsic columns skipped at compile time) and the 16 partial Grams of a frame meet once in LDS.
 // ---------------------------------------------------------------------------------------------
+// Where each accumulated triangle entry goes inside the compact per-frame record
+// C (21) | [B|g] (6 x K1) | A (K1 x K1, both halves), worked out at compile time: dst | mirror << 16 (0xffff = none).
+// W = 1 leaves out the camera x pose entries (k_gram1w keeps those in LDS and writes them separately).
+template <int K, int W>
+struct RecMap {
+    static constexpr int D = K + 6, NC = D + 1, K1 = K + 1;
+    static constexpr int N = NC * (NC + 1) / 2 - (W ? 6 * K : 0);
+    uint32_t d[N];
+    constexpr RecMap() : d{} {
+        int r = 0;
+        for (int i = 0; i < NC; ++i)
+            for (int j = i; j < NC; ++j) {
+                const bool ip = i >= K && i < D, jp = j >= K && j < D;      // pose columns
+                if (W && !ip && jp && i < K) continue;
+                const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
+                uint32_t a = 0, b = 0xffff;
+                if (ip && jp) a = (j - K) * (j - K + 1) / 2 + (i - K);
+                else if (!ip && jp) a = 21 + (j - K) * K1 + ci;             // i camera, j pose
+                else if (ip && !jp) a = 21 + (i - K) * K1 + K;              // i pose, j = r
+                else { a = 21 + 6 * K1 + ci * K1 + cj; b = 21 + 6 * K1 + cj * K1 + ci; }
+                d[r++] = a | (b << 16);
+            }
+    }
+};
+template <int K, int W> __device__ const RecMap<K, W> g_recmap = RecMap<K, W>();
+
 #ifndef CCAL_GRAMV_WPB
 #define CCAL_GRAMV_WPB 2          // wavefronts per workgroup (4 frames each)
 #endif
@@ -385,17 +411,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
             const int ff = fbase + g;
             if (e >= NE || ff >= a.n_obs) continue;
-            int i = 0, rem = e;
-            while (rem >= NC - i) { rem -= NC - i; ++i; }
-            const int j = i + rem;
+            const uint32_t m = g_recmap<K, 0>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
-            const bool ip = i >= K && i < D, jp = j >= K && j < D;      // pose columns
-            const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
-            if (ip && jp) rec[(j - K) * (j - K + 1) / 2 + (i - K)] = v;
-            else if (!ip && jp) rec[21 + (j - K) * K1 + ci] = v;                         // i camera, j pose
-            else if (ip && !jp) rec[21 + (i - K) * K1 + K] = v;                          // i pose, j = r
-            else { rec[21 + 6 * K1 + ci * K1 + cj] = v; rec[21 + 6 * K1 + cj * K1 + ci] = v; if (i == D) a.cost_f[ff] = v; }
+            rec[m & 0xffff] = v;
+            if ((m >> 16) != 0xffff) rec[m >> 16] = v;
+            if (e == NE - 1) a.cost_f[ff] = v;                       // the last entry is r x r
         }
     }
 }
@@ -604,18 +625,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
             const int ff = fbase + g;
             if (e >= NR || ff >= a.n_obs) continue;
-            // register entry -> (i, j): camera rows hold j = i..K-1 and j = D (their pose columns are in LDS)
-            int i = 0, rem = e;
-            while (rem >= (i < K ? K - i + 1 : NC - i)) { rem -= (i < K ? K - i + 1 : NC - i); ++i; }
-            const int j = i < K ? (rem < K - i ? i + rem : D) : i + rem;
+            const uint32_t m = g_recmap<K, 1>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
-            const bool ip = i >= K && i < D, jp = j >= K && j < D;      // pose columns
-            const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
-            if (ip && jp) rec[(j - K) * (j - K + 1) / 2 + (i - K)] = v;
-            else if (!ip && jp) rec[21 + (j - K) * K1 + ci] = v;                         // i camera, j pose
-            else if (ip && !jp) rec[21 + (i - K) * K1 + K] = v;                          // i pose, j = r
-            else { rec[21 + 6 * K1 + ci * K1 + cj] = v; rec[21 + 6 * K1 + cj * K1 + ci] = v; if (i == D) a.cost_f[ff] = v; }
+            rec[m & 0xffff] = v;
+            if ((m >> 16) != 0xffff) rec[m >> 16] = v;
+            if (e == NR - 1) a.cost_f[ff] = v;                       // the last entry is r x r
         }
     }
 }
