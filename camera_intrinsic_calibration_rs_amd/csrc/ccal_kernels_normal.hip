@@ -3,7 +3,7 @@
 // back-substitution.  Replaces tiny-solver's sparse J^T J assembly + sparse Cholesky (call sites
 // src/util.rs:455, 670) by the exact arrow-structure elimination described in SURVEY 8(e).
 #include "ccal_device.hpp"
-#include "ccal_normal.hpp"
+#include "ccal_fused.hpp"
 
 namespace ccal {
 
@@ -20,7 +20,10 @@ struct GramArgs {
     const int64_t* goff;
     double* G;
     double* cost_o;
-    const int32_t* stop;     // != 0: the Gauss-Newton loop has converged, an iteration enqueued ahead does nothing
+    // device-resident loop: st != NULL selects between this set (index 0) and the second one by st->cur ^ sel
+    // (sel 1 = the candidate), and a finished solve makes the launch empty
+    const DevState* st; int32_t sel;
+    const double* intr2; const double* poses2; const double* extr2; double* G2; double* cost_o2;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -33,7 +36,13 @@ struct GramArgs {
 template <int MODEL, bool OF, bool OTHER>
 __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const KArgs& a = ga.k;
-    if (*ga.stop) return;
+    if (ga.st && ga.st->done) return;
+    const bool second = ga.st && ((ga.st->cur ^ ga.sel) & 1);
+    const double* p_intr = second ? ga.intr2 : a.intr;
+    const double* p_poses = second ? ga.poses2 : a.poses;
+    const double* p_extr = second ? ga.extr2 : a.extr;
+    double* p_G = second ? ga.G2 : ga.G;
+    double* p_cost = second ? ga.cost_o2 : ga.cost_o;
     constexpr int D = block_dim(MODEL, OF, OTHER);
     // Other-camera blocks: d r / d tvec_0_b = (d r / d tvec_c_0) R_c0, so those three columns are linear combinations
     // of three others with per-camera constant coefficients.  When the remaining D - 3 + 1 columns fit ONE 16 x 16
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[o]);
     const int64_t start = a.obs_off[o];
     const int n = (int)(a.obs_off[o + 1] - start);
-    const double* th_g = a.intr + a.cam * CCAL_PMAX;
+    const double* th_g = p_intr + a.cam * CCAL_PMAX;
     double th[model_np(MODEL)];
 #pragma unroll
     for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
@@ -68,10 +77,10 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     {
         double pose[6], ex[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pose[i] = a.poses[(int64_t)slot * 6 + i];
+        for (int i = 0; i < 6; ++i) pose[i] = p_poses[(int64_t)slot * 6 + i];
         if constexpr (OTHER) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ex[i] = a.extr[a.cam * 6 + i];
+            for (int i = 0; i < 6; ++i) ex[i] = p_extr[a.cam * 6 + i];
         }
         double fcr[OTHER ? FC_SIZE : 39];
         frame_setup<OTHER>(pose, ex, fcr);
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     }
 
     // C/D layout of v_mfma_f64_16x16x4_f64: lane l, register v holds D[(l >> 4) + 4 v][l & 15]
-    double* Go = ga.G + ga.goff[o];
+    double* Go = p_G + ga.goff[o];
     const int gi = lane >> 4, gj = lane & 15;
     if constexpr (CMP) {
         // compact tile -> LDS -> the block-upper-triangular 32-stride layout k_schur reads (rows 0..15 x all columns,
@@ -175,13 +184,13 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
                     for (int n2 = 0; n2 < 3; ++n2) val += R1[m * 3 + (-ci - 1)] * R1[n2 * 3 + (-cj - 1)] * tile[(TC + m) * 17 + TC + n2];
             }
             Go[i * 32 + j] = val;
-            if (i == D && j == D) ga.cost_o[o] = val;
+            if (i == D && j == D) p_cost[o] = val;
         }
     } else if constexpr (T == 1) {
         const d4 acc = acc00a + acc00b;
 #pragma unroll
         for (int v = 0; v < 4; ++v) Go[(gi + 4 * v) * NCP + gj] = acc[v];
-        if (gi + 4 * (RC / 4) == RC && gj == RC) ga.cost_o[o] = acc[RC / 4];
+        if (gi + 4 * (RC / 4) == RC && gj == RC) p_cost[o] = acc[RC / 4];
     } else {
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
             Go[(16 + gi + 4 * v) * NCP + 16 + gj] = acc11[v];
         }
         constexpr int dl = RC - 16;  // residual column lives in tile (1,1)
-        if (gi + 4 * (dl / 4) == dl && gj == dl) ga.cost_o[o] = acc11[dl / 4];
+        if (gi + 4 * (dl / 4) == dl && gj == dl) p_cost[o] = acc11[dl / 4];
     }
 }
 
@@ -239,7 +248,22 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = cand ? p->d_intr_c : p->d_intr; a.poses = cand ? p->d_poses_c : p->d_poses; a.extr = cand ? p->d_extr_c : p->d_extr;
     a.huber_delta = p->huber_delta;
-    ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf]; ga.stop = w->flags + 3;
+    ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf];
+    CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
+}
+// device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1]); sel 1 = evaluate the candidate
+hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, int sel, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    GramArgs ga = {};
+    KArgs& a = ga.k;
+    a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
+    a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
+    a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
+    a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
+    ga.intr2 = p->d_intr_c; ga.poses2 = p->d_poses_c; ga.extr2 = p->d_extr_c;
+    a.huber_delta = p->huber_delta;
+    ga.goff = w->d_goff; ga.G = w->G[w->cur]; ga.cost_o = w->cost_o[w->cur]; ga.G2 = w->G[w->cur ^ 1]; ga.cost_o2 = w->cost_o[w->cur ^ 1];
+    ga.st = st; ga.sel = sel;
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
 }
 
@@ -254,6 +278,7 @@ struct SchurArgs {
     int32_t n_slots, K, RB, PF, n_pw;
     double lambda, min_diag, max_diag;
     double* partial; double* pf; int32_t* flags;
+    const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
 };
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
@@ -309,7 +334,9 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
     }
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
     __syncthreads();
-    if (gw >= a.n_pw || a.flags[3]) return;
+    if (gw >= a.n_pw || (a.st && a.st->done)) return;
+    const double* p_G = (a.st && a.st->cur) ? a.G2 : a.G;
+    const double lambda = a.st ? a.st->lambda : a.lambda;
 
     int o0n = gw < a.n_slots ? a.slot_off[gw] : 0, o1n = gw < a.n_slots ? a.slot_off[gw + 1] : 0;
     for (int s = gw; s < a.n_slots; s += a.n_pw) {
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
         for (int oi = o0; oi < o1; ++oi) {
             const int64_t desc = a.slot_desc[oi];
             const int cam = (int)(desc & 7);
-            const double* Go = a.G + (desc >> 3);
+            const double* Go = p_G + (desc >> 3);
             const int64_t* tb = tab + cbase[cam];
             const int nc2 = cnc2[cam];
             // table entries, then all of this lane's Gram entries (NC <= 22: at most 8 per lane; one memory latency per
@@ -355,7 +382,7 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
                 double t = Cm[i * 6 + j];
-                if (i == j && a.lambda > 0.0) t += a.lambda * clampd(dC[i], a.min_diag, a.max_diag);
+                if (i == j && lambda > 0.0) t += lambda * clampd(dC[i], a.min_diag, a.max_diag);
 #pragma unroll
                 for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
                 if (i == j) {
@@ -406,9 +433,11 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
     for (int e = lane; e < RB; e += 64) a.partial[(int64_t)e * a.n_pw + gw] = acc[e];
 }
 
-hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s) {
+hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
+                        const DevState* st) {
     const NormalWs* w = p->nws;
     SchurArgs a = {};
+    a.st = st; a.G2 = w->G[gbuf ^ 1];
     a.G = w->G[gbuf]; a.slot_desc = w->d_slot_desc; a.slot_off = w->d_slot_off;
     a.caminfo = w->d_caminfo; a.n_cams = p->n_cams;
     a.n_slots = p->n_slots; a.K = w->K; a.RB = w->RB; a.PF = w->PF; a.n_pw = w->n_pw;
@@ -442,25 +471,27 @@ __device__ __forceinline__ double block_sum_256(double v, double* sh) {
     return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-__global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw, double* red, const int32_t* stop) {
+__global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw, double* red, const DevState* st) {
     __shared__ double sh[4];
-    if (*stop) return;
+    if (st && st->done) return;
     const double* src = partial + (int64_t)blockIdx.x * n_pw;
     double v = 0.0;
     for (int i = threadIdx.x; i < n_pw; i += 256) v += src[i];
     const double t = block_sum_256(v, sh);
     if (threadIdx.x == 0) red[blockIdx.x] = t;
 }
-hipError_t launch_reduce(const ccal_problem* p, hipStream_t s) {
+hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw, w->red, w->flags + 3);
+    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw, w->red, st);
     return hipGetLastError();
 }
 
 // scal[0] = sum_o cost_o, scal[1] = sum_s mc_slot   (block 0 / block 1)
-__global__ __launch_bounds__(256) void k_sum2(const double* a, int na, const double* b, int nb, double* out, const int32_t* flags) {
+__global__ __launch_bounds__(256) void k_sum2(const double* a, const double* a2, int na, const double* b, int nb, double* out,
+                                              const int32_t* flags, const DevState* st, int sel) {
     __shared__ double sh[4];
-    if (flags[3]) return;
+    if (st && st->done) return;
+    if (st && ((st->cur ^ sel) & 1)) a = a2;         // device-resident loop: a = set 0, a2 = set 1, sel 1 = the candidate
     const double* src = blockIdx.x == 0 ? a : b;
     const int n = blockIdx.x == 0 ? na : nb;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
@@ -478,24 +509,81 @@ __global__ __launch_bounds__(256) void k_sum2(const double* a, int na, const dou
 }
 hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal, w->flags);
+    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[gbuf], w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal, w->flags,
+                       (const DevState*)nullptr, 0);
+    return hipGetLastError();
+}
+// device-resident loop: which != 0 sums the candidate set's costs (set index st->cur ^ 1), which == 0 the current set's
+hipError_t launch_sum_cost_dev(const ccal_problem* p, const DevState* st, int which, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[w->cur], w->cost_o[w->cur ^ 1], p->n_obs, w->mc_slot, p->n_slots, w->scal,
+                       w->flags, st, which ? 1 : 0);
     return hipGetLastError();
 }
 
-// Gauss-Newton stop test on the device, mirroring the host's (tiny-solver's rules): it only makes the iteration
-// that was enqueued ahead of the host's decision free.  scal[4] keeps the previous cost.
-__global__ void k_gn_decide(double* scal, int32_t* flags, int init, double min_error, double min_abs, double min_rel) {
-    if (flags[3]) return;
-    const double cur = scal[0];
-    if (init) { scal[4] = cur; if (!(fabs(cur) <= 1.7976931348623157e308)) flags[3] = 1; return; }
-    if (flags[0] || flags[1]) { flags[3] = 1; return; }
-    const double last = scal[4];
-    scal[4] = cur;
-    if (cur < min_error || cur != cur || fabs(last - cur) < min_abs || fabs(last - cur) / last < min_rel) flags[3] = 1;
+// k_gdecide: the decisions of the general loop on the device (the same rules as the host loop it replaced, which
+// are the oracle's: tiny-solver's Gauss-Newton tests / the Ceres-style trust region) + status for the polling host.
+//   scal: 0 cost of the evaluated set, 1 model decrease of the pose blocks, 2 of the camera block
+__global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int32_t* flags, int init, int seq, int verbose) {
+    if (!st->done) {
+        const double cand = scal[0];
+        const bool lin_fail = flags[0] || flags[1];
+        int done = 0;
+        if (init) {
+            st->cur_cost = cand; st->initial_cost = cand;
+            if (!(fabs(cand) <= 1.7976931348623157e308)) done = CCAL_ERR_NONFINITE + 1;
+        } else if (st->method != CCAL_METHOD_LM) {
+            st->iter += 1;
+            if (lin_fail) done = CCAL_ERR_NOT_PD + 1;            // solve failed -> None; the step is not applied
+            else {
+                st->cur ^= 1;                                    // Gauss-Newton: x <- candidate, unconditionally
+                const double last = st->cur_cost;
+                st->last_cost = last; st->cur_cost = cand;
+                if (cand < st->min_error) done = CCAL_OK + 1;
+                else if (cand != cand) done = CCAL_ERR_NONFINITE + 1;
+                else if (fabs(last - cand) < st->min_abs) done = CCAL_OK + 1;
+                else if (fabs(last - cand) / last < st->min_rel) done = CCAL_OK + 1;
+                else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
+            }
+        } else {
+            st->iter += 1;
+            const double cur = st->cur_cost, mc = scal[1] + scal[2];
+            const double rho = (cur - cand) / mc;
+            const bool fin = fabs(cand) <= 1.7976931348623157e308;
+            if (!lin_fail && fin && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * cur)) {
+                // predicted decrease below the thresholds: converged
+                if (cand < cur) { st->cur ^= 1; st->cur_cost = cand; st->lm_accepted += 1; }
+                done = CCAL_OK + 1;
+            } else if (!lin_fail && fin && mc > 0.0 && rho > 0.0) {
+                st->cur ^= 1;
+                st->last_cost = cur; st->cur_cost = cand; st->lm_accepted += 1;
+                const double t = 2.0 * rho - 1.0;
+                st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                st->dec = 2.0;
+                if (cand < st->min_error) done = CCAL_OK + 1;
+                else if (fabs(cur - cand) < st->min_abs) done = CCAL_OK + 1;
+                else if (fabs(cur - cand) / cur < st->min_rel) done = CCAL_OK + 1;
+            } else {
+                st->lm_rejected += 1;
+                st->radius /= st->dec; st->dec *= 2.0;
+                if (lin_fail) { flags[0] = 0; flags[1] = 0; }
+                if (st->radius < 1e-32) done = CCAL_ERR_NO_CONVERGENCE + 1;
+            }
+            st->lambda = 1.0 / st->radius;
+            if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
+        }
+        st->done = done;
+        if (verbose) printf("[ccal %s] iter %d cost %.12g radius %.3g\n", st->method == CCAL_METHOD_LM ? "LM" : "GN", st->iter, st->cur_cost, st->radius);
+    }
+    hs->done = st->done; hs->iter = st->iter; hs->cur = st->cur;
+    hs->lm_accepted = st->lm_accepted; hs->lm_rejected = st->lm_rejected;
+    hs->cur_cost = st->cur_cost; hs->initial_cost = st->initial_cost; hs->radius = st->radius;
+    __threadfence_system();
+    hs->seq = seq;
 }
-hipError_t launch_gn_decide(const ccal_problem* p, bool init, double min_error, double min_abs, double min_rel, hipStream_t s) {
+hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, bool verbose, hipStream_t s) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_gn_decide, dim3(1), dim3(1), 0, s, w->scal, w->flags, init ? 1 : 0, min_error, min_abs, min_rel);
+    hipLaunchKernelGGL(k_gdecide, dim3(1), dim3(1), 0, s, st, hs, w->scal, w->flags, init ? 1 : 0, seq, verbose ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -508,15 +596,21 @@ struct SolveArgs {
     double lambda, min_diag, max_diag;
     const double* intr; const double* extr; double* intr_c; double* extr_c; int32_t n_intr, n_extr;
     double* dc; double* scal; int32_t* flags;
+    const DevState* st;            // device-resident loop: current set = st->cur (0: intr/extr, 1: intr_c/extr_c), lambda from the state
 };
-__global__ __launch_bounds__(64) void k_solve(const SolveArgs a) {
+__global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
+    SolveArgs a = a0;
+    if (a.st) {
+        if (a.st->done) return;
+        a.lambda = a.st->lambda;
+        if (a.st->cur) { a.intr = a0.intr_c; a.extr = a0.extr_c; a.intr_c = const_cast<double*>(a0.intr); a.extr_c = const_cast<double*>(a0.extr); }
+    }
     __shared__ double S[CCAL_KMAX * (CCAL_KMAX + 1)];
     __shared__ double x[CCAL_KMAX];
     __shared__ int bad;
     const int K = a.K, K1 = K + 1, lane = threadIdx.x;
     const double* hdiag = a.red + K1 * K1;
     const double* gc = hdiag + K;
-    if (a.flags[3]) return;
     __shared__ int fxs[CCAL_KMAX];
     ColInfo ci = {};
     if (lane < K) { ci = a.cols[lane]; fxs[lane] = ci.fixed; }
@@ -595,9 +689,10 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a) {
     for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
     if (lane == 0) a.scal[2] = mc;
 }
-hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s) {
+hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st) {
     const NormalWs* w = p->nws;
     SolveArgs a = {};
+    a.st = st;
     a.red = w->red; a.cols = w->cols; a.K = w->K; a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
     a.intr = p->d_intr; a.extr = p->d_extr; a.intr_c = p->d_intr_c; a.extr_c = p->d_extr_c;
     a.n_intr = p->n_cams * CCAL_PMAX; a.n_extr = p->n_cams * 6;
@@ -613,11 +708,16 @@ hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, d
 struct BacksubArgs {
     const double* pf; const double* dc; const double* poses; double* poses_c; double* mc_slot;
     int32_t n_slots, K, PF; double lambda, min_diag, max_diag;
-    const int32_t* stop;
+    const DevState* st;
 };
-__global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a) {
+__global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     __shared__ double dcs[CCAL_KMAX];
-    if (*a.stop) return;
+    BacksubArgs a = a0;
+    if (a.st) {
+        if (a.st->done) return;
+        a.lambda = a.st->lambda;
+        if (a.st->cur) { a.poses = a0.poses_c; a.poses_c = const_cast<double*>(a0.poses); }
+    }
     if (threadIdx.x < a.K) dcs[threadIdx.x] = a.dc[threadIdx.x];
     __syncthreads();
     const int s = blockIdx.x * 256 + threadIdx.x;
@@ -658,13 +758,14 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a) {
     }
     a.mc_slot[s] = mc;
 }
-hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s) {
+hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st) {
     const NormalWs* w = p->nws;
     if (p->n_slots == 0) return hipSuccess;
     BacksubArgs a = {};
+    a.st = st;
     a.pf = w->pf; a.dc = w->dc; a.poses = p->d_poses; a.poses_c = p->d_poses_c; a.mc_slot = w->mc_slot;
     a.n_slots = p->n_slots; a.K = w->K; a.PF = w->PF; a.lambda = lambda;
-    a.min_diag = min_diag; a.max_diag = max_diag; a.stop = w->flags + 3;
+    a.min_diag = min_diag; a.max_diag = max_diag;
     hipLaunchKernelGGL(k_backsub, dim3((p->n_slots + 255) / 256), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -56,6 +56,11 @@ struct NormalWs {
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
     int64_t g_len = 0;
+    struct DevState* d_gstate = nullptr;       // general loop: optimizer state on the device,
+    struct HostStatus* h_gstatus = nullptr;    //   its published copy (pinned, host-coherent)
+    struct DevState* h_gstate = nullptr;       //   and the pinned staging of its initial value
+    hipStream_t side = nullptr;                // result download past the early-exit group enqueued ahead
+    bool tail_pending = false;
     struct FusedWs* fws = nullptr;             // single-camera fused path (ccal_fused.hpp)
 };
 
@@ -80,13 +85,20 @@ void normal_ws_destroy(ccal_problem* p);
 int normal_ws_ensure(ccal_problem* p);          // allocate on first use
 int normal_upload_cols(ccal_problem* p);        // bounds / fixed flags -> device
 
-// launchers (ccal_kernels_normal.hip); `cand` selects parameter set and G buffer
+// launchers (ccal_kernels_normal.hip).  Host-driven form: `cand` / gbuf / lambda select parameter set, G buffer and
+// damping.  Device-resident form (st != NULL, *_dev): set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1]),
+// the kernels pick the current set by st->cur, take lambda from st->lambda and do nothing once st->done is set.
+struct DevState;
+struct HostStatus;
 hipError_t launch_gram(const ccal_problem* p, int cam, bool use_candidate_params, int gbuf, hipStream_t s);
-hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s);
-hipError_t launch_reduce(const ccal_problem* p, hipStream_t s);
-hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s);
-hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s);
-hipError_t launch_gn_decide(const ccal_problem* p, bool init, double min_error, double min_abs, double min_rel, hipStream_t s);
+hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, int sel, hipStream_t s);
+hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
+                        const DevState* st = nullptr);
+hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st = nullptr);
+hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
+hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
 hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s);   // scal[0] = sum cost_o[gbuf], scal[1] = sum mc_slot
+hipError_t launch_sum_cost_dev(const ccal_problem* p, const DevState* st, int candidate, hipStream_t s);
+hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, bool verbose, hipStream_t s);
 
 }  // namespace ccal

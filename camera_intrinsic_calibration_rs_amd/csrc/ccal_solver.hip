@@ -44,6 +44,10 @@ void normal_ws_destroy(ccal_problem* p) {
                      w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
+    if (w->d_gstate) (void)hipFree(w->d_gstate);
+    if (w->side) (void)hipStreamDestroy(w->side);
+    if (w->h_gstatus) (void)hipHostFree(w->h_gstatus);
+    if (w->h_gstate) (void)hipHostFree(w->h_gstate);
     if (FusedWs* f = w->fws) {
         void* fp[] = { f->pf[0], f->pf[1], f->praw[0], f->praw[1], f->partial, f->red, f->d_state, f->fcbuf, f->mc_f, f->cost_f };
         for (void* q : fp) if (q) (void)hipFree(q);
@@ -151,6 +155,11 @@ int normal_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMalloc((void**)&w->scal, 8 * sizeof(double)));
     HIP_TRY(ctx, hipMemset(w->scal, 0, 8 * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->flags, 4 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->d_gstate, sizeof(DevState)));
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstatus, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstate, sizeof(DevState), hipHostMallocDefault));
+    std::memset((void*)w->h_gstatus, 0, sizeof(HostStatus));
     HIP_TRY(ctx, hipMemset(w->flags, 0, 4 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_pinned, (size_t)(w->RB + 16) * sizeof(double), hipHostMallocDefault));
@@ -203,6 +212,28 @@ static int enqueue_reduce_system(ccal_problem* p, int gbuf, double lambda, doubl
     HIP_TRY(ctx, launch_reduce(p, ctx->stream));
     if (p->allreduce) {
         if (p->allreduce(p->allreduce_user, w->red, (size_t)w->RB, (void*)ctx->stream) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+    }
+    return CCAL_OK;
+}
+
+// Host side of the device-resident loops: spin on the status word a decision kernel publishes to pinned memory.
+static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const DevState* d_state, int target) {
+    const auto tw = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (hst->seq < target) {
+        if ((++spins & 0xFFF) == 0) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
+            if (el > 0.002 && hipStreamQuery(st) == hipSuccess && hst->seq < target) {
+                // stream drained but the word did not arrive: fall back to an explicit copy
+                DevState ds;
+                HIP_TRY(ctx, hipMemcpy(&ds, d_state, sizeof ds, hipMemcpyDeviceToHost));
+                hst->done = ds.done; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
+                hst->lm_rejected = ds.lm_rejected; hst->cur_cost = ds.cur_cost; hst->initial_cost = ds.initial_cost;
+                hst->seq = target;
+                break;
+            }
+            if (el > 30.0) { ctx->err = "device-resident solve timed out"; return CCAL_ERR_HIP; }
+        }
     }
     return CCAL_OK;
 }
@@ -312,26 +343,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         }
         return seq;
     };
-    auto wait_seq = [&](int target) -> int {
-        const auto tw = std::chrono::steady_clock::now();
-        long spins = 0;
-        while (hst->seq < target) {
-            if ((++spins & 0xFFF) == 0) {
-                const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-                if (el > 0.002 && hipStreamQuery(st) == hipSuccess && hst->seq < target) {
-                    // stream drained but the word did not arrive: fall back to an explicit copy
-                    DevState ds;
-                    HIP_TRY(ctx, hipMemcpy(&ds, f->d_state, sizeof ds, hipMemcpyDeviceToHost));
-                    hst->done = ds.done; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
-                    hst->lm_rejected = ds.lm_rejected; hst->cur_cost = ds.cur_cost; hst->initial_cost = ds.initial_cost;
-                    hst->seq = target;
-                    break;
-                }
-                if (el > 30.0) { ctx->err = "fused solve timed out"; return CCAL_ERR_HIP; }
-            }
-        }
-        return CCAL_OK;
-    };
+    auto wait_seq = [&](int target) -> int { return wait_status(ctx, st, hst, f->d_state, target); };
 
     // keep two groups in flight: the GPU never waits for the host, the host wastes at most two
     // early-exit groups after convergence
@@ -443,159 +455,90 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
     // single camera: device-resident loop (sharded LM needs a second all-reduce per iteration -> general loop)
     if (p->n_cams == 1 && p->n_obs > 0 && !(p->allreduce && lm) && !std::getenv("CCAL_DISABLE_FUSED"))
         return solve_fused(p, o, intr_io, poses_io, rep);
-    if ((rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
-    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
+    // General loop (several cameras, sharded LM, or CCAL_DISABLE_FUSED): device-resident as well.  One group =
+    //   k_schur -> k_reduce -> (all-reduce red) -> k_solve -> k_backsub -> k_gram at the candidate (per camera) -> k_sum2
+    //   -> (all-reduce cost, model decrease) -> k_gdecide
+    // every kernel picks the current parameter / Gram set by st->cur and its damping from st->lambda, k_gdecide applies
+    // the oracle's accept / reject / stop rules and publishes a status word; the host only enqueues groups (one ahead
+    // of the group it waits for) and polls.  Set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1]).
     NormalWs* w = p->nws;
     hipStream_t st = ctx->stream;
+    if (w->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); w->tail_pending = false; }   // a stale k_gdecide must not publish into this solve
+    if ((rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
+    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
     const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
-    ccal_report R = {};
-    double* h = w->h_pinned;
-    int32_t* hflags = reinterpret_cast<int32_t*>(h + 8);
     const auto t0 = std::chrono::steady_clock::now();
-
+    DevState* hs0 = w->h_gstate;
+    std::memset(hs0, 0, sizeof *hs0);
+    hs0->radius = o->lm_initial_radius; hs0->dec = 2.0;
+    hs0->lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
+    hs0->min_error = o->min_error; hs0->min_abs = o->min_abs_error_decrease; hs0->min_rel = o->min_rel_error_decrease;
+    hs0->max_iter = o->max_iterations; hs0->method = o->method;
+    HIP_TRY(ctx, hipMemcpyAsync(w->d_gstate, hs0, sizeof(DevState), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
-    // cost and Gram at the starting point
-    double radius = o->lm_initial_radius, dec = 2.0;
-    double lambda = lm ? 1.0 / radius : 0.0;
-    if ((rc = enqueue_gram(p, false, w->cur)) != CCAL_OK) return rc;
-    HIP_TRY(ctx, launch_sum_cost(p, w->cur, st));
-    if (p->allreduce && p->allreduce(p->allreduce_user, w->scal, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
-    HIP_TRY(ctx, hipMemcpyAsync(h, w->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipStreamSynchronize(st));
-    double cur = h[0];
-    R.initial_cost = cur;
-    int status = CCAL_OK;
-    if (!std::isfinite(cur)) status = CCAL_ERR_NONFINITE;
-    bool need_system = true;      // red must be (re)built from G[cur] with the current lambda
-
-    if (!lm && status == CCAL_OK) {
-        // Gauss-Newton accepts every step, so iteration i+1 can be enqueued before the host has seen the cost of
-        // iteration i: the GPU never waits for the host, which only decides when to stop.  Exactly one iteration
-        // is enqueued ahead (a fixed rule: sharded ranks issue identical collective sequences); its candidate
-        // goes to the buffers of x_{i-1}, so stopping at iteration i leaves x_{i+1} of that iteration intact.
-        hipEvent_t ev[2];
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&ev[1], hipEventDisableTiming));
-        struct EvGuard { hipEvent_t* e; ~EvGuard() { (void)hipEventDestroy(e[0]); (void)hipEventDestroy(e[1]); } } evg{ ev };
-        auto enqueue_iter = [&](int slot) -> int {
-            int r = enqueue_reduce_system(p, w->cur, 0.0, min_d, max_d);
-            if (r != CCAL_OK) return r;
-            HIP_TRY(ctx, launch_solve(p, 0.0, min_d, max_d, st));
-            HIP_TRY(ctx, launch_backsub(p, 0.0, min_d, max_d, st));
-            const int cand = w->cur ^ 1;
-            if ((r = enqueue_gram(p, true, cand)) != CCAL_OK) return r;
-            HIP_TRY(ctx, launch_sum_cost(p, cand, st));
-            if (p->allreduce && p->allreduce(p->allreduce_user, w->scal, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
-            HIP_TRY(ctx, launch_gn_decide(p, false, o->min_error, o->min_abs_error_decrease, o->min_rel_error_decrease, st));
-            HIP_TRY(ctx, hipMemcpyAsync(h + 8 * slot, w->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipMemcpyAsync(h + 8 * slot + 4, w->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(ctx, hipEventRecord(ev[slot], st));
-            std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
-            w->cur = cand;
-            return CCAL_OK;
-        };
-        auto undo_last = [&]() {
-            std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
-            w->cur ^= 1;
-        };
-        HIP_TRY(ctx, launch_gn_decide(p, true, 0.0, 0.0, 0.0, st));
-        if ((rc = enqueue_iter(0)) != CCAL_OK) return rc;
-        for (int it = 0; it < o->max_iterations; ++it) {
-            const bool ahead = it + 1 < o->max_iterations;
-            if (ahead && (rc = enqueue_iter((it + 1) & 1)) != CCAL_OK) return rc;
-            HIP_TRY(ctx, hipEventSynchronize(ev[it & 1]));
-            const double* hs = h + 8 * (it & 1);
-            const int32_t* hf = reinterpret_cast<const int32_t*>(hs + 4);
-            R.iterations++;
-            bool stop = false;
-            if (hf[0] || hf[1]) {            // solve failed -> None; the step of this iteration is not applied
-                status = CCAL_ERR_NOT_PD; ctx->err = "normal equations are not positive definite";
-                undo_last();
-                stop = true;
-            } else {
-                const double last = cur;
-                cur = hs[0];
-                if (o->verbose) std::printf("[ccal GN] iter %d cost %.12g\n", it, cur);
-                if (cur < o->min_error) stop = true;
-                else if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; stop = true; }
-                else if (std::fabs(last - cur) < o->min_abs_error_decrease) stop = true;
-                else if (std::fabs(last - cur) / last < o->min_rel_error_decrease) stop = true;
-                else if (it == o->max_iterations - 1) status = CCAL_ERR_NO_CONVERGENCE;
-            }
-            if (stop) { if (ahead) undo_last(); break; }
+    HostStatus* hst = w->h_gstatus;
+    hst->seq = 0; hst->done = 0;
+    const DevState* ds = w->d_gstate;
+    int seq = 0;
+    auto ar = [&](double* buf, size_t n) -> int {
+        if (p->allreduce && p->allreduce(p->allreduce_user, buf, n, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+        return CCAL_OK;
+    };
+    auto enqueue = [&](bool init) -> int {          // returns the sequence number that marks the group's end, < 0 on error
+        if (!init) {
+            HIP_TRYN(ctx, launch_schur(p, w->cur, 0.0, min_d, max_d, st, ds));
+            HIP_TRYN(ctx, launch_reduce(p, st, ds));
+            if (ar(w->red, (size_t)w->RB) != CCAL_OK) return -CCAL_ERR_HIP;
+            HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds));
+            HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
         }
-        HIP_TRY(ctx, hipMemsetAsync(w->flags + 3, 0, sizeof(int32_t), st));     // behind the (skipped) iteration enqueued ahead
+        for (int c = 0; c < p->n_cams; ++c) HIP_TRYN(ctx, launch_gram_dev(p, c, ds, init ? 0 : 1, st));
+        HIP_TRYN(ctx, launch_sum_cost_dev(p, ds, init ? 0 : 1, st));
+        if (ar(w->scal, 2) != CCAL_OK) return -CCAL_ERR_HIP;
+        HIP_TRYN(ctx, launch_gdecide(p, w->d_gstate, hst, init, ++seq, o->verbose != 0, st));
+        return seq;
+    };
+    std::vector<int> pending;
+    int enq = 0;
+    const int max_groups = o->max_iterations + 1;
+    // sharded solves: every rank issues the same sequence of collectives (the decisions come from all-reduced sums);
+    // no group is enqueued ahead there, so a finished solve leaves no stray collective behind
+    static const int env_gdepth = [] { const char* e = std::getenv("CCAL_GENERAL_DEPTH"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    const int depth = p->allreduce ? 1 : env_gdepth;
+    bool finished = false;
+    while (!finished) {
+        while ((int)pending.size() < depth && enq < max_groups) {
+            const int sq = enqueue(enq == 0);
+            if (sq < 0) return -sq;
+            pending.push_back(sq); ++enq;
+        }
+        if (pending.empty()) break;
+        if ((rc = wait_status(ctx, st, hst, w->d_gstate, pending.front())) != CCAL_OK) return rc;
+        pending.erase(pending.begin());
+        if (hst->done) finished = true;
     }
-
-    for (int it = 0; lm && status == CCAL_OK && it < o->max_iterations; ++it) {
-        if (need_system) {
-            if ((rc = enqueue_reduce_system(p, w->cur, lambda, min_d, max_d)) != CCAL_OK) return rc;
-            need_system = false;
-        }
-        HIP_TRY(ctx, launch_solve(p, lambda, min_d, max_d, st));
-        HIP_TRY(ctx, launch_backsub(p, lambda, min_d, max_d, st));
-        const int cand = w->cur ^ 1;
-        if ((rc = enqueue_gram(p, true, cand)) != CCAL_OK) return rc;
-        HIP_TRY(ctx, launch_sum_cost(p, cand, st));
-        if (p->allreduce && p->allreduce(p->allreduce_user, w->scal, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
-        HIP_TRY(ctx, hipMemcpyAsync(h, w->scal, 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipMemcpyAsync(hflags, w->flags, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
-        R.iterations++;
-        const double cand_cost = h[0], mc = h[1] + h[2];
-        const bool lin_fail = hflags[0] || hflags[1];
-        if (!lm) {
-            if (lin_fail) { status = CCAL_ERR_NOT_PD; ctx->err = "normal equations are not positive definite"; break; }   // solve failed -> None
-            // accept unconditionally (Gauss-Newton): x <- candidate
-            std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
-            w->cur = cand; need_system = true;
-            const double last = cur;
-            cur = cand_cost;
-            if (o->verbose) std::printf("[ccal GN] iter %d cost %.12g\n", it, cur);
-            if (cur < o->min_error) break;
-            if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
-            if (std::fabs(last - cur) < o->min_abs_error_decrease) break;
-            if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
-        } else {
-            const double rho = (cur - cand_cost) / mc;
-            // predicted decrease below the thresholds: converged (the re-weighted cost is not monotone under
-            // exact steps at the optimum, so waiting for an accepted tiny decrease would only shrink the radius)
-            if (!lin_fail && std::isfinite(cand_cost) && mc >= 0.0 &&
-                (mc < o->min_abs_error_decrease || mc < o->min_rel_error_decrease * cur)) {
-                if (cand_cost < cur) {
-                    std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
-                    w->cur = cand; cur = cand_cost; R.lm_accepted++;
-                }
-                break;
-            }
-            if (!lin_fail && std::isfinite(cand_cost) && mc > 0.0 && rho > 0.0) {
-                std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
-                w->cur = cand;
-                const double last = cur;
-                cur = cand_cost; R.lm_accepted++;
-                const double t = 2.0 * rho - 1.0;
-                radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
-                dec = 2.0;
-                if (o->verbose) std::printf("[ccal LM] iter %d accept cost %.12g rho %.3g radius %.3g\n", it, cur, rho, radius);
-                if (cur < o->min_error) break;
-                if (std::fabs(last - cur) < o->min_abs_error_decrease) break;
-                if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
-            } else {
-                R.lm_rejected++;
-                radius /= dec; dec *= 2.0;
-                if (lin_fail) HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
-                if (o->verbose) std::printf("[ccal LM] iter %d reject (cand %.12g) radius %.3g\n", it, cand_cost, radius);
-                if (radius < 1e-32) { status = CCAL_ERR_NO_CONVERGENCE; break; }
-            }
-            lambda = 1.0 / radius;
-            need_system = true;          // same or new G[cur], new lambda
-        }
-        if (it == o->max_iterations - 1) status = CCAL_ERR_NO_CONVERGENCE;
+    // the deciding k_gdecide published after a system-scope fence: the result is complete; it is downloaded through a
+    // side stream so that it does not queue behind the early-exit group enqueued ahead (drained before the next solve)
+    hipStream_t dl = st;
+    if (hst->done && !pending.empty()) { dl = w->side; w->tail_pending = true; }
+    else HIP_TRY(ctx, hipStreamSynchronize(st));
+    int status = hst->done ? hst->done - 1 : CCAL_ERR_NO_CONVERGENCE;
+    if (hst->cur == 1) {             // the accepted point lives in set 1: make it set 0 for whoever comes next
+        std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+        w->cur ^= 1;
     }
-    R.final_cost = cur; R.status = status;
-    rc = ccal_download_params(p, intr_io, poses_io, extr_io);
+    ccal_report R = {};
+    R.status = status; R.iterations = hst->iter; R.lm_accepted = hst->lm_accepted; R.lm_rejected = hst->lm_rejected;
+    R.initial_cost = hst->initial_cost; R.final_cost = hst->cur_cost;
+    HIP_TRY(ctx, hipMemcpyAsync(intr_io, p->d_intr, sizeof(double) * p->n_cams * CCAL_PMAX, hipMemcpyDeviceToHost, dl));
+    if (poses_io && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(poses_io, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToHost, dl));
+    if (extr_io) HIP_TRY(ctx, hipMemcpyAsync(extr_io, p->d_extr, sizeof(double) * p->n_cams * 6, hipMemcpyDeviceToHost, dl));
+    HIP_TRY(ctx, hipStreamSynchronize(dl));
+    if (p->one_focal) for (int c = 0; c < p->n_cams; ++c) intr_io[c * CCAL_PMAX + 1] = intr_io[c * CCAL_PMAX];   // fy = f (src/util.rs:467-470)
+    rc = CCAL_OK;
     R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rep) *rep = R;
+    if (status == CCAL_ERR_NOT_PD) ctx->err = "normal equations are not positive definite";
     if (rc != CCAL_OK) return rc;
     return status;
 }
