@@ -57,5 +57,6 @@ hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* fused_
 hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s);
 hipError_t launch_cost1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
+hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s);     // state := "first evaluation of set 0 with this lambda"
 
 }  // namespace ccal

@@ -1166,6 +1166,16 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
     __shared__ HeadShared hs;
     head_body(a, hs, true);
 }
+// ccal_build_normal_dev on a single camera: evaluate set 0 as a first evaluation (no pose update) with this damping
+__global__ void k_state_eval(DevState* st, double lambda) {
+    st->done = 0; st->cur = 0; st->first = 1; st->iter = 0;
+    st->lambda = lambda; st->lambda_solve = 0.0;
+    st->method = lambda > 0.0 ? CCAL_METHOD_LM : CCAL_METHOD_GN;
+}
+hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s) {
+    hipLaunchKernelGGL(k_state_eval, dim3(1), dim3(1), 0, s, st, lambda);
+    return hipGetLastError();
+}
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();

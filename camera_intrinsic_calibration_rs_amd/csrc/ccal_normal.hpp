@@ -55,6 +55,7 @@ struct NormalWs {
     ColInfo* cols = nullptr;                   // [K]
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
+    bool red_fused = false;                    // the last ccal_build_normal_dev left its sums in fws->red (single camera)
     int64_t g_len = 0;
     struct DevState* d_gstate = nullptr;       // general loop: optimizer state on the device,
     struct HostStatus* h_gstatus = nullptr;    //   its published copy (pinned, host-coherent)

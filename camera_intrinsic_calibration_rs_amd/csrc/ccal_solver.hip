@@ -216,6 +216,32 @@ static int enqueue_reduce_system(ccal_problem* p, int gbuf, double lambda, doubl
     return CCAL_OK;
 }
 
+// Argument block of the single-camera kernels: set 0 = (p->d_intr, p->d_poses), set 1 = the *_c buffers.
+static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double max_diag) {
+    const NormalWs* w = p->nws;
+    const FusedWs* f = w->fws;
+    FusedArgs fa = {};
+    fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
+    fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
+    fa.n_obs = p->n_obs; fa.K = p->K; fa.PF = w->PF; fa.PRAW = f->PRAW; fa.n_pw = f->n_pw;
+    fa.fcbuf = f->fcbuf; fa.mc_f = f->mc_f; fa.cost_f = f->cost_f;
+    fa.huber_delta = p->huber_delta; fa.min_diag = min_diag; fa.max_diag = max_diag;
+    fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
+    fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
+    fa.dc = w->dc; fa.st = f->d_state; fa.st_flags = w->flags; fa.partial = f->partial; fa.red = f->red;
+    fa.ticket = w->flags + 2;
+    return fa;
+}
+// register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR/AGPR file next to the row math
+// (measured at 10 000 frames, GN solve: KB4 0.58 vs 0.60 ms, OPENCV5 0.59 vs 0.55 ms); matrix-core Gram
+// otherwise.  CCAL_GRAM=mfma|valu overrides.
+static bool fused_use_valu_gram(const ccal_problem* p) {
+    const int ncols = p->cams[0].D + 1;
+    bool v = ncols * (ncols + 1) / 2 <= 120;      // UCM, EUCM, KB4; OPENCV5 (136 entries) is faster on the matrix cores
+    if (const char* g = std::getenv("CCAL_GRAM")) v = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 136;
+    return v;
+}
+
 // Host side of the device-resident loops: spin on the status word a decision kernel publishes to pinned memory.
 static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const DevState* d_state, int target) {
     const auto tw = std::chrono::steady_clock::now();
@@ -284,16 +310,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     HostStatus* hst = f->h_status;
     hst->seq = 0; hst->done = 0;
 
-    FusedArgs fa = {};
-    fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
-    fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
-    fa.n_obs = p->n_obs; fa.K = K; fa.PF = w->PF; fa.PRAW = f->PRAW; fa.n_pw = f->n_pw;
-    fa.fcbuf = f->fcbuf; fa.mc_f = f->mc_f; fa.cost_f = f->cost_f;
-    fa.huber_delta = p->huber_delta; fa.min_diag = o->lm_min_diagonal; fa.max_diag = o->lm_max_diagonal;
-    fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
-    fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
-    fa.dc = w->dc; fa.st = f->d_state; fa.st_flags = w->flags; fa.partial = f->partial; fa.red = f->red;
-    fa.ticket = w->flags + 2;
+    FusedArgs fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
     // CCAL_FUSE_TAIL=1: the last Schur workgroup reduces and decides itself (two launches per GN iteration
     // instead of four).  Off by default: measured 10 us per iteration SLOWER than the split launches on
     // MI355X (10k frames 0.51 vs 0.46 ms, 1k frames 0.23 vs 0.20 ms for 3 GN iterations) - the ticket round
@@ -307,12 +324,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
     ha.min_diag = o->lm_min_diagonal; ha.max_diag = o->lm_max_diagonal;
     const int model = p->cams[0].model;
-    // register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR/AGPR file next to the row math
-    // (measured at 10 000 frames, GN solve: KB4 0.58 vs 0.60 ms, OPENCV5 0.59 vs 0.55 ms); matrix-core Gram
-    // otherwise.  CCAL_GRAM=mfma|valu overrides.
-    const int ncols = p->cams[0].D + 1;
-    bool use_valu_gram = ncols * (ncols + 1) / 2 <= 120;      // UCM, EUCM, KB4; OPENCV5 (136 entries) is faster on the matrix cores
-    if (const char* g = std::getenv("CCAL_GRAM")) use_valu_gram = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 136;
+    const bool use_valu_gram = fused_use_valu_gram(p);
     int seq = 0;
     auto enqueue = [&]() -> int {         // one evaluation + decision + solve; returns the seq that marks its end
         if (use_valu_gram) HIP_TRYN(ctx, launch_gram1v(model, p->one_focal, fa, st));
@@ -414,6 +426,23 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda) {
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     NormalWs* w = p->nws;
+    w->red_fused = false;
+    if (p->n_cams == 1 && p->n_obs > 0 && !p->allreduce && !std::getenv("CCAL_DISABLE_FUSED")) {
+        // single camera: the device loop's own kernels (register / LDS Gram + per-frame elimination), evaluated at the
+        // current parameters with the state set to "first evaluation"; fws->red = [A_dir | Y^T Y | . | .]
+        ccal_ctx* ctx = p->ctx;
+        if ((rc = fused_ws_ensure(p)) != CCAL_OK) return rc;
+        FusedWs* f = w->fws;
+        hipStream_t st = ctx->stream;
+        const FusedArgs fa = make_fused_args(p, 1e-6, 1e32);
+        HIP_TRY(ctx, launch_state_eval(f->d_state, lambda, st));
+        if (fused_use_valu_gram(p)) HIP_TRY(ctx, launch_gram1v(p->cams[0].model, p->one_focal, fa, st));
+        else HIP_TRY(ctx, launch_gram1(p->cams[0].model, p->one_focal, fa, st));
+        HIP_TRY(ctx, launch_schur1(fa, 0, nullptr, st));
+        HIP_TRY(ctx, launch_reduce1(fa, 0, 2 * (p->K + 1) * (p->K + 1), st));
+        w->red_fused = true;
+        return CCAL_OK;
+    }
     if ((rc = enqueue_gram(p, false, w->cur)) != CCAL_OK) return rc;
     return enqueue_reduce_system(p, w->cur, lambda, 1e-6, 1e32);
 }
@@ -428,20 +457,36 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
     NormalWs* w = p->nws;
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), ctx->stream));
     if ((rc = ccal_build_normal_dev(p, lambda)) != CCAL_OK) return rc;
-    double* h = w->h_pinned;
-    HIP_TRY(ctx, hipMemcpyAsync(h, w->red, w->RB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    int32_t flags[4];
-    HIP_TRY(ctx, hipMemcpyAsync(flags, w->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     const int K = w->K, K1 = K + 1;
-    const double* hd = h + K1 * K1;
-    if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
-        double v = h[i * K1 + j];
-        if (i == j && lambda > 0.0) v += lambda * std::min(std::max(hd[i], 1e-6), 1e32);
-        S[i * K + j] = v;
+    int32_t flags[4];
+    if (w->red_fused) {
+        // [A_dir | Y^T Y]: S = A_dir - Y^T Y on the camera block, b its last column, cost = the r x r corner of A_dir
+        double* h = w->fws->h_stage;
+        HIP_TRY(ctx, hipMemcpyAsync(h, w->fws->red, 2 * K1 * K1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(flags, w->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double* A = h; const double* Y = h + K1 * K1;
+        if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+            double v = A[i * K1 + j] - Y[i * K1 + j];
+            if (i == j && lambda > 0.0) v += lambda * std::min(std::max(A[i * K1 + i], 1e-6), 1e32);
+            S[i * K + j] = v;
+        }
+        if (b) for (int i = 0; i < K; ++i) b[i] = A[i * K1 + K] - Y[i * K1 + K];
+        if (cost) *cost = A[K * K1 + K];
+    } else {
+        double* h = w->h_pinned;
+        HIP_TRY(ctx, hipMemcpyAsync(h, w->red, w->RB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(flags, w->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double* hd = h + K1 * K1;
+        if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
+            double v = h[i * K1 + j];
+            if (i == j && lambda > 0.0) v += lambda * std::min(std::max(hd[i], 1e-6), 1e32);
+            S[i * K + j] = v;
+        }
+        if (b) for (int i = 0; i < K; ++i) b[i] = h[i * K1 + K];
+        if (cost) *cost = h[w->RB - 1];
     }
-    if (b) for (int i = 0; i < K; ++i) b[i] = h[i * K1 + K];
-    if (cost) *cost = h[w->RB - 1];
     if (flags[0]) { ctx->err = "a frame's pose block is not positive definite"; return CCAL_ERR_NOT_PD; }
     return CCAL_OK;
 }
