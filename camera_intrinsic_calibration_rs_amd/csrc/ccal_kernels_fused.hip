@@ -657,8 +657,6 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
 }
 template <int MODEL, bool OF>
 static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
-    // enough wavefronts to fill 1024 SIMDs: 16 lanes per frame from ~4000 frames up, a whole wave per frame
-    // for TUM-VI-sized problems (a few hundred frames)
     // More wavefronts than SIMDs (>= 2000 frames): k_gram1w, two wavefronts per SIMD (10 000 frames: 40 vs 53 us).
     // Below that every wavefront has a SIMD to itself and k_gram1v's all-register accumulators are a little faster.
     // CCAL_GRAMV_LDSACC=0|1 forces one or the other.
@@ -666,13 +664,18 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     constexpr int NCt = block_dim(MODEL, OF, false) + 1;
     // larger triangles (KB4) do not fit two wavefronts per SIMD without scratch: k_gram1v there
     const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 105);
+    static const int lpf_env = [] { const char* e = std::getenv("CCAL_GRAMV_LPF"); return e ? std::atoi(e) : 0; }();
+    // measured optimum of the whole build (tools/time_kernels.py --what normal, CCAL_GRAMV_LPF sweep): a wavefront per
+    // frame up to one wavefront per SIMD (1 024 frames), 32 lanes per frame up to ~4 800 frames (<= 2 400 wavefronts on
+    // 2 048 slots), 16 beyond
+    const int lpf = lpf_env ? lpf_env : (a.n_obs > 4800 ? 16 : a.n_obs > 1024 ? 32 : 64);
     if (w) {
-        if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16, true>(a, s);
-        if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32, true>(a, s);
+        if (lpf == 16) return launch_gram1v_l<MODEL, OF, 16, true>(a, s);
+        if (lpf == 32) return launch_gram1v_l<MODEL, OF, 32, true>(a, s);
         return launch_gram1v_l<MODEL, OF, 64, true>(a, s);
     }
-    if (a.n_obs >= 4000) return launch_gram1v_l<MODEL, OF, 16, false>(a, s);
-    if (a.n_obs >= 2000) return launch_gram1v_l<MODEL, OF, 32, false>(a, s);
+    if (lpf == 16) return launch_gram1v_l<MODEL, OF, 16, false>(a, s);
+    if (lpf == 32) return launch_gram1v_l<MODEL, OF, 32, false>(a, s);
     return launch_gram1v_l<MODEL, OF, 64, false>(a, s);
 }
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {

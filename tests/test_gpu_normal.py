@@ -178,10 +178,11 @@ def test_lm_hard_start_never_crashes(gpu_ctx):
     assert rep.lm_accepted + rep.lm_rejected == rep.iterations or rep.status != _ffi.OK
 
 
-@pytest.mark.parametrize("n_frames", [700, 2500, 4100])
+@pytest.mark.parametrize("n_frames", [700, 1500, 2500, 5000])
 def test_solve_all_lane_mappings(gpu_ctx, oracle, n_frames):
-    """The register-Gram kernel maps 64 / 32 / 16 lanes to a frame depending on the problem size
-    (< 2000, < 4000, >= 4000 frames): every mapping against the oracle, ragged frames included."""
+    """The register-Gram kernels map 64 / 32 / 16 lanes to a frame depending on the problem size (<= 1024, <= 4800,
+    more) and keep all accumulators in registers below 2000 frames (k_gram1v) or part of them in LDS above
+    (k_gram1w): every combination against the oracle, ragged frames included."""
     sp = synth.make_problem(n_frames, "eucm", ragged=True, outlier_frac=0.01)
     gp, op = _pair(gpu_ctx, oracle, sp)
     intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
