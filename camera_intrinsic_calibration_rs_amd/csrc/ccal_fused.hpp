@@ -54,6 +54,7 @@ hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // VALU Gram (<= 105 triangle entries)
 hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* fused_head, hipStream_t s);   // fused_head != NULL: last workgroup reduces + decides + solves
+hipError_t launch_schur1m(const FusedArgs& a, int set_sel, hipStream_t s);   // four frames per wavefront; needs a.n_pw = 4 ceil(n_obs / 16)
 hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s);
 hipError_t launch_cost1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);

@@ -894,6 +894,131 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
     __syncthreads();
     head_body(ha, hs, false);
 }
+// k_schur1m: the same elimination with FOUR frames per wavefront (16 lanes each) - k_schur1 keeps 64 lanes busy with
+// one frame's 7 columns and 49 sums, so a 10 000-frame problem is 10 000 latency-bound wavefronts (381 vector + 520
+// scalar instructions each, 46 % of the time waiting); here the same instruction stream serves four frames.
+// One pass per wavefront: the grid covers all frames (n_pw = 4 ceil(n_obs / 16)).
+template <int K>
+__global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel) {
+    constexpr int K1 = K + 1, NA = K1 * K1;
+    constexpr int NQ = (NA + 15) / 16;                    // A / Y^T Y entries per lane
+    constexpr int REC = 21 + 6 * K1 + NA;                 // C (21) | [B|g] (6 x K1) | A (K1 x K1)
+    constexpr int GS = (REC + 6 * K1 + 1) & ~1;           // per frame in LDS: record | Y (6 x K1)
+    __shared__ double smem[16 * GS];
+    __shared__ double blk[16][2 * NA];
+    const DevState* st = a.st;
+    if (st->done) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, gl = lane & 15;
+    const int f = (blockIdx.x * WAVES_PER_BLOCK + wave) * 4 + grp;
+    const bool active = f < a.n_obs;
+    double* R = smem + (wave * 4 + grp) * GS;
+    double* Ym = R + REC;
+    const int cur = st->cur, first = st->first;
+    const int set = set_sel ? cur : (first ? cur : (cur ^ 1));
+    const double lambda = st->lambda;
+    double accA[NQ], accY[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
+    if (active) {
+        const double* rec = a.praw[set] + (int64_t)f * a.PRAW;
+        for (int e = gl; e < REC; e += 16) R[e] = rec[e];
+    }
+    const int slot = active ? a.obs_slot[f] : 0;
+    wsync();
+    bool ok = true;
+    if (active) {
+        // 6x6 Cholesky of C + lambda clamp(diag C) from the packed lower triangle; every lane of the frame's 16 runs it
+        double L[21], dC[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dC[i] = R[i * (i + 1) / 2 + i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = R[i * (i + 1) / 2 + j];
+                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) {
+                    ok = ok && (t > 0.0) && (t < 1.7e308);
+                    double sq, rsq;
+                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
+                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;
+                } else {
+                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
+                }
+            }
+        }
+        double* pf = a.pf[set] + (int64_t)slot * a.PF;
+        const double* Bm = R + 21;
+        if (!ok) {
+            if (gl == 0) a.st_flags[0] = 1;
+            for (int e = gl; e < a.PF; e += 16) pf[e] = 0.0;
+            for (int e = gl; e < 6 * K1; e += 16) Ym[e] = 0.0;
+        } else {
+            if (gl < K1) {
+                double y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double t = Bm[i * K1 + gl];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
+                    y[i] = t * L[i * (i + 1) / 2 + i];
+                    Ym[i * K1 + gl] = y[i];
+                    pf[21 + i * K1 + gl] = y[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 21; ++i) if (gl == (i & 15)) pf[i] = L[i];       // static register indices: no scratch
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (gl == 8 + i) { pf[21 + 6 * K1 + i] = Bm[i * K1 + K]; pf[21 + 6 * K1 + 6 + i] = dC[i]; }
+        }
+    }
+    wsync();
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = gl + 16 * q;
+            if (e < NA) {
+                const int i = e / K1, j = e - i * K1;
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+                accY[q] = t;
+                // a pose block that is not positive definite poisons the cost entry (see k_schur1)
+                accA[q] = (ok || e != K * K1 + K) ? R[21 + 6 * K1 + e] : __builtin_nan("");
+            }
+        }
+    }
+    // the sixteen frames of the workgroup combine in LDS (fixed order), one flush per workgroup
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int e = gl + 16 * q;
+        if (e < NA) { blk[wave * 4 + grp][e] = accA[q]; blk[wave * 4 + grp][NA + e] = accY[q]; }
+    }
+    __syncthreads();
+    const int nblk = a.n_pw / WAVES_PER_BLOCK;
+    for (int e = threadIdx.x; e < 2 * NA; e += 256) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += blk[g][e];
+        a.partial[(int64_t)e * nblk + blockIdx.x] = t;
+    }
+}
+hipError_t launch_schur1m(const FusedArgs& a, int set_sel, hipStream_t s) {
+    const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
+    switch (a.K) {
+        case 4: hipLaunchKernelGGL(k_schur1m<4>, grid, blk, 0, s, a, set_sel); break;
+        case 5: hipLaunchKernelGGL(k_schur1m<5>, grid, blk, 0, s, a, set_sel); break;
+        case 6: hipLaunchKernelGGL(k_schur1m<6>, grid, blk, 0, s, a, set_sel); break;
+        case 7: hipLaunchKernelGGL(k_schur1m<7>, grid, blk, 0, s, a, set_sel); break;
+        case 8: hipLaunchKernelGGL(k_schur1m<8>, grid, blk, 0, s, a, set_sel); break;
+        case 9: hipLaunchKernelGGL(k_schur1m<9>, grid, blk, 0, s, a, set_sel); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* ha, hipStream_t s) {
     const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
     const HeadArgs h = ha ? *ha : HeadArgs{};

@@ -232,6 +232,14 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.ticket = w->flags + 2;
     return fa;
 }
+// Per-frame elimination with four frames per wavefront (k_schur1m) when one pass covers the problem; sets fa.n_pw.
+static bool fused_use_schur1m(const ccal_problem* p, FusedArgs& fa) {
+    static const bool off = [] { const char* e = std::getenv("CCAL_SCHUR1M"); return e && e[0] == '0'; }();
+    const int n_pw = (p->n_obs + 15) / 16 * 4;
+    if (off || n_pw > p->nws->fws->n_pw) return false;
+    fa.n_pw = n_pw;
+    return true;
+}
 // register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR/AGPR file next to the row math
 // (measured at 10 000 frames, GN solve: KB4 0.58 vs 0.60 ms, OPENCV5 0.59 vs 0.55 ms); matrix-core Gram
 // otherwise.  CCAL_GRAM=mfma|valu overrides.
@@ -319,6 +327,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     const char* env_tw = std::getenv("CCAL_FUSED_TAIL_WAVES");
     const bool fuse_tail = !p->allreduce && env_ft && env_ft[0] == '1';
     if (fuse_tail) fa.n_pw = std::min(f->n_pw, std::max(4, (env_tw ? std::atoi(env_tw) : 2048) / 4 * 4));
+    const bool schur_m = !fuse_tail && fused_use_schur1m(p, fa);
     HeadArgs ha = {};
     ha.st = f->d_state; ha.hs = hst; ha.red = f->red; ha.cols = w->cols; ha.flags = w->flags;
     ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
@@ -334,7 +343,8 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
                 ha.phase = 3; ha.seq = ++seq;
                 HIP_TRYN(ctx, launch_schur1(fa, 0, &ha, st));
             } else {
-                HIP_TRYN(ctx, launch_schur1(fa, 0, nullptr, st));
+                if (schur_m) HIP_TRYN(ctx, launch_schur1m(fa, 0, st));
+                else HIP_TRYN(ctx, launch_schur1(fa, 0, nullptr, st));
                 HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
                 if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)f->RB1, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
                 ha.phase = 3; ha.seq = ++seq;
@@ -348,7 +358,8 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
             if (fuse_tail) {
                 HIP_TRYN(ctx, launch_schur1(fa, 1, &ha, st));
             } else {
-                HIP_TRYN(ctx, launch_schur1(fa, 1, nullptr, st));
+                if (schur_m) HIP_TRYN(ctx, launch_schur1m(fa, 1, st));
+                else HIP_TRYN(ctx, launch_schur1(fa, 1, nullptr, st));
                 HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
                 HIP_TRYN(ctx, launch_head(ha, st));
             }
@@ -434,11 +445,13 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda) {
         if ((rc = fused_ws_ensure(p)) != CCAL_OK) return rc;
         FusedWs* f = w->fws;
         hipStream_t st = ctx->stream;
-        const FusedArgs fa = make_fused_args(p, 1e-6, 1e32);
+        FusedArgs fa = make_fused_args(p, 1e-6, 1e32);
+        const bool schur_m = fused_use_schur1m(p, fa);
         HIP_TRY(ctx, launch_state_eval(f->d_state, lambda, st));
         if (fused_use_valu_gram(p)) HIP_TRY(ctx, launch_gram1v(p->cams[0].model, p->one_focal, fa, st));
         else HIP_TRY(ctx, launch_gram1(p->cams[0].model, p->one_focal, fa, st));
-        HIP_TRY(ctx, launch_schur1(fa, 0, nullptr, st));
+        if (schur_m) HIP_TRY(ctx, launch_schur1m(fa, 0, st));
+        else HIP_TRY(ctx, launch_schur1(fa, 0, nullptr, st));
         HIP_TRY(ctx, launch_reduce1(fa, 0, 2 * (p->K + 1) * (p->K + 1), st));
         w->red_fused = true;
         return CCAL_OK;
