@@ -88,4 +88,18 @@ hipError_t validation_stats_device(const ccal_problem* p, int cam, const double*
 // ccal_kernels_init.hip
 hipError_t launch_pose_init(const ccal_problem* p, int cam, const double* d_intr, double* d_poses_obs, int32_t* d_valid,
                             int min_points, hipStream_t s);
+// Dynamic LDS above 48 KiB has to be enabled per kernel AND per device: remember the largest size enabled on each
+// device of this process (contexts on several GPUs may share the process).
+struct DynLdsGuard { size_t enabled[16] = {}; };
+inline hipError_t ensure_dyn_lds(const void* fn, size_t lds, DynLdsGuard& g) {
+    if (lds <= 48 * 1024) return hipSuccess;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    size_t& have = g.enabled[dev & 15];
+    if (lds <= have) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) have = lds;
+    return e;
+}
 }  // namespace ccal

@@ -184,13 +184,8 @@ static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
     int blocks = (a.n_list + CCAL_EVAL_WPB - 1) / CCAL_EVAL_WPB;
     if (blocks == 0) return hipSuccess;
     if (CCAL_EVAL_PERSIST > 0) blocks = std::min(blocks, 256 * CCAL_EVAL_PERSIST);
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER>), lds, lds_guard); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
     return hipGetLastError();
 }

@@ -645,12 +645,8 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int WSL = G * 40 + RED;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
     auto kern = W ? k_gram1w<MODEL, OF, LPF> : k_gram1v<MODEL, OF, LPF>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
     const int fpb = G * CCAL_GRAMV_WPB;
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
@@ -696,13 +692,8 @@ template <int MODEL, bool OF>
 static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
     constexpr int WS = 40 + GRAM_TILE_CORNERS * 34;
     const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram1<MODEL, OF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_gram1<MODEL, OF>), lds, lds_guard); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_gram1<MODEL, OF>), dim3((a.n_obs + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), dim3(256), lds, s, a);
     return hipGetLastError();
 }

@@ -212,13 +212,8 @@ static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
     const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
     const int blocks = (ga.k.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks == 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gram<MODEL, OF, OTHER>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_gram<MODEL, OF, OTHER>), lds, lds_guard); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_gram<MODEL, OF, OTHER>), dim3(blocks), dim3(256), lds, s, ga);
     return hipGetLastError();
 }
@@ -448,12 +443,8 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     int tab_entries = 0;
     for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
     const size_t lds = sizeof(double) * ((size_t)WS * WAVES_PER_BLOCK + tab_entries);
-    static size_t attr_lds = 0;
-    if (lds > 48 * 1024 && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_lds = lds;
-    }
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur), lds, lds_guard); e != hipSuccess) return e;
     const int blocks = (w->n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     hipLaunchKernelGGL(k_schur, dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
