@@ -62,6 +62,7 @@ void ccal_ctx_destroy(ccal_ctx* ctx) {
 const char* ccal_last_error(const ccal_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int ccal_sync(ccal_ctx* ctx) {
     if (!ctx) return CCAL_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CCAL_OK;
 }
@@ -234,6 +235,7 @@ int ccal_upload_params(ccal_problem* p, const double* intr, const double* poses,
 int ccal_download_params(ccal_problem* p, double* intr, double* poses, double* extr) {
     if (!p) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (intr) HIP_TRY(ctx, hipMemcpyAsync(intr, p->d_intr, sizeof(double) * p->n_cams * CCAL_PMAX, hipMemcpyDeviceToHost, ctx->stream));
     if (poses && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(poses, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToHost, ctx->stream));
     if (extr) HIP_TRY(ctx, hipMemcpyAsync(extr, p->d_extr, sizeof(double) * p->n_cams * 6, hipMemcpyDeviceToHost, ctx->stream));
@@ -255,6 +257,7 @@ static KArgs make_args(const ccal_problem* p, int cam) {
 int ccal_eval_dev(ccal_problem* p, int apply_loss, double* r_dev, double* J_dev) {
     if (!p || !r_dev || !J_dev) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));      // the caller's thread may have another device current
     for (int c = 0; c < p->n_cams; ++c) {
         KArgs a = make_args(p, c);
         a.apply_loss = apply_loss; a.r_out = r_dev; a.J_out = J_dev;

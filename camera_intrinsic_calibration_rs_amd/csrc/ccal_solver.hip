@@ -434,6 +434,7 @@ int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
 
 int ccal_build_normal_dev(ccal_problem* p, double lambda) {
     if (!p) return CCAL_ERR_INVALID_ARG;
+    HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     NormalWs* w = p->nws;
@@ -507,6 +508,7 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
 int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
     if (!p || !o || !intr_io || (!poses_io && p->n_slots)) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     const bool lm = o->method == CCAL_METHOD_LM;
