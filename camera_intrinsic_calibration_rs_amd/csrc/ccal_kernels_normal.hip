@@ -477,47 +477,11 @@ hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* s
     return hipGetLastError();
 }
 
-// scal[0] = sum_o cost_o, scal[1] = sum_s mc_slot   (block 0 / block 1)
-__global__ __launch_bounds__(256) void k_sum2(const double* a, const double* a2, int na, const double* b, int nb, double* out,
-                                              const int32_t* flags, const DevState* st, int sel) {
-    __shared__ double sh[4];
-    if (st && st->done) return;
-    if (st && ((st->cur ^ sel) & 1)) a = a2;         // device-resident loop: a = set 0, a2 = set 1, sel 1 = the candidate
-    const double* src = blockIdx.x == 0 ? a : b;
-    const int n = blockIdx.x == 0 ? na : nb;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
-    int i = threadIdx.x;
-    for (; i + 7 * 256 < n; i += 8 * 256) {          // eight loads in flight per thread; fixed order
-        v0 += src[i];           v1 += src[i + 256];     v2 += src[i + 2 * 256]; v3 += src[i + 3 * 256];
-        v4 += src[i + 4 * 256]; v5 += src[i + 5 * 256]; v6 += src[i + 6 * 256]; v7 += src[i + 7 * 256];
-    }
-    for (; i < n; i += 256) v0 += src[i];
-    const double v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
-    const double t = block_sum_256(v, sh);
-    // a failed linear solve on this rank poisons the cost: the all-reduce of a sharded solve carries the NaN to
-    // every rank, so all of them reject (LM) or stop (GN) at the same iteration
-    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x == 0 && (flags[0] | flags[1])) ? __builtin_nan("") : t;
-}
-hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s) {
-    const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[gbuf], w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal, w->flags,
-                       (const DevState*)nullptr, 0);
-    return hipGetLastError();
-}
-// device-resident loop: which != 0 sums the candidate set's costs (set index st->cur ^ 1), which == 0 the current set's
-hipError_t launch_sum_cost_dev(const ccal_problem* p, const DevState* st, int which, hipStream_t s) {
-    const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_sum2, dim3(2), dim3(256), 0, s, w->cost_o[w->cur], w->cost_o[w->cur ^ 1], p->n_obs, w->mc_slot, p->n_slots, w->scal,
-                       w->flags, st, which ? 1 : 0);
-    return hipGetLastError();
-}
-
 // k_gdecide: the decisions of the general loop on the device (the same rules as the host loop it replaced, which
 // are the oracle's: tiny-solver's Gauss-Newton tests / the Ceres-style trust region) + status for the polling host.
 //   scal: 0 cost of the evaluated set, 1 model decrease of the pose blocks, 2 of the camera block
-__global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int32_t* flags, int init, int seq, int verbose) {
+__device__ void gdecide_body(DevState* st, HostStatus* hs, double cand, double mc_pose, double mc_cam, int32_t* flags, int init, int seq) {
     if (!st->done) {
-        const double cand = scal[0];
         const bool lin_fail = flags[0] || flags[1];
         int done = 0;
         if (init) {
@@ -538,7 +502,7 @@ __global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int3
             }
         } else {
             st->iter += 1;
-            const double cur = st->cur_cost, mc = scal[1] + scal[2];
+            const double cur = st->cur_cost, mc = mc_pose + mc_cam;
             const double rho = (cur - cand) / mc;
             const bool fin = fabs(cand) <= 1.7976931348623157e308;
             if (!lin_fail && fin && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * cur)) {
@@ -564,7 +528,6 @@ __global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int3
             if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
         }
         st->done = done;
-        if (verbose) printf("[ccal %s] iter %d cost %.12g radius %.3g\n", st->method == CCAL_METHOD_LM ? "LM" : "GN", st->iter, st->cur_cost, st->radius);
     }
     hs->done = st->done; hs->iter = st->iter; hs->cur = st->cur;
     hs->lm_accepted = st->lm_accepted; hs->lm_rejected = st->lm_rejected;
@@ -572,9 +535,61 @@ __global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int3
     __threadfence_system();
     hs->seq = seq;
 }
-hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, bool verbose, hipStream_t s) {
+__global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int32_t* flags, int init, int seq) {
+    gdecide_body(st, hs, scal[0], scal[1], scal[2], flags, init, seq);
+}
+
+// scal[0] = sum_o cost_o, scal[1] = sum_s mc_slot (first / second half of ONE 512-thread workgroup); with `decide` the
+// same workgroup goes on to take the decision (no all-reduce between the two: one launch less per iteration)
+__global__ __launch_bounds__(512) void k_sum2(const double* a, const double* a2, int na, const double* b, int nb, double* out,
+                                              int32_t* flags, DevState* st, int sel, HostStatus* hs, int decide, int init, int seq) {
+    __shared__ double sh[8];
+    if (st && st->done) {
+        if (decide && threadIdx.x == 0) gdecide_body(st, hs, 0.0, 0.0, 0.0, flags, init, seq);      // publishes only
+        return;
+    }
+    if (st && ((st->cur ^ sel) & 1)) a = a2;         // device-resident loop: a = set 0, a2 = set 1, sel 1 = the candidate
+    const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
+    const double* src = half == 0 ? a : b;
+    const int n = half == 0 ? na : nb;
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
+    int i = t;
+    for (; i + 7 * 256 < n; i += 8 * 256) {          // eight loads in flight per thread; fixed order
+        v0 += src[i];           v1 += src[i + 256];     v2 += src[i + 2 * 256]; v3 += src[i + 3 * 256];
+        v4 += src[i + 4 * 256]; v5 += src[i + 5 * 256]; v6 += src[i + 6 * 256]; v7 += src[i + 7 * 256];
+    }
+    for (; i < n; i += 256) v0 += src[i];
+    double v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // a failed linear solve on this rank poisons the cost: the all-reduce of a sharded solve carries the NaN to
+        // every rank, so all of them reject (LM) or stop (GN) at the same iteration
+        const double cost = (flags[0] | flags[1]) ? __builtin_nan("") : (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        const double mcp = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+        out[0] = cost; out[1] = mcp;
+        if (decide) gdecide_body(st, hs, cost, mcp, out[2], flags, init, seq);
+    }
+}
+hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_gdecide, dim3(1), dim3(1), 0, s, st, hs, w->scal, w->flags, init ? 1 : 0, seq, verbose ? 1 : 0);
+    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(512), 0, s, w->cost_o[gbuf], w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal, w->flags,
+                       (DevState*)nullptr, 0, (HostStatus*)nullptr, 0, 0, 0);
+    return hipGetLastError();
+}
+// device-resident loop: which != 0 sums the candidate set's costs (set index st->cur ^ 1), which == 0 the current set's;
+// hs != NULL: decide and publish in the same launch (no all-reduce hook between the sums and the decision)
+hipError_t launch_sum_cost_dev(const ccal_problem* p, DevState* st, int which, HostStatus* hs, bool init, int seq, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(512), 0, s, w->cost_o[w->cur], w->cost_o[w->cur ^ 1], p->n_obs, w->mc_slot, p->n_slots, w->scal,
+                       w->flags, st, which ? 1 : 0, hs, hs ? 1 : 0, init ? 1 : 0, seq);
+    return hipGetLastError();
+}
+hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    hipLaunchKernelGGL(k_gdecide, dim3(1), dim3(1), 0, s, st, hs, w->scal, w->flags, init ? 1 : 0, seq);
     return hipGetLastError();
 }
 
@@ -693,8 +708,10 @@ hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, d
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_backsub: one thread per frame slot.  dp = -L^-T (y_r + Y dc); poses_c = poses + dp;
-// mc_slot = dp^T (lambda D_p dp - g_p)
+// k_backsub: 16 lanes per frame slot (16 slots per workgroup).  dp = -L^-T (y_r + Y dc); poses_c = poses + dp;
+// mc_slot = dp^T (lambda D_p dp - g_p).  The slot's record is staged in LDS with coalesced loads (one thread per slot
+// walking its 148-double record alone cost 13 us at 10 000 slots), six lanes form the rows of y_r + Y dc, one lane
+// back-substitutes - the same operation order as before.
 // ---------------------------------------------------------------------------------------------
 struct BacksubArgs {
     const double* pf; const double* dc; const double* poses; double* poses_c; double* mc_slot;
@@ -703,6 +720,7 @@ struct BacksubArgs {
 };
 __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     __shared__ double dcs[CCAL_KMAX];
+    extern __shared__ double smem[];                       // [16][PF + 6]
     BacksubArgs a = a0;
     if (a.st) {
         if (a.st->done) return;
@@ -710,28 +728,35 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
         if (a.st->cur) { a.poses = a0.poses_c; a.poses_c = const_cast<double*>(a0.poses); }
     }
     if (threadIdx.x < a.K) dcs[threadIdx.x] = a.dc[threadIdx.x];
+    const int g = threadIdx.x >> 4, gl = threadIdx.x & 15;
+    const int s = blockIdx.x * 16 + g;
+    const bool active = s < a.n_slots;
+    const int K1 = a.K + 1, RS = a.PF + 6;
+    double* R = smem + g * RS;
+    if (active) {
+        const double* pf = a.pf + (int64_t)s * a.PF;
+        for (int e = gl; e < a.PF; e += 16) R[e] = pf[e];
+    }
     __syncthreads();
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.n_slots) return;
-    const int K1 = a.K + 1;
-    const double* pf = a.pf + (int64_t)s * a.PF;
-    double L[21];
-#pragma unroll
-    for (int i = 0; i < 21; ++i) L[i] = pf[i];
-    double dp[6];
-    if (L[0] == 0.0) {          // no observations / failed factorisation: pose unchanged
+    if (active && gl < 6) {
+        const double* yr = R + 21 + gl * K1;
+        double t = yr[a.K];
+        for (int j = 0; j < a.K; ++j) t += yr[j] * dcs[j];
+        R[a.PF + gl] = -t;
+    }
+    __syncthreads();
+    if (!active || gl != 0) return;
+    if (R[0] == 0.0) {          // no observations / failed factorisation: pose unchanged
 #pragma unroll
         for (int i = 0; i < 6; ++i) a.poses_c[(int64_t)s * 6 + i] = a.poses[(int64_t)s * 6 + i];
         a.mc_slot[s] = 0.0;
         return;
     }
+    double L[21], dp[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const double* yr = pf + 21 + i * K1;
-        double t = yr[a.K];
-        for (int j = 0; j < a.K; ++j) t += yr[j] * dcs[j];
-        dp[i] = -t;
-    }
+    for (int i = 0; i < 21; ++i) L[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dp[i] = R[a.PF + i];
 #pragma unroll
     for (int i = 5; i >= 0; --i) {     // L^T x = rhs, diagonal stored inverted
         double t = dp[i];
@@ -742,7 +767,7 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     double mc = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
-        const double gp = pf[21 + 6 * K1 + i], dC = pf[21 + 6 * K1 + 6 + i];
+        const double gp = R[21 + 6 * K1 + i], dC = R[21 + 6 * K1 + 6 + i];
         const double Dii = a.lambda > 0.0 ? a.lambda * clampd(dC, a.min_diag, a.max_diag) : 0.0;
         mc += dp[i] * (Dii * dp[i] - gp);
         a.poses_c[(int64_t)s * 6 + i] = a.poses[(int64_t)s * 6 + i] + dp[i];
@@ -757,7 +782,10 @@ hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag,
     a.pf = w->pf; a.dc = w->dc; a.poses = p->d_poses; a.poses_c = p->d_poses_c; a.mc_slot = w->mc_slot;
     a.n_slots = p->n_slots; a.K = w->K; a.PF = w->PF; a.lambda = lambda;
     a.min_diag = min_diag; a.max_diag = max_diag;
-    hipLaunchKernelGGL(k_backsub, dim3((p->n_slots + 255) / 256), dim3(256), 0, s, a);
+    const size_t lds = sizeof(double) * 16 * (size_t)(w->PF + 6);
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_backsub), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_backsub, dim3((p->n_slots + 15) / 16), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

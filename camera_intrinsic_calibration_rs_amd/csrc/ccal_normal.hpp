@@ -99,7 +99,7 @@ hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* s
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
 hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
 hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s);   // scal[0] = sum cost_o[gbuf], scal[1] = sum mc_slot
-hipError_t launch_sum_cost_dev(const ccal_problem* p, const DevState* st, int candidate, hipStream_t s);
-hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, bool verbose, hipStream_t s);
+hipError_t launch_sum_cost_dev(const ccal_problem* p, DevState* st, int candidate, HostStatus* hs_or_null, bool init, int seq, hipStream_t s);
+hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, hipStream_t s);
 
 }  // namespace ccal

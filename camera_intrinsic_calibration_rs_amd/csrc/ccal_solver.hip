@@ -553,9 +553,13 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
             HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
         }
         for (int c = 0; c < p->n_cams; ++c) HIP_TRYN(ctx, launch_gram_dev(p, c, ds, init ? 0 : 1, st));
-        HIP_TRYN(ctx, launch_sum_cost_dev(p, ds, init ? 0 : 1, st));
-        if (ar(w->scal, 2) != CCAL_OK) return -CCAL_ERR_HIP;
-        HIP_TRYN(ctx, launch_gdecide(p, w->d_gstate, hst, init, ++seq, o->verbose != 0, st));
+        if (!p->allreduce) {         // sums and decision in one launch
+            HIP_TRYN(ctx, launch_sum_cost_dev(p, w->d_gstate, init ? 0 : 1, hst, init, ++seq, st));
+        } else {
+            HIP_TRYN(ctx, launch_sum_cost_dev(p, w->d_gstate, init ? 0 : 1, nullptr, init, 0, st));
+            if (ar(w->scal, 2) != CCAL_OK) return -CCAL_ERR_HIP;
+            HIP_TRYN(ctx, launch_gdecide(p, w->d_gstate, hst, init, ++seq, st));
+        }
         return seq;
     };
     std::vector<int> pending;
@@ -575,6 +579,7 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
         if (pending.empty()) break;
         if ((rc = wait_status(ctx, st, hst, w->d_gstate, pending.front())) != CCAL_OK) return rc;
         pending.erase(pending.begin());
+        if (o->verbose) std::printf("[ccal %s] iter %d cost %.12g radius %.3g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost, hst->radius);
         if (hst->done) finished = true;
     }
     // the deciding k_gdecide published after a system-scope fence: the result is complete; it is downloaded through a
