@@ -38,13 +38,17 @@ __device__ __forceinline__ void wave_lds_sync() {
 #define CCAL_EVAL_PERSIST 0      // >0: that many workgroups per CU, each wave strides over frames
 #endif
 
+constexpr int eval_tile_stride(int D) { return 2 * D + ((D & 1) ? 4 : 2); }
 template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : 40; }   // 39 used, keep 16-B alignment
 
 template <int MODEL, bool OF, bool OTHER>
 __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int TW = 2 * D;            // doubles per block Jacobian
-    constexpr int TS = TW + 2;           // padded LDS row stride (keeps 16-B alignment, spreads banks)
+    // padded LDS row stride: even (16-B aligned rows) with TS / 2 odd, so that the ds_write_b128 of 16 consecutive
+    // lanes land in 16 different bank quads.  TW + 2 does that only for even D: with D = 15 (OPENCV5) the stride was
+    // 32 doubles = every lane on the same banks (79 us instead of 64 for 10 000 frames)
+    constexpr int TS = eval_tile_stride(D);
     constexpr int FCN = fc_doubles<OTHER>();
     constexpr int WS = FCN + 64 * TS;    // doubles of LDS per wave
     extern __shared__ double smem[];
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
 template <int MODEL, bool OF, bool OTHER>
 static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
-    constexpr int WS = fc_doubles<OTHER>() + 64 * (2 * D + 2);
+    constexpr int WS = fc_doubles<OTHER>() + 64 * eval_tile_stride(D);
     const size_t lds = sizeof(double) * WS * CCAL_EVAL_WPB;
     int blocks = (a.n_list + CCAL_EVAL_WPB - 1) / CCAL_EVAL_WPB;
     if (blocks == 0) return hipSuccess;
