@@ -15,13 +15,16 @@
 
 namespace ccal {
 
-// Frame constants, laid out in LDS (doubles).  cam0 factor uses FC_RC/FC_TC/FC_A only.
+// Frame constants, laid out in LDS (doubles).  cam0 factor uses FC_RC/FC_TC/FC_A only (FC_N0 entries).
 //   p      = RC X + TC
-//   dp/drvec_0_b[k] = A_k X                (A_k = dR0/dw_k for cam 0, R1 dR0/dw_k for cam c>0)
+//   dp/drvec_0_b[k] = a_k x (RC X)         d(R X) = dphi x (R X) with dphi = J_l(w) dw: a_k is the k-th column of the
+//                                          left Jacobian of SO(3) (cam 0), rotated by R1 for cam c > 0 - three vectors
+//                                          and a cross product instead of three 3 x 3 matrices dR/dw_k
 //   dp/dtvec_0_b    = I (cam 0) or R1
-//   dp/drvec_c_0[k] = B_k X + BK_k         (B_k = dR1/dw_k R0, BK_k = dR1/dw_k t0)
+//   dp/drvec_c_0[k] = b_k x (p - t1)       b_k = k-th column of J_l(rvec_c_0), t1 = tvec_c_0
 //   dp/dtvec_c_0    = I
-constexpr int FC_RC = 0, FC_TC = 9, FC_A = 12, FC_R1 = 39, FC_B = 48, FC_BK = 75, FC_SIZE = 84;
+constexpr int FC_RC = 0, FC_TC = 9, FC_A = 12, FC_N0 = 21, FC_N0P = 22;
+constexpr int FC_R1 = 22, FC_B = 31, FC_T1 = 40, FC_SIZE = 44;
 
 // 1/x and (sqrt x, 1/sqrt x) from the hardware seeds (v_rcp_f64 / v_rsq_f64) plus two fused
 // Newton / Goldschmidt steps: <= 1-2 ulp, a third of the instructions of the IEEE division / sqrt
@@ -131,6 +134,12 @@ __device__ inline void mat3_vec(const double* A, const double* v, double* o) {
 
 // Fill the frame constants for one observation frame.  pose = rvec,tvec of T_0_b; extr = rvec,tvec
 // of T_c_0 (OTHER only).  Every lane computes the same values; `fc` may be registers or LDS.
+// k-th column of the left Jacobian from the derivative of the rotation: [a_k]x = (dR/dw_k) R^T
+__device__ inline void left_jacobian_col(const double* Gk, const double* R, double* a) {
+    a[0] = Gk[6] * R[3] + Gk[7] * R[4] + Gk[8] * R[5];      // (G R^T)[2][1]
+    a[1] = Gk[0] * R[6] + Gk[1] * R[7] + Gk[2] * R[8];      // (G R^T)[0][2]
+    a[2] = Gk[3] * R[0] + Gk[4] * R[1] + Gk[5] * R[2];      // (G R^T)[1][0]
+}
 template <bool OTHER>
 __device__ inline void frame_setup(const double* pose, const double* extr, double* fc) {
     double R0[9], G0[27];
@@ -141,7 +150,7 @@ __device__ inline void frame_setup(const double* pose, const double* extr, doubl
 #pragma unroll
         for (int i = 0; i < 3; ++i) fc[FC_TC + i] = pose[3 + i];
 #pragma unroll
-        for (int i = 0; i < 27; ++i) fc[FC_A + i] = G0[i];
+        for (int k = 0; k < 3; ++k) left_jacobian_col(G0 + 9 * k, R0, fc + FC_A + 3 * k);
     } else {
         double R1[9], G1[27], tmp[9], v[3];
         so3_exp_jac(extr, R1, G1);
@@ -153,18 +162,16 @@ __device__ inline void frame_setup(const double* pose, const double* extr, doubl
         for (int i = 0; i < 3; ++i) fc[FC_TC + i] = v[i] + extr[3 + i];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            mat3_mul(R1, G0 + 9 * k, tmp);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) fc[FC_A + 9 * k + i] = tmp[i];
-            mat3_mul(G1 + 9 * k, R0, tmp);
-#pragma unroll
-            for (int i = 0; i < 9; ++i) fc[FC_B + 9 * k + i] = tmp[i];
-            mat3_vec(G1 + 9 * k, pose + 3, v);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) fc[FC_BK + 3 * k + i] = v[i];
+            double a0[3];
+            left_jacobian_col(G0 + 9 * k, R0, a0);
+            mat3_vec(R1, a0, fc + FC_A + 3 * k);             // R1 (a x b) = (R1 a) x (R1 b)
+            left_jacobian_col(G1 + 9 * k, R1, fc + FC_B + 3 * k);
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) fc[FC_R1 + i] = R1[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fc[FC_T1 + i] = extr[3 + i];
+        fc[FC_N0] = 0.0; fc[FC_SIZE - 1] = 0.0;              // padding entries
     }
 }
 
@@ -283,9 +290,11 @@ __device__ __forceinline__ void corner_block(const double* th, const double* fc,
     constexpr int P = model_np(MODEL);
     constexpr int ND = P - 4;
     constexpr int PE = P - (ONE_FOCAL ? 1 : 0);
-    const double px = fc[FC_RC + 0] * X + fc[FC_RC + 1] * Y + fc[FC_RC + 2] * Z + fc[FC_TC + 0];
-    const double py = fc[FC_RC + 3] * X + fc[FC_RC + 4] * Y + fc[FC_RC + 5] * Z + fc[FC_TC + 1];
-    const double pz = fc[FC_RC + 6] * X + fc[FC_RC + 7] * Y + fc[FC_RC + 8] * Z + fc[FC_TC + 2];
+    // rotated board point first: the rotation columns need it without the translation
+    const double rx = fc[FC_RC + 0] * X + fc[FC_RC + 1] * Y + fc[FC_RC + 2] * Z;
+    const double ry = fc[FC_RC + 3] * X + fc[FC_RC + 4] * Y + fc[FC_RC + 5] * Z;
+    const double rz = fc[FC_RC + 6] * X + fc[FC_RC + 7] * Y + fc[FC_RC + 8] * Z;
+    const double px = rx + fc[FC_TC + 0], py = ry + fc[FC_TC + 1], pz = rz + fc[FC_TC + 2];
     double mx, my, dmx[3], dmy[3], ddx[ND], ddy[ND];
     project_partials<MODEL>(th, px, py, pz, mx, my, dmx, dmy, ddx, ddy);
     const double fx = th[0], fy = th[1];
@@ -305,13 +314,13 @@ __device__ __forceinline__ void corner_block(const double* th, const double* fc,
     // d(u,v)/dp
     const double ju[3] = { fx * dmx[0], fx * dmx[1], fx * dmx[2] };
     const double jv[3] = { fy * dmy[0], fy * dmy[1], fy * dmy[2] };
-    // rvec_0_b columns: A_k X
+    // rvec_0_b columns: a_k x (RC X)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const double* A = fc + FC_A + 9 * k;
-        const double qx = A[0] * X + A[1] * Y + A[2] * Z;
-        const double qy = A[3] * X + A[4] * Y + A[5] * Z;
-        const double qz = A[6] * X + A[7] * Y + A[8] * Z;
+        const double* A = fc + FC_A + 3 * k;
+        const double qx = A[1] * rz - A[2] * ry;
+        const double qy = A[2] * rx - A[0] * rz;
+        const double qz = A[0] * ry - A[1] * rx;
         Ju[PE + k] = ju[0] * qx + ju[1] * qy + ju[2] * qz;
         Jv[PE + k] = jv[0] * qx + jv[1] * qy + jv[2] * qz;
     }
@@ -325,13 +334,13 @@ __device__ __forceinline__ void corner_block(const double* th, const double* fc,
             Ju[PE + 3 + k] = ju[0] * R1[k] + ju[1] * R1[3 + k] + ju[2] * R1[6 + k];
             Jv[PE + 3 + k] = jv[0] * R1[k] + jv[1] * R1[3 + k] + jv[2] * R1[6 + k];
         }
+        const double wx = px - fc[FC_T1 + 0], wy = py - fc[FC_T1 + 1], wz = pz - fc[FC_T1 + 2];     // R1 (R0 X + t0)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {   // rvec_c_0: B_k X + BK_k
-            const double* B = fc + FC_B + 9 * k;
-            const double* bk = fc + FC_BK + 3 * k;
-            const double qx = B[0] * X + B[1] * Y + B[2] * Z + bk[0];
-            const double qy = B[3] * X + B[4] * Y + B[5] * Z + bk[1];
-            const double qz = B[6] * X + B[7] * Y + B[8] * Z + bk[2];
+        for (int k = 0; k < 3; ++k) {   // rvec_c_0: b_k x (p - t1)
+            const double* B = fc + FC_B + 3 * k;
+            const double qx = B[1] * wz - B[2] * wy;
+            const double qy = B[2] * wx - B[0] * wz;
+            const double qz = B[0] * wy - B[1] * wx;
             Ju[PE + 6 + k] = ju[0] * qx + ju[1] * qy + ju[2] * qz;
             Jv[PE + 6 + k] = jv[0] * qx + jv[1] * qy + jv[2] * qz;
         }

@@ -39,7 +39,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 #endif
 
 constexpr int eval_tile_stride(int D) { return 2 * D + ((D & 1) ? 4 : 2); }
-template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : 40; }   // 39 used, keep 16-B alignment
+template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : FC_N0P; }   // padded to keep 16-B alignment
 
 template <int MODEL, bool OF, bool OTHER>
 __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) ex[i] = a.extr[a.cam * 6 + i];
         }
-        double fcr[OTHER ? FC_SIZE : 39];
+        double fcr[OTHER ? FC_SIZE : FC_N0];
         frame_setup<OTHER>(pose, ex, fcr);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < (OTHER ? FC_SIZE : 39); ++i) fc[i] = fcr[i];
+            for (int i = 0; i < (OTHER ? FC_SIZE : FC_N0); ++i) fc[i] = fcr[i];
         }
     }
     wave_lds_sync();
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) ex[i] = a.extr[a.cam * 6 + i];
         }
-        double fcr[OTHER ? FC_SIZE : 39];
+        double fcr[OTHER ? FC_SIZE : FC_N0];
         frame_setup<OTHER>(pose, ex, fcr);
         if (lane == 0) {
 #pragma unroll

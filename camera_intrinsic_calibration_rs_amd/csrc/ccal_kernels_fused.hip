@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     constexpr int D = block_dim(MODEL, OF, false);
     constexpr int K = D - 6, K1 = K + 1;
     constexpr int RS = 16, CS = 2 * RS + 2;
-    constexpr int WS = 40 + GRAM_TILE_CORNERS * CS;
+    constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * CS;
     extern __shared__ double smem[];
     const DevState* st = a.st;
     if (st->done) return;
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     const int f = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (f >= a.n_obs) return;
     double* fc = smem + wave * WS;
-    double* tile = fc + 40;
+    double* tile = fc + FC_N0P;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
@@ -130,11 +130,11 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
             for (int i = 0; i < 6; ++i) if (lane == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
         }
         if (lane == 0) a.mc_f[f] = mc;
-        double fcr[39];
+        double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 39; ++i) fc[i] = fcr[i];
+            for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
         }
     }
     wsync();
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     constexpr int NE = NC * (NC + 1) / 2;           // upper triangle
     constexpr int HALF = (NE + 1) / 2;              // entries reduced per LDS round
     constexpr int LS = HALF | 1;                    // odd row stride (doubles): conflict-free column sums
-    constexpr int WSL = G * 40 + 64 * LS;           // per wave: G frames' constants | reduction buffer
+    constexpr int WSL = G * FC_N0P + 64 * LS;           // per wave: G frames' constants | reduction buffer
     constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
     extern __shared__ double smem[];
     const DevState* st = a.st;
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     const bool active = f < a.n_obs;
     const int fa_ = active ? f : 0;
     double* fcw = smem + wave * WSL;
-    double* fc = fcw + grp * 40;
-    double* red = fcw + G * 40;
+    double* fc = fcw + grp * FC_N0P;
+    double* red = fcw + G * FC_N0P;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
@@ -332,11 +332,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             }
         }
         if (active && gl == 0) a.mc_f[f] = mc;
-        double fcr[39];
+        double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
         if (gl == 0) {
 #pragma unroll
-            for (int i = 0; i < 39; ++i) fc[i] = fcr[i];
+            for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
         }
     }
     wsync();
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     constexpr int HALF = (NR + 1) / 2;              // register entries reduced per LDS round
     constexpr int LS = HALF | 1;                    // odd row stride (doubles): conflict-free column sums
     constexpr int RED = NL * LSA > 64 * LS ? NL * LSA : 64 * LS;
-    constexpr int WSL = G * 40 + RED;               // per wave: G frames' constants | accumulators / reduction buffer
+    constexpr int WSL = G * FC_N0P + RED;               // per wave: G frames' constants | accumulators / reduction buffer
     constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
     constexpr int NQA = (G * NL + 63) / 64;
     extern __shared__ double smem[];
@@ -451,8 +451,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const bool active = f < a.n_obs;
     const int fa_ = active ? f : 0;
     double* fcw = smem + wave * WSL;
-    double* fc = fcw + grp * 40;
-    double* red = fcw + G * 40;
+    double* fc = fcw + grp * FC_N0P;
+    double* red = fcw + G * FC_N0P;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
@@ -509,11 +509,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             }
         }
         if (active && gl == 0) a.mc_f[f] = mc;
-        double fcr[39];
+        double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
         if (gl == 0) {
 #pragma unroll
-            for (int i = 0; i < 39; ++i) fc[i] = fcr[i];
+            for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
         }
     }
     wsync();
@@ -642,7 +642,7 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int NE = NC * (NC + 1) / 2, NL = 6 * (NC - 7);
     constexpr int HALF = ((W ? NE - NL : NE) + 1) / 2;
     constexpr int RED = (W && NL * 65 > 64 * (HALF | 1)) ? NL * 65 : 64 * (HALF | 1);
-    constexpr int WSL = G * 40 + RED;
+    constexpr int WSL = G * FC_N0P + RED;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
     auto kern = W ? k_gram1w<MODEL, OF, LPF> : k_gram1v<MODEL, OF, LPF>;
     static DynLdsGuard lds_guard;
@@ -690,7 +690,7 @@ hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStrea
 
 template <int MODEL, bool OF>
 static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
-    constexpr int WS = 40 + GRAM_TILE_CORNERS * 34;
+    constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * 34;
     const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
     static DynLdsGuard lds_guard;
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_gram1<MODEL, OF>), lds, lds_guard); e != hipSuccess) return e;

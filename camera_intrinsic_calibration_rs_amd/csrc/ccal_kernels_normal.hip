@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     constexpr int RS = T == 1 ? 16 : 24;      // doubles per staged row
     constexpr int CS = 2 * RS + 2;            // doubles per corner (two rows + pad)
     constexpr int NCP = 16 * T;
-    constexpr int FCN = OTHER ? FC_SIZE : 40;
+    constexpr int FCN = OTHER ? FC_SIZE : FC_N0P;
     constexpr int WS = FCN + GRAM_TILE_CORNERS * CS;   // rows are staged 32 corners at a time (LDS -> occupancy)
     extern __shared__ double smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -82,11 +82,11 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) ex[i] = p_extr[a.cam * 6 + i];
         }
-        double fcr[OTHER ? FC_SIZE : 39];
+        double fcr[OTHER ? FC_SIZE : FC_N0];
         frame_setup<OTHER>(pose, ex, fcr);
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < (OTHER ? FC_SIZE : 39); ++i) fc[i] = fcr[i];
+            for (int i = 0; i < (OTHER ? FC_SIZE : FC_N0); ++i) fc[i] = fcr[i];
         }
     }
     wave_sync_lds();
@@ -208,7 +208,7 @@ static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int T = (gram_compact(MODEL, OF, OTHER) ? D - 2 : D + 1) <= 16 ? 1 : 2;
     constexpr int RS = T == 1 ? 16 : 24;
-    constexpr int WS = (OTHER ? FC_SIZE : 40) + GRAM_TILE_CORNERS * (2 * RS + 2);
+    constexpr int WS = (OTHER ? FC_SIZE : FC_N0P) + GRAM_TILE_CORNERS * (2 * RS + 2);
     const size_t lds = sizeof(double) * WS * WAVES_PER_BLOCK;
     const int blocks = (ga.k.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks == 0) return hipSuccess;
