@@ -222,18 +222,19 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
 // ---------------------------------------------------------------------------------------------
 // Where each accumulated triangle entry goes inside the compact per-frame record
 // C (21) | [B|g] (6 x K1) | A (K1 x K1, both halves), worked out at compile time: dst | mirror << 16 (0xffff = none).
-// W = 1 leaves out the camera x pose entries (k_gram1w keeps those in LDS and writes them separately).
+// W = number of leading camera columns whose products with the pose columns are left out (k_gram1w keeps those in LDS
+// and writes them separately).
 template <int K, int W>
 struct RecMap {
     static constexpr int D = K + 6, NC = D + 1, K1 = K + 1;
-    static constexpr int N = NC * (NC + 1) / 2 - (W ? 6 * K : 0);
+    static constexpr int N = NC * (NC + 1) / 2 - 6 * W;
     uint32_t d[N];
     constexpr RecMap() : d{} {
         int r = 0;
         for (int i = 0; i < NC; ++i)
             for (int j = i; j < NC; ++j) {
                 const bool ip = i >= K && i < D, jp = j >= K && j < D;      // pose columns
-                if (W && !ip && jp && i < K) continue;
+                if (!ip && jp && i < W) continue;
                 const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
                 uint32_t a = 0, b = 0xffff;
                 if (ip && jp) a = (j - K) * (j - K + 1) / 2 + (i - K);
@@ -433,7 +434,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     constexpr int K = D - 6, K1 = K + 1;
     constexpr int NC = D + 1;                       // columns of [J | r]
     constexpr int NE = NC * (NC + 1) / 2;           // upper triangle
-    constexpr int NL = 6 * K;                       // camera x pose entries: LDS accumulators
+#ifndef CCAL_GRAMW_NLC
+#define CCAL_GRAMW_NLC 3          // measured at 10 000 frames (EUCM): 6 -> 53.2, 4 -> 51.8, 3 -> 51.0, 2 -> 56.1 us per build
+#endif
+    // camera columns whose products with the pose columns are LDS accumulators: as few as keeps two wavefronts per SIMD
+    constexpr int NLC = CCAL_GRAMW_NLC < K ? CCAL_GRAMW_NLC : K;
+    constexpr int NL = 6 * NLC;
     constexpr int NR = NE - NL;                     // the rest: registers
     constexpr int LSA = 65;                         // lane stride of an LDS accumulator row
     constexpr int HALF = (NR + 1) / 2;              // register entries reduced per LDS round
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             for (int j = i; j < NC; ++j) {
                 const bool bu = (i >= K || nz_u<OF>(i)) && (j >= K || nz_u<OF>(j));
                 const bool bv = (i >= K || nz_v<OF>(i)) && (j >= K || nz_v<OF>(j));
-                if (i < K && j >= K && j < D) {          // camera x pose: LDS accumulator of this lane
+                if (i < NLC && j >= K && j < D) {        // camera x pose: LDS accumulator of this lane
                     double t = bu ? su[i] * su[j] : 0.0;
                     if (bv) t = __builtin_fma(sv[i], sv[j], t);
                     __hip_atomic_fetch_add(red + el * LSA + lane, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
             const int ff = fbase + g;
             if (e >= NR || ff >= a.n_obs) continue;
-            const uint32_t m = g_recmap<K, 1>.d[e];
+            const uint32_t m = g_recmap<K, NLC>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
             rec[m & 0xffff] = v;
@@ -639,7 +645,7 @@ template <int MODEL, bool OF, int LPF, bool W>
 static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int G = 64 / LPF;
     constexpr int NC = block_dim(MODEL, OF, false) + 1;
-    constexpr int NE = NC * (NC + 1) / 2, NL = 6 * (NC - 7);
+    constexpr int NE = NC * (NC + 1) / 2, NL = 6 * (CCAL_GRAMW_NLC < NC - 7 ? CCAL_GRAMW_NLC : NC - 7);
     constexpr int HALF = ((W ? NE - NL : NE) + 1) / 2;
     constexpr int RED = (W && NL * 65 > 64 * (HALF | 1)) ? NL * 65 : 64 * (HALF | 1);
     constexpr int WSL = G * FC_N0P + RED;
