@@ -229,3 +229,47 @@ def test_one_degenerate_frame_gn_not_pd_lm_recovers(gpu_ctx, fused, monkeypatch)
     intr, _, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
     assert rep.status == _ffi.OK
     assert (np.abs(intr[0, :4] / sp.intr_gt[0, :4] - 1)).max() < 5e-3
+
+
+def test_six_cameras_matches_oracle(gpu_ctx, oracle):
+    """Six one-focal UCM cameras: reduced system K = 6 * 4 + 5 * 6 = 54 (CCAL_KMAX is 64); eight would be 74 and must be
+    refused at problem creation, not crash later."""
+    sp = synth.make_problem(12, "ucm", n_cams=6, xy_same_focal=True)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0)
+    intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0)
+    assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations) and rep.status == 0
+    assert (np.abs(intr[:, :5] / intr_o[:, :5] - 1)).max() <= 1e-9
+    np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-9)
+    sp8 = synth.make_problem(4, "ucm", n_cams=8, xy_same_focal=True)
+    with pytest.raises(CcalError) as ei:
+        Problem.from_synth(gpu_ctx, sp8)
+    assert ei.value.code == _ffi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("n_corners,n_frames", [(400, 6), (700, 3), (24, 30), (6, 40)])
+def test_frames_of_any_size(gpu_ctx, oracle, n_corners, n_frames):
+    """Frames far larger than the 144-corner board (several 64-corner tiles per wavefront, lanes per frame that do not
+    divide the corner count) and down to the reference's minimum of 24 corners - and 6, twice the fewest that give a
+    full-rank pose block: mode E and the solve against the oracle."""
+    from camera_intrinsic_calibration_rs_amd.engine import make_desc
+    base = synth.make_problem(n_frames, "eucm")
+    rng = np.random.default_rng(n_corners)
+    off, X, U = [0], [], []
+    for f in range(n_frames):
+        idx = rng.choice(np.arange(base.obs_offsets[f], base.obs_offsets[f + 1]), size=n_corners, replace=n_corners > 144)
+        X.append(base.p3d[idx]); U.append(base.p2d[idx]); off.append(off[-1] + n_corners)
+    X = np.concatenate(X).astype(np.float32); U = np.concatenate(U).astype(np.float32)
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, n_frames, [0] * n_frames, list(range(n_frames)),
+                        np.array(off, dtype=np.int64), X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
+    gp = Problem(gpu_ctx, d, keep)
+    op = oracle.OracleProblem(d, keep)
+    r, J = gp.eval(base.intr0, base.poses0)
+    ro, Jo = op.eval(base.intr0, base.poses0)
+    assert np.abs(r - ro).max() < 1e-10 and (np.abs(J - Jo) / np.maximum(1.0, np.abs(Jo))).max() < 1e-11
+    opts = default_opts(_ffi.METHOD_LM if n_corners < 24 else _ffi.METHOD_GN)
+    intr, poses, _, rep = gp.solve(base.intr0, base.poses0, opts=opts)
+    intr_o, poses_o, _, rep_o = op.solve(base.intr0, base.poses0, opts=opts)
+    assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations)
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * max(rep_o.final_cost, 1e-6)
+    assert (np.abs(intr[0, :6] - intr_o[0, :6]) / np.abs(intr_o[0, :6])).max() <= 1e-6
