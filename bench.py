@@ -167,6 +167,23 @@ def main():
                 extra[f"{name}_status"] = rep.status
                 extra[f"{name}_max_rel_intrinsics_err_vs_gt"] = float(
                     np.abs(intr[0, :4] / sp.intr_gt[0, :4] - 1).max())
+            # the size of a real single-camera session (BASELINE configs[0]: TUM-VI calib-cam1 has a few hundred
+            # frames): a 600-frame and a 1 000-frame (configs[1]) slice of the same synthetic set, whole ccal_solve calls
+            for nf in (600, 1000):
+                if args.frames < nf:
+                    continue
+                sub = sp.shard(0, args.frames // nf) if args.frames > nf else sp
+                sprob = Problem.from_synth(ctx, sub)
+                for name, method in (("gn", 0), ("lm", 1)):
+                    best = None
+                    for _ in range(3):
+                        _, _, _, rep = sprob.solve(sub.intr0, sub.poses0, sub.extr0, opts=default_opts(method))
+                        if best is None or rep.solve_ms < best.solve_ms:
+                            best = rep
+                    extra[f"frames{sub.n_slots}_{name}"] = {"iterations": best.iterations, "solve_ms": best.solve_ms,
+                                                           "iters_per_s": best.iterations / (best.solve_ms * 1e-3),
+                                                           "status": best.status}
+                sprob.close()
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)
         out["extra"] = extra
