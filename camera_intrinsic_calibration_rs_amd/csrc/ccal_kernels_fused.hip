@@ -6,9 +6,10 @@
 //   k_gram1      one wavefront per frame: weighted rows sqrt(w) [J | r] -> LDS (32 corners at a time)
 //                -> v_mfma_f64_16x16x4_f64 Gram -> compact record per frame:
 //                C = H_pp (21) | [B | g_p] (6 x (K+1)) | A = [J_c | r]^T W [J_c | r] ((K+1)^2)
-//   k_schur1     persistent wavefronts over frame slots: 6x6 Cholesky (+ LM damping), Y = L^-1 [B|g],
-//                per-slot record for the next back-substitution, A_dir and Y^T Y accumulated in registers,
-//                one flush per wave (deterministic, no atomics).  An LM rejection re-runs only this kernel.
+//   k_schur1m    four frames per wavefront: 6x6 Cholesky (+ LM damping), Y = L^-1 [B|g], per-slot record for the
+//                next back-substitution, A_dir and Y^T Y summed per workgroup in a fixed order (no atomics).
+//                An LM rejection re-runs only this kernel.  (k_schur1: one frame per wavefront, problems too large
+//                for one pass and the opt-in fused reduce + decide tail.)
 //   k_reduce1    fixed-order sum over waves -> red (the all-reduce buffer of sharded solves)
 //   k_cost1      (LM) sum of per-frame costs and model decreases
 //   k_head       one wavefront: accept / reject / convergence tests (tiny-solver's rules or the Ceres-style

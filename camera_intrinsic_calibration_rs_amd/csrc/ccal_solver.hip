@@ -3,8 +3,9 @@
 // The loop restates tiny_solver::GaussNewtonOptimizer::optimize as the reference calls it
 // (src/util.rs:443-463, 668-670; defaults in ccal_set_defaults) -- per iteration: Jacobian at x,
 // solve the normal equations, x <- clamp(x + dx), error(x), stop on min_error / |d error| thresholds --
-// and adds a Ceres-style Levenberg-Marquardt mode on the same kernels.  One host synchronisation per
-// iteration (two doubles + flags); everything else is stream-ordered device work.
+// and adds a Ceres-style Levenberg-Marquardt mode on the same kernels.  Both loops (single camera: solve_fused,
+// everything else: the general loop in ccal_solve) are device-resident: the decisions run in a kernel, the host
+// enqueues groups of launches one ahead and polls a status word in pinned memory.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
