@@ -41,6 +41,8 @@ namespace ccal {
 void normal_ws_destroy(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (!w) return;
+    // early-exit groups of the last solve may still be queued: they publish into the pinned status words freed below
+    if (w->tail_pending || (w->fws && w->fws->tail_pending)) (void)hipStreamSynchronize(p->ctx->stream);
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
                      w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc };
     for (void* q : ptrs) if (q) (void)hipFree(q);
