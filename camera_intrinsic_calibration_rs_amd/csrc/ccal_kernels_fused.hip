@@ -14,8 +14,8 @@
 //   k_cost1      (LM) sum of per-frame costs and model decreases
 //   k_head       one wavefront: accept / reject / convergence tests (tiny-solver's rules or the Ceres-style
 //                trust region), K x K solve, candidate intrinsics, status to pinned host memory
-// Same arithmetic and decision sequence as the general loop in ccal_solver.hip (multi-camera problems,
-// sharded LM); parity tests cover both.
+// Same arithmetic and decision sequence as the general loop in ccal_solver.hip (multi-camera problems);
+// parity tests cover both.
 #include <algorithm>
 #include <cstdlib>
 
@@ -1060,7 +1060,8 @@ hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t 
     hipLaunchKernelGGL(k_reduce1, dim3(count), dim3(256), 0, s, a.partial, a.n_pw / WAVES_PER_BLOCK, first, a.red, a.st);
     return hipGetLastError();
 }
-__global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const double* mc_f, int n, double* out, const DevState* st) {
+__global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const double* mc_f, int n, double* out, const DevState* st,
+                                                const int32_t* flags) {
     if (st->done) return;
     __shared__ double sh[16];
     const double* src = blockIdx.x == 0 ? cost_f : mc_f;
@@ -1069,10 +1070,12 @@ __global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const doub
     for (; i + 1024 < n; i += 2048) { v0 += src[i]; v1 += src[i + 1024]; }
     if (i < n) v0 += src[i];
     const double t = block_sum(v0 + v1, sh);
-    if (threadIdx.x == 0) out[blockIdx.x] = t;
+    // a failed elimination / camera solve on this rank poisons the cost: in a sharded solve the all-reduce carries the
+    // NaN to every rank and all of them reject the step together (this rank would have rejected it anyway)
+    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x == 0 && (flags[0] | flags[1])) ? __builtin_nan("") : t;
 }
 hipError_t launch_cost1(const FusedArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_cost1, dim3(2), dim3(1024), 0, s, a.cost_f, a.mc_f, a.n_obs, a.red + 2 * (a.K + 1) * (a.K + 1), a.st);
+    hipLaunchKernelGGL(k_cost1, dim3(2), dim3(1024), 0, s, a.cost_f, a.mc_f, a.n_obs, a.red + 2 * (a.K + 1) * (a.K + 1), a.st, a.st_flags);
     return hipGetLastError();
 }
 

@@ -354,7 +354,10 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
                 HIP_TRYN(ctx, launch_head(ha, st));
             }
         } else {
+            // sharded LM: two small all-reduces per group - [cost, model decrease of the pose blocks] before the
+            // decision, [A_dir | Y^T Y] before the camera solve; the decisions are then identical on every rank
             HIP_TRYN(ctx, launch_cost1(fa, st));
+            if (p->allreduce && p->allreduce(p->allreduce_user, f->red + 2 * K1 * K1, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
             ha.phase = 1 | 4; ha.seq = ++seq;       // decide; the group's status is published by its last step
             HIP_TRYN(ctx, launch_head(ha, st));
             ha.phase = 2; ha.seq = ++seq;
@@ -364,6 +367,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
                 if (schur_m) HIP_TRYN(ctx, launch_schur1m(fa, 1, st));
                 else HIP_TRYN(ctx, launch_schur1(fa, 1, nullptr, st));
                 HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
+                if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)(2 * K1 * K1), (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
                 HIP_TRYN(ctx, launch_head(ha, st));
             }
         }
@@ -515,8 +519,8 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     const bool lm = o->method == CCAL_METHOD_LM;
-    // single camera: device-resident loop (sharded LM needs a second all-reduce per iteration -> general loop)
-    if (p->n_cams == 1 && p->n_obs > 0 && !(p->allreduce && lm) && !std::getenv("CCAL_DISABLE_FUSED"))
+    // single camera: its own device-resident loop (GN and LM, sharded or not)
+    if (p->n_cams == 1 && p->n_obs > 0 && !std::getenv("CCAL_DISABLE_FUSED"))
         return solve_fused(p, o, intr_io, poses_io, rep);
     // General loop (several cameras, sharded LM, or CCAL_DISABLE_FUSED): device-resident as well.  One group =
     //   k_schur -> k_reduce -> (all-reduce red) -> k_solve -> k_backsub -> k_gram at the candidate (per camera) -> k_sum2

@@ -40,23 +40,19 @@ def test_solve_with_rccl_hook_single_rank():
             gp.set_allreduce(counting)
             calls.clear()
             got = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
-            if method == 0:      # same device-resident loop with and without the hook: bitwise identical
-                np.testing.assert_array_equal(ref[0], got[0])
-                np.testing.assert_array_equal(ref[1], got[1])
-            else:                # hook + LM takes the general loop (different summation order)
-                np.testing.assert_allclose(ref[0], got[0], rtol=1e-9, atol=1e-12)
-                np.testing.assert_allclose(ref[1], got[1], rtol=0, atol=1e-9)
+            # same device-resident loop with and without the hook: bitwise identical
+            np.testing.assert_array_equal(ref[0], got[0])
+            np.testing.assert_array_equal(ref[1], got[1])
             assert ref[3].iterations == got[3].iterations
             K = gp.K
             if method == 0:
-                # single-camera GN runs the device-resident loop: ONE packed all-reduce per evaluation
-                # ([A_dir | Y^T Y | cost | mc], 2 (K+1)^2 + 2 doubles)
+                # GN: ONE packed all-reduce per evaluation ([A_dir | Y^T Y | cost | mc], 2 (K+1)^2 + 2 doubles)
                 assert set(calls) == {2 * (K + 1) ** 2 + 2}
                 assert len(calls) == got[3].iterations + 1          # deterministic sequence: no speculative group with a hook
             else:
-                # sharded LM uses the general loop: one packed-system all-reduce per linear solve
-                # + one 2-double all-reduce per cost evaluation
-                assert calls.count((K + 1) ** 2 + 2 * K + 1) >= got[3].iterations
+                # LM: per group [cost, model decrease] before the decision and [A_dir | Y^T Y] before the camera solve
                 assert calls.count(2) == got[3].iterations + 1
+                assert calls.count(2 * (K + 1) ** 2) == got[3].iterations + 1
+                assert len(calls) == 2 * (got[3].iterations + 1)
     finally:
         dist.destroy_process_group()
