@@ -16,13 +16,15 @@ struct DevState {                 // lives in device memory; updated by k_head o
     int32_t first;                // 1 until the starting point has been evaluated
     int32_t done;                 // 0 = running, else ccal_status + 1
     int32_t iter, max_iter, method;
-    int32_t lm_accepted, lm_rejected, accepted_now, pad;
+    int32_t lm_accepted, lm_rejected, accepted_now;
+    int32_t done_seq;             // sequence number of the step that set `done` (0 while running)
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState is staged as doubles");
 
 struct HostStatus {               // pinned, host-coherent; written at the end of k_head
     volatile int32_t seq;
     volatile int32_t done, iter, cur, lm_accepted, lm_rejected;
+    volatile int32_t done_seq;    // which step finished the solve: the host acts on `done` only once it has waited for that step
     volatile double cur_cost, initial_cost, radius;
 };
 

@@ -733,7 +733,7 @@ struct HeadShared {               // LDS of the decision / solve step
 };
 __device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
     HostStatus* hs = a.hs;
-    hs->done = s->done; hs->iter = s->iter; hs->cur = s->cur;
+    hs->done = s->done; hs->done_seq = s->done_seq; hs->iter = s->iter; hs->cur = s->cur;
     hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
     hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
     __threadfence_system();
@@ -1216,6 +1216,7 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
             // sharded solve see): None, like the failed linear solve of the reference
             if (!lm && a.flags[0] && (done == 0 || done == CCAL_ERR_NONFINITE + 1)) done = CCAL_ERR_NOT_PD + 1;
             st->done = done;
+            if (done && !st->done_seq) st->done_seq = a.seq;
         }
         __syncthreads();
     }
@@ -1250,7 +1251,7 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
         __syncthreads();
         if (bad) {
             if (lane == 0) {
-                if (!lm) st->done = CCAL_ERR_NOT_PD + 1;
+                if (!lm) { st->done = CCAL_ERR_NOT_PD + 1; if (!st->done_seq) st->done_seq = a.seq; }
                 else a.flags[1] = 1;                 // LM: the next decision rejects and shrinks the radius
                 st->mc_cam = 0.0; st->lambda_solve = lambda;
             }

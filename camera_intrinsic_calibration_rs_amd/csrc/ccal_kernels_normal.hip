@@ -528,8 +528,9 @@ __device__ void gdecide_body(DevState* st, HostStatus* hs, double cand, double m
             if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
         }
         st->done = done;
+        if (done && !st->done_seq) st->done_seq = seq;
     }
-    hs->done = st->done; hs->iter = st->iter; hs->cur = st->cur;
+    hs->done = st->done; hs->done_seq = st->done_seq; hs->iter = st->iter; hs->cur = st->cur;
     hs->lm_accepted = st->lm_accepted; hs->lm_rejected = st->lm_rejected;
     hs->cur_cost = st->cur_cost; hs->initial_cost = st->initial_cost; hs->radius = st->radius;
     __threadfence_system();

@@ -264,7 +264,7 @@ static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const Dev
                 // stream drained but the word did not arrive: fall back to an explicit copy
                 DevState ds;
                 HIP_TRY(ctx, hipMemcpy(&ds, d_state, sizeof ds, hipMemcpyDeviceToHost));
-                hst->done = ds.done; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
+                hst->done = ds.done; hst->done_seq = ds.done_seq; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
                 hst->lm_rejected = ds.lm_rejected; hst->cur_cost = ds.cur_cost; hst->initial_cost = ds.initial_cost;
                 hst->seq = target;
                 break;
@@ -319,7 +319,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         HIP_TRY(ctx, launch_unpack1(ua, st));
     }
     HostStatus* hst = f->h_status;
-    hst->seq = 0; hst->done = 0;
+    hst->seq = 0; hst->done = 0; hst->done_seq = 0;
 
     FusedArgs fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
     // CCAL_FUSE_TAIL=1: the last Schur workgroup reduces and decides itself (two launches per GN iteration
@@ -383,21 +383,28 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     int status = CCAL_OK;
     bool finished = false;
     while (!finished) {
-        // Sharded solves (all-reduce hook set) must issue the SAME sequence of collectives on every rank:
-        // no speculative group there -- the next group is enqueued only after this one's status is known
-        // (identical on all ranks, it is computed from the all-reduced sums).
+        // Sharded solves (all-reduce hook set) must issue the SAME sequence of collectives on every rank.  They do:
+        // the fill rule below is a function of the group that reported `done` only (groups enqueued = that index +
+        // depth, whatever the host timing), and `done` is decided from all-reduced sums, identically on every rank.
+        // Default with a hook: no group ahead (CCAL_FUSED_DEPTH_HOOK=2 enqueues one; on a 1-rank RCCL group the extra
+        // early-exit group with its hook calls cost as much as the overlap gained: 0.46 vs 0.42 ms LM at 1 000 frames).
         static const int env_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH"); return e ? std::max(1, std::atoi(e)) : 2; }();
-        const int depth = p->allreduce ? 1 : env_depth;
+        static const int env_depth_hook = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH_HOOK"); return e ? std::max(1, std::atoi(e)) : 1; }();
+        const int depth = p->allreduce ? env_depth_hook : env_depth;
         while ((int)pending.size() < depth && enq < max_groups) {
             const int s = enqueue();
             if (s < 0) return -s;
             pending.push_back(s); ++enq;
         }
         if (pending.empty()) break;
-        rc = wait_seq(pending.front());
+        const int waited = pending.front();
+        rc = wait_seq(waited);
         if (rc != CCAL_OK) return rc;
         pending.erase(pending.begin());
-        if (hst->done) { status = hst->done - 1; finished = true; }
+        // act on `done` only when it was set by a step this thread has waited for: a later group may already have
+        // published it, and how many groups get enqueued must not depend on that race (sharded ranks would issue
+        // different numbers of collectives)
+        if (hst->done && hst->done_seq <= waited) { status = hst->done - 1; finished = true; }
         else if (o->verbose) std::printf("[ccal fused %s] iter %d cost %.12g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost);
     }
     // hst->done was published by the last instruction of the deciding k_head (after a system-scope fence): everything
@@ -544,7 +551,7 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
     HIP_TRY(ctx, hipMemcpyAsync(w->d_gstate, hs0, sizeof(DevState), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
     HostStatus* hst = w->h_gstatus;
-    hst->seq = 0; hst->done = 0;
+    hst->seq = 0; hst->done = 0; hst->done_seq = 0;
     const DevState* ds = w->d_gstate;
     int seq = 0;
     auto ar = [&](double* buf, size_t n) -> int {
@@ -572,8 +579,8 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
     std::vector<int> pending;
     int enq = 0;
     const int max_groups = o->max_iterations + 1;
-    // sharded solves: every rank issues the same sequence of collectives (the decisions come from all-reduced sums);
-    // no group is enqueued ahead there, so a finished solve leaves no stray collective behind
+    // sharded solves: every rank issues the same sequence of collectives - the decisions come from all-reduced sums and
+    // the number of groups enqueued depends only on the group that reported `done` (that index + depth)
     static const int env_gdepth = [] { const char* e = std::getenv("CCAL_GENERAL_DEPTH"); return e ? std::max(1, std::atoi(e)) : 2; }();
     const int depth = p->allreduce ? 1 : env_gdepth;
     bool finished = false;
@@ -584,10 +591,11 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, doub
             pending.push_back(sq); ++enq;
         }
         if (pending.empty()) break;
-        if ((rc = wait_status(ctx, st, hst, w->d_gstate, pending.front())) != CCAL_OK) return rc;
+        const int waited = pending.front();
+        if ((rc = wait_status(ctx, st, hst, w->d_gstate, waited)) != CCAL_OK) return rc;
         pending.erase(pending.begin());
         if (o->verbose) std::printf("[ccal %s] iter %d cost %.12g radius %.3g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost, hst->radius);
-        if (hst->done) finished = true;
+        if (hst->done && hst->done_seq <= waited) finished = true;     // see solve_fused: no dependence on publication races
     }
     // the deciding k_gdecide published after a system-scope fence: the result is complete; it is downloaded through a
     // side stream so that it does not queue behind the early-exit group enqueued ahead (drained before the next solve)

@@ -45,14 +45,16 @@ def test_solve_with_rccl_hook_single_rank():
             np.testing.assert_array_equal(ref[1], got[1])
             assert ref[3].iterations == got[3].iterations
             K = gp.K
+            # with a hook no group is enqueued ahead: exactly iterations + 1 evaluations, on every rank
+            groups = got[3].iterations + 1
             if method == 0:
-                # GN: ONE packed all-reduce per evaluation ([A_dir | Y^T Y | cost | mc], 2 (K+1)^2 + 2 doubles)
+                # GN: ONE packed all-reduce per group ([A_dir | Y^T Y | cost | mc], 2 (K+1)^2 + 2 doubles)
                 assert set(calls) == {2 * (K + 1) ** 2 + 2}
-                assert len(calls) == got[3].iterations + 1          # deterministic sequence: no speculative group with a hook
+                assert len(calls) == groups
             else:
                 # LM: per group [cost, model decrease] before the decision and [A_dir | Y^T Y] before the camera solve
-                assert calls.count(2) == got[3].iterations + 1
-                assert calls.count(2 * (K + 1) ** 2) == got[3].iterations + 1
-                assert len(calls) == 2 * (got[3].iterations + 1)
+                assert calls.count(2) == groups
+                assert calls.count(2 * (K + 1) ** 2) == groups
+                assert len(calls) == 2 * groups
     finally:
         dist.destroy_process_group()
