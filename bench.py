@@ -213,14 +213,16 @@ def main():
             try:
                 prob.set_allreduce(make_allreduce_hook(device=dev))
                 with torch.cuda.stream(stream):
-                    best = None
-                    for _ in range(3):
-                        i2, p2, _, rep = prob.solve(intr_start, sp.poses0, sp.extr0, opts=default_opts(0))
-                        if best is None or rep.solve_ms < best.solve_ms:
-                            best = rep
-                result.update(iterations=best.iterations, solve_ms=best.solve_ms, status=best.status,
-                              final_cost=best.final_cost, iters_per_s=best.iterations / (best.solve_ms * 1e-3),
-                              frames_total=args.frames * world)
+                    for name, method in (("gn", 0), ("lm", 1)):
+                        best = None
+                        for _ in range(3):
+                            i2, p2, _, rep = prob.solve(intr_start, sp.poses0, sp.extr0, opts=default_opts(method))
+                            if best is None or rep.solve_ms < best.solve_ms:
+                                best = rep
+                        result[name] = dict(iterations=best.iterations, solve_ms=best.solve_ms, status=best.status,
+                                            final_cost=best.final_cost,
+                                            iters_per_s=best.iterations / (best.solve_ms * 1e-3))
+                result["frames_total"] = args.frames * world
             except Exception as e:  # noqa: BLE001
                 result["error"] = repr(e)
             finally:
@@ -231,7 +233,7 @@ def main():
         if th.is_alive():
             result = {"error": "timeout (120 s) in the sharded solve"}
         if rank == 0:
-            out.setdefault("extra", {})["sharded_gn"] = result
+            out.setdefault("extra", {})["sharded_solve"] = result
         if th.is_alive():
             if rank == 0:
                 print(json.dumps(out), flush=True)
