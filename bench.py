@@ -44,11 +44,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # CCAL_BENCH_BACKEND=gloo (developer switch): exercise the multi-rank code path on a box with fewer GPUs than
+    # ranks - ranks then share devices; the measured numbers mean nothing there
+    backend = os.environ.get("CCAL_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from camera_intrinsic_calibration_rs_amd import synth
     from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
@@ -56,7 +63,7 @@ def main():
     # ---- synthetic calib frames for this rank (weak scaling: F frames per GPU) -------------------
     sp = synth.make_problem(args.frames, args.model, seed=0xC0FFEE + 1000003 * rank)
     stream = torch.cuda.Stream(device=dev)
-    ctx = Context(local_rank, stream=stream.cuda_stream)
+    ctx = Context(dev_index, stream=stream.cuda_stream)
     prob = Problem.from_synth(ctx, sp)
     D = prob.block_dim(0)
     n_corners = prob.n_corners

@@ -58,3 +58,73 @@ def test_solve_with_rccl_hook_single_rank():
                 assert len(calls) == 2 * groups
     finally:
         dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _gpu_worker(rank, world, port, model, n_cams, method, n_frames, q):
+    """One rank of a sharded solve on the PRODUCT path (HIP kernels + the all-reduce hook on device buffers).  The GPU box
+    has one GPU: both ranks use cuda:0 and the process group is gloo (it all-reduces CUDA tensors through the host),
+    which exercises everything except RCCL itself."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_intrinsic_calibration_rs_amd.dist import gather_poses, make_allreduce_hook
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = Context(0, stream=stream.cuda_stream)
+    sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+    shard = sp.shard(rank, world)
+    gp = Problem.from_synth(ctx, shard)
+    gp.apply_reference_bounds()
+    calls = []
+    hook = make_allreduce_hook(device=dev)
+
+    def counting(ptr, count, st):
+        calls.append(count)
+        return hook(ptr, count, st)
+
+    gp.set_allreduce(counting)
+    intr, poses, extr, rep = gp.solve(shard.intr0, shard.poses0, shard.extr0, opts=default_opts(method))
+    poses_all = gather_poses(poses, sp.n_slots)
+    q.put((rank, intr, extr, poses_all, rep.iterations, rep.final_cost, rep.status, list(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("model,n_cams,method", [("eucm", 1, 0), ("eucm", 1, 1), ("eucm", 2, 0), ("kb4", 2, 1)])
+def test_two_ranks_on_the_device_path(model, n_cams, method):
+    """Frame-sharded solve, two ranks, HIP kernels on both: identical camera block on both ranks (bit for bit), the same
+    collective sequence on both ranks, and the single-process solve of the whole problem up to summation order."""
+    import torch.multiprocessing as mp
+    n_frames = 41                                      # odd: shards of 20 and 21 slots
+    sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+    ctx0 = Context(0)
+    full = Problem.from_synth(ctx0, sp)
+    full.apply_reference_bounds()
+    intr1, poses1, extr1, rep1 = full.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_gpu_worker, args=(r, 2, port, model, n_cams, method, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, i0, e0, p0, it0, c0, s0, calls0), (_, i1, e1, p1, it1, c1, s1, calls1) = res
+    np.testing.assert_array_equal(i0, i1); np.testing.assert_array_equal(e0, e1)
+    assert calls0 == calls1 and len(calls0) > 0
+    assert it0 == it1 == rep1.iterations and s0 == s1 == rep1.status == 0
+    np.testing.assert_allclose(i0, intr1, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(e0, extr1, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(p0, poses1, rtol=0, atol=1e-9)
+    assert abs(c0 - rep1.final_cost) <= 1e-10 * rep1.final_cost
