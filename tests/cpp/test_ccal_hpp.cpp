@@ -40,11 +40,7 @@ static void test_rvec_tvec_conversion() {
 
 template <class T> static T rd(std::ifstream& f) { T v; f.read(reinterpret_cast<char*>(&v), sizeof v); return v; }
 
-int main(int argc, char** argv) {
-    test_reprojection_factor();
-    test_rvec_tvec_conversion();
-    if (argc < 2) { std::printf("{\"unit_tests\": \"ok\"}\n"); return 0; }
-    std::ifstream f(argv[1], std::ios::binary);
+static std::vector<std::optional<FrameFeature>> read_frames(std::ifstream& f) {
     const int n_frames = rd<int32_t>(f);
     std::vector<std::optional<FrameFeature>> frames(n_frames);
     for (int i = 0; i < n_frames; ++i) {
@@ -58,6 +54,51 @@ int main(int argc, char** argv) {
         }
         frames[i] = ff;
     }
+    return frames;
+}
+
+// The reference's two-camera flow (src/bin/camera_calibration.rs:262-320): per-camera calib_camera, init_camera_extrinsic,
+// calib_all_camera_with_extrinsics.  Fixture: "RIG2", then per camera its frames, model id, parameters, width, height.
+static int run_rig(std::ifstream& f) {
+    std::vector<std::vector<std::optional<FrameFeature>>> frames;
+    std::vector<GenericModel> cams;
+    for (int c = 0; c < 2; ++c) {
+        frames.push_back(read_frames(f));
+        const int model_id = rd<int32_t>(f), P = rd<int32_t>(f);
+        std::vector<double> params(P); for (auto& v : params) v = rd<double>(f);
+        const double w = rd<double>(f), h = rd<double>(f);
+        cams.emplace_back(model_id, params, w, h);
+    }
+    std::vector<GenericModel> solo;
+    std::vector<std::map<size_t, RvecTvec>> rtvecs;
+    for (int c = 0; c < 2; ++c) {
+        const auto r = calib_camera(frames[c], cams[c], false, 0, false);
+        if (!r) { std::printf("{\"result\": null}\n"); return 0; }
+        solo.push_back(r->first); rtvecs.push_back(r->second);
+    }
+    const auto t_i_0 = init_camera_extrinsic(rtvecs);
+    const auto all = calib_all_camera_with_extrinsics(solo, t_i_0, rtvecs, frames, false, 0, false);
+    if (!all) { std::printf("{\"result\": null}\n"); return 0; }
+    std::printf("{\"params\": [");
+    for (int c = 0; c < 2; ++c) {
+        std::printf("%s[", c ? ", " : "");
+        for (size_t i = 0; i < all->intrinsics[c].params().size(); ++i) std::printf("%s%.17g", i ? ", " : "", all->intrinsics[c].params()[i]);
+        std::printf("]");
+    }
+    const auto e = all->t_i_0[1].as6();
+    std::printf("], \"t_1_0\": [");
+    for (int i = 0; i < 6; ++i) std::printf("%s%.17g", i ? ", " : "", e[i]);
+    std::printf("], \"n_board_poses\": %zu}\n", all->board_poses.size());
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    test_reprojection_factor();
+    test_rvec_tvec_conversion();
+    if (argc < 2) { std::printf("{\"unit_tests\": \"ok\"}\n"); return 0; }
+    std::ifstream f(argv[1], std::ios::binary);
+    if (argc > 2 && std::strcmp(argv[2], "rig") == 0) return run_rig(f);
+    const auto frames = read_frames(f);
     const int model_id = rd<int32_t>(f), P = rd<int32_t>(f);
     std::vector<double> params(P); for (auto& v : params) v = rd<double>(f);
     const double w = rd<double>(f), h = rd<double>(f);
