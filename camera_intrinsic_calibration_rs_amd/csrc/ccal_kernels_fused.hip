@@ -832,9 +832,10 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
 #pragma unroll
                 for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
                 accY[q] += t;
-                // a pose block that is not positive definite poisons the cost entry: in a sharded solve the NaN
-                // reaches every rank through the all-reduce, so all of them stop in the same group
-                accA[q] += (ok || e != K * K1 + K) ? adir[q] : __builtin_nan("");
+                // a pose block that is not positive definite poisons the cost entry with +inf: in a sharded solve it
+                // reaches every rank through the all-reduce and all of them stop in the same group with NOT_PD; a cost
+                // that is NaN already (diverged parameters) stays NaN and reads as NONFINITE, like in the oracle
+                accA[q] += (ok || e != K * K1 + K || adir[q] != adir[q]) ? adir[q] : __builtin_huge_val();
             }
         }
         wsync();
@@ -984,7 +985,7 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel)
                 for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
                 accY[q] = t;
                 // a pose block that is not positive definite poisons the cost entry (see k_schur1)
-                accA[q] = (ok || e != K * K1 + K) ? R[21 + 6 * K1 + e] : __builtin_nan("");
+                accA[q] = (ok || e != K * K1 + K || R[21 + 6 * K1 + e] != R[21 + 6 * K1 + e]) ? R[21 + 6 * K1 + e] : __builtin_huge_val();
             }
         }
     }
@@ -1072,7 +1073,7 @@ __global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const doub
     const double t = block_sum(v0 + v1, sh);
     // a failed elimination / camera solve on this rank poisons the cost: in a sharded solve the all-reduce carries the
     // NaN to every rank and all of them reject the step together (this rank would have rejected it anyway)
-    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x == 0 && (flags[0] | flags[1])) ? __builtin_nan("") : t;
+    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x == 0 && (flags[0] | flags[1]) && t == t) ? __builtin_huge_val() : t;
 }
 hipError_t launch_cost1(const FusedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_cost1, dim3(2), dim3(1024), 0, s, a.cost_f, a.mc_f, a.n_obs, a.red + 2 * (a.K + 1) * (a.K + 1), a.st, a.st_flags);
@@ -1168,7 +1169,8 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
             int done = 0;
             if (st->first) {
                 st->cur_cost = cost_e; st->initial_cost = cost_e; st->first = 0;
-                if (!(cost_e == cost_e) || !(fabs(cost_e) < 1.7e308)) done = CCAL_ERR_NONFINITE + 1;
+                if (!(cost_e == cost_e)) done = CCAL_ERR_NONFINITE + 1;
+                else if (!(fabs(cost_e) < 1.7e308)) done = (lm ? CCAL_ERR_NONFINITE : CCAL_ERR_NOT_PD) + 1;   // GN: +inf = a pose block failed (on some rank)
                 st->accepted_now = 1;
             } else if (!lm) {
                 // Gauss-Newton: the candidate is the new point (tiny-solver applies dx unconditionally)
@@ -1178,6 +1180,7 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
                 st->accepted_now = 1;
                 if (cur < st->min_error) done = CCAL_OK + 1;
                 else if (!(cur == cur)) done = CCAL_ERR_NONFINITE + 1;
+                else if (!(fabs(cur) < 1.7e308)) done = CCAL_ERR_NOT_PD + 1;       // +inf: a pose block failed (on some rank)
                 else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
                 else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
                 else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
@@ -1212,9 +1215,6 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
                 if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
                 st->lambda = 1.0 / st->radius;
             }
-            // GN: a pose block of this rank failed at the evaluated point (its NaN cost is what the other ranks of a
-            // sharded solve see): None, like the failed linear solve of the reference
-            if (!lm && a.flags[0] && (done == 0 || done == CCAL_ERR_NONFINITE + 1)) done = CCAL_ERR_NOT_PD + 1;
             st->done = done;
             if (done && !st->done_seq) st->done_seq = a.seq;
         }

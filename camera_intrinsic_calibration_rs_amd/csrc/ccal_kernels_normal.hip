@@ -486,7 +486,8 @@ __device__ void gdecide_body(DevState* st, HostStatus* hs, double cand, double m
         int done = 0;
         if (init) {
             st->cur_cost = cand; st->initial_cost = cand;
-            if (!(fabs(cand) <= 1.7976931348623157e308)) done = CCAL_ERR_NONFINITE + 1;
+            if (cand != cand) done = CCAL_ERR_NONFINITE + 1;
+            else if (!(fabs(cand) <= 1.7976931348623157e308)) done = CCAL_ERR_NOT_PD + 1;
         } else if (st->method != CCAL_METHOD_LM) {
             st->iter += 1;
             if (lin_fail) done = CCAL_ERR_NOT_PD + 1;            // solve failed -> None; the step is not applied
@@ -496,6 +497,7 @@ __device__ void gdecide_body(DevState* st, HostStatus* hs, double cand, double m
                 st->last_cost = last; st->cur_cost = cand;
                 if (cand < st->min_error) done = CCAL_OK + 1;
                 else if (cand != cand) done = CCAL_ERR_NONFINITE + 1;
+                else if (!(fabs(cand) <= 1.7976931348623157e308)) done = CCAL_ERR_NOT_PD + 1;     // +inf from another rank's failed solve
                 else if (fabs(last - cand) < st->min_abs) done = CCAL_OK + 1;
                 else if (fabs(last - cand) / last < st->min_rel) done = CCAL_OK + 1;
                 else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
@@ -566,9 +568,10 @@ __global__ __launch_bounds__(512) void k_sum2(const double* a, const double* a2,
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
-        // a failed linear solve on this rank poisons the cost: the all-reduce of a sharded solve carries the NaN to
-        // every rank, so all of them reject (LM) or stop (GN) at the same iteration
-        const double cost = (flags[0] | flags[1]) ? __builtin_nan("") : (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        // a failed linear solve on this rank poisons the cost with +inf: the all-reduce of a sharded solve carries it to
+        // every rank, so all of them reject (LM) or stop with NOT_PD (GN) at the same iteration
+        const double csum = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        const double cost = ((flags[0] | flags[1]) && csum == csum) ? __builtin_huge_val() : csum;    // +inf: failed solve; NaN stays NaN
         const double mcp = (sh[4] + sh[5]) + (sh[6] + sh[7]);
         out[0] = cost; out[1] = mcp;
         if (decide) gdecide_body(st, hs, cost, mcp, out[2], flags, init, seq);

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Developer tool: randomised parity sweep, device vs oracle (mode E, normal equations, GN / LM solves) over random
+models, camera counts, frame counts, ragged frames, outliers, one-focal, bounds and disabled distortions."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from camera_intrinsic_calibration_rs_amd import synth, _ffi
+from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts, CcalError
+from oracle import binding as ob
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=60.0)
+ap.add_argument("--seed", type=int, default=1)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+ctx = Context(0)
+t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []
+while time.time() - t0 < args.seconds:
+    model = rng.choice(["ucm", "eucm", "kb4", "opencv5"])
+    n_cams = int(rng.choice([1, 1, 1, 2, 3]))
+    frames = int(rng.choice([3, 7, 20, 45, 130, 300])) if n_cams == 1 else int(rng.choice([5, 12, 30]))
+    kw = dict(n_cams=n_cams, seed=int(rng.integers(1, 1 << 30)), ragged=bool(rng.integers(0, 2)),
+              xy_same_focal=bool(rng.integers(0, 2)), outlier_frac=float(rng.choice([0.0, 0.01, 0.05])))
+    sp = synth.make_problem(frames, model, **kw)
+    gp = Problem.from_synth(ctx, sp); op = ob.OracleProblem.from_synth(sp)
+    case = dict(model=str(model), frames=frames, **kw)
+    try:
+        r, J = gp.eval(sp.intr0, sp.poses0, sp.extr0); ro, Jo = op.eval(sp.intr0, sp.poses0, sp.extr0)
+        worst["r"] = max(worst["r"], float(np.abs(r - ro).max()))
+        worst["J"] = max(worst["J"], float((np.abs(J - Jo) / np.maximum(1.0, np.abs(Jo))).max()))
+        lam = float(rng.choice([0.0, 1e-4]))
+        S, b, c = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam); So, bo, co = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        worst["S"] = max(worst["S"], float(np.abs(S - So).max() / np.abs(So).max()))
+        if rng.integers(0, 2):
+            gp.apply_reference_bounds(); op.apply_reference_bounds()
+        method = int(rng.integers(0, 2))
+        o = default_opts(method)
+        try:
+            g = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=o); gs = (g[3].status, g[3].iterations)
+        except CcalError as e:
+            g = None; gs = (e.code, -1)
+        orc = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=o); os_ = (orc[3].status, orc[3].iterations)
+        if g is None or gs[0] != 0 or os_[0] != 0:
+            if gs[0] != os_[0]:
+                fails.append(dict(case=case, what="status", gpu=gs, oracle=os_))
+        else:
+            P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[str(model)]]
+            scale = np.maximum(np.abs(orc[0][:, :P]), 1e-3)
+            di = float((np.abs(g[0][:, :P] - orc[0][:, :P]) / scale).max()); dp = float(np.abs(g[1] - orc[1]).max())
+            worst["intr"] = max(worst["intr"], di); worst["poses"] = max(worst["poses"], dp)
+            if gs != os_ or di > 1e-6 or dp > 1e-6:
+                fails.append(dict(case=case, what="solve", gpu=gs, oracle=os_, d_intr=di, d_poses=dp, method=method))
+    except Exception as e:  # noqa: BLE001
+        fails.append(dict(case=case, what="exception", err=repr(e)))
+    gp.close(); n += 1
+print(json.dumps(dict(cases=n, worst=worst, n_fail=len(fails), fails=fails[:6]), indent=1))
