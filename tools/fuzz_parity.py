@@ -19,6 +19,8 @@ while time.time() - t0 < args.seconds:
     model = rng.choice(["ucm", "eucm", "kb4", "opencv5"])
     n_cams = int(rng.choice([1, 1, 1, 2, 3]))
     frames = int(rng.choice([3, 7, 20, 45, 130, 300])) if n_cams == 1 else int(rng.choice([5, 12, 30]))
+    if n_cams == 1 and rng.random() < 0.04:        # every lanes-per-frame mapping / both register-Gram kernels / k_schur1m
+        frames = int(rng.choice([1100, 2300, 5200]))
     kw = dict(n_cams=n_cams, seed=int(rng.integers(1, 1 << 30)), ragged=bool(rng.integers(0, 2)),
               xy_same_focal=bool(rng.integers(0, 2)), outlier_frac=float(rng.choice([0.0, 0.01, 0.05])))
     sp = synth.make_problem(frames, model, **kw)
