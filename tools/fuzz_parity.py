@@ -14,7 +14,7 @@ ap.add_argument("--seed", type=int, default=1)
 args = ap.parse_args()
 rng = np.random.default_rng(args.seed)
 ctx = Context(0)
-t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []
+t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []; both_none = []
 while time.time() - t0 < args.seconds:
     model = rng.choice(["ucm", "eucm", "kb4", "opencv5"])
     n_cams = int(rng.choice([1, 1, 1, 2, 3]))
@@ -43,8 +43,10 @@ while time.time() - t0 < args.seconds:
             g = None; gs = (e.code, -1)
         orc = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=o); os_ = (orc[3].status, orc[3].iterations)
         if g is None or gs[0] != 0 or os_[0] != 0:
-            if gs[0] != os_[0]:
-                fails.append(dict(case=case, what="status", gpu=gs, oracle=os_))
+            if (gs[0] == 0) != (os_[0] == 0):
+                fails.append(dict(case=case, what="one side solved, the other did not", gpu=gs, oracle=os_))
+            elif gs[0] != os_[0]:
+                both_none.append(dict(case=case, gpu=gs, oracle=os_))      # the reference's None on both sides, different code
         else:
             P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[str(model)]]
             scale = np.maximum(np.abs(orc[0][:, :P]), 1e-3)
@@ -55,4 +57,5 @@ while time.time() - t0 < args.seconds:
     except Exception as e:  # noqa: BLE001
         fails.append(dict(case=case, what="exception", err=repr(e)))
     gp.close(); n += 1
-print(json.dumps(dict(cases=n, worst=worst, n_fail=len(fails), fails=fails[:6]), indent=1))
+print(json.dumps(dict(cases=n, worst=worst, n_fail=len(fails), fails=fails[:6], n_both_none_different_code=len(both_none),
+                      both_none=both_none[:3]), indent=1))
