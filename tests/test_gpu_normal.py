@@ -273,3 +273,46 @@ def test_frames_of_any_size(gpu_ctx, oracle, n_corners, n_frames):
     assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations)
     assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * max(rep_o.final_cost, 1e-6)
     assert (np.abs(intr[0, :6] - intr_o[0, :6]) / np.abs(intr_o[0, :6])).max() <= 1e-6
+
+
+def _tile(sp, rep):
+    """`rep` copies of a single-camera synthetic problem, frames renumbered (a large problem without regenerating it)."""
+    import dataclasses
+    n = sp.obs_offsets[-1]
+    offs = np.concatenate([[0]] + [sp.obs_offsets[1:] + k * n for k in range(rep)]).astype(np.int64)
+    return dataclasses.replace(
+        sp, n_slots=sp.n_slots * rep, obs_cam=np.tile(sp.obs_cam, rep),
+        obs_slot=np.concatenate([sp.obs_slot + k * sp.n_slots for k in range(rep)]).astype(np.int32), obs_offsets=offs,
+        p3d=np.tile(sp.p3d, (rep, 1)), p2d=np.tile(sp.p2d, (rep, 1)),
+        poses_gt=np.tile(sp.poses_gt, (rep, 1)), poses0=np.tile(sp.poses0, (rep, 1)))
+
+
+def test_config4_size_properties(gpu_ctx):
+    """BASELINE configs[3] size on ONE GPU: 50 000 frames x 144 corners (7.2 M blocks, 1.5 GB of r and J).  Size-independent
+    properties: the squared norm of the loss-weighted residual (mode E) is the cost the normal-equation builder reports
+    (mode N); the cost is additive over frame shards; five copies of a 10 000-frame problem have five times its cost
+    and the same optimum."""
+    base = synth.make_problem(10000, "eucm")
+    sp = _tile(base, 5)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    assert gp.n_corners == 50000 * 144
+    r, J = gp.eval(sp.intr0, sp.poses0, apply_loss=True)
+    assert np.isfinite(r).all() and np.isfinite(J).all()
+    S, b, cost = gp.build_normal(sp.intr0, sp.poses0)
+    assert abs(float((r * r).sum()) - cost) <= 1e-11 * cost
+    del r, J
+    gb = Problem.from_synth(gpu_ctx, base)
+    Sb, bb, cost_b = gb.build_normal(base.intr0, base.poses0)
+    assert abs(cost - 5.0 * cost_b) <= 1e-11 * cost
+    assert np.abs(S - 5.0 * Sb).max() <= 1e-9 * np.abs(S).max() and np.abs(b - 5.0 * bb).max() <= 1e-9 * np.abs(b).max()
+    shard_cost = 0.0
+    for k in range(4):
+        sh = sp.shard(k, 4)
+        shard_cost += Problem.from_synth(gpu_ctx, sh).build_normal(sh.intr0, sh.poses0)[2]
+    assert abs(shard_cost - cost) <= 1e-11 * cost
+    intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0)
+    intr_b, poses_b, _, rep_b = gb.solve(base.intr0, base.poses0)
+    assert rep.status == 0 and rep.iterations == rep_b.iterations
+    assert np.abs(intr[0, :6] / intr_b[0, :6] - 1).max() <= 1e-9
+    np.testing.assert_allclose(poses[:10000], poses_b, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(poses[40000:], poses_b, rtol=0, atol=1e-9)
