@@ -316,3 +316,20 @@ def test_config4_size_properties(gpu_ctx):
     assert np.abs(intr[0, :6] / intr_b[0, :6] - 1).max() <= 1e-9
     np.testing.assert_allclose(poses[:10000], poses_b, rtol=0, atol=1e-9)
     np.testing.assert_allclose(poses[40000:], poses_b, rtol=0, atol=1e-9)
+
+
+def test_two_camera_rig_at_scale(gpu_ctx):
+    """BASELINE configs[4] shape at scale (two EUCM cameras x 4 000 frames, 1.15 M blocks): GN and LM reach the same
+    optimum, intrinsics and the inter-camera transform sit at the noise floor around ground truth."""
+    sp = synth.make_problem(4000, "eucm", n_cams=2)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    gp.apply_reference_bounds()
+    i_gn, p_gn, e_gn, r_gn = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(_ffi.METHOD_GN))
+    i_lm, p_lm, e_lm, r_lm = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(_ffi.METHOD_LM))
+    assert r_gn.status == 0 and r_lm.status == 0
+    assert np.abs(i_gn[:, :6] / i_lm[:, :6] - 1).max() < 1e-6
+    np.testing.assert_allclose(e_gn, e_lm, rtol=0, atol=1e-7)
+    assert np.abs(i_gn[:, :6] / sp.intr_gt[:, :6] - 1).max() < 1e-3
+    assert np.abs(e_gn[1, 3:] - sp.extr_gt[1, 3:]).max() < 2e-4            # metres
+    assert np.abs(e_gn[1, :3] - sp.extr_gt[1, :3]).max() < 5e-4            # radians
+    assert 0.015 < r_gn.final_cost / gp.n_corners < 0.025
