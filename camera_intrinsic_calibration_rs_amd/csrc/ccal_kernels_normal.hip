@@ -155,36 +155,39 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     double* Go = p_G + ga.goff[o];
     const int gi = lane >> 4, gj = lane & 15;
     if constexpr (CMP) {
-        // compact tile -> LDS -> the block-upper-triangular 32-stride layout k_schur reads (rows 0..15 x all columns,
-        // rows 16.. x columns 16..), with the tvec_0_b rows / columns restored: column a = sum_m R_c0[m][a] tvec_c_0[m]
+        // compact tile -> the block-upper-triangular 32-stride layout k_schur reads (rows 0..15 x all columns, rows 16.. x
+        // columns 16..), with the tvec_0_b rows / columns restored: column a = sum_m R_c0[m][a] tvec_c_0[m].
+        // Three branch-free passes: the tile's own entries straight from the accumulator registers, the 3 x 16 restored
+        // rows (+ their mirror), the 3 x 3 restored block.
         const d4 acc = acc00a + acc00b;
+        constexpr int TC = PE + 6;                          // first tvec_c_0 column of the compact tile
         wave_sync_lds();
 #pragma unroll
-        for (int v = 0; v < 4; ++v) tile[(gi + 4 * v) * 17 + gj] = acc[v];
+        for (int v = 0; v < 4; ++v) {
+            const int ci = gi + 4 * v, cj = gj;
+            tile[ci * 17 + cj] = acc[v];
+            const int i = ci < PE + 3 ? ci : ci + 3, j = cj < PE + 3 ? cj : cj + 3;     // compact -> virtual column
+            if (!(i >= 16 && j < 16)) Go[i * 32 + j] = acc[v];                          // lower-left tile is never read
+            if (ci == RC && cj == RC) p_cost[o] = acc[v];
+        }
         wave_sync_lds();
-        constexpr int NV = D + 1, TC = PE + 6;            // virtual columns; first tvec_c_0 column of the compact tile
         const double* R1 = fc + FC_R1;
-        for (int e = lane; e < NV * NV; e += 64) {
-            const int i = e / NV, j = e - i * NV;
-            if (i >= 16 && j < 16) continue;                // lower-left tile is never read
-            const int ci = i < PE + 3 ? i : (i < PE + 6 ? -(i - PE - 3) - 1 : i - 3);
-            const int cj = j < PE + 3 ? j : (j < PE + 6 ? -(j - PE - 3) - 1 : j - 3);
+        if (lane < 48) {
+            const int aa = lane >> 4, cj = lane & 15;
             double val = 0.0;
-            if (ci >= 0 && cj >= 0) val = tile[ci * 17 + cj];
-            else if (ci < 0 && cj >= 0) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m) val += R1[m * 3 + (-ci - 1)] * tile[(TC + m) * 17 + cj];
-            } else if (ci >= 0) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) val += R1[m * 3 + (-cj - 1)] * tile[ci * 17 + TC + m];
-            } else {
-#pragma unroll
-                for (int m = 0; m < 3; ++m)
-#pragma unroll
-                    for (int n2 = 0; n2 < 3; ++n2) val += R1[m * 3 + (-ci - 1)] * R1[n2 * 3 + (-cj - 1)] * tile[(TC + m) * 17 + TC + n2];
-            }
+            for (int m = 0; m < 3; ++m) val += R1[m * 3 + aa] * tile[(TC + m) * 17 + cj];
+            const int i = PE + 3 + aa, j = cj < PE + 3 ? cj : cj + 3;
             Go[i * 32 + j] = val;
-            if (i == D && j == D) p_cost[o] = val;
+            if (j < 16) Go[j * 32 + i] = val;
+        } else if (lane < 57) {
+            const int aa = (lane - 48) / 3, ab = (lane - 48) % 3;
+            double val = 0.0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int n2 = 0; n2 < 3; ++n2) val += R1[m * 3 + aa] * R1[n2 * 3 + ab] * tile[(TC + m) * 17 + TC + n2];
+            Go[(PE + 3 + aa) * 32 + PE + 3 + ab] = val;
         }
     } else if constexpr (T == 1) {
         const d4 acc = acc00a + acc00b;
