@@ -658,8 +658,9 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         }
         const double piv = __shfl(t, j, 64);
         if (!(piv > 0.0) || !(piv < 1.7e308)) { if (lane == 0) bad = 1; break; }      // uniform
-        const double sq = sqrt(piv), inv = 1.0 / sq;
-        if (lane == j) S[j * LD + j] = sq;
+        double sq, inv;
+        fast_sqrt_rsqrt(piv, sq, inv);                    // hardware seed + Newton steps (<= 2 ulp), not the IEEE sqrt + division expansions
+        if (lane == j) S[j * LD + j] = inv;               // the diagonal is kept inverted: the solves below multiply
         else if (lane > j && lane < K) S[lane * LD + j] = t * inv;
         __syncthreads();
     }
@@ -672,12 +673,12 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     {   // two triangular solves: lane i owns x_i, the finished component travels by shuffle
         double xi = lane < K ? x[lane] : 0.0;
         for (int j = 0; j < K; ++j) {
-            if (lane == j) xi = xi / S[j * LD + j];
+            if (lane == j) xi = xi * S[j * LD + j];
             const double xj = __shfl(xi, j, 64);
             if (lane > j && lane < K) xi -= S[lane * LD + j] * xj;
         }
         for (int j = K - 1; j >= 0; --j) {
-            if (lane == j) xi = xi / S[j * LD + j];
+            if (lane == j) xi = xi * S[j * LD + j];
             const double xj = __shfl(xi, j, 64);
             if (lane < j) xi -= S[j * LD + lane] * xj;
         }
