@@ -817,10 +817,16 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
                     pf[21 + i * K1 + lane] = y[i];
                 }
             }
+            {   // lane i stores L[i], lane i the damping diagonal dC[i]: a select chain over static register indices (no
+                // scratch) and ONE coalesced store each, instead of 27 single-lane predicated stores
+                double lv = L[0], dv = dC[0];
 #pragma unroll
-            for (int i = 0; i < 21; ++i) if (lane == i) pf[i] = L[i];        // static register indices: no scratch
+                for (int i = 1; i < 21; ++i) lv = lane == i ? L[i] : lv;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) if (lane == 32 + i) { pf[21 + 6 * K1 + i] = Bm[i * K1 + K]; pf[21 + 6 * K1 + 6 + i] = dC[i]; }
+                for (int i = 1; i < 6; ++i) dv = lane == i ? dC[i] : dv;
+                if (lane < 21) pf[lane] = lv;
+                if (lane < 6) { pf[21 + 6 * K1 + lane] = Bm[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dv; }
+            }
         }
         wsync();
 #pragma unroll
@@ -967,10 +973,18 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel)
                     pf[21 + i * K1 + gl] = y[i];
                 }
             }
+            {   // lane gl stores L[gl] and L[16 + gl], dC[gl]: select chains over static register indices, coalesced stores
+                double l0 = L[0], l1 = L[16], dv = dC[0];
 #pragma unroll
-            for (int i = 0; i < 21; ++i) if (gl == (i & 15)) pf[i] = L[i];       // static register indices: no scratch
+                for (int i = 1; i < 16; ++i) l0 = gl == i ? L[i] : l0;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) if (gl == 8 + i) { pf[21 + 6 * K1 + i] = Bm[i * K1 + K]; pf[21 + 6 * K1 + 6 + i] = dC[i]; }
+                for (int i = 17; i < 21; ++i) l1 = gl == i - 16 ? L[i] : l1;
+#pragma unroll
+                for (int i = 1; i < 6; ++i) dv = gl == i ? dC[i] : dv;
+                pf[gl] = l0;
+                if (gl < 5) pf[16 + gl] = l1;
+                if (gl < 6) { pf[21 + 6 * K1 + gl] = Bm[gl * K1 + K]; pf[21 + 6 * K1 + 6 + gl] = dv; }
+            }
         }
     }
     wsync();

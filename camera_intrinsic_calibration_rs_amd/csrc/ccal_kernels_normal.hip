@@ -412,10 +412,15 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 pf[21 + i * K1 + j] = y[i];
             }
         }
+        {   // lane i stores L[i] / dC[i]: select chains over static register indices (no scratch), coalesced stores
+            double lv = L[0], dv = dC[0];
 #pragma unroll
-        for (int i = 0; i < 21; ++i) if (lane == i) pf[i] = L[i];          // static register indices: no scratch
+            for (int i = 1; i < 21; ++i) lv = lane == i ? L[i] : lv;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) if (lane == 32 + i) { pf[21 + 6 * K1 + i] = Baug[i * K1 + K]; pf[21 + 6 * K1 + 6 + i] = dC[i]; }
+            for (int i = 1; i < 6; ++i) dv = lane == i ? dC[i] : dv;
+            if (lane < 21) pf[lane] = lv;
+            if (lane < 6) { pf[21 + 6 * K1 + lane] = Baug[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dv; }
+        }
         wave_sync_lds();
         // A -= Y^T Y
         const float rk1 = 1.0f / (float)K1;
