@@ -167,7 +167,7 @@ def main():
             extra["mode_N_build_ms"] = ms
             extra["mode_N_evals_per_s"] = n_corners / (ms * 1e-3)
             extra["mode_N_note"] = ("ccal_build_normal_dev: reduced normal equations [S | b | cost] from resident parameters "
-                                   "(single camera: k_gram1w + k_schur1 + k_reduce1)")
+                                   "(single camera: k_gram1w + k_schur1m + k_reduce1)")
             for name, method in (("gn", 0), ("lm", 1)):
                 best = None
                 for _ in range(3):                      # wall time of the whole ccal_solve call, best of 3
