@@ -11,9 +11,9 @@ PMAX = 10
 MAX_CAMS = 8
 KMAX = 64
 
-OK, ERR_INVALID_ARG, ERR_HIP, ERR_NONFINITE, ERR_NOT_PD, ERR_NO_CONVERGENCE, ERR_UNSUPPORTED = range(7)
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_NONFINITE, ERR_NOT_PD, ERR_NO_CONVERGENCE, ERR_UNSUPPORTED, ERR_NO_MEMORY = range(8)
 STATUS_NAMES = ["CCAL_OK", "CCAL_ERR_INVALID_ARG", "CCAL_ERR_HIP", "CCAL_ERR_NONFINITE", "CCAL_ERR_NOT_PD",
-                "CCAL_ERR_NO_CONVERGENCE", "CCAL_ERR_UNSUPPORTED"]
+                "CCAL_ERR_NO_CONVERGENCE", "CCAL_ERR_UNSUPPORTED", "CCAL_ERR_NO_MEMORY"]
 METHOD_GN, METHOD_LM = 0, 1
 
 _dp = C.POINTER(C.c_double)
@@ -44,8 +44,13 @@ class SolverOpts(C.Structure):
 class Report(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("iterations", C.c_int32), ("lm_accepted", C.c_int32), ("lm_rejected", C.c_int32),
-        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms", C.c_double), ("reserved", C.c_double),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms", C.c_double),
+        ("lm_spec_hits", C.c_int32), ("lm_spec_misses", C.c_int32),
     ]
+
+
+class ModelConventions(C.Structure):
+    _fields_ = [("kb4_small_radius", C.c_double), ("dist_lo", (C.c_double * 5) * 4), ("dist_hi", (C.c_double * 5) * 4)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -70,6 +75,14 @@ SYMBOLS = [
     ("ccal_apply_reference_bounds", C.c_int, [_vp]),
     ("ccal_disable_distortions", C.c_int, [_vp, C.c_int, _dp]),
     ("ccal_set_allreduce", C.c_int, [_vp, ALLREDUCE_FN, _vp]),
+    ("ccal_set_rccl_comm", C.c_int, [_vp, _vp]),
+    ("ccal_rccl_available", C.c_int, []),
+    ("ccal_rccl_version", C.c_int, []),
+    ("ccal_rccl_unique_id", C.c_int, [_vp]),
+    ("ccal_rccl_comm_create", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
+    ("ccal_rccl_comm_destroy", C.c_int, [_vp]),
+    ("ccal_get_model_conventions", C.c_int, [_vp, C.POINTER(ModelConventions)]),
+    ("ccal_set_model_conventions", C.c_int, [_vp, C.POINTER(ModelConventions)]),
     ("ccal_num_corners", C.c_int64, [_vp]),
     ("ccal_reduced_dim", C.c_int, [_vp]),
     ("ccal_block_dim", C.c_int, [_vp, C.c_int]),
@@ -83,6 +96,7 @@ SYMBOLS = [
     ("ccal_build_normal", C.c_int, [_vp, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp]),
     ("ccal_build_normal_dev", C.c_int, [_vp, C.c_double]),
     ("ccal_solve", C.c_int, [_vp, C.POINTER(SolverOpts), _dp, _dp, _dp, C.POINTER(Report)]),
+    ("ccal_solve_dev", C.c_int, [_vp, C.POINTER(SolverOpts), C.POINTER(Report)]),
     ("ccal_init_poses", C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
     ("ccal_init_camera_extrinsic", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(Report)]),
     ("ccal_convert_model", C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,

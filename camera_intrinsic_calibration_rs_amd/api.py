@@ -352,7 +352,7 @@ def convert_model(source_model: GenericModel, target_model: GenericModel, disabl
                                 target_model.model_id, tgt.ctypes.data_as(C.POINTER(C.c_double)),
                                 float(source_model.width()), float(source_model.height()), int(disabled_distortions),
                                 None, C.byref(rep))
-    if rc != _ffi.OK:
+    if rc not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE):                                 # max_iterations: the reference keeps the result
         raise CcalError(rc, "ccal_convert_model: " + c.last_error())                 # `.unwrap()` in the reference (:276)
     target_model.set_params(tgt)
     return target_model

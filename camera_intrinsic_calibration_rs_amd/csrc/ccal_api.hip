@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "ccal_internal.hpp"
@@ -32,10 +33,32 @@ static int upload(ccal_ctx* ctx, T** dst, const T* src, size_t n) {
     return CCAL_OK;
 }
 
+static void default_conventions(ccal_model_conventions* cv) {
+    cv->kb4_small_radius = kDefaultKb4SmallRadius;
+    for (int m = 0; m < kNumModels; ++m)
+        for (int i = 0; i < kMaxDist; ++i) { cv->dist_lo[m][i] = kDefaultDistLo[m][i]; cv->dist_hi[m][i] = kDefaultDistHi[m][i]; }
+}
+static_assert(sizeof(((ccal_model_conventions*)nullptr)->dist_lo) == sizeof(kDefaultDistLo), "conventions table shape");
+
 extern "C" {
 
-const char* ccal_version(void) { return "ccal-mi355x 0.1.0 (gfx950)"; }
-int ccal_model_num_params(int model) { return (model >= 0 && model <= 3) ? model_np(model) : -1; }
+int ccal_get_model_conventions(const ccal_ctx* ctx, ccal_model_conventions* out) {
+    if (!ctx || !out) return CCAL_ERR_INVALID_ARG;
+    *out = ctx->conv;
+    return CCAL_OK;
+}
+int ccal_set_model_conventions(ccal_ctx* ctx, const ccal_model_conventions* in) {
+    if (!ctx) return CCAL_ERR_INVALID_ARG;
+    if (!in) { default_conventions(&ctx->conv); return CCAL_OK; }
+    if (!(in->kb4_small_radius >= 0.0)) return CCAL_ERR_INVALID_ARG;
+    for (int m = 0; m < kNumModels; ++m)
+        for (int i = 0; i < model_np(m) - 4; ++i) if (!(in->dist_lo[m][i] <= in->dist_hi[m][i])) return CCAL_ERR_INVALID_ARG;
+    ctx->conv = *in;
+    return CCAL_OK;
+}
+
+const char* ccal_version(void) { return "ccal-mi355x 0.2.0 (gfx950)"; }
+int ccal_model_num_params(int model) { return (model >= 0 && model < kNumModels) ? model_np(model) : -1; }
 
 int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
     if (!out) return CCAL_ERR_INVALID_ARG;
@@ -43,7 +66,8 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return CCAL_ERR_HIP;
     ccal_ctx* c = new (std::nothrow) ccal_ctx();
-    if (!c) return CCAL_ERR_HIP;
+    if (!c) return CCAL_ERR_NO_MEMORY;
+    default_conventions(&c->conv);
     c->device = device_id;
     if (hipSetDevice(device_id) != hipSuccess) { delete c; return CCAL_ERR_HIP; }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
@@ -79,12 +103,14 @@ int ccal_set_defaults(ccal_solver_opts* o) {
 int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem** out) {
     if (!ctx || !d || !out) return CCAL_ERR_INVALID_ARG;
     *out = nullptr;
+    CCAL_API_TRY
     if (d->n_cams < 1 || d->n_cams > CCAL_MAX_CAMS || d->n_slots < 0 || d->n_obs < 0 || !d->model ||
         (d->n_obs > 0 && (!d->obs_cam || !d->obs_slot || !d->obs_offsets)))
         return fail(ctx, CCAL_ERR_INVALID_ARG, "bad problem description");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ccal_problem* p = new (std::nothrow) ccal_problem();
-    if (!p) return fail(ctx, CCAL_ERR_HIP, "out of host memory");
+    struct Destroy { void operator()(ccal_problem* q) const { ccal_problem_destroy(q); } };
+    std::unique_ptr<ccal_problem, Destroy> hold(new ccal_problem());      // freed on every early return and on a throw
+    ccal_problem* p = hold.get();
     p->ctx = ctx; p->n_cams = d->n_cams; p->n_slots = d->n_slots; p->n_obs = d->n_obs;
     p->one_focal = d->xy_same_focal != 0; p->huber_delta = d->huber_delta;
     p->cams.resize(d->n_cams);
@@ -92,36 +118,44 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     for (int c = 0; c < d->n_cams; ++c) {
         CamLayout& cl = p->cams[c];
         cl.model = d->model[c];
-        if (cl.model < 0 || cl.model > 3) { delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "unknown camera model"); }
+        if (cl.model < 0 || cl.model >= kNumModels) return fail(ctx, CCAL_ERR_INVALID_ARG, "unknown camera model");
         cl.P = model_np(cl.model); cl.Peff = cl.P - (p->one_focal ? 1 : 0);
         cl.D = cl.Peff + (c == 0 ? 6 : 12);
         cl.col_theta = K; K += cl.Peff;
         if (c > 0) { cl.col_extr = K; K += 6; }
         cl.width = d->width ? d->width[c] : 0.0; cl.height = d->height ? d->height[c] : 0.0;
     }
-    if (K > CCAL_KMAX) { delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "reduced system too large"); }
+    if (K > CCAL_KMAX) return fail(ctx, CCAL_ERR_INVALID_ARG, "reduced system too large");
     p->K = K;
-    p->h_obs_off.assign(d->obs_offsets, d->obs_offsets + d->n_obs + 1);
-    p->h_obs_cam.assign(d->obs_cam, d->obs_cam + d->n_obs);
-    p->h_obs_slot.assign(d->obs_slot, d->obs_slot + d->n_obs);
-    if (d->n_obs == 0) p->h_obs_off.assign(1, 0);
+    if (d->n_obs > 0) {
+        p->h_obs_off.assign(d->obs_offsets, d->obs_offsets + d->n_obs + 1);
+        p->h_obs_cam.assign(d->obs_cam, d->obs_cam + d->n_obs);
+        p->h_obs_slot.assign(d->obs_slot, d->obs_slot + d->n_obs);
+    } else {
+        p->h_obs_off.assign(1, 0);
+    }
     p->h_joff.resize(d->n_obs + 1);
+    // one observation frame per (camera, slot): the reference has one FrameFeature per camera and frame index
+    // (src/util.rs:595-601), and the single-camera kernels index their per-frame records by slot
+    std::vector<uint8_t> seen((size_t)d->n_cams * (size_t)std::max(d->n_slots, 1), 0);
     int64_t j = 0;
     for (int o = 0; o < d->n_obs; ++o) {
         const int cam = p->h_obs_cam[o], slot = p->h_obs_slot[o];
         const int64_t n = p->h_obs_off[o + 1] - p->h_obs_off[o];
-        if (cam < 0 || cam >= d->n_cams || slot < 0 || slot >= d->n_slots || n < 0 || p->h_obs_off[0] != 0) {
-            delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "bad observation frame table");
-        }
+        if (cam < 0 || cam >= d->n_cams || slot < 0 || slot >= d->n_slots || n < 0 || p->h_obs_off[0] != 0)
+            return fail(ctx, CCAL_ERR_INVALID_ARG, "bad observation frame table");
+        uint8_t& sn = seen[(size_t)cam * d->n_slots + slot];
+        if (sn) return fail(ctx, CCAL_ERR_INVALID_ARG, "two observation frames for the same (camera, slot)");
+        sn = 1;
         p->h_joff[o] = j; j += n * 2 * p->cams[cam].D;
         p->cams[cam].obs.push_back(o);
     }
     p->h_joff[d->n_obs] = j; p->j_len = j;
     p->n_corners = p->h_obs_off[d->n_obs];
     const size_t nc = (size_t)p->n_corners;
-    if (nc && (!d->p3d_x || !d->p3d_y || !d->p3d_z || !d->p2d_u || !d->p2d_v)) { delete p; return fail(ctx, CCAL_ERR_INVALID_ARG, "null corner arrays"); }
+    if (nc && (!d->p3d_x || !d->p3d_y || !d->p3d_z || !d->p2d_u || !d->p2d_v)) return fail(ctx, CCAL_ERR_INVALID_ARG, "null corner arrays");
     int rc;
-#define UP(dst, src, n) if ((rc = upload(ctx, &p->dst, src, n)) != CCAL_OK) { ccal_problem_destroy(p); return rc; }
+#define UP(dst, src, n) if ((rc = upload(ctx, &p->dst, src, n)) != CCAL_OK) return rc;
     UP(d_x, d->p3d_x, nc) UP(d_y, d->p3d_y, nc) UP(d_z, d->p3d_z, nc) UP(d_u, d->p2d_u, nc) UP(d_v, d->p2d_v, nc)
     UP(d_obs_off, p->h_obs_off.data(), p->h_obs_off.size())
     UP(d_joff, p->h_joff.data(), p->h_joff.size())
@@ -134,14 +168,14 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
     for (int i = 0; i < 6; ++i) {
         if (hipMalloc((void**)bufs[i], sz[i] * sizeof(double)) != hipSuccess ||
-            hipMemsetAsync(*bufs[i], 0, sz[i] * sizeof(double), ctx->stream) != hipSuccess) {
-            ccal_problem_destroy(p); return fail(ctx, CCAL_ERR_HIP, "hipMalloc(params) failed");
-        }
+            hipMemsetAsync(*bufs[i], 0, sz[i] * sizeof(double), ctx->stream) != hipSuccess)
+            return fail(ctx, CCAL_ERR_HIP, "hipMalloc(params) failed");
     }
     p->lo.assign(ni, 0.0); p->hi.assign(ni, 0.0); p->has_bound.assign(ni, 0); p->fixed.assign(ni, 0);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess) { ccal_problem_destroy(p); return fail(ctx, CCAL_ERR_HIP, "upload failed"); }
-    *out = p;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, CCAL_ERR_HIP, "upload failed");
+    *out = hold.release();
     return CCAL_OK;
+    CCAL_API_CATCH(ctx)
 }
 
 void ccal_problem_destroy(ccal_problem* p) {
@@ -181,24 +215,20 @@ int ccal_unfix_param(ccal_problem* p, int cam, int idx) {
     p->fixed[cam * CCAL_PMAX + idx] = 0; return CCAL_OK;
 }
 
-// set_problem_parameter_bound (src/util.rs:29-49).  The distortion bounds come from
-// camera-intrinsic-model's distortion_params_bound(), whose source is absent: the values below are this
-// build's documented assumption and can be overridden with ccal_set_bounds.
+// set_problem_parameter_bound (src/util.rs:29-49).  The distortion bounds come from camera-intrinsic-model's
+// distortion_params_bound(), whose source is absent: the values are the context's conventions table (defaults in
+// ccal_models.hpp, ccal_set_model_conventions to change them); single entries can be overridden with ccal_set_bounds.
 int ccal_apply_reference_bounds(ccal_problem* p) {
     if (!p) return CCAL_ERR_INVALID_ARG;
     const int shift = p->one_focal ? 1 : 0;
+    const ccal_model_conventions& cv = p->ctx->conv;
     for (int c = 0; c < p->n_cams; ++c) {
         const CamLayout& cl = p->cams[c];
         ccal_set_bounds(p, c, 0, 0.0, 10000.0);
         ccal_set_bounds(p, c, 1 - shift, 0.0, 10000.0);
         ccal_set_bounds(p, c, 2 - shift, 0.0, cl.width);
         ccal_set_bounds(p, c, 3 - shift, 0.0, cl.height);
-        switch (cl.model) {
-            case kUCM: ccal_set_bounds(p, c, 4 - shift, 1e-6, 1.0); break;
-            case kEUCM: ccal_set_bounds(p, c, 4 - shift, 1e-6, 1.0); ccal_set_bounds(p, c, 5 - shift, 1e-6, 100.0); break;
-            case kKB4: for (int i = 4; i < 8; ++i) ccal_set_bounds(p, c, i - shift, -1.0, 1.0); break;
-            default: for (int i = 4; i < 9; ++i) ccal_set_bounds(p, c, i - shift, -1.0, 1.0); break;
-        }
+        for (int i = 4; i < cl.P; ++i) ccal_set_bounds(p, c, i - shift, cv.dist_lo[cl.model][i - 4], cv.dist_hi[cl.model][i - 4]);
     }
     return CCAL_OK;
 }
@@ -250,7 +280,7 @@ static KArgs make_args(const ccal_problem* p, int cam) {
     a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
-    a.huber_delta = p->huber_delta;
+    a.huber_delta = p->huber_delta; a.kb4_eps = p->ctx->conv.kb4_small_radius;
     return a;
 }
 
@@ -268,7 +298,7 @@ int ccal_eval_dev(ccal_problem* p, int apply_loss, double* r_dev, double* J_dev)
 
 int ccal_eval(ccal_problem* p, const double* intr, const double* poses, const double* extr,
               int apply_loss, double* r_out, double* J_out) {
-    if (!p || !intr || (!poses && p->n_slots) || !r_out || !J_out) return CCAL_ERR_INVALID_ARG;
+    if (!p || !intr || (!poses && p->n_slots) || (!extr && p->n_cams > 1) || !r_out || !J_out) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
@@ -285,7 +315,7 @@ int ccal_eval(ccal_problem* p, const double* intr, const double* poses, const do
 }
 
 int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr, double* err_out) {
-    if (!p || !intr || (!poses && p->n_slots) || !err_out) return CCAL_ERR_INVALID_ARG;
+    if (!p || !intr || (!poses && p->n_slots) || (!extr && p->n_cams > 1) || !err_out) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
@@ -326,7 +356,7 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
 // sorted; median = e[len/2]; avg_99 = sum_{i < len*99/100} e_i / (len*99/100).
 int ccal_validation(ccal_problem* p, int cam, const double* intr, const double* poses, const double* extr,
                     double* avg_99, double* median) {
-    if (!p || cam < 0 || cam >= p->n_cams || !avg_99 || !median || !intr || (!poses && p->n_slots)) return CCAL_ERR_INVALID_ARG;
+    if (!p || cam < 0 || cam >= p->n_cams || !avg_99 || !median || !intr || (!poses && p->n_slots) || (!extr && p->n_cams > 1)) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* ctx = p->ctx;
     if (p->cams[cam].obs.empty()) return fail(ctx, CCAL_ERR_INVALID_ARG, "camera has no observations");
     int rc = ccal_upload_params(p, intr, poses, extr);

@@ -47,7 +47,7 @@ __device__ bool unproject_ray(const double* th, double u, double v, double& x, d
         return true;
     } else if constexpr (MODEL == kKB4) {
         const double r = sqrt(r2);
-        if (r < 1e-8) { x = mx; y = my; z = 1.0; return true; }
+        if (r < kUnprojectSmallRadius) { x = mx; y = my; z = 1.0; return true; }
         double t = r;
         for (int it = 0; it < 20; ++it) {
             const double t2 = t * t;
@@ -62,7 +62,7 @@ __device__ bool unproject_ray(const double* th, double u, double v, double& x, d
         x = mx * s; y = my * s; z = cos(t);
         return true;
     } else {
-        const double k1 = th[4], k2 = th[5], p1 = th[6], p2 = th[7], k3 = th[8];
+        const double k1 = th[OCV5_K1], k2 = th[OCV5_K2], p1 = th[OCV5_P1], p2 = th[OCV5_P2], k3 = th[OCV5_K3];
         double xx = mx, yy = my;
         for (int it = 0; it < 50; ++it) {
             const double q = xx * xx + yy * yy;
@@ -103,14 +103,14 @@ struct ConvArgs {
     double* rays;                               // [n_grid][CONV_REC]
     int32_t n_rows, n_cols, edge, steps;
     double* out;                                // [P (P+1)/2 | P | s | n_points]
+    double kb4_eps;                             // ccal_model_conventions.kb4_small_radius
 };
 
 template <int SRC>
 __global__ __launch_bounds__(256) void k_convert_rays(const ConvArgs a) {
     const int n = a.n_rows * a.n_cols;
-    double th[model_np(SRC)];
-#pragma unroll
-    for (int i = 0; i < model_np(SRC); ++i) th[i] = a.src[i];
+    double th[th_len<SRC>()];
+    load_theta<SRC, false>(a.src, a.kb4_eps, th);
     for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
         const int r = a.edge + (k / a.n_cols) * a.steps, c = a.edge + (k % a.n_cols) * a.steps;
         double x = 0.0, y = 0.0, z = 0.0, u0 = 0.0, v0 = 0.0, state = 0.0;
@@ -127,9 +127,8 @@ template <int TGT>
 __global__ __launch_bounds__(256) void k_convert_gram(const ConvArgs a) {
     constexpr int P = model_np(TGT), ND = P - 4, NT = P * (P + 1) / 2, NA = NT + P + 2;
     __shared__ double part[4][NA];
-    double th[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) th[i] = a.tgt[i];
+    double th[th_len<TGT>()];
+    load_theta<TGT, false>(a.tgt, a.kb4_eps, th);
     double acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.0;
@@ -191,15 +190,10 @@ void chol_solve_host(const double* L, int n, double* x) {
     for (int i = 0; i < n; ++i) { double t = x[i]; for (int k = 0; k < i; ++k) t -= L[i * n + k] * x[k]; x[i] = t / L[i * n + i]; }
     for (int i = n - 1; i >= 0; --i) { double t = x[i]; for (int k = i + 1; k < n; ++k) t -= L[k * n + i] * x[k]; x[i] = t / L[i * n + i]; }
 }
-// distortion bounds of set_problem_parameter_bound (src/util.rs:29-48), same table as ccal_apply_reference_bounds
-void reference_bounds(int model, double w, double h, double* lo, double* hi) {
+// bounds of set_problem_parameter_bound (src/util.rs:29-48); distortion part from the context's conventions table
+void reference_bounds(const ccal_model_conventions& cv, int model, double w, double h, double* lo, double* hi) {
     lo[0] = 0.0; hi[0] = 10000.0; lo[1] = 0.0; hi[1] = 10000.0; lo[2] = 0.0; hi[2] = w; lo[3] = 0.0; hi[3] = h;
-    switch (model) {
-        case kUCM: lo[4] = 1e-6; hi[4] = 1.0; break;
-        case kEUCM: lo[4] = 1e-6; hi[4] = 1.0; lo[5] = 1e-6; hi[5] = 100.0; break;
-        case kKB4: for (int i = 4; i < 8; ++i) { lo[i] = -1.0; hi[i] = 1.0; } break;
-        default: for (int i = 4; i < 9; ++i) { lo[i] = -1.0; hi[i] = 1.0; } break;
-    }
+    for (int i = 4; i < model_np(model); ++i) { lo[i] = cv.dist_lo[model][i - 4]; hi[i] = cv.dist_hi[model][i - 4]; }
 }
 inline double huber_w(double s, double delta) { return s <= delta * delta ? 1.0 : delta / std::sqrt(s); }
 }  // namespace
@@ -238,14 +232,14 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
     double* d_buf = nullptr;                    // [src 10 | tgt 10 | out 64 | rays]
     HIP_TRY(ctx, hipMalloc((void**)&d_buf, sizeof(double) * (size_t)(20 + 64 + (size_t)n_grid * CONV_REC)));
     struct Free { double* p; ~Free() { (void)hipFree(p); } } guard{ d_buf };
-    ConvArgs a{ d_buf, d_buf + 10, d_buf + 84, n_rows, n_cols, (int32_t)edge, steps, d_buf + 20 };
+    ConvArgs a{ d_buf, d_buf + 10, d_buf + 84, n_rows, n_cols, (int32_t)edge, steps, d_buf + 20, ctx->conv.kb4_small_radius };
 
     double th[CCAL_PMAX] = { 0 }, lo[CCAL_PMAX], hi[CCAL_PMAX];
     for (int i = 0; i < P; ++i) th[i] = tgt_params_io[i];
     for (int i = 0; i < 4; ++i) th[i] = src_params[i];                      // util.rs:256-258
     bool fx[CCAL_PMAX] = { false };
     for (int i = 0; i < disabled_distortions; ++i) { fx[P - 1 - i] = true; th[P - 1 - i] = 0.0; }
-    reference_bounds(tgt_model, width, height, lo, hi);
+    reference_bounds(ctx->conv, tgt_model, width, height, lo, hi);
 
     HIP_TRY(ctx, hipMemcpyAsync(d_buf, src_params, sizeof(double) * PS, hipMemcpyHostToDevice, st));
     switch (src_model) {

@@ -175,6 +175,17 @@ __device__ inline void frame_setup(const double* pose, const double* extr, doubl
     }
 }
 
+// Intrinsics of one camera as the kernels hold them: th[0 .. P) = FULL model parameters (fy := fx with ONE_FOCAL)
+// and th[P] = the run-time convention slot (KB4: the small-radius threshold of project_one, dead for the others).
+template <int MODEL> __host__ __device__ constexpr int th_len() { return model_np(MODEL) + 1; }
+template <int MODEL, bool ONE_FOCAL>
+__device__ __forceinline__ void load_theta(const double* th_g, double kb4_small_radius, double* th) {
+#pragma unroll
+    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    if constexpr (ONE_FOCAL) th[1] = th[0];
+    th[model_np(MODEL)] = kb4_small_radius;
+}
+
 // Normalised projection m = (mx, my) with partials w.r.t. the camera-frame point (dmx[3], dmy[3])
 // and w.r.t. the distortion parameters th[4..P) (ddx[ND], ddy[ND]).
 template <int MODEL>
@@ -205,7 +216,7 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
         const double r2 = x * x + y * y;
         double r, ir;
         fast_sqrt_rsqrt(r2, r, ir);          // r2 == 0 gives NaN here and falls into the pinhole branch below
-        if (r > 1e-8) {
+        if (r > th[model_np(kKB4)]) {          // run-time convention slot (load_theta): ccal_model_conventions.kb4_small_radius
             const double t = atan2(r, z);
             const double t2 = t * t;
             const double k1 = th[4], k2 = th[5], k3 = th[6], k4 = th[7];
@@ -232,8 +243,8 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
 #pragma unroll
             for (int i = 0; i < 4; ++i) { ddx[i] = 0.0; ddy[i] = 0.0; }
         }
-    } else {   // OPENCV5 [k1,k2,p1,p2,k3]
-        const double k1 = th[4], k2 = th[5], p1 = th[6], p2 = th[7], k3 = th[8];
+    } else {   // OPENCV5, parameter order from ccal_models.hpp
+        const double k1 = th[OCV5_K1], k2 = th[OCV5_K2], p1 = th[OCV5_P1], p2 = th[OCV5_P2], k3 = th[OCV5_K3];
         const double iz = fast_rcp(z);
         const double xn = x * iz, yn = y * iz;
         const double xx = xn * xn, yy = yn * yn, xy = xn * yn;
@@ -249,8 +260,8 @@ __device__ __forceinline__ void project_partials(const double* th, double x, dou
         dmx[0] = xd_x * iz; dmx[1] = xd_y * iz; dmx[2] = -(xd_x * xn + xd_y * yn) * iz;
         dmy[0] = yd_x * iz; dmy[1] = yd_y * iz; dmy[2] = -(yd_x * xn + yd_y * yn) * iz;
         const double r4 = r2 * r2, r6 = r4 * r2;
-        ddx[0] = xn * r2; ddx[1] = xn * r4; ddx[2] = 2.0 * xy;        ddx[3] = r2 + 2.0 * xx; ddx[4] = xn * r6;
-        ddy[0] = yn * r2; ddy[1] = yn * r4; ddy[2] = r2 + 2.0 * yy;   ddy[3] = 2.0 * xy;      ddy[4] = yn * r6;
+        ddx[OCV5_K1 - 4] = xn * r2; ddx[OCV5_K2 - 4] = xn * r4; ddx[OCV5_P1 - 4] = 2.0 * xy;        ddx[OCV5_P2 - 4] = r2 + 2.0 * xx; ddx[OCV5_K3 - 4] = xn * r6;
+        ddy[OCV5_K1 - 4] = yn * r2; ddy[OCV5_K2 - 4] = yn * r4; ddy[OCV5_P1 - 4] = r2 + 2.0 * yy;   ddy[OCV5_P2 - 4] = 2.0 * xy;      ddy[OCV5_K3 - 4] = yn * r6;
     }
 }
 
@@ -267,16 +278,16 @@ __device__ __forceinline__ void project_uv(const double* th, double x, double y,
         mx = x * inv; my = y * inv;
     } else if constexpr (MODEL == kKB4) {
         const double r = sqrt(x * x + y * y);
-        if (r > 1e-8) {
+        if (r > th[model_np(kKB4)]) {
             const double t = atan2(r, z), t2 = t * t;
             const double s = t * (1.0 + t2 * (th[4] + t2 * (th[5] + t2 * (th[6] + t2 * th[7])))) / r;
             mx = x * s; my = y * s;
         } else { mx = x / z; my = y / z; }
     } else {
         const double iz = 1.0 / z, xn = x * iz, yn = y * iz, xx = xn * xn, yy = yn * yn, xy = xn * yn, r2 = xx + yy;
-        const double rad = 1.0 + r2 * (th[4] + r2 * (th[5] + r2 * th[8]));
-        mx = xn * rad + 2.0 * th[6] * xy + th[7] * (r2 + 2.0 * xx);
-        my = yn * rad + th[6] * (r2 + 2.0 * yy) + 2.0 * th[7] * xy;
+        const double rad = 1.0 + r2 * (th[OCV5_K1] + r2 * (th[OCV5_K2] + r2 * th[OCV5_K3]));
+        mx = xn * rad + 2.0 * th[OCV5_P1] * xy + th[OCV5_P2] * (r2 + 2.0 * xx);
+        my = yn * rad + th[OCV5_P1] * (r2 + 2.0 * yy) + 2.0 * th[OCV5_P2] * xy;
     }
     u = th[0] * mx + th[2]; v = th[1] * my + th[3];
 }

@@ -1,12 +1,25 @@
-// Device-resident optimizer state and argument blocks of the single-camera fast path
-// (ccal_kernels_fused.hip, driven by solve_fused() in ccal_solver.hip).
+// Device-resident optimizer state, the decision rule shared by both device loops, and the argument blocks of the
+// single-camera fast path (ccal_kernels_fused.hip, driven by solve_fused() in ccal_solver.hip).
+//
+// One GROUP of launches = one evaluation + one reduced system + ONE all-reduce + one decision/solve, for Gauss-Newton
+// and for Levenberg-Marquardt alike:
+//     Gram at the evaluated set  ->  pose elimination (Schur)  ->  reduce  ->  [all-reduce]  ->  decide + camera solve
+// GN accepts every step, so the system eliminated at the candidate is always the next one to solve.  LM does not know
+// the next damping before the (all-reduced) cost of the candidate is known; it eliminates SPECULATIVELY with
+// lambda_spec = the damping an accepted step gets when the gain ratio is near 1 (radius * 3, the trust-region rule's
+// cap - the usual case near convergence).  A hit: the sums at hand are the next system, the step costs one group like
+// GN.  A miss (another radius factor) or a rejected step: the decision sets `redo`, and the next group skips its Gram,
+// re-eliminates the accepted set from its stored per-frame records with the right damping and solves - the same work
+// the previous two-phase LM group did for every step, now only for those.  Every group carries exactly one
+// collective, whatever the decisions: sharded ranks cannot disagree on the sequence.
 #pragma once
 #include "ccal_normal.hpp"
 
 namespace ccal {
 
-struct DevState {                 // lives in device memory; updated by k_head only (sizeof % 8 == 0)
-    double lambda;                // damping of the NEXT pose elimination / camera solve (0 for GN)
+struct DevState {                 // lives in device memory; updated by the decision kernels only (sizeof % 8 == 0)
+    double lambda;                // damping of the system to solve next (0 for GN)
+    double lambda_spec;           // LM: damping of the speculative elimination at the candidate
     double lambda_solve;          // damping that produced the current dc (model decrease of the pose blocks)
     double radius, dec;
     double cur_cost, last_cost, initial_cost;
@@ -14,51 +27,157 @@ struct DevState {                 // lives in device memory; updated by k_head o
     double min_error, min_abs, min_rel;
     int32_t cur;                  // parameter set (0/1) holding the accepted point
     int32_t first;                // 1 until the starting point has been evaluated
+    int32_t redo;                 // 1: the next group re-eliminates the accepted set with `lambda` (no evaluation, no decision)
     int32_t done;                 // 0 = running, else ccal_status + 1
     int32_t iter, max_iter, method;
-    int32_t lm_accepted, lm_rejected, accepted_now;
+    int32_t lm_accepted, lm_rejected;
+    int32_t sys_failed;           // a pose block of the system that produced the candidate was not positive definite (any rank)
+    int32_t cam_failed;           // the camera system that produced the candidate was not positive definite
     int32_t done_seq;             // sequence number of the step that set `done` (0 while running)
+    int32_t spec_hits, spec_misses;   // LM: accepted steps whose speculative elimination was / was not the next system
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState is staged as doubles");
 
-struct HostStatus {               // pinned, host-coherent; written at the end of k_head
+struct HostStatus {               // pinned, host-coherent; written at the end of a decision kernel
     volatile int32_t seq;
     volatile int32_t done, iter, cur, lm_accepted, lm_rejected;
     volatile int32_t done_seq;    // which step finished the solve: the host acts on `done` only once it has waited for that step
+    volatile int32_t spec_hits, spec_misses;
     volatile double cur_cost, initial_cost, radius;
 };
+
+// What an accepted LM step whose gain ratio is near 1 does to the radius: the rule's cap.  The same expression as in
+// optimizer_decide, so that a hit is a bitwise comparison.
+__host__ __device__ inline double lm_radius_cap(double radius) { return fmin(1e16, radius / (1.0 / 3.0)); }
+
+// The optimizer's decision for one group, from all-reduced sums only (identical on every rank of a sharded solve):
+//   cost      sum rho'(s) s of the evaluated set (the starting point in the first group, the candidate afterwards)
+//   mc_pose   model decrease of the pose blocks for the step that produced the candidate
+//   sys_fail  a pose block of the system at hand was not positive definite (count over all ranks > 0)
+// tiny-solver's Gauss-Newton rules (src/util.rs:455: accept unconditionally; stop on min_error, |d| < 1e-5,
+// |d| / last < 1e-5, max_iterations) or the Ceres-style trust region of the LM mode.
+// Returns true when the reduced system at hand is the one to solve now.
+__device__ inline bool optimizer_decide(DevState* st, double cost, double mc_pose, bool sys_fail, int seq) {
+    const bool lm = st->method == CCAL_METHOD_LM;
+    int done = 0;
+    bool solve = false;
+    if (st->redo) {                                   // re-elimination group: the decision was taken one group ago
+        st->redo = 0;
+        solve = true;
+    } else if (st->first) {
+        st->cur_cost = cost; st->initial_cost = cost; st->first = 0;
+        if (!(cost == cost)) done = CCAL_ERR_NONFINITE + 1;
+        else if (!(fabs(cost) < 1.7e308)) done = (lm ? CCAL_ERR_NONFINITE : CCAL_ERR_NOT_PD) + 1;
+        solve = true;
+    } else if (!lm) {
+        // Gauss-Newton: the candidate is the new point (tiny-solver applies dx unconditionally)
+        st->cur ^= 1;
+        const double last = st->cur_cost, cur = cost;
+        st->last_cost = last; st->cur_cost = cur; st->iter += 1;
+        if (cur < st->min_error) done = CCAL_OK + 1;
+        else if (!(cur == cur)) done = CCAL_ERR_NONFINITE + 1;
+        else if (!(fabs(cur) < 1.7e308)) done = CCAL_ERR_NOT_PD + 1;
+        else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
+        else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
+        else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
+        solve = true;
+    } else {
+        const double mc = st->mc_cam + mc_pose;
+        const double rho = (st->cur_cost - cost) / mc;
+        st->iter += 1;
+        const bool lin_fail = st->sys_failed || st->cam_failed;      // the candidate came out of a failed linear solve
+        const bool fin = fabs(cost) < 1.7e308;
+        if (!lin_fail && fin && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * st->cur_cost)) {
+            // predicted decrease below the thresholds: converged (the re-weighted Huber cost is not monotone at the optimum)
+            if (cost < st->cur_cost) { st->cur ^= 1; st->last_cost = st->cur_cost; st->cur_cost = cost; st->lm_accepted += 1; }
+            done = CCAL_OK + 1;
+        } else if (!lin_fail && fin && mc > 0.0 && rho > 0.0) {
+            st->cur ^= 1;
+            const double last = st->cur_cost, cur = cost;
+            st->last_cost = last; st->cur_cost = cur; st->lm_accepted += 1;
+            const double t = 2.0 * rho - 1.0;
+            st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            st->dec = 2.0;
+            if (cur < st->min_error) done = CCAL_OK + 1;
+            else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
+            else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
+            st->lambda = 1.0 / st->radius;
+            if (!done) {
+                if (st->lambda == st->lambda_spec) { solve = true; st->spec_hits += 1; }      // the sums at hand are the next system
+                else { st->redo = 1; st->spec_misses += 1; }
+            }
+        } else {
+            st->lm_rejected += 1;
+            st->radius /= st->dec; st->dec *= 2.0;
+            if (st->radius < 1e-32) done = CCAL_ERR_NO_CONVERGENCE + 1;
+            st->lambda = 1.0 / st->radius;
+            if (!done) st->redo = 1;
+        }
+        st->sys_failed = 0; st->cam_failed = 0;
+        if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
+    }
+    if (!done && solve && sys_fail) {
+        // the system about to be solved has a pose block that is not positive definite: Gauss-Newton has no step
+        // (tiny-solver: None); LM solves with that block frozen and rejects the candidate at the next decision
+        if (!lm) done = CCAL_ERR_NOT_PD + 1;
+        else st->sys_failed = 1;
+    }
+    if (lm) st->lambda_spec = 1.0 / lm_radius_cap(st->radius);
+    st->done = done;
+    if (done && !st->done_seq) st->done_seq = seq;
+    return solve && !done;
+}
+
+__device__ inline void publish_host_status(HostStatus* hs, const DevState* s, int seq) {
+    hs->done = s->done; hs->done_seq = s->done_seq; hs->iter = s->iter; hs->cur = s->cur;
+    hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
+    hs->spec_hits = s->spec_hits; hs->spec_misses = s->spec_misses;
+    hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
+    __threadfence_system();
+    hs->seq = seq;                   // the host polls this word; kernel completion flushes it at the latest
+}
+
+// Which parameter / record set a group's kernels work on, and with which damping.
+__device__ __forceinline__ int eval_set(const DevState* st) { return st->first ? st->cur : (st->cur ^ 1); }
+__device__ __forceinline__ int schur_set(const DevState* st) { return st->redo ? st->cur : eval_set(st); }
+__device__ __forceinline__ double schur_lambda(const DevState* st) {
+    return (st->method == CCAL_METHOD_LM && !st->first && !st->redo) ? st->lambda_spec : st->lambda;
+}
 
 struct FusedArgs {
     const float* x; const float* y; const float* z; const float* u; const float* v;
     const int64_t* obs_off; const int32_t* obs_slot;
     int32_t n_obs, K, PF, PRAW, n_pw;
     double huber_delta, min_diag, max_diag;
+    double kb4_eps;                // ccal_model_conventions.kb4_small_radius of the context
     double* intr[2]; double* poses[2]; double* pf[2]; double* praw[2];
     double* fcbuf; double* mc_f; double* cost_f;
-    const double* dc; const DevState* st; int32_t* st_flags;
+    const double* dc; const DevState* st;
     double* partial; double* red;
-    int32_t* ticket;               // arrival counter of the fused reduce + head tail of k_schur1
 };
 
+// red / partial rows of the single-camera path: [A_dir (K1 x K1) | Y^T Y (K1 x K1) | mc_pose | failed pose blocks]
+__host__ __device__ constexpr int fused_red_size(int K) { return 2 * (K + 1) * (K + 1) + 2; }
+
 struct HeadArgs {
-    DevState* st; HostStatus* hs; const double* red; const ColInfo* cols; int32_t* flags;
+    DevState* st; HostStatus* hs; const double* red; const ColInfo* cols;
     double* intr[2]; double* dc;
-    int32_t K, phase, seq;
+    int32_t K, seq;
     double min_diag, max_diag;
 };
 
 struct UnpackArgs {               // staging block (doubles): [intr CCAL_PMAX | DevState | ColInfo x CCAL_KMAX | poses np6]
     const double* stage; int64_t small_doubles, np6;
+    int32_t poses_on_device;      // ccal_solve_dev: the starting point is already in intr0 / poses0, only state + columns are staged
     double* intr0; double* intr1; double* poses0; double* poses1;
-    DevState* st; ColInfo* cols; int32_t* flags;
+    DevState* st; ColInfo* cols;
 };
 hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // VALU Gram (<= 105 triangle entries)
-hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* fused_head, hipStream_t s);   // fused_head != NULL: last workgroup reduces + decides + solves
-hipError_t launch_schur1m(const FusedArgs& a, int set_sel, hipStream_t s);   // four frames per wavefront; needs a.n_pw = 4 ceil(n_obs / 16)
-hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s);
-hipError_t launch_cost1(const FusedArgs& a, hipStream_t s);
+hipError_t launch_schur1(const FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size)
+hipError_t launch_schur1m(const FusedArgs& a, hipStream_t s);   // four frames per wavefront; needs a.n_pw = 4 ceil(n_obs / 16)
+hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s);     // state := "first evaluation of set 0 with this lambda"
 

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -27,6 +29,7 @@ struct KArgs {
     const double* poses;           // [n_slots][6]
     const double* extr;            // [n_cams][6]
     double huber_delta;
+    double kb4_eps;                // ccal_model_conventions.kb4_small_radius of the context
     int32_t apply_loss;
     double* r_out;                 // mode E
     double* J_out;
@@ -50,6 +53,7 @@ struct ccal_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    ccal_model_conventions conv;   // run-time model conventions (defaults: ccal_models.hpp)
 };
 
 struct ccal_problem {
@@ -75,14 +79,32 @@ struct ccal_problem {
     ccal::NormalWs* nws = nullptr;
     // lazily sized scratch for host<->device staging of ccal_eval
     double *d_r = nullptr, *d_J = nullptr, *d_err = nullptr;
-    ccal_allreduce_fn allreduce = nullptr;
+    ccal_allreduce_fn allreduce = nullptr;     // callback form of the step's collective (tests over gloo)
     void* allreduce_user = nullptr;
+    void* rccl_comm = nullptr;                 // ncclComm_t: the library issues ncclAllReduce itself (ccal_set_rccl_comm)
+    bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
 };
 
+// No exception crosses the C ABI (include/ccal.h:9): every extern "C" body that can allocate host memory (operator new,
+// std::vector, std::string) runs between CCAL_API_TRY and CCAL_API_CATCH(ctx).  ctx may be NULL.
+#define CCAL_API_TRY try {
+#define CCAL_API_CATCH(ctx_expr)                                                                   \
+    }                                                                                              \
+    catch (const std::bad_alloc&) { ccal::note_error((ctx_expr), "out of host memory"); return CCAL_ERR_NO_MEMORY; }  \
+    catch (const std::exception& e_) { ccal::note_error((ctx_expr), e_.what()); return CCAL_ERR_HIP; }                \
+    catch (...) { ccal::note_error((ctx_expr), "unknown C++ exception"); return CCAL_ERR_HIP; }
+
 namespace ccal {
+inline void note_error(ccal_ctx* ctx, const char* msg) noexcept {
+    if (!ctx) return;
+    try { ctx->err = msg; } catch (...) { }
+}
+inline void note_error(const ccal_ctx*, const char*) noexcept {}
 // kernel launchers (ccal_kernels.hip)
 hipError_t launch_eval(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
 hipError_t launch_reproj_err(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
+// ccal_rccl.hip: in-place sum over the ranks of an ncclComm_t, ordered on the stream; returns a ccal_status
+int rccl_allreduce_sum(ccal_ctx* ctx, void* comm, double* buf, size_t count, hipStream_t st);
 // ccal_kernels_stats.hip
 hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
 // ccal_kernels_init.hip

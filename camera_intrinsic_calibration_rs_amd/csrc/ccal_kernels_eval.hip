@@ -62,10 +62,8 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     const int64_t start = a.obs_off[o];
     const int n = (int)(a.obs_off[o + 1] - start);
     const double* th_g = a.intr + a.cam * CCAL_PMAX;
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
-    if constexpr (OF) th[1] = th[0];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
 
     {   // frame constants -> LDS (every lane computes, lane 0 stores)
         double pose[6], ex[6];
@@ -150,10 +148,8 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
     const int64_t start = a.obs_off[o];
     const int n = (int)(a.obs_off[o + 1] - start);
     const double* th_g = a.intr + a.cam * CCAL_PMAX;
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
-    if constexpr (OF) th[1] = th[0];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
     {
         double pose[6], ex[6];
 #pragma unroll

@@ -11,7 +11,6 @@
 //                An LM rejection re-runs only this kernel.  (k_schur1: one frame per wavefront, problems too large
 //                for one pass and the opt-in fused reduce + decide tail.)
 //   k_reduce1    fixed-order sum over waves -> red (the all-reduce buffer of sharded solves)
-//   k_cost1      (LM) sum of per-frame costs and model decreases
 //   k_head       one wavefront: accept / reject / convergence tests (tiny-solver's rules or the Ceres-style
 //                trust region), K x K solve, candidate intrinsics, status to pinned host memory
 // Same arithmetic and decision sequence as the general loop in ccal_solver.hip (multi-camera problems);
@@ -42,14 +41,15 @@ __device__ __forceinline__ double clampd1(double v, double lo, double hi) { retu
 __global__ __launch_bounds__(256) void k_unpack1(const UnpackArgs a) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
     const double* small = a.stage;
-    const double* poses = a.stage + a.small_doubles;
-    for (int64_t e = t; e < a.np6; e += nt) { const double v = poses[e]; a.poses0[e] = v; a.poses1[e] = v; }
+    // ccal_solve_dev: the starting point already sits in set 0 on the device - only mirror it into set 1
+    const double* poses = a.poses_on_device ? a.poses0 : a.stage + a.small_doubles;
+    for (int64_t e = t; e < a.np6; e += nt) { const double v = poses[e]; if (!a.poses_on_device) a.poses0[e] = v; a.poses1[e] = v; }
     if (blockIdx.x == 0) {
         constexpr int NS = (int)(sizeof(DevState) / sizeof(double)), NCOL = (int)(CCAL_KMAX * sizeof(ColInfo) / sizeof(double));
-        for (int e = threadIdx.x; e < CCAL_PMAX; e += 256) { a.intr0[e] = small[e]; a.intr1[e] = small[e]; }
+        const double* intr = a.poses_on_device ? a.intr0 : small;
+        for (int e = threadIdx.x; e < CCAL_PMAX; e += 256) { const double v = intr[e]; if (!a.poses_on_device) a.intr0[e] = v; a.intr1[e] = v; }
         for (int e = threadIdx.x; e < NS; e += 256) reinterpret_cast<double*>(a.st)[e] = small[CCAL_PMAX + e];
         for (int e = threadIdx.x; e < NCOL; e += 256) reinterpret_cast<double*>(a.cols)[e] = small[CCAL_PMAX + NS + e];
-        if (threadIdx.x < 4) a.flags[threadIdx.x] = 0;
     }
 }
 hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * CS;
     extern __shared__ double smem[];
     const DevState* st = a.st;
-    if (st->done) return;
+    if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int f = blockIdx.x * WAVES_PER_BLOCK + wave;
     if (f >= a.n_obs) return;
@@ -78,10 +78,8 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
-    if constexpr (OF) th[1] = th[0];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
     const int64_t start = a.obs_off[f];
     const int n = (int)(a.obs_off[f + 1] - start);
     // software prefetch: the first pass's corner rows are requested before the (long, latency-bound)
@@ -269,7 +267,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
     extern __shared__ double smem[];
     const DevState* st = a.st;
-    if (st->done) return;
+    if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane / LPF, gl = lane % LPF;
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
@@ -281,10 +279,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
-    if constexpr (OF) th[1] = th[0];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
     float pX, pY, pZ, pU, pV;
@@ -451,7 +447,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     constexpr int NQA = (G * NL + 63) / 64;
     extern __shared__ double smem[];
     const DevState* st = a.st;
-    if (st->done) return;
+    if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane / LPF, gl = lane % LPF;
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
@@ -463,10 +459,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
-    if constexpr (OF) th[1] = th[0];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
     float pX, pY, pZ, pU, pV;
@@ -719,8 +713,10 @@ hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_schur1: persistent wavefronts over frames.  set_sel 0: the set evaluated by the last k_gram1
-// (GN: eliminate right away); 1: the accepted set st->cur (LM: after the decision).
+// k_schur1: persistent wavefronts over frames (problems too large for one pass of k_schur1m).  Works on the set and
+// with the damping the state prescribes (schur_set / schur_lambda in ccal_fused.hpp): the set just evaluated, or - in a
+// re-elimination group - the accepted set, whose records an LM rejection left untouched.
+// Per workgroup partial sums: [A_dir | Y^T Y | model decrease of the pose blocks | pose blocks that failed].
 // ---------------------------------------------------------------------------------------------
 struct HeadShared {               // LDS of the decision / solve step
     DevState S0;
@@ -729,41 +725,28 @@ struct HeadShared {               // LDS of the decision / solve step
     double x[10];
     double cur_intr[CCAL_PMAX];   // current intrinsics (full layout)
     int fx[10];                   // fixed flags of the camera columns
-    int bad;
+    int bad, solve;
 };
-__device__ __forceinline__ void publish_status(const HeadArgs& a, const DevState* s) {
-    HostStatus* hs = a.hs;
-    hs->done = s->done; hs->done_seq = s->done_seq; hs->iter = s->iter; hs->cur = s->cur;
-    hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
-    hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
-    __threadfence_system();
-    hs->seq = a.seq;                 // the host polls this word; kernel completion flushes it at the latest
-}
-
-__device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red);
 
 template <int K>
-__global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, const HeadArgs ha, int fuse_head) {
-    constexpr int K1 = K + 1;
-    constexpr int NQ = (K1 * K1 + 63) / 64;
+__global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
+    constexpr int K1 = K + 1, NA = K1 * K1;
+    constexpr int NQ = (NA + 63) / 64;
     constexpr int WSL = ((36 + 12 * K1) + 1) & ~1;      // C[36] | [B|g][6][K1] | Y[6][K1]
     __shared__ double smem[WAVES_PER_BLOCK * WSL];
     const DevState* st = a.st;
-    if (st->done) {                  // finished earlier: the host still waits for this group's sequence number
-        if (fuse_head && blockIdx.x == 0 && threadIdx.x == 0) publish_status(ha, st);
-        return;
-    }
+    if (st->done) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     double* Cm = smem + wave * WSL;
     double* Bm = Cm + 36;
     double* Ym = Bm + 6 * K1;
-    const int cur = st->cur, first = st->first;
-    const int set = set_sel ? cur : (first ? cur : (cur ^ 1));
-    const double lambda = st->lambda;
+    const int set = schur_set(st);
+    const double lambda = schur_lambda(st);
     double accA[NQ], accY[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
+    double acc_mc = 0.0, acc_fail = 0.0;             // wave-uniform
     // packed-lower index of this lane (lanes 0..20)
     int li = 0, lr = lane;
     while (lr > li && li < 6) { lr -= li + 1; ++li; }
@@ -775,7 +758,8 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
         for (int e = lane; e < 6 * K1; e += 64) Bm[e] = rec[21 + e];
         double adir[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { const int e = lane + 64 * q; adir[q] = e < K1 * K1 ? rec[21 + 6 * K1 + e] : 0.0; }
+        for (int q = 0; q < NQ; ++q) { const int e = lane + 64 * q; adir[q] = e < NA ? rec[21 + 6 * K1 + e] : 0.0; }
+        acc_mc += a.mc_f[f];
         wsync();
         // 6x6 Cholesky of C + lambda clamp(diag C): every lane runs the same factorisation (diag inverted)
         double L[21], dC[6];
@@ -801,7 +785,7 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
         }
         double* pf = a.pf[set] + (int64_t)slot * a.PF;
         if (!ok) {
-            if (lane == 0) a.st_flags[0] = 1;
+            acc_fail += 1.0;
             for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
             for (int e = lane; e < 6 * K1; e += 64) Ym[e] = 0.0;
         } else {
@@ -832,85 +816,42 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a, int set_sel, 
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = lane + 64 * q;
-            if (e < K1 * K1) {
+            if (e < NA) {
                 const int i = e / K1, j = e - i * K1;
                 double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
                 accY[q] += t;
-                // a pose block that is not positive definite poisons the cost entry with +inf: in a sharded solve it
-                // reaches every rank through the all-reduce and all of them stop in the same group with NOT_PD; a cost
-                // that is NaN already (diverged parameters) stays NaN and reads as NONFINITE, like in the oracle
-                accA[q] += (ok || e != K * K1 + K || adir[q] != adir[q]) ? adir[q] : __builtin_huge_val();
+                accA[q] += adir[q];
             }
         }
         wsync();
     }
     // the four waves of the workgroup combine in LDS (fixed order), one flush per workgroup
-    __shared__ double blk[WAVES_PER_BLOCK][2 * K1 * K1];
+    __shared__ double blk[WAVES_PER_BLOCK][2 * NA + 2];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = lane + 64 * q;
-        if (e < K1 * K1) { blk[wave][e] = accA[q]; blk[wave][K1 * K1 + e] = accY[q]; }
+        if (e < NA) { blk[wave][e] = accA[q]; blk[wave][NA + e] = accY[q]; }
     }
+    if (lane == 0) { blk[wave][2 * NA] = acc_mc; blk[wave][2 * NA + 1] = acc_fail; }
     __syncthreads();
-    const int nblk = a.n_pw / WAVES_PER_BLOCK;
-    if (!fuse_head) {                // [entry][workgroup]: k_reduce1 sums one entry per workgroup
-        for (int e = threadIdx.x; e < 2 * K1 * K1; e += 256)
-            a.partial[(int64_t)e * nblk + blockIdx.x] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
-        return;
-    }
-    // Fused tail: partials as [workgroup][entry]; the last workgroup to arrive sums them in workgroup order
-    // (deterministic whichever workgroup that is) and runs the decision / camera solve - no separate
-    // reduce and head launches.  The per-XCD L2s are not coherent with each other, and an agent-scope
-    // release fence per workgroup means a whole-L2 writeback per workgroup (measured: +75 us per iteration).
-    // Instead the partials travel as agent-scope relaxed atomics (sc1: write-through stores, L2-bypassing
-    // loads), ordered against the ticket by waiting for the stores' acknowledgements.
-    constexpr int RB1 = 2 * K1 * K1;
-    for (int e = threadIdx.x; e < RB1; e += 256)
-        __hip_atomic_store(&a.partial[(int64_t)blockIdx.x * RB1 + e], (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __shared__ int is_last;
-    __shared__ HeadShared hs;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int t = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (t == (int)gridDim.x - 1);
-        if (is_last) __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-    }
-    __syncthreads();
-    if (!is_last) return;
-    for (int e = threadIdx.x; e < RB1; e += 256) {
-        const double* src = a.partial + e;
-        double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-        int i = 0;
-#pragma unroll 4
-        for (; i + 3 < nblk; i += 4) {
-            v0 += __hip_atomic_load(src + (int64_t)i * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v1 += __hip_atomic_load(src + (int64_t)(i + 1) * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v2 += __hip_atomic_load(src + (int64_t)(i + 2) * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            v3 += __hip_atomic_load(src + (int64_t)(i + 3) * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        for (; i < nblk; ++i) v0 += __hip_atomic_load(src + (int64_t)i * RB1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        hs.red[e] = (v0 + v1) + (v2 + v3);
-    }
-    if (threadIdx.x < 2) hs.red[2 * K1 * K1 + threadIdx.x] = a.red[2 * K1 * K1 + threadIdx.x];    // cost / mc of k_cost1 (LM)
-    __syncthreads();
-    head_body(ha, hs, false);
+    const int nblk = a.n_pw / WAVES_PER_BLOCK;      // [entry][workgroup]: k_reduce1 sums one entry per workgroup
+    for (int e = threadIdx.x; e < 2 * NA + 2; e += 256)
+        a.partial[(int64_t)e * nblk + blockIdx.x] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
 }
 // k_schur1m: the same elimination with FOUR frames per wavefront (16 lanes each) - k_schur1 keeps 64 lanes busy with
 // one frame's 7 columns and 49 sums, so a 10 000-frame problem is 10 000 latency-bound wavefronts (381 vector + 520
 // scalar instructions each, 46 % of the time waiting); here the same instruction stream serves four frames.
 // One pass per wavefront: the grid covers all frames (n_pw = 4 ceil(n_obs / 16)).
 template <int K>
-__global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel) {
+__global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
     constexpr int K1 = K + 1, NA = K1 * K1;
     constexpr int NQ = (NA + 15) / 16;                    // A / Y^T Y entries per lane
     constexpr int REC = 21 + 6 * K1 + NA;                 // C (21) | [B|g] (6 x K1) | A (K1 x K1)
     constexpr int GS = (REC + 6 * K1 + 1) & ~1;           // per frame in LDS: record | Y (6 x K1)
     __shared__ double smem[16 * GS];
-    __shared__ double blk[16][2 * NA];
+    __shared__ double blk[16][2 * NA + 2];
     const DevState* st = a.st;
     if (st->done) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -919,15 +860,16 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel)
     const bool active = f < a.n_obs;
     double* R = smem + (wave * 4 + grp) * GS;
     double* Ym = R + REC;
-    const int cur = st->cur, first = st->first;
-    const int set = set_sel ? cur : (first ? cur : (cur ^ 1));
-    const double lambda = st->lambda;
+    const int set = schur_set(st);
+    const double lambda = schur_lambda(st);
     double accA[NQ], accY[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
+    double mcv = 0.0;
     if (active) {
         const double* rec = a.praw[set] + (int64_t)f * a.PRAW;
         for (int e = gl; e < REC; e += 16) R[e] = rec[e];
+        if (gl == 0) mcv = a.mc_f[f];
     }
     const int slot = active ? a.obs_slot[f] : 0;
     wsync();
@@ -957,7 +899,6 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel)
         double* pf = a.pf[set] + (int64_t)slot * a.PF;
         const double* Bm = R + 21;
         if (!ok) {
-            if (gl == 0) a.st_flags[0] = 1;
             for (int e = gl; e < a.PF; e += 16) pf[e] = 0.0;
             for (int e = gl; e < 6 * K1; e += 16) Ym[e] = 0.0;
         } else {
@@ -998,8 +939,7 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel)
 #pragma unroll
                 for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
                 accY[q] = t;
-                // a pose block that is not positive definite poisons the cost entry (see k_schur1)
-                accA[q] = (ok || e != K * K1 + K || R[21 + 6 * K1 + e] != R[21 + 6 * K1 + e]) ? R[21 + 6 * K1 + e] : __builtin_huge_val();
+                accA[q] = R[21 + 6 * K1 + e];
             }
         }
     }
@@ -1009,47 +949,48 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a, int set_sel)
         const int e = gl + 16 * q;
         if (e < NA) { blk[wave * 4 + grp][e] = accA[q]; blk[wave * 4 + grp][NA + e] = accY[q]; }
     }
+    if (gl == 0) { blk[wave * 4 + grp][2 * NA] = mcv; blk[wave * 4 + grp][2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
     __syncthreads();
     const int nblk = a.n_pw / WAVES_PER_BLOCK;
-    for (int e = threadIdx.x; e < 2 * NA; e += 256) {
+    for (int e = threadIdx.x; e < 2 * NA + 2; e += 256) {
         double t = 0.0;
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += blk[g][e];
         a.partial[(int64_t)e * nblk + blockIdx.x] = t;
     }
 }
-hipError_t launch_schur1m(const FusedArgs& a, int set_sel, hipStream_t s) {
+hipError_t launch_schur1m(const FusedArgs& a, hipStream_t s) {
     const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
+    if (grid.x == 0) return hipSuccess;
     switch (a.K) {
-        case 4: hipLaunchKernelGGL(k_schur1m<4>, grid, blk, 0, s, a, set_sel); break;
-        case 5: hipLaunchKernelGGL(k_schur1m<5>, grid, blk, 0, s, a, set_sel); break;
-        case 6: hipLaunchKernelGGL(k_schur1m<6>, grid, blk, 0, s, a, set_sel); break;
-        case 7: hipLaunchKernelGGL(k_schur1m<7>, grid, blk, 0, s, a, set_sel); break;
-        case 8: hipLaunchKernelGGL(k_schur1m<8>, grid, blk, 0, s, a, set_sel); break;
-        case 9: hipLaunchKernelGGL(k_schur1m<9>, grid, blk, 0, s, a, set_sel); break;
+        case 4: hipLaunchKernelGGL(k_schur1m<4>, grid, blk, 0, s, a); break;
+        case 5: hipLaunchKernelGGL(k_schur1m<5>, grid, blk, 0, s, a); break;
+        case 6: hipLaunchKernelGGL(k_schur1m<6>, grid, blk, 0, s, a); break;
+        case 7: hipLaunchKernelGGL(k_schur1m<7>, grid, blk, 0, s, a); break;
+        case 8: hipLaunchKernelGGL(k_schur1m<8>, grid, blk, 0, s, a); break;
+        case 9: hipLaunchKernelGGL(k_schur1m<9>, grid, blk, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_schur1(const FusedArgs& a, int set_sel, const HeadArgs* ha, hipStream_t s) {
+hipError_t launch_schur1(const FusedArgs& a, hipStream_t s) {
     const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
-    const HeadArgs h = ha ? *ha : HeadArgs{};
-    const int fuse = ha ? 1 : 0;
+    if (grid.x == 0) return hipSuccess;
     switch (a.K) {
-        case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a, set_sel, h, fuse); break;
-        case 5: hipLaunchKernelGGL(k_schur1<5>, grid, blk, 0, s, a, set_sel, h, fuse); break;
-        case 6: hipLaunchKernelGGL(k_schur1<6>, grid, blk, 0, s, a, set_sel, h, fuse); break;
-        case 7: hipLaunchKernelGGL(k_schur1<7>, grid, blk, 0, s, a, set_sel, h, fuse); break;
-        case 8: hipLaunchKernelGGL(k_schur1<8>, grid, blk, 0, s, a, set_sel, h, fuse); break;
-        case 9: hipLaunchKernelGGL(k_schur1<9>, grid, blk, 0, s, a, set_sel, h, fuse); break;
+        case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a); break;
+        case 5: hipLaunchKernelGGL(k_schur1<5>, grid, blk, 0, s, a); break;
+        case 6: hipLaunchKernelGGL(k_schur1<6>, grid, blk, 0, s, a); break;
+        case 7: hipLaunchKernelGGL(k_schur1<7>, grid, blk, 0, s, a); break;
+        case 8: hipLaunchKernelGGL(k_schur1<8>, grid, blk, 0, s, a); break;
+        case 9: hipLaunchKernelGGL(k_schur1<9>, grid, blk, 0, s, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_reduce1: red[first + b] = sum_w partial[first + b][w];  k_cost1: red[2 K1^2 .. +1] = sum cost_f, sum mc_f
+// k_reduce1: red[b] = sum_w partial[b][w], one workgroup per entry, fixed order (no atomics: bitwise reproducible)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double block_sum(double v, double* sh) {
 #pragma unroll
@@ -1060,43 +1001,26 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
     return t;
 }
-__global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_pw, int first, double* red, const DevState* st) {
+__global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_pw, double* red, const DevState* st) {
     if (st->done) return;
     __shared__ double sh[4];
-    const double* src = partial + (int64_t)(first + blockIdx.x) * n_pw;
+    const double* src = partial + (int64_t)blockIdx.x * n_pw;
     double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
     int i = threadIdx.x;
     for (; i + 768 < n_pw; i += 1024) { v0 += src[i]; v1 += src[i + 256]; v2 += src[i + 512]; v3 += src[i + 768]; }
     for (; i < n_pw; i += 256) v0 += src[i];
     const double t = block_sum((v0 + v1) + (v2 + v3), sh);
-    if (threadIdx.x == 0) red[first + blockIdx.x] = t;
+    if (threadIdx.x == 0) red[blockIdx.x] = t;
 }
-hipError_t launch_reduce1(const FusedArgs& a, int first, int count, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce1, dim3(count), dim3(256), 0, s, a.partial, a.n_pw / WAVES_PER_BLOCK, first, a.red, a.st);
-    return hipGetLastError();
-}
-__global__ __launch_bounds__(1024) void k_cost1(const double* cost_f, const double* mc_f, int n, double* out, const DevState* st,
-                                                const int32_t* flags) {
-    if (st->done) return;
-    __shared__ double sh[16];
-    const double* src = blockIdx.x == 0 ? cost_f : mc_f;
-    double v0 = 0.0, v1 = 0.0;
-    int i = threadIdx.x;
-    for (; i + 1024 < n; i += 2048) { v0 += src[i]; v1 += src[i + 1024]; }
-    if (i < n) v0 += src[i];
-    const double t = block_sum(v0 + v1, sh);
-    // a failed elimination / camera solve on this rank poisons the cost: in a sharded solve the all-reduce carries the
-    // NaN to every rank and all of them reject the step together (this rank would have rejected it anyway)
-    if (threadIdx.x == 0) out[blockIdx.x] = (blockIdx.x == 0 && (flags[0] | flags[1]) && t == t) ? __builtin_huge_val() : t;
-}
-hipError_t launch_cost1(const FusedArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_cost1, dim3(2), dim3(1024), 0, s, a.cost_f, a.mc_f, a.n_obs, a.red + 2 * (a.K + 1) * (a.K + 1), a.st, a.st_flags);
+hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce1, dim3(fused_red_size(a.K)), dim3(256), 0, s, a.partial, a.n_pw / WAVES_PER_BLOCK, a.red, a.st);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_head: one wavefront.  phase bit 0 = decide (accept / reject / stop), bit 1 = solve, bit 2 = do not publish.
-// red = [A_dir (K1*K1) | Y^T Y (K1*K1) | cost | mc_pose]
+// k_head: one wavefront.  Decision (optimizer_decide, ccal_fused.hpp) on the all-reduced sums, then - when the sums at
+// hand are the system to solve - the K x K camera solve and the candidate intrinsics.
+// red = [A_dir (K1*K1) | Y^T Y (K1*K1) | mc_pose | failed pose blocks]
 // The optimizer state is staged in LDS once (the global copy is touched twice per launch).
 // ---------------------------------------------------------------------------------------------
 // S (LDS, row stride 11) x = rhs (LDS) by Cholesky, entirely in registers of every lane; lane 0 writes x back.
@@ -1148,96 +1072,37 @@ __device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
     return ok;
 }
 
-// Runs on the first wavefront of the calling workgroup (all threads must call it: it contains workgroup
-// barriers).  stage_red: copy the reduced sums from global memory (standalone k_head); otherwise the caller
-// has already put A_dir | Y^T Y | cost | mc into hs.red (fused tail of k_schur1).
-__device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
+__global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
+    __shared__ HeadShared hs;
     DevState& S0 = hs.S0;
     double* red = hs.red; double* S = hs.S; double* x = hs.x; int& bad = hs.bad;
     const int K = a.K, K1 = K + 1;
-    const int lane = threadIdx.x < 64 ? (int)threadIdx.x : (1 << 28);      // other waves only keep the barriers company
-    // everything the solve phase needs from global memory is requested up front, next to the state: one memory
-    // latency instead of a chain of three (state -> column info -> intrinsics)
+    const int lane = threadIdx.x;
+    // everything the solve needs from global memory is requested up front, next to the state: one memory latency
+    // instead of a chain of three (state -> column info -> intrinsics)
     ColInfo ci = {};
     double intr_a = 0.0, intr_b = 0.0;
-    if (a.phase & 2) {
-        if (lane < K) ci = a.cols[lane];
-        if (lane < CCAL_PMAX) { intr_a = a.intr[0][lane]; intr_b = a.intr[1][lane]; }
-    }
-    {   // stage state (+ reduced sums)
+    if (lane < K) ci = a.cols[lane];
+    if (lane < CCAL_PMAX) { intr_a = a.intr[0][lane]; intr_b = a.intr[1][lane]; }
+    {   // stage state + reduced sums
         const double* src = reinterpret_cast<const double*>(a.st);
         double* dst = reinterpret_cast<double*>(&S0);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
-        if (stage_red) for (int e = lane; e < 2 * K1 * K1 + 2; e += 64) red[e] = a.red[e];
+        for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red[e];
         if (lane < K) hs.fx[lane] = ci.fixed;
     }
     __syncthreads();
     DevState* st = &S0;
-    if (st->done) { if (lane == 0) publish_status(a, st); return; }
+    if (st->done) { if (lane == 0) publish_host_status(a.hs, st, a.seq); return; }     // the host still waits for this group's number
     const double* Ad = red;
     const double* Yt = red + K1 * K1;
     const bool lm = st->method == CCAL_METHOD_LM;
-    if (a.phase & 1) {
-        if (lane == 0) {
-            const double cost_e = lm ? red[2 * K1 * K1] : Ad[K * K1 + K];
-            int done = 0;
-            if (st->first) {
-                st->cur_cost = cost_e; st->initial_cost = cost_e; st->first = 0;
-                if (!(cost_e == cost_e)) done = CCAL_ERR_NONFINITE + 1;
-                else if (!(fabs(cost_e) < 1.7e308)) done = (lm ? CCAL_ERR_NONFINITE : CCAL_ERR_NOT_PD) + 1;   // GN: +inf = a pose block failed (on some rank)
-                st->accepted_now = 1;
-            } else if (!lm) {
-                // Gauss-Newton: the candidate is the new point (tiny-solver applies dx unconditionally)
-                st->cur ^= 1;
-                const double last = st->cur_cost, cur = cost_e;
-                st->last_cost = last; st->cur_cost = cur; st->iter += 1;
-                st->accepted_now = 1;
-                if (cur < st->min_error) done = CCAL_OK + 1;
-                else if (!(cur == cur)) done = CCAL_ERR_NONFINITE + 1;
-                else if (!(fabs(cur) < 1.7e308)) done = CCAL_ERR_NOT_PD + 1;       // +inf: a pose block failed (on some rank)
-                else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
-                else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
-                else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
-            } else {
-                const double mc = st->mc_cam + red[2 * K1 * K1 + 1];
-                const double rho = (st->cur_cost - cost_e) / mc;
-                st->iter += 1;
-                const bool lin_fail = a.flags[0] || a.flags[1];
-                if (!lin_fail && fabs(cost_e) < 1.7e308 && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * st->cur_cost)) {
-                    // predicted decrease below the thresholds: converged (see ccal_solver.hip)
-                    if (cost_e < st->cur_cost) { st->cur ^= 1; st->last_cost = st->cur_cost; st->cur_cost = cost_e; st->lm_accepted += 1; }
-                    st->accepted_now = 0;
-                    done = CCAL_OK + 1;
-                } else if (!lin_fail && fabs(cost_e) < 1.7e308 && mc > 0.0 && rho > 0.0) {
-                    st->cur ^= 1;
-                    const double last = st->cur_cost, cur = cost_e;
-                    st->last_cost = last; st->cur_cost = cur; st->lm_accepted += 1;
-                    const double t = 2.0 * rho - 1.0;
-                    st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                    st->dec = 2.0;
-                    st->accepted_now = 1;
-                    if (cur < st->min_error) done = CCAL_OK + 1;
-                    else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
-                    else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
-                } else {
-                    st->lm_rejected += 1;
-                    st->radius /= st->dec; st->dec *= 2.0;
-                    st->accepted_now = 0;
-                    if (lin_fail) { a.flags[0] = 0; a.flags[1] = 0; }
-                    if (st->radius < 1e-32) done = CCAL_ERR_NO_CONVERGENCE + 1;
-                }
-                if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
-                st->lambda = 1.0 / st->radius;
-            }
-            st->done = done;
-            if (done && !st->done_seq) st->done_seq = a.seq;
-        }
-        __syncthreads();
-    }
-    if ((a.phase & 2) && !st->done) {
+    if (lane == 0) hs.solve = optimizer_decide(st, Ad[K * K1 + K], red[2 * K1 * K1], red[2 * K1 * K1 + 1] > 0.0, a.seq) ? 1 : 0;
+    __syncthreads();
+    if (hs.solve) {
         const double lambda = st->lambda;
         const int cur = st->cur;
-        if (lane == 0) bad = (!lm && a.flags[0]) ? 1 : 0;     // GN: a frame's pose block failed at this point -> None
+        if (lane == 0) bad = 0;
         for (int e = lane; e < K * K; e += 64) {
             const int i = e / K, j = e - i * K;
             double v = Ad[i * K1 + j] - Yt[i * K1 + j];
@@ -1266,7 +1131,7 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
         if (bad) {
             if (lane == 0) {
                 if (!lm) { st->done = CCAL_ERR_NOT_PD + 1; if (!st->done_seq) st->done_seq = a.seq; }
-                else a.flags[1] = 1;                 // LM: the next decision rejects and shrinks the radius
+                else st->cam_failed = 1;             // LM: the next decision rejects and shrinks the radius
                 st->mc_cam = 0.0; st->lambda_solve = lambda;
             }
             if (lane < K) a.dc[lane] = 0.0;
@@ -1302,18 +1167,12 @@ __device__ void head_body(const HeadArgs& a, HeadShared& hs, bool stage_red) {
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
     }
     __syncthreads();
-    // phase bit 2: an intermediate step of a group (LM's decision before its elimination) - the host waits for the
-    // group's last sequence number only, so nothing is published unless the solve just finished
-    if (lane == 0 && (!(a.phase & 4) || st->done)) publish_status(a, st);
-}
-__global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
-    __shared__ HeadShared hs;
-    head_body(a, hs, true);
+    if (lane == 0) publish_host_status(a.hs, st, a.seq);
 }
 // ccal_build_normal_dev on a single camera: evaluate set 0 as a first evaluation (no pose update) with this damping
 __global__ void k_state_eval(DevState* st, double lambda) {
-    st->done = 0; st->cur = 0; st->first = 1; st->iter = 0;
-    st->lambda = lambda; st->lambda_solve = 0.0;
+    st->done = 0; st->cur = 0; st->first = 1; st->redo = 0; st->iter = 0;
+    st->lambda = lambda; st->lambda_spec = lambda; st->lambda_solve = 0.0;
     st->method = lambda > 0.0 ? CCAL_METHOD_LM : CCAL_METHOD_GN;
 }
 hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s) {

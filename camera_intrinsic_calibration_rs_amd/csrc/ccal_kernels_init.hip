@@ -29,7 +29,7 @@ __device__ __forceinline__ bool unproject_normalized(const double* th, double u,
         return true;
     } else if constexpr (MODEL == kKB4) {
         const double r = sqrt(r2);
-        if (r < 1e-8) { xn = mx; yn = my; return true; }
+        if (r < kUnprojectSmallRadius) { xn = mx; yn = my; return true; }
         double t = r;
         for (int it = 0; it < 10; ++it) {
             const double t2 = t * t;
@@ -42,7 +42,7 @@ __device__ __forceinline__ bool unproject_normalized(const double* th, double u,
         xn = mx * s; yn = my * s;
         return true;
     } else {
-        const double k1 = th[4], k2 = th[5], p1 = th[6], p2 = th[7], k3 = th[8];
+        const double k1 = th[OCV5_K1], k2 = th[OCV5_K2], p1 = th[OCV5_P1], p2 = th[OCV5_P2], k3 = th[OCV5_K3];
         double x = mx, y = my;
         for (int it = 0; it < 25; ++it) {
             const double q = x * x + y * y;

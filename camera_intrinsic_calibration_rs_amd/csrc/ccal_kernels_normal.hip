@@ -20,9 +20,10 @@ struct GramArgs {
     const int64_t* goff;
     double* G;
     double* cost_o;
-    // device-resident loop: st != NULL selects between this set (index 0) and the second one by st->cur ^ sel
-    // (sel 1 = the candidate), and a finished solve makes the launch empty
-    const DevState* st; int32_t sel;
+    // device-resident loop: st != NULL evaluates the set the state prescribes (eval_set: the starting point in the first
+    // group, the candidate afterwards; index 0 = this set, 1 = the second one); finished solves and re-elimination
+    // groups make the launch empty
+    const DevState* st;
     const double* intr2; const double* poses2; const double* extr2; double* G2; double* cost_o2;
 };
 
@@ -36,8 +37,8 @@ struct GramArgs {
 template <int MODEL, bool OF, bool OTHER>
 __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const KArgs& a = ga.k;
-    if (ga.st && ga.st->done) return;
-    const bool second = ga.st && ((ga.st->cur ^ ga.sel) & 1);
+    if (ga.st && (ga.st->done || ga.st->redo)) return;
+    const bool second = ga.st && eval_set(ga.st) == 1;
     const double* p_intr = second ? ga.intr2 : a.intr;
     const double* p_poses = second ? ga.poses2 : a.poses;
     const double* p_extr = second ? ga.extr2 : a.extr;
@@ -70,10 +71,8 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const int64_t start = a.obs_off[o];
     const int n = (int)(a.obs_off[o + 1] - start);
     const double* th_g = p_intr + a.cam * CCAL_PMAX;
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
-    if constexpr (OF) th[1] = th[0];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
     {
         double pose[6], ex[6];
 #pragma unroll
@@ -245,12 +244,12 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
     a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = cand ? p->d_intr_c : p->d_intr; a.poses = cand ? p->d_poses_c : p->d_poses; a.extr = cand ? p->d_extr_c : p->d_extr;
-    a.huber_delta = p->huber_delta;
+    a.huber_delta = p->huber_delta; a.kb4_eps = p->ctx->conv.kb4_small_radius;
     ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf];
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
 }
-// device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1]); sel 1 = evaluate the candidate
-hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, int sel, hipStream_t s) {
+// device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1])
+hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s) {
     const NormalWs* w = p->nws;
     GramArgs ga = {};
     KArgs& a = ga.k;
@@ -259,9 +258,9 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, i
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
     ga.intr2 = p->d_intr_c; ga.poses2 = p->d_poses_c; ga.extr2 = p->d_extr_c;
-    a.huber_delta = p->huber_delta;
+    a.huber_delta = p->huber_delta; a.kb4_eps = p->ctx->conv.kb4_small_radius;
     ga.goff = w->d_goff; ga.G = w->G[w->cur]; ga.cost_o = w->cost_o[w->cur]; ga.G2 = w->G[w->cur ^ 1]; ga.cost_o2 = w->cost_o[w->cur ^ 1];
-    ga.st = st; ga.sel = sel;
+    ga.st = st;
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
 }
 
@@ -275,7 +274,7 @@ struct SchurArgs {
     const int32_t* slot_off; const int32_t* caminfo; int32_t n_cams;
     int32_t n_slots, K, RB, PF, n_pw;
     double lambda, min_diag, max_diag;
-    double* partial; double* pf; int32_t* flags;
+    double* partial; double* pf; const double* mc_slot;
     const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
 };
 
@@ -317,7 +316,7 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                         off = ii * K1 + jj;
                         if (i == j && ii < K) xoff = K1 * K1 + ii;                    // hdiag
                         else if (jj == K && ii < K) xoff = K1 * K1 + K + ii;           // g_c
-                        else if (ii == K && jj == K) xoff = RB - 1;                    // cost = sum rho' s
+                        else if (ii == K && jj == K) xoff = K1 * K1 + 2 * K;           // cost = sum rho' s
                     }                                                                  // camera row x pose column: its transpose is taken
                 } else if (kj == 0) {
                     off = RB + ii * K1 + jj;                                           // Baug
@@ -333,14 +332,15 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
     __syncthreads();
     if (gw >= a.n_pw || (a.st && a.st->done)) return;
-    const double* p_G = (a.st && a.st->cur) ? a.G2 : a.G;
-    const double lambda = a.st ? a.st->lambda : a.lambda;
+    const double* p_G = (a.st && schur_set(a.st) == 1) ? a.G2 : a.G;
+    const double lambda = a.st ? schur_lambda(a.st) : a.lambda;
 
     int o0n = gw < a.n_slots ? a.slot_off[gw] : 0, o1n = gw < a.n_slots ? a.slot_off[gw + 1] : 0;
     for (int s = gw; s < a.n_slots; s += a.n_pw) {
         const int o0 = o0n, o1 = o1n;
         if (s + a.n_pw < a.n_slots) { o0n = a.slot_off[s + a.n_pw]; o1n = a.slot_off[s + a.n_pw + 1]; }   // next slot's range: off the critical path
         double* pf = a.pf + (int64_t)s * a.PF;
+        if (lane == 0) acc[RB - 2] += a.mc_slot[s];       // model decrease of this slot's pose block for the step under decision
         if (o0 == o1) {                                   // slot without observations
             for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
             continue;
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
             }
         }
         if (!ok) {
-            if (lane == 0) a.flags[0] = 1;
+            if (lane == 0) acc[RB - 1] += 1.0;            // failed pose blocks (all-reduced with the sums: every rank sees them)
             for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
             wave_sync_lds();
             continue;
@@ -445,7 +445,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     a.caminfo = w->d_caminfo; a.n_cams = p->n_cams;
     a.n_slots = p->n_slots; a.K = w->K; a.RB = w->RB; a.PF = w->PF; a.n_pw = w->n_pw;
     a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
-    a.partial = w->partial; a.pf = w->pf; a.flags = w->flags;
+    a.partial = w->partial; a.pf = w->pf; a.mc_slot = w->mc_slot;
     const int K1 = w->K + 1;
     const int WS = ((w->RB + 12 * K1 + 36) + 1) & ~1;
     int tab_entries = 0;
@@ -485,148 +485,36 @@ hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* s
     return hipGetLastError();
 }
 
-// k_gdecide: the decisions of the general loop on the device (the same rules as the host loop it replaced, which
-// are the oracle's: tiny-solver's Gauss-Newton tests / the Ceres-style trust region) + status for the polling host.
-//   scal: 0 cost of the evaluated set, 1 model decrease of the pose blocks, 2 of the camera block
-__device__ void gdecide_body(DevState* st, HostStatus* hs, double cand, double mc_pose, double mc_cam, int32_t* flags, int init, int seq) {
-    if (!st->done) {
-        const bool lin_fail = flags[0] || flags[1];
-        int done = 0;
-        if (init) {
-            st->cur_cost = cand; st->initial_cost = cand;
-            if (cand != cand) done = CCAL_ERR_NONFINITE + 1;
-            else if (!(fabs(cand) <= 1.7976931348623157e308)) done = CCAL_ERR_NOT_PD + 1;
-        } else if (st->method != CCAL_METHOD_LM) {
-            st->iter += 1;
-            if (lin_fail) done = CCAL_ERR_NOT_PD + 1;            // solve failed -> None; the step is not applied
-            else {
-                st->cur ^= 1;                                    // Gauss-Newton: x <- candidate, unconditionally
-                const double last = st->cur_cost;
-                st->last_cost = last; st->cur_cost = cand;
-                if (cand < st->min_error) done = CCAL_OK + 1;
-                else if (cand != cand) done = CCAL_ERR_NONFINITE + 1;
-                else if (!(fabs(cand) <= 1.7976931348623157e308)) done = CCAL_ERR_NOT_PD + 1;     // +inf from another rank's failed solve
-                else if (fabs(last - cand) < st->min_abs) done = CCAL_OK + 1;
-                else if (fabs(last - cand) / last < st->min_rel) done = CCAL_OK + 1;
-                else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
-            }
-        } else {
-            st->iter += 1;
-            const double cur = st->cur_cost, mc = mc_pose + mc_cam;
-            const double rho = (cur - cand) / mc;
-            const bool fin = fabs(cand) <= 1.7976931348623157e308;
-            if (!lin_fail && fin && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * cur)) {
-                // predicted decrease below the thresholds: converged
-                if (cand < cur) { st->cur ^= 1; st->cur_cost = cand; st->lm_accepted += 1; }
-                done = CCAL_OK + 1;
-            } else if (!lin_fail && fin && mc > 0.0 && rho > 0.0) {
-                st->cur ^= 1;
-                st->last_cost = cur; st->cur_cost = cand; st->lm_accepted += 1;
-                const double t = 2.0 * rho - 1.0;
-                st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                st->dec = 2.0;
-                if (cand < st->min_error) done = CCAL_OK + 1;
-                else if (fabs(cur - cand) < st->min_abs) done = CCAL_OK + 1;
-                else if (fabs(cur - cand) / cur < st->min_rel) done = CCAL_OK + 1;
-            } else {
-                st->lm_rejected += 1;
-                st->radius /= st->dec; st->dec *= 2.0;
-                if (lin_fail) { flags[0] = 0; flags[1] = 0; }
-                if (st->radius < 1e-32) done = CCAL_ERR_NO_CONVERGENCE + 1;
-            }
-            st->lambda = 1.0 / st->radius;
-            if (!done && st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
-        }
-        st->done = done;
-        if (done && !st->done_seq) st->done_seq = seq;
-    }
-    hs->done = st->done; hs->done_seq = st->done_seq; hs->iter = st->iter; hs->cur = st->cur;
-    hs->lm_accepted = st->lm_accepted; hs->lm_rejected = st->lm_rejected;
-    hs->cur_cost = st->cur_cost; hs->initial_cost = st->initial_cost; hs->radius = st->radius;
-    __threadfence_system();
-    hs->seq = seq;
-}
-__global__ void k_gdecide(DevState* st, HostStatus* hs, const double* scal, int32_t* flags, int init, int seq) {
-    gdecide_body(st, hs, scal[0], scal[1], scal[2], flags, init, seq);
-}
-
-// scal[0] = sum_o cost_o, scal[1] = sum_s mc_slot (first / second half of ONE 512-thread workgroup); with `decide` the
-// same workgroup goes on to take the decision (no all-reduce between the two: one launch less per iteration)
-__global__ __launch_bounds__(512) void k_sum2(const double* a, const double* a2, int na, const double* b, int nb, double* out,
-                                              int32_t* flags, DevState* st, int sel, HostStatus* hs, int decide, int init, int seq) {
-    __shared__ double sh[8];
-    if (st && st->done) {
-        if (decide && threadIdx.x == 0) gdecide_body(st, hs, 0.0, 0.0, 0.0, flags, init, seq);      // publishes only
-        return;
-    }
-    if (st && ((st->cur ^ sel) & 1)) a = a2;         // device-resident loop: a = set 0, a2 = set 1, sel 1 = the candidate
-    const int half = threadIdx.x >> 8, t = threadIdx.x & 255;
-    const double* src = half == 0 ? a : b;
-    const int n = half == 0 ? na : nb;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0, v5 = 0.0, v6 = 0.0, v7 = 0.0;
-    int i = t;
-    for (; i + 7 * 256 < n; i += 8 * 256) {          // eight loads in flight per thread; fixed order
-        v0 += src[i];           v1 += src[i + 256];     v2 += src[i + 2 * 256]; v3 += src[i + 3 * 256];
-        v4 += src[i + 4 * 256]; v5 += src[i + 5 * 256]; v6 += src[i + 6 * 256]; v7 += src[i + 7 * 256];
-    }
-    for (; i < n; i += 256) v0 += src[i];
-    double v = ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        // a failed linear solve on this rank poisons the cost with +inf: the all-reduce of a sharded solve carries it to
-        // every rank, so all of them reject (LM) or stop with NOT_PD (GN) at the same iteration
-        const double csum = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-        const double cost = ((flags[0] | flags[1]) && csum == csum) ? __builtin_huge_val() : csum;    // +inf: failed solve; NaN stays NaN
-        const double mcp = (sh[4] + sh[5]) + (sh[6] + sh[7]);
-        out[0] = cost; out[1] = mcp;
-        if (decide) gdecide_body(st, hs, cost, mcp, out[2], flags, init, seq);
-    }
-}
-hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s) {
-    const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(512), 0, s, w->cost_o[gbuf], w->cost_o[gbuf], p->n_obs, w->mc_slot, p->n_slots, w->scal, w->flags,
-                       (DevState*)nullptr, 0, (HostStatus*)nullptr, 0, 0, 0);
-    return hipGetLastError();
-}
-// device-resident loop: which != 0 sums the candidate set's costs (set index st->cur ^ 1), which == 0 the current set's;
-// hs != NULL: decide and publish in the same launch (no all-reduce hook between the sums and the decision)
-hipError_t launch_sum_cost_dev(const ccal_problem* p, DevState* st, int which, HostStatus* hs, bool init, int seq, hipStream_t s) {
-    const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_sum2, dim3(1), dim3(512), 0, s, w->cost_o[w->cur], w->cost_o[w->cur ^ 1], p->n_obs, w->mc_slot, p->n_slots, w->scal,
-                       w->flags, st, which ? 1 : 0, hs, hs ? 1 : 0, init ? 1 : 0, seq);
-    return hipGetLastError();
-}
-hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, hipStream_t s) {
-    const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_gdecide, dim3(1), dim3(1), 0, s, st, hs, w->scal, w->flags, init ? 1 : 0, seq);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------------------------
-// k_solve: one wavefront.  S = A[0:K,0:K] + lambda clamp(hdiag), rhs = -b, fixed columns -> identity,
-// in-LDS Cholesky, dc, candidate intrinsics/extrinsics = clamp(x + dc), model decrease of the camera block.
+// k_solve: one wavefront.  Device-resident loop (st != NULL): first the optimizer's decision on the all-reduced sums
+// (optimizer_decide, ccal_fused.hpp - the same function as the single-camera loop), then, when the sums at hand are
+// the system to solve:  S = A[0:K,0:K] + lambda clamp(hdiag), rhs = -b, fixed columns -> identity, in-LDS Cholesky,
+// dc, candidate intrinsics/extrinsics = clamp(x + dc), model decrease of the camera block; status word for the host.
 // ---------------------------------------------------------------------------------------------
 struct SolveArgs {
-    const double* red; const ColInfo* cols; int32_t K;
+    const double* red; const ColInfo* cols; int32_t K, RB;
     double lambda, min_diag, max_diag;
     const double* intr; const double* extr; double* intr_c; double* extr_c; int32_t n_intr, n_extr;
     double* dc; double* scal; int32_t* flags;
-    const DevState* st;            // device-resident loop: current set = st->cur (0: intr/extr, 1: intr_c/extr_c), lambda from the state
+    DevState* st;                  // device-resident loop: current set = st->cur (0: intr/extr, 1: intr_c/extr_c), lambda from the state
+    HostStatus* hs; int32_t seq;
 };
 __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     SolveArgs a = a0;
+    __shared__ int go;
+    const int lane = threadIdx.x;
     if (a.st) {
-        if (a.st->done) return;
+        if (a.st->done) { if (lane == 0) publish_host_status(a.hs, a.st, a.seq); return; }
+        if (lane == 0) go = optimizer_decide(a.st, a.red[a.RB - 3], a.red[a.RB - 2], a.red[a.RB - 1] > 0.0, a.seq) ? 1 : 0;
+        __syncthreads();
+        if (!go) { if (lane == 0) publish_host_status(a.hs, a.st, a.seq); return; }
         a.lambda = a.st->lambda;
         if (a.st->cur) { a.intr = a0.intr_c; a.extr = a0.extr_c; a.intr_c = const_cast<double*>(a0.intr); a.extr_c = const_cast<double*>(a0.extr); }
     }
     __shared__ double S[CCAL_KMAX * (CCAL_KMAX + 1)];
     __shared__ double x[CCAL_KMAX];
     __shared__ int bad;
-    const int K = a.K, K1 = K + 1, lane = threadIdx.x;
+    const int K = a.K, K1 = K + 1;
     const double* hdiag = a.red + K1 * K1;
     const double* gc = hdiag + K;
     __shared__ int fxs[CCAL_KMAX];
@@ -671,7 +559,16 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     }
     __syncthreads();
     if (bad) {
-        if (lane == 0) { a.flags[1] = 1; a.scal[2] = 0.0; }
+        if (lane == 0) {
+            a.flags[1] = 1; a.scal[2] = 0.0;
+            if (a.st) {
+                // Gauss-Newton has no step (tiny-solver: None); LM rejects the (unchanged) candidate at the next decision
+                if (a.st->method != CCAL_METHOD_LM) { a.st->done = CCAL_ERR_NOT_PD + 1; if (!a.st->done_seq) a.st->done_seq = a.seq; }
+                else a.st->cam_failed = 1;
+                a.st->mc_cam = 0.0; a.st->lambda_solve = a.lambda;
+                publish_host_status(a.hs, a.st, a.seq);
+            }
+        }
         if (lane < K) a.dc[lane] = 0.0;
         return;
     }
@@ -706,13 +603,17 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
-    if (lane == 0) a.scal[2] = mc;
+    if (lane == 0) {
+        a.scal[2] = mc;
+        if (a.st) { a.st->mc_cam = mc; a.st->lambda_solve = a.lambda; publish_host_status(a.hs, a.st, a.seq); }
+    }
 }
-hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st) {
+hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st,
+                        HostStatus* hs, int seq) {
     const NormalWs* w = p->nws;
     SolveArgs a = {};
-    a.st = st;
-    a.red = w->red; a.cols = w->cols; a.K = w->K; a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
+    a.st = st; a.hs = hs; a.seq = seq;
+    a.red = w->red; a.cols = w->cols; a.K = w->K; a.RB = w->RB; a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
     a.intr = p->d_intr; a.extr = p->d_extr; a.intr_c = p->d_intr_c; a.extr_c = p->d_extr_c;
     a.n_intr = p->n_cams * CCAL_PMAX; a.n_extr = p->n_cams * 6;
     a.dc = w->dc; a.scal = w->scal; a.flags = w->flags;
@@ -736,7 +637,7 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     extern __shared__ double smem[];                       // [16][PF + 6]
     BacksubArgs a = a0;
     if (a.st) {
-        if (a.st->done) return;
+        if (a.st->done || a.st->redo) return;      // finished, or this group's decision asked for a re-elimination (nothing was solved)
         a.lambda = a.st->lambda;
         if (a.st->cur) { a.poses = a0.poses_c; a.poses_c = const_cast<double*>(a0.poses); }
     }

@@ -22,9 +22,9 @@ namespace ccal {
 // corners whose weighted rows are staged in LDS at a time by the Gram kernels (32 or 64)
 constexpr int GRAM_TILE_CORNERS = CCAL_GRAM_TILE;
 
-// layout of the reduced buffer red[RB]:  A[(K+1)*(K+1)] | hdiag[K] | gc[K] | cost
+// layout of the reduced buffer red[RB]:  A[(K+1)*(K+1)] | hdiag[K] | gc[K] | cost | mc_pose | failed pose blocks
 //   A = [[S, b],[b^T, *]] undamped in the camera block (pose damping already inside the Schur terms)
-inline int red_size(int K) { return (K + 1) * (K + 1) + 2 * K + 1; }
+inline int red_size(int K) { return (K + 1) * (K + 1) + 2 * K + 3; }
 // per-slot record pf[PF]: L (21, row-major lower, diagonal stored inverted) | Y[6][K+1] | g_p[6] | dC[6]
 inline int pf_size(int K) { return (21 + 6 * (K + 1) + 12 + 1) & ~1; }
 
@@ -50,8 +50,8 @@ struct NormalWs {
     double* pf = nullptr;                      // [n_slots][PF]
     double* dc = nullptr;                      // [K]
     double* mc_slot = nullptr;                 // [n_slots]
-    double* scal = nullptr;                    // [8]: 0 cost(cand) 1 mc_p 2 mc_c 4 previous cost (k_gn_decide)
-    int32_t* flags = nullptr;                  // [4]: 0 slot Cholesky failed, 1 camera Cholesky failed, 2 ticket, 3 GN loop stopped
+    double* scal = nullptr;                    // [8]: 2 = model decrease of the camera block (host-driven form)
+    int32_t* flags = nullptr;                  // [4]: 1 = camera Cholesky failed (host-driven ccal_build_normal form only)
     ColInfo* cols = nullptr;                   // [K]
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
@@ -92,14 +92,12 @@ int normal_upload_cols(ccal_problem* p);        // bounds / fixed flags -> devic
 struct DevState;
 struct HostStatus;
 hipError_t launch_gram(const ccal_problem* p, int cam, bool use_candidate_params, int gbuf, hipStream_t s);
-hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, int sel, hipStream_t s);
+hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s);
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
                         const DevState* st = nullptr);
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st = nullptr);
-hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
+hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st = nullptr,
+                        HostStatus* hs = nullptr, int seq = 0);
 hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
-hipError_t launch_sum_cost(const ccal_problem* p, int gbuf, hipStream_t s);   // scal[0] = sum cost_o[gbuf], scal[1] = sum mc_slot
-hipError_t launch_sum_cost_dev(const ccal_problem* p, DevState* st, int candidate, HostStatus* hs_or_null, bool init, int seq, hipStream_t s);
-hipError_t launch_gdecide(const ccal_problem* p, DevState* st, HostStatus* hs, bool init, int seq, hipStream_t s);
 
 }  // namespace ccal

@@ -4,7 +4,7 @@
 // (src/util.rs:443-463, 668-670; defaults in ccal_set_defaults) -- per iteration: Jacobian at x,
 // solve the normal equations, x <- clamp(x + dx), error(x), stop on min_error / |d error| thresholds --
 // and adds a Ceres-style Levenberg-Marquardt mode on the same kernels.  Both loops (single camera: solve_fused,
-// everything else: the general loop in ccal_solve) are device-resident: the decisions run in a kernel, the host
+// everything else: solve_general) are device-resident: the decisions run in a kernel, the host
 // enqueues groups of launches one ahead and polls a status word in pinned memory.
 #include <algorithm>
 #include <chrono>
@@ -41,8 +41,10 @@ namespace ccal {
 void normal_ws_destroy(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (!w) return;
-    // early-exit groups of the last solve may still be queued: they publish into the pinned status words freed below
-    if (w->tail_pending || (w->fws && w->fws->tail_pending)) (void)hipStreamSynchronize(p->ctx->stream);
+    // early-exit groups of the last solve (or of a solve that ended in an error) may still be queued: they publish into
+    // the pinned status words freed below
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
                      w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc };
     for (void* q : ptrs) if (q) (void)hipFree(q);
@@ -68,11 +70,12 @@ static int fused_ws_ensure(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (w->fws) return CCAL_OK;
     ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     FusedWs* f = new FusedWs();
     w->fws = f;
     const int K1 = p->K + 1;
     f->PRAW = (21 + 6 * K1 + K1 * K1 + 1) & ~1;
-    f->RB1 = 2 * K1 * K1 + 2;
+    f->RB1 = fused_red_size(p->K);
     const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
     int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 16384);   // 4 workgroups of 4 waves per CU
     f->n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
@@ -208,16 +211,23 @@ static int enqueue_gram(ccal_problem* p, bool cand, int gbuf) {
     for (int c = 0; c < p->n_cams; ++c) HIP_TRY(ctx, launch_gram(p, c, cand, gbuf, ctx->stream));
     return CCAL_OK;
 }
+
+// The step's one collective: in-place sum of `n` doubles over the ranks, ordered on the context stream.  Native RCCL
+// when a communicator is set (ccal_rccl.hip), else the callback, else nothing (single GPU).
+static int allreduce(ccal_problem* p, double* buf, size_t n) {
+    ccal_ctx* ctx = p->ctx;
+    if (p->rccl_comm) return rccl_allreduce_sum(ctx, p->rccl_comm, buf, n, ctx->stream);
+    if (p->allreduce && p->allreduce(p->allreduce_user, buf, n, (void*)ctx->stream) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
+    return CCAL_OK;
+}
+
 // schur + reduce (+ all-reduce) of G[gbuf] -> red
 static int enqueue_reduce_system(ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag) {
     ccal_ctx* ctx = p->ctx;
     NormalWs* w = p->nws;
     HIP_TRY(ctx, launch_schur(p, gbuf, lambda, min_diag, max_diag, ctx->stream));
     HIP_TRY(ctx, launch_reduce(p, ctx->stream));
-    if (p->allreduce) {
-        if (p->allreduce(p->allreduce_user, w->red, (size_t)w->RB, (void*)ctx->stream) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
-    }
-    return CCAL_OK;
+    return allreduce(p, w->red, (size_t)w->RB);
 }
 
 // Argument block of the single-camera kernels: set 0 = (p->d_intr, p->d_poses), set 1 = the *_c buffers.
@@ -229,11 +239,10 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
     fa.n_obs = p->n_obs; fa.K = p->K; fa.PF = w->PF; fa.PRAW = f->PRAW; fa.n_pw = f->n_pw;
     fa.fcbuf = f->fcbuf; fa.mc_f = f->mc_f; fa.cost_f = f->cost_f;
-    fa.huber_delta = p->huber_delta; fa.min_diag = min_diag; fa.max_diag = max_diag;
+    fa.huber_delta = p->huber_delta; fa.min_diag = min_diag; fa.max_diag = max_diag; fa.kb4_eps = p->ctx->conv.kb4_small_radius;
     fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
-    fa.dc = w->dc; fa.st = f->d_state; fa.st_flags = w->flags; fa.partial = f->partial; fa.red = f->red;
-    fa.ticket = w->flags + 2;
+    fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
     return fa;
 }
 // Per-frame elimination with four frames per wavefront (k_schur1m) when one pass covers the problem; sets fa.n_pw.
@@ -253,6 +262,17 @@ static bool fused_use_valu_gram(const ccal_problem* p) {
     if (const char* g = std::getenv("CCAL_GRAM")) v = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 136;
     return v;
 }
+// Gram + elimination + reduce of one group on the single-camera path (everything but the collective and the decision)
+static hipError_t enqueue_fused_system(const ccal_problem* p, const FusedArgs& fa, bool schur_m, hipStream_t st) {
+    hipError_t e = hipSuccess;
+    if (p->n_obs > 0) {            // a rank whose shard is empty still takes part in the collective, with zeros
+        e = fused_use_valu_gram(p) ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
+        if (e != hipSuccess) return e;
+        e = schur_m ? launch_schur1m(fa, st) : launch_schur1(fa, st);
+        if (e != hipSuccess) return e;
+    }
+    return launch_reduce1(fa, st);
+}
 
 // Host side of the device-resident loops: spin on the status word a decision kernel publishes to pinned memory.
 static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const DevState* d_state, int target) {
@@ -267,6 +287,7 @@ static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const Dev
                 HIP_TRY(ctx, hipMemcpy(&ds, d_state, sizeof ds, hipMemcpyDeviceToHost));
                 hst->done = ds.done; hst->done_seq = ds.done_seq; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
                 hst->lm_rejected = ds.lm_rejected; hst->cur_cost = ds.cur_cost; hst->initial_cost = ds.initial_cost;
+                hst->spec_hits = ds.spec_hits; hst->spec_misses = ds.spec_misses;
                 hst->seq = target;
                 break;
             }
@@ -276,13 +297,39 @@ static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const Dev
     return CCAL_OK;
 }
 
+static void init_state(DevState* s, const ccal_solver_opts* o) {
+    std::memset(s, 0, sizeof *s);
+    const bool lm = o->method == CCAL_METHOD_LM;
+    s->radius = o->lm_initial_radius; s->dec = 2.0;
+    s->lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
+    s->lambda_spec = lm ? 1.0 / lm_radius_cap(o->lm_initial_radius) : 0.0;
+    s->min_error = o->min_error; s->min_abs = o->min_abs_error_decrease; s->min_rel = o->min_rel_error_decrease;
+    s->cur = 0; s->first = 1; s->max_iter = o->max_iterations; s->method = o->method;
+}
+// Groups the host may enqueue at most: one per decision plus one re-elimination group per LM decision, plus the first.
+static int max_groups_for(const ccal_solver_opts* o) {
+    return (o->method == CCAL_METHOD_LM ? 2 : 1) * std::max(o->max_iterations, 0) + 2;
+}
+// How many groups are kept in flight ahead of the one the host waits for.  With native RCCL the collective is just
+// another stream operation, so sharded solves run ahead like single-GPU ones; a callback is host code - the loop waits
+// for every group before the next one (no collective is ever issued for a solve that has finished).
+static int groups_in_flight(const ccal_problem* p, const char* env_name) {
+    if (p->allreduce && !p->rccl_comm) {
+        static const int hook_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH_HOOK"); return e ? std::max(1, std::atoi(e)) : 1; }();
+        return hook_depth;
+    }
+    const char* e = std::getenv(env_name);
+    return e ? std::max(1, std::atoi(e)) : 2;
+}
+
 // ---------------------------------------------------------------------------------------------
-// Single-camera fused path: the host only enqueues (k_normal1, k_reduce1, k_head) groups, two
-// iterations ahead, and watches a status word in pinned memory; accept/reject, damping, convergence
-// tests and the camera solve run on the device (ccal_kernels_fused.hip).  Same decisions and the same
-// arithmetic as the general loop in ccal_solve below.
+// Single-camera path: the host only enqueues groups (gram, elimination, reduce, [all-reduce], head) and watches a
+// status word in pinned memory; accept/reject, damping, convergence tests and the camera solve run on the device
+// (ccal_kernels_fused.hip).  Same decision function and the same arithmetic as the general loop below.
+// host_io: parameters come from / go back to the caller's host arrays (ccal_solve); otherwise they are and stay on
+// the device (ccal_solve_dev).
 // ---------------------------------------------------------------------------------------------
-static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, ccal_report* rep) {
+static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io, double* intr_io, double* poses_io, ccal_report* rep) {
     ccal_ctx* ctx = p->ctx;
     NormalWs* w = p->nws;
     int rc = fused_ws_ensure(p);
@@ -290,17 +337,11 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     FusedWs* f = w->fws;
     hipStream_t st = ctx->stream;
     const bool lm = o->method == CCAL_METHOD_LM;
-    const int K = p->K, K1 = K + 1;
+    const int K = p->K;
     const auto t0 = std::chrono::steady_clock::now();
 
-    DevState hs0;
-    std::memset(&hs0, 0, sizeof hs0);
-    hs0.radius = o->lm_initial_radius; hs0.dec = 2.0;
-    hs0.lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
-    hs0.min_error = o->min_error; hs0.min_abs = o->min_abs_error_decrease; hs0.min_rel = o->min_rel_error_decrease;
-    hs0.cur = 0; hs0.first = 1; hs0.done = 0; hs0.iter = 0; hs0.max_iter = o->max_iterations; hs0.method = o->method;
     // one pinned staging block [intr | state | cols | poses] -> ONE async copy -> k_unpack1 (both parameter sets start
-    // from the caller's values; slots without observations never change)
+    // from the same values; slots without observations never change).  ccal_solve_dev stages only the ~1 KB head.
     static_assert(sizeof(ColInfo) % 8 == 0, "ColInfo is staged as doubles");
     if (f->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); f->tail_pending = false; }   // stale k_head must not publish into this solve
     const size_t np6 = (size_t)p->n_slots * 6;
@@ -309,98 +350,60 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
     DevState* h_state = reinterpret_cast<DevState*>(h_intr + CCAL_PMAX);
     ColInfo* h_cols = reinterpret_cast<ColInfo*>(h_state + 1);
     double* h_poses = f->h_stage + small_doubles;
-    std::memcpy(h_poses, poses_io, np6 * sizeof(double));
-    std::memcpy(h_intr, intr_io, CCAL_PMAX * sizeof(double));
-    *h_state = hs0;
+    if (host_io) {
+        std::memcpy(h_poses, poses_io, np6 * sizeof(double));
+        std::memcpy(h_intr, intr_io, CCAL_PMAX * sizeof(double));
+    }
+    init_state(h_state, o);
     build_cols(p, h_cols);
-    HIP_TRY(ctx, hipMemcpyAsync(f->d_stage, f->h_stage, (small_doubles + np6) * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(f->d_stage, f->h_stage, (small_doubles + (host_io ? np6 : 0)) * sizeof(double), hipMemcpyHostToDevice, st));
     {
-        UnpackArgs ua = { f->d_stage, (int64_t)small_doubles, (int64_t)np6, p->d_intr, p->d_intr_c, p->d_poses, p->d_poses_c,
-                          f->d_state, w->cols, w->flags };
+        UnpackArgs ua = { f->d_stage, (int64_t)small_doubles, (int64_t)np6, host_io ? 0 : 1, p->d_intr, p->d_intr_c, p->d_poses, p->d_poses_c,
+                          f->d_state, w->cols };
         HIP_TRY(ctx, launch_unpack1(ua, st));
     }
     HostStatus* hst = f->h_status;
     hst->seq = 0; hst->done = 0; hst->done_seq = 0;
 
     FusedArgs fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
-    // CCAL_FUSE_TAIL=1: the last Schur workgroup reduces and decides itself (two launches per GN iteration
-    // instead of four).  Off by default: measured 10 us per iteration SLOWER than the split launches on
-    // MI355X (10k frames 0.51 vs 0.46 ms, 1k frames 0.23 vs 0.20 ms for 3 GN iterations) - the ticket round
-    // trip, the L2-bypassing reduction and the serial decision on one CU cost more than two launches do.
-    const char* env_ft = std::getenv("CCAL_FUSE_TAIL");
-    const char* env_tw = std::getenv("CCAL_FUSED_TAIL_WAVES");
-    const bool fuse_tail = !p->allreduce && env_ft && env_ft[0] == '1';
-    if (fuse_tail) fa.n_pw = std::min(f->n_pw, std::max(4, (env_tw ? std::atoi(env_tw) : 2048) / 4 * 4));
-    const bool schur_m = !fuse_tail && fused_use_schur1m(p, fa);
+    const bool schur_m = fused_use_schur1m(p, fa);
     HeadArgs ha = {};
-    ha.st = f->d_state; ha.hs = hst; ha.red = f->red; ha.cols = w->cols; ha.flags = w->flags;
+    ha.st = f->d_state; ha.hs = hst; ha.red = f->red; ha.cols = w->cols;
     ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
     ha.min_diag = o->lm_min_diagonal; ha.max_diag = o->lm_max_diagonal;
-    const int model = p->cams[0].model;
-    const bool use_valu_gram = fused_use_valu_gram(p);
     int seq = 0;
-    auto enqueue = [&]() -> int {         // one evaluation + decision + solve; returns the seq that marks its end
-        if (use_valu_gram) HIP_TRYN(ctx, launch_gram1v(model, p->one_focal, fa, st));
-        else HIP_TRYN(ctx, launch_gram1(model, p->one_focal, fa, st));
-        if (!lm) {
-            if (fuse_tail) {
-                ha.phase = 3; ha.seq = ++seq;
-                HIP_TRYN(ctx, launch_schur1(fa, 0, &ha, st));
-            } else {
-                if (schur_m) HIP_TRYN(ctx, launch_schur1m(fa, 0, st));
-                else HIP_TRYN(ctx, launch_schur1(fa, 0, nullptr, st));
-                HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
-                if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)f->RB1, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
-                ha.phase = 3; ha.seq = ++seq;
-                HIP_TRYN(ctx, launch_head(ha, st));
-            }
-        } else {
-            // sharded LM: two small all-reduces per group - [cost, model decrease of the pose blocks] before the
-            // decision, [A_dir | Y^T Y] before the camera solve; the decisions are then identical on every rank
-            HIP_TRYN(ctx, launch_cost1(fa, st));
-            if (p->allreduce && p->allreduce(p->allreduce_user, f->red + 2 * K1 * K1, 2, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
-            ha.phase = 1 | 4; ha.seq = ++seq;       // decide; the group's status is published by its last step
-            HIP_TRYN(ctx, launch_head(ha, st));
-            ha.phase = 2; ha.seq = ++seq;
-            if (fuse_tail) {
-                HIP_TRYN(ctx, launch_schur1(fa, 1, &ha, st));
-            } else {
-                if (schur_m) HIP_TRYN(ctx, launch_schur1m(fa, 1, st));
-                else HIP_TRYN(ctx, launch_schur1(fa, 1, nullptr, st));
-                HIP_TRYN(ctx, launch_reduce1(fa, 0, 2 * K1 * K1, st));
-                if (p->allreduce && p->allreduce(p->allreduce_user, f->red, (size_t)(2 * K1 * K1), (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return -CCAL_ERR_HIP; }
-                HIP_TRYN(ctx, launch_head(ha, st));
-            }
-        }
+    // after the first enqueue an error exit leaves kernels in flight that publish into the pinned status word:
+    // the next solve / the destructor must drain the stream first
+    auto fail_enqueued = [&](int code) -> int { f->tail_pending = true; return code; };
+    auto enqueue = [&]() -> int {         // one group: evaluation + elimination + ONE collective + decision/solve; returns its seq
+        HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));
+        if (int e = allreduce(p, f->red, (size_t)f->RB1); e != CCAL_OK) return -e;
+        ha.seq = ++seq;
+        HIP_TRYN(ctx, launch_head(ha, st));
         return seq;
     };
-    auto wait_seq = [&](int target) -> int { return wait_status(ctx, st, hst, f->d_state, target); };
 
-    // keep two groups in flight: the GPU never waits for the host, the host wastes at most two
+    // keep `depth` groups in flight: the GPU never waits for the host, the host wastes at most depth - 1
     // early-exit groups after convergence
     std::vector<int> pending;
     int enq = 0;
-    const int max_groups = o->max_iterations + 1;
+    const int max_groups = max_groups_for(o);
+    const int depth = groups_in_flight(p, "CCAL_FUSED_DEPTH");
     int status = CCAL_OK;
     bool finished = false;
     while (!finished) {
-        // Sharded solves (all-reduce hook set) must issue the SAME sequence of collectives on every rank.  They do:
-        // the fill rule below is a function of the group that reported `done` only (groups enqueued = that index +
-        // depth, whatever the host timing), and `done` is decided from all-reduced sums, identically on every rank.
-        // Default with a hook: no group ahead (CCAL_FUSED_DEPTH_HOOK=2 enqueues one; on a 1-rank RCCL group the extra
-        // early-exit group with its hook calls cost as much as the overlap gained: 0.46 vs 0.42 ms LM at 1 000 frames).
-        static const int env_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH"); return e ? std::max(1, std::atoi(e)) : 2; }();
-        static const int env_depth_hook = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH_HOOK"); return e ? std::max(1, std::atoi(e)) : 1; }();
-        const int depth = p->allreduce ? env_depth_hook : env_depth;
+        // Sharded solves must issue the SAME sequence of collectives on every rank.  They do: every group carries exactly
+        // one, the fill rule below is a function of the group that reported `done` only (groups enqueued = that index +
+        // depth - 1, whatever the host timing), and `done` is decided from all-reduced sums, identically on every rank.
         while ((int)pending.size() < depth && enq < max_groups) {
             const int s = enqueue();
-            if (s < 0) return -s;
+            if (s < 0) return fail_enqueued(-s);
             pending.push_back(s); ++enq;
         }
         if (pending.empty()) break;
         const int waited = pending.front();
-        rc = wait_seq(waited);
-        if (rc != CCAL_OK) return rc;
+        rc = wait_status(ctx, st, hst, f->d_state, waited);
+        if (rc != CCAL_OK) return fail_enqueued(rc);
         pending.erase(pending.begin());
         // act on `done` only when it was set by a step this thread has waited for: a later group may already have
         // published it, and how many groups get enqueued must not depend on that race (sharded ranks would issue
@@ -409,32 +412,122 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, double* intr_
         else if (o->verbose) std::printf("[ccal fused %s] iter %d cost %.12g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost);
     }
     // hst->done was published by the last instruction of the deciding k_head (after a system-scope fence): everything
-    // the result depends on is complete.  The download goes through a side stream so that it does not queue behind
-    // the (at most two) early-exit groups still in the main stream; the next solve drains those before it starts.
+    // the result depends on is complete.  A download goes through a side stream so that it does not queue behind
+    // the early-exit groups still in the main stream; the next solve drains those before it starts.
     hipStream_t dl = st;
     if (hst->done && !pending.empty()) { dl = f->side; f->tail_pending = true; }
     else HIP_TRY(ctx, hipStreamSynchronize(st));
-    struct { int done, iter, cur, acc, rej; double cur_cost, initial_cost; } ds =
-        { hst->done, hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->cur_cost, hst->initial_cost };
+    struct { int done, iter, cur, acc, rej, hits, misses; double cur_cost, initial_cost; } ds =
+        { hst->done, hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->spec_hits, hst->spec_misses, hst->cur_cost, hst->initial_cost };
     if (!ds.done) { status = CCAL_ERR_NO_CONVERGENCE; }
     else status = ds.done - 1;
     if (ds.cur == 1) { std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); }
     ccal_report R = {};
     R.status = status; R.iterations = ds.iter; R.lm_accepted = ds.acc; R.lm_rejected = ds.rej;
+    R.lm_spec_hits = ds.hits; R.lm_spec_misses = ds.misses;
     R.initial_cost = ds.initial_cost; R.final_cost = ds.cur_cost;
-    if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));
-    HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, dl));
-    HIP_TRY(ctx, hipStreamSynchronize(dl));
-    std::memcpy(poses_io, h_poses, np6 * sizeof(double));
-    std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
-    if (p->one_focal) intr_io[1] = intr_io[0];           // fy = f (src/util.rs:467-470)
-    rc = CCAL_OK;
+    if (host_io) {
+        if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));
+        HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, dl));
+        HIP_TRY(ctx, hipStreamSynchronize(dl));
+        std::memcpy(poses_io, h_poses, np6 * sizeof(double));
+        std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
+        if (p->one_focal) intr_io[1] = intr_io[0];           // fy = f (src/util.rs:467-470)
+    }
     R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (rep) *rep = R;
     if (status == CCAL_ERR_NOT_PD) ctx->err = "normal equations are not positive definite";
-    if (rc != CCAL_OK) return rc;
     return status;
 }
+
+// ---------------------------------------------------------------------------------------------
+// General loop (several cameras, or CCAL_DISABLE_FUSED): device-resident as well, the same group shape:
+//   k_gram per camera at the evaluated set -> k_schur -> k_reduce -> (ONE all-reduce) -> k_solve (decision + camera
+//   solve + candidate intrinsics / extrinsics) -> k_backsub (candidate poses, model decrease per slot)
+// every kernel picks its parameter / Gram set and damping from the device state, k_solve applies the shared decision
+// function and publishes a status word; the host only enqueues groups and polls.
+// Set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1]).
+// ---------------------------------------------------------------------------------------------
+static int solve_general(ccal_problem* p, const ccal_solver_opts* o, bool host_io, double* intr_io, double* poses_io, double* extr_io,
+                         ccal_report* rep) {
+    ccal_ctx* ctx = p->ctx;
+    NormalWs* w = p->nws;
+    hipStream_t st = ctx->stream;
+    int rc;
+    const bool lm = o->method == CCAL_METHOD_LM;
+    if (w->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); w->tail_pending = false; }   // a stale k_solve must not publish into this solve
+    if (host_io && (rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
+    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
+    const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
+    const auto t0 = std::chrono::steady_clock::now();
+    init_state(w->h_gstate, o);
+    HIP_TRY(ctx, hipMemcpyAsync(w->d_gstate, w->h_gstate, sizeof(DevState), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
+    if (p->n_slots) HIP_TRY(ctx, hipMemsetAsync(w->mc_slot, 0, (size_t)p->n_slots * sizeof(double), st));
+    HostStatus* hst = w->h_gstatus;
+    hst->seq = 0; hst->done = 0; hst->done_seq = 0;
+    DevState* ds = w->d_gstate;
+    int seq = 0;
+    auto fail_enqueued = [&](int code) -> int { w->tail_pending = true; return code; };
+    auto enqueue = [&]() -> int {          // returns the sequence number that marks the group's end, < 0 on error
+        for (int c = 0; c < p->n_cams; ++c) HIP_TRYN(ctx, launch_gram_dev(p, c, ds, st));
+        HIP_TRYN(ctx, launch_schur(p, w->cur, 0.0, min_d, max_d, st, ds));
+        HIP_TRYN(ctx, launch_reduce(p, st, ds));
+        if (int e = allreduce(p, w->red, (size_t)w->RB); e != CCAL_OK) return -e;
+        HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds, hst, ++seq));
+        HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
+        return seq;
+    };
+    std::vector<int> pending;
+    int enq = 0;
+    const int max_groups = max_groups_for(o);
+    // sharded solves: every rank issues the same sequence of collectives - one per group, the decisions come from
+    // all-reduced sums and the number of groups enqueued depends only on the group that reported `done`
+    const int depth = groups_in_flight(p, "CCAL_GENERAL_DEPTH");
+    bool finished = false;
+    while (!finished) {
+        while ((int)pending.size() < depth && enq < max_groups) {
+            const int sq = enqueue();
+            if (sq < 0) return fail_enqueued(-sq);
+            pending.push_back(sq); ++enq;
+        }
+        if (pending.empty()) break;
+        const int waited = pending.front();
+        if ((rc = wait_status(ctx, st, hst, w->d_gstate, waited)) != CCAL_OK) return fail_enqueued(rc);
+        pending.erase(pending.begin());
+        if (o->verbose) std::printf("[ccal %s] iter %d cost %.12g radius %.3g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost, hst->radius);
+        if (hst->done && hst->done_seq <= waited) finished = true;     // see solve_fused: no dependence on publication races
+    }
+    // the deciding k_solve published after a system-scope fence: the result is complete; it is downloaded through a
+    // side stream so that it does not queue behind the early-exit group enqueued ahead (drained before the next solve)
+    hipStream_t dl = st;
+    if (hst->done && !pending.empty()) { dl = w->side; w->tail_pending = true; }
+    else HIP_TRY(ctx, hipStreamSynchronize(st));
+    int status = hst->done ? hst->done - 1 : CCAL_ERR_NO_CONVERGENCE;
+    if (hst->cur == 1) {             // the accepted point lives in set 1: make it set 0 for whoever comes next
+        std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
+        w->cur ^= 1;
+    }
+    ccal_report R = {};
+    R.status = status; R.iterations = hst->iter; R.lm_accepted = hst->lm_accepted; R.lm_rejected = hst->lm_rejected;
+    R.lm_spec_hits = hst->spec_hits; R.lm_spec_misses = hst->spec_misses;
+    R.initial_cost = hst->initial_cost; R.final_cost = hst->cur_cost;
+    if (host_io) {
+        HIP_TRY(ctx, hipMemcpyAsync(intr_io, p->d_intr, sizeof(double) * p->n_cams * CCAL_PMAX, hipMemcpyDeviceToHost, dl));
+        if (poses_io && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(poses_io, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToHost, dl));
+        if (extr_io) HIP_TRY(ctx, hipMemcpyAsync(extr_io, p->d_extr, sizeof(double) * p->n_cams * 6, hipMemcpyDeviceToHost, dl));
+        HIP_TRY(ctx, hipStreamSynchronize(dl));
+        if (p->one_focal) for (int c = 0; c < p->n_cams; ++c) intr_io[c * CCAL_PMAX + 1] = intr_io[c * CCAL_PMAX];   // fy = f (src/util.rs:467-470)
+    }
+    R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rep) *rep = R;
+    if (status == CCAL_ERR_NOT_PD) ctx->err = "normal equations are not positive definite";
+    return status;
+}
+
+// single camera: its own device-resident loop (GN and LM, sharded or not, empty shards included); the choice must not
+// depend on anything rank-local, or sharded ranks would issue different collectives
+static bool use_fused_path(const ccal_problem* p) { return p->n_cams == 1 && !std::getenv("CCAL_DISABLE_FUSED"); }
 
 extern "C" {
 
@@ -449,50 +542,49 @@ int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
 
 int ccal_build_normal_dev(ccal_problem* p, double lambda) {
     if (!p) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
     HIP_TRY(p->ctx, hipSetDevice(p->ctx->device));
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     NormalWs* w = p->nws;
     w->red_fused = false;
-    if (p->n_cams == 1 && p->n_obs > 0 && !p->allreduce && !std::getenv("CCAL_DISABLE_FUSED")) {
+    if (p->n_cams == 1 && p->n_obs > 0 && !p->sharded() && !std::getenv("CCAL_DISABLE_FUSED")) {
         // single camera: the device loop's own kernels (register / LDS Gram + per-frame elimination), evaluated at the
-        // current parameters with the state set to "first evaluation"; fws->red = [A_dir | Y^T Y | . | .]
+        // current parameters with the state set to "first evaluation"; fws->red = [A_dir | Y^T Y | . | failed blocks]
         ccal_ctx* ctx = p->ctx;
         if ((rc = fused_ws_ensure(p)) != CCAL_OK) return rc;
         FusedWs* f = w->fws;
         hipStream_t st = ctx->stream;
+        if (f->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); f->tail_pending = false; }
         FusedArgs fa = make_fused_args(p, 1e-6, 1e32);
         const bool schur_m = fused_use_schur1m(p, fa);
         HIP_TRY(ctx, launch_state_eval(f->d_state, lambda, st));
-        if (fused_use_valu_gram(p)) HIP_TRY(ctx, launch_gram1v(p->cams[0].model, p->one_focal, fa, st));
-        else HIP_TRY(ctx, launch_gram1(p->cams[0].model, p->one_focal, fa, st));
-        if (schur_m) HIP_TRY(ctx, launch_schur1m(fa, 0, st));
-        else HIP_TRY(ctx, launch_schur1(fa, 0, nullptr, st));
-        HIP_TRY(ctx, launch_reduce1(fa, 0, 2 * (p->K + 1) * (p->K + 1), st));
+        HIP_TRY(ctx, enqueue_fused_system(p, fa, schur_m, st));
         w->red_fused = true;
         return CCAL_OK;
     }
+    if (w->tail_pending) { HIP_TRY(p->ctx, hipStreamSynchronize(p->ctx->stream)); w->tail_pending = false; }
     if ((rc = enqueue_gram(p, false, w->cur)) != CCAL_OK) return rc;
     return enqueue_reduce_system(p, w->cur, lambda, 1e-6, 1e32);
+    CCAL_API_CATCH(p->ctx)
 }
 
 int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, const double* extr,
                       double lambda, double* S, double* b, double* cost) {
-    if (!p || !intr || (!poses && p->n_slots)) return CCAL_ERR_INVALID_ARG;
+    if (!p || !intr || (!poses && p->n_slots) || (!extr && p->n_cams > 1)) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
     ccal_ctx* ctx = p->ctx;
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
     if ((rc = normal_ws_ensure(p)) != CCAL_OK) return rc;
     NormalWs* w = p->nws;
-    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), ctx->stream));
     if ((rc = ccal_build_normal_dev(p, lambda)) != CCAL_OK) return rc;
     const int K = w->K, K1 = K + 1;
-    int32_t flags[4];
+    double failed = 0.0;
     if (w->red_fused) {
-        // [A_dir | Y^T Y]: S = A_dir - Y^T Y on the camera block, b its last column, cost = the r x r corner of A_dir
+        // [A_dir | Y^T Y | . | failed]: S = A_dir - Y^T Y on the camera block, b its last column, cost = the r x r corner of A_dir
         double* h = w->fws->h_stage;
-        HIP_TRY(ctx, hipMemcpyAsync(h, w->fws->red, 2 * K1 * K1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(flags, w->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(h, w->fws->red, (size_t)w->fws->RB1 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const double* A = h; const double* Y = h + K1 * K1;
         if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
@@ -502,10 +594,10 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
         }
         if (b) for (int i = 0; i < K; ++i) b[i] = A[i * K1 + K] - Y[i * K1 + K];
         if (cost) *cost = A[K * K1 + K];
+        failed = h[2 * K1 * K1 + 1];
     } else {
         double* h = w->h_pinned;
         HIP_TRY(ctx, hipMemcpyAsync(h, w->red, w->RB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(flags, w->flags, sizeof flags, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const double* hd = h + K1 * K1;
         if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
@@ -514,114 +606,36 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
             S[i * K + j] = v;
         }
         if (b) for (int i = 0; i < K; ++i) b[i] = h[i * K1 + K];
-        if (cost) *cost = h[w->RB - 1];
+        if (cost) *cost = h[w->RB - 3];
+        failed = h[w->RB - 1];
     }
-    if (flags[0]) { ctx->err = "a frame's pose block is not positive definite"; return CCAL_ERR_NOT_PD; }
+    if (failed > 0.0) { ctx->err = "a frame's pose block is not positive definite"; return CCAL_ERR_NOT_PD; }
     return CCAL_OK;
+    CCAL_API_CATCH(p->ctx)
 }
 
-int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
-    if (!p || !o || !intr_io || (!poses_io && p->n_slots)) return CCAL_ERR_INVALID_ARG;
+static int solve_entry(ccal_problem* p, const ccal_solver_opts* o, bool host_io, double* intr_io, double* poses_io, double* extr_io,
+                       ccal_report* rep) {
     ccal_ctx* ctx = p->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
-    const bool lm = o->method == CCAL_METHOD_LM;
-    // single camera: its own device-resident loop (GN and LM, sharded or not)
-    if (p->n_cams == 1 && p->n_obs > 0 && !std::getenv("CCAL_DISABLE_FUSED"))
-        return solve_fused(p, o, intr_io, poses_io, rep);
-    // General loop (several cameras, sharded LM, or CCAL_DISABLE_FUSED): device-resident as well.  One group =
-    //   k_schur -> k_reduce -> (all-reduce red) -> k_solve -> k_backsub -> k_gram at the candidate (per camera) -> k_sum2
-    //   -> (all-reduce cost, model decrease) -> k_gdecide
-    // every kernel picks the current parameter / Gram set by st->cur and its damping from st->lambda, k_gdecide applies
-    // the oracle's accept / reject / stop rules and publishes a status word; the host only enqueues groups (one ahead
-    // of the group it waits for) and polls.  Set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1]).
-    NormalWs* w = p->nws;
-    hipStream_t st = ctx->stream;
-    if (w->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); w->tail_pending = false; }   // a stale k_gdecide must not publish into this solve
-    if ((rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
-    if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
-    const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
-    const auto t0 = std::chrono::steady_clock::now();
-    DevState* hs0 = w->h_gstate;
-    std::memset(hs0, 0, sizeof *hs0);
-    hs0->radius = o->lm_initial_radius; hs0->dec = 2.0;
-    hs0->lambda = lm ? 1.0 / o->lm_initial_radius : 0.0;
-    hs0->min_error = o->min_error; hs0->min_abs = o->min_abs_error_decrease; hs0->min_rel = o->min_rel_error_decrease;
-    hs0->max_iter = o->max_iterations; hs0->method = o->method;
-    HIP_TRY(ctx, hipMemcpyAsync(w->d_gstate, hs0, sizeof(DevState), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
-    HostStatus* hst = w->h_gstatus;
-    hst->seq = 0; hst->done = 0; hst->done_seq = 0;
-    const DevState* ds = w->d_gstate;
-    int seq = 0;
-    auto ar = [&](double* buf, size_t n) -> int {
-        if (p->allreduce && p->allreduce(p->allreduce_user, buf, n, (void*)st) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
-        return CCAL_OK;
-    };
-    auto enqueue = [&](bool init) -> int {          // returns the sequence number that marks the group's end, < 0 on error
-        if (!init) {
-            HIP_TRYN(ctx, launch_schur(p, w->cur, 0.0, min_d, max_d, st, ds));
-            HIP_TRYN(ctx, launch_reduce(p, st, ds));
-            if (ar(w->red, (size_t)w->RB) != CCAL_OK) return -CCAL_ERR_HIP;
-            HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds));
-            HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
-        }
-        for (int c = 0; c < p->n_cams; ++c) HIP_TRYN(ctx, launch_gram_dev(p, c, ds, init ? 0 : 1, st));
-        if (!p->allreduce) {         // sums and decision in one launch
-            HIP_TRYN(ctx, launch_sum_cost_dev(p, w->d_gstate, init ? 0 : 1, hst, init, ++seq, st));
-        } else {
-            HIP_TRYN(ctx, launch_sum_cost_dev(p, w->d_gstate, init ? 0 : 1, nullptr, init, 0, st));
-            if (ar(w->scal, 2) != CCAL_OK) return -CCAL_ERR_HIP;
-            HIP_TRYN(ctx, launch_gdecide(p, w->d_gstate, hst, init, ++seq, st));
-        }
-        return seq;
-    };
-    std::vector<int> pending;
-    int enq = 0;
-    const int max_groups = o->max_iterations + 1;
-    // sharded solves: every rank issues the same sequence of collectives - the decisions come from all-reduced sums and
-    // the number of groups enqueued depends only on the group that reported `done` (that index + depth)
-    static const int env_gdepth = [] { const char* e = std::getenv("CCAL_GENERAL_DEPTH"); return e ? std::max(1, std::atoi(e)) : 2; }();
-    const int depth = p->allreduce ? 1 : env_gdepth;
-    bool finished = false;
-    while (!finished) {
-        while ((int)pending.size() < depth && enq < max_groups) {
-            const int sq = enqueue(enq == 0);
-            if (sq < 0) return -sq;
-            pending.push_back(sq); ++enq;
-        }
-        if (pending.empty()) break;
-        const int waited = pending.front();
-        if ((rc = wait_status(ctx, st, hst, w->d_gstate, waited)) != CCAL_OK) return rc;
-        pending.erase(pending.begin());
-        if (o->verbose) std::printf("[ccal %s] iter %d cost %.12g radius %.3g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost, hst->radius);
-        if (hst->done && hst->done_seq <= waited) finished = true;     // see solve_fused: no dependence on publication races
-    }
-    // the deciding k_gdecide published after a system-scope fence: the result is complete; it is downloaded through a
-    // side stream so that it does not queue behind the early-exit group enqueued ahead (drained before the next solve)
-    hipStream_t dl = st;
-    if (hst->done && !pending.empty()) { dl = w->side; w->tail_pending = true; }
-    else HIP_TRY(ctx, hipStreamSynchronize(st));
-    int status = hst->done ? hst->done - 1 : CCAL_ERR_NO_CONVERGENCE;
-    if (hst->cur == 1) {             // the accepted point lives in set 1: make it set 0 for whoever comes next
-        std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
-        w->cur ^= 1;
-    }
-    ccal_report R = {};
-    R.status = status; R.iterations = hst->iter; R.lm_accepted = hst->lm_accepted; R.lm_rejected = hst->lm_rejected;
-    R.initial_cost = hst->initial_cost; R.final_cost = hst->cur_cost;
-    HIP_TRY(ctx, hipMemcpyAsync(intr_io, p->d_intr, sizeof(double) * p->n_cams * CCAL_PMAX, hipMemcpyDeviceToHost, dl));
-    if (poses_io && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(poses_io, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToHost, dl));
-    if (extr_io) HIP_TRY(ctx, hipMemcpyAsync(extr_io, p->d_extr, sizeof(double) * p->n_cams * 6, hipMemcpyDeviceToHost, dl));
-    HIP_TRY(ctx, hipStreamSynchronize(dl));
-    if (p->one_focal) for (int c = 0; c < p->n_cams; ++c) intr_io[c * CCAL_PMAX + 1] = intr_io[c * CCAL_PMAX];   // fy = f (src/util.rs:467-470)
-    rc = CCAL_OK;
-    R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (rep) *rep = R;
-    if (status == CCAL_ERR_NOT_PD) ctx->err = "normal equations are not positive definite";
-    if (rc != CCAL_OK) return rc;
-    return status;
+    if (use_fused_path(p)) return solve_fused(p, o, host_io, intr_io, poses_io, rep);
+    return solve_general(p, o, host_io, intr_io, poses_io, extr_io, rep);
+}
+
+int ccal_solve(ccal_problem* p, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
+    if (!p || !o || !intr_io || (!poses_io && p->n_slots) || (!extr_io && p->n_cams > 1)) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    return solve_entry(p, o, true, intr_io, poses_io, extr_io, rep);
+    CCAL_API_CATCH(p->ctx)
+}
+
+int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* o, ccal_report* rep) {
+    if (!p || !o) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    return solve_entry(p, o, false, nullptr, nullptr, nullptr, rep);
+    CCAL_API_CATCH(p->ctx)
 }
 
 }  // extern "C"

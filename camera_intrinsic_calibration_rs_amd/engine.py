@@ -51,6 +51,30 @@ class Context:
         if rc != _ffi.OK:
             raise CcalError(rc, "ccal_sync", self.last_error())
 
+    # -- model conventions (what this build assumes about the absent camera-intrinsic-model crate) -----------
+    def model_conventions(self) -> _ffi.ModelConventions:
+        cv = _ffi.ModelConventions()
+        rc = self.lib.ccal_get_model_conventions(self.handle, C.byref(cv))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_get_model_conventions")
+        return cv
+
+    def set_model_conventions(self, cv: "_ffi.ModelConventions | None"):
+        rc = self.lib.ccal_set_model_conventions(self.handle, C.byref(cv) if cv is not None else None)
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_set_model_conventions")
+
+    # -- native RCCL communicator of this context's GPU (frame-sharded solves) --------------------------------
+    def rccl_comm_create(self, world: int, rank: int, unique_id: bytes) -> int:
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id is 128 bytes")
+        buf = C.create_string_buffer(unique_id, 128)
+        h = C.c_void_p()
+        rc = self.lib.ccal_rccl_comm_create(self.handle, int(world), int(rank), buf, C.byref(h))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_rccl_comm_create", self.last_error())
+        return h.value
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.ccal_ctx_destroy(self.handle)
@@ -61,6 +85,23 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+def rccl_available() -> bool:
+    return bool(_ffi.load().ccal_rccl_available())
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 calls this and hands the 128 bytes to every rank)."""
+    buf = C.create_string_buffer(128)
+    rc = _ffi.load().ccal_rccl_unique_id(buf)
+    if rc != _ffi.OK:
+        raise CcalError(rc, "ccal_rccl_unique_id")
+    return buf.raw
+
+
+def rccl_comm_destroy(comm: int) -> None:
+    _ffi.load().ccal_rccl_comm_destroy(C.c_void_p(comm))
 
 
 def make_desc(n_cams, model, width, height, xy_same_focal, n_slots, obs_cam, obs_slot, obs_offsets,
@@ -117,6 +158,7 @@ class Problem:
         self.handle = h
         self.n_cams = desc.n_cams
         self.n_slots = desc.n_slots
+        self.n_obs = int(desc.n_obs)
         self.n_corners = int(self.lib.ccal_num_corners(h))
         self.K = int(self.lib.ccal_reduced_dim(h))
         self.j_len = int(self.lib.ccal_jacobian_len(h))
@@ -168,6 +210,10 @@ class Problem:
         self._cb = _ffi.ALLREDUCE_FN(tramp)
         self._check(self.lib.ccal_set_allreduce(self.handle, self._cb, None), "ccal_set_allreduce")
 
+    def set_rccl_comm(self, comm: "int | None"):
+        """ncclComm_t (from Context.rccl_comm_create or the host's own RCCL): the library issues the step's all-reduce itself."""
+        self._check(self.lib.ccal_set_rccl_comm(self.handle, C.c_void_p(comm) if comm else None), "ccal_set_rccl_comm")
+
     # -- mode E -----------------------------------------------------------------------------------
     def _params(self, intr, poses, extr):
         intr = _f64(intr, (self.n_cams, PMAX))
@@ -216,11 +262,21 @@ class Problem:
             raise CcalError(rc, "ccal_solve", self.ctx.last_error())
         return intr, poses, extr, rep
 
+    def solve_dev(self, opts: _ffi.SolverOpts | None = None, raise_on_error=True) -> _ffi.Report:
+        """ccal_solve_dev: start from the parameters on the device (upload_params / a previous solve), leave the result
+        there (download_params fetches it)."""
+        opts = opts or default_opts()
+        rep = _ffi.Report()
+        rc = self.lib.ccal_solve_dev(self.handle, C.byref(opts), C.byref(rep))
+        if rc not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE) and raise_on_error:
+            raise CcalError(rc, "ccal_solve_dev", self.ctx.last_error())
+        return rep
+
     # -- pose initialisation (src/util.rs:418-436) ---------------------------------------------------
     def init_poses(self, intr, min_points: int = 10):
         """T_cam_board per observation frame [n_obs, 6] and the number of corners used (0 = no pose)."""
         intr = _f64(intr, (self.n_cams, PMAX))
-        n_obs = len(self._keep["obs_cam"]) if self._keep is not None else 0
+        n_obs = self.n_obs                                   # from the description the library holds, not from the keep-alive arrays
         poses = np.zeros((max(n_obs, 1), 6)); used = np.zeros(max(n_obs, 1), dtype=np.int32)
         self._check(self.lib.ccal_init_poses(self.handle, _dp(intr), int(min_points), _dp(poses),
                                              used.ctypes.data_as(C.POINTER(C.c_int32))), "ccal_init_poses")

@@ -22,7 +22,7 @@
  *                            block (src/optimization/factors.rs:152-173, 204-228)
  *   ccal_build_normal        tiny-solver's J^T J / J^T r assembly (call sites src/util.rs:455,670),
  *                            with the per-frame pose blocks eliminated exactly (Schur)
- *   ccal_solve               GaussNewtonOptimizer::optimize(&problem, &initial_values, None)
+ *   ccal_solve / _dev        GaussNewtonOptimizer::optimize(&problem, &initial_values, None)
  *                            src/util.rs:443-463 and 668-670 (+ an LM mode)
  *   ccal_init_poses          the unproject + sqpnp pose initialisation inside calib_camera  src/util.rs:418-436
  *   ccal_reprojection_errors / ccal_validation
@@ -67,7 +67,8 @@ typedef enum {
     CCAL_ERR_NONFINITE = 3,       /* NaN/Inf cost: tiny-solver returns None (src/util.rs:455-457) */
     CCAL_ERR_NOT_PD = 4,          /* Cholesky of the normal equations failed: None */
     CCAL_ERR_NO_CONVERGENCE = 5,  /* informational: max_iterations reached (reference still returns Some) */
-    CCAL_ERR_UNSUPPORTED = 6
+    CCAL_ERR_UNSUPPORTED = 6,
+    CCAL_ERR_NO_MEMORY = 7        /* host allocation failed inside the library (never thrown across the ABI) */
 } ccal_status;
 
 typedef enum {                    /* camera-intrinsic-model GenericModel variants on the hot path */
@@ -76,6 +77,16 @@ typedef enum {                    /* camera-intrinsic-model GenericModel variant
     CCAL_MODEL_KB4 = 2,           /* [fx,fy,cx,cy,k1,k2,k3,k4]                                     */
     CCAL_MODEL_OPENCV5 = 3        /* [fx,fy,cx,cy,k1,k2,p1,p2,k3]                                  */
 } ccal_model;
+
+/* What this build assumes about the crate camera-intrinsic-model 0.8 (Cargo.toml:25; its source is not part of the
+ * reference tree) and can be changed at run time, per context, without rebuilding a kernel.  Defaults:
+ * camera_intrinsic_calibration_rs_amd/csrc/ccal_models.hpp (which also holds the compile-time conventions: the OPENCV5
+ * parameter order and the unprojection thresholds). */
+typedef struct {
+    double kb4_small_radius;       /* KB4 project_one: sqrt(x^2+y^2) <= this -> pinhole limit.  Default 1e-8 */
+    double dist_lo[4][5];          /* [ccal_model][i]: lower / upper bound of distortion parameter 4 + i, i.e. what */
+    double dist_hi[4][5];          /* distortion_params_bound() returns (applied at src/util.rs:40-48)             */
+} ccal_model_conventions;
 
 typedef struct ccal_ctx ccal_ctx;          /* one GPU + one HIP stream; single caller */
 typedef struct ccal_problem ccal_problem;  /* inputs resident in HBM + workspaces */
@@ -126,13 +137,20 @@ typedef struct {
     double initial_cost;           /* sum over blocks of rho'(s) * s at the start (tiny-solver's "error") */
     double final_cost;
     double solve_ms;               /* wall time of the iteration loop */
-    double reserved;
+    int32_t lm_spec_hits;          /* LM: accepted steps whose speculative elimination was the next system (one group) */
+    int32_t lm_spec_misses;        /*     ... and those that needed a re-elimination group                              */
 } ccal_report;
 
-/* Optional all-reduce hook for frame-sharded multi-GPU solves: called once per linear solve
- * with a device pointer to `count` doubles ([S | b | cost | aux]) that must be summed in place
- * over all ranks, ordered on `hip_stream`.  NULL = single GPU. */
+/* Frame-sharded multi-GPU solves (one process per GPU, every rank holds a contiguous range of frame slots and the
+ * same camera parameters): ONE in-place sum of a small device buffer ([reduced system | cost | model decrease | failed
+ * blocks], 100..400 doubles) over all ranks per optimizer step, Gauss-Newton and Levenberg-Marquardt alike.
+ *   ccal_set_rccl_comm   the library calls ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, stream) itself,
+ *                        stream-ordered, and keeps enqueueing steps ahead of the host.  The production path.
+ *   ccal_set_allreduce   a callback does the sum (ordered on `hip_stream`) - for transports other than RCCL
+ *                        (the tests use gloo); the loop then waits for every step before it enqueues the next.
+ * Neither set = single GPU. */
 typedef int (*ccal_allreduce_fn)(void* user, double* device_buf, size_t count, void* hip_stream);
+#define CCAL_RCCL_UNIQUE_ID_BYTES 128
 
 /* ---- context ---------------------------------------------------------------------------- */
 int ccal_ctx_create(int device_id, void* hip_stream /* hipStream_t or NULL = own stream */, ccal_ctx** out);
@@ -140,6 +158,11 @@ void ccal_ctx_destroy(ccal_ctx* ctx);
 const char* ccal_last_error(const ccal_ctx* ctx);
 const char* ccal_version(void);
 int ccal_model_num_params(int model);            /* 5 / 6 / 8 / 9, -1 if unknown */
+/* Conventions of a context: read them, change a field, set them (in == NULL restores the defaults).  They apply to
+ * everything the context evaluates afterwards (kernels receive the threshold as an argument) and to later
+ * ccal_apply_reference_bounds / ccal_convert_model calls. */
+int ccal_get_model_conventions(const ccal_ctx* ctx, ccal_model_conventions* out);
+int ccal_set_model_conventions(ccal_ctx* ctx, const ccal_model_conventions* in);
 
 /* ---- problem ---------------------------------------------------------------------------- */
 int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* desc, ccal_problem** out);
@@ -152,6 +175,15 @@ int ccal_unfix_param(ccal_problem* p, int cam, int eff_idx);
 int ccal_apply_reference_bounds(ccal_problem* p);                 /* src/util.rs:29-49 for every camera */
 int ccal_disable_distortions(ccal_problem* p, int n_disabled, double* intr_io /* zeroed in place */);
 int ccal_set_allreduce(ccal_problem* p, ccal_allreduce_fn fn, void* user);
+int ccal_set_rccl_comm(ccal_problem* p, void* nccl_comm /* ncclComm_t created by the host or by ccal_rccl_comm_create; NULL = none */);
+/* Communicator bootstrap for hosts that do not link RCCL themselves: rank 0 draws an id, hands its 128 bytes to every
+ * rank by any means (file, socket, MPI, the launcher's store), every rank creates its communicator on its context's GPU.
+ * RCCL is resolved at run time (the instance already loaded into the process, else librccl.so.1). */
+int ccal_rccl_available(void);                                    /* 1 if an RCCL library could be resolved */
+int ccal_rccl_version(void);                                      /* ncclGetVersion, 0 if unavailable */
+int ccal_rccl_unique_id(void* id_out /* CCAL_RCCL_UNIQUE_ID_BYTES */);
+int ccal_rccl_comm_create(ccal_ctx* ctx, int world, int rank, const void* id /* 128 bytes */, void** comm_out);
+int ccal_rccl_comm_destroy(void* comm);
 
 int64_t ccal_num_corners(const ccal_problem* p);
 int ccal_reduced_dim(const ccal_problem* p);                      /* K */
@@ -178,9 +210,13 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
                       double lambda, double* S, double* b, double* cost);
 int ccal_build_normal_dev(ccal_problem* p, double lambda);   /* uses uploaded params; result stays on device */
 
-/* ---- the optimizer loop -------------------------------------------------------------------- */
+/* ---- the optimizer loop --------------------------------------------------------------------
+ * ccal_solve: host pointers in and out (poses staged through pinned memory both ways).
+ * ccal_solve_dev: the starting point is what ccal_upload_params (or a previous solve) left on the device, the result
+ * stays there (ccal_download_params fetches it); the call itself moves ~1 KB to the device and polls a status word. */
 int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
                double* intr_io, double* poses_io, double* extr_io, ccal_report* report);
+int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* opts, ccal_report* report);
 
 /* ---- per-frame pose initialisation (src/util.rs:418-436) ---------------------------------
  * What calib_camera does before it builds the problem: unproject the detections with the current model,

@@ -1,0 +1,123 @@
+"""GPU: behaviour of the C-ABI boundary itself -- argument checking, the run-time model-conventions table, entry points
+a binding can misuse.  Everything goes through the C ABI (ctypes), errors are status codes, never aborts."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from camera_intrinsic_calibration_rs_amd import _ffi, synth
+from camera_intrinsic_calibration_rs_amd.engine import CcalError, Context, Problem, default_opts, make_desc
+
+pytestmark = pytest.mark.gpu
+
+_dp = C.POINTER(C.c_double)
+
+
+def test_duplicate_camera_slot_pair_is_rejected(gpu_ctx):
+    """One FrameFeature per (camera, frame index) in the reference (src/util.rs:595-601); the per-slot records of the
+    single-camera kernels rely on it."""
+    sp = synth.make_problem(3, "eucm")
+    x, y, z, u, v = sp.soa()
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, 3, [0, 0, 0], [0, 1, 1], sp.obs_offsets, x, y, z, u, v, 1.0)
+    with pytest.raises(CcalError) as ei:
+        Problem(gpu_ctx, d, keep)
+    assert ei.value.code == _ffi.ERR_INVALID_ARG
+    assert "same (camera, slot)" in gpu_ctx.last_error()
+
+
+def test_multi_camera_entry_points_require_extrinsics(gpu_ctx):
+    """extr == NULL with a second camera used to evaluate with whatever an earlier solve left on the device."""
+    sp = synth.make_problem(4, "eucm", n_cams=2)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    lib = gp.lib
+    intr = np.ascontiguousarray(sp.intr0); poses = np.ascontiguousarray(sp.poses0)
+    r = np.empty((gp.n_corners, 2)); J = np.empty(gp.j_len)
+    ip, pp = intr.ctypes.data_as(_dp), poses.ctypes.data_as(_dp)
+    assert lib.ccal_eval(gp.handle, ip, pp, None, 0, r.ctypes.data_as(_dp), J.ctypes.data_as(_dp)) == _ffi.ERR_INVALID_ARG
+    S = np.empty((gp.K, gp.K)); b = np.empty(gp.K); c = C.c_double()
+    assert lib.ccal_build_normal(gp.handle, ip, pp, None, 0.0, S.ctypes.data_as(_dp), b.ctypes.data_as(_dp), C.byref(c)) == _ffi.ERR_INVALID_ARG
+    rep = _ffi.Report(); o = default_opts()
+    assert lib.ccal_solve(gp.handle, C.byref(o), ip, pp, None, C.byref(rep)) == _ffi.ERR_INVALID_ARG
+    a = C.c_double(); m = C.c_double()
+    assert lib.ccal_validation(gp.handle, 1, ip, pp, None, C.byref(a), C.byref(m)) == _ffi.ERR_INVALID_ARG
+    # single camera: extr is not used, NULL is fine
+    sp1 = synth.make_problem(4, "eucm")
+    g1 = Problem.from_synth(gpu_ctx, sp1)
+    i1 = np.ascontiguousarray(sp1.intr0); p1 = np.ascontiguousarray(sp1.poses0)
+    r1 = np.empty((g1.n_corners, 2)); J1 = np.empty(g1.j_len)
+    assert lib.ccal_eval(g1.handle, i1.ctypes.data_as(_dp), p1.ctypes.data_as(_dp), None, 0, r1.ctypes.data_as(_dp), J1.ctypes.data_as(_dp)) == 0
+
+
+def test_init_poses_without_keepalive_arrays(gpu_ctx):
+    """Problem(ctx, desc) without the keep-alive dict: the output buffers are sized from the description."""
+    sp = synth.make_problem(5, "eucm")
+    x, y, z, u, v = sp.soa()
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, 5, sp.obs_cam, sp.obs_slot, sp.obs_offsets, x, y, z, u, v, 1.0)
+    gp = Problem(gpu_ctx, d)            # arrays stay alive through `keep` in this scope
+    poses, used = gp.init_poses(sp.intr0)
+    assert poses.shape == (5, 6) and (used == 144).all()
+    assert np.abs(poses[:, 3:] - sp.poses_gt[:, 3:]).max() < 0.05
+    del keep
+
+
+def test_model_conventions_roundtrip_and_validation():
+    ctx = Context(0)
+    cv = ctx.model_conventions()
+    assert cv.kb4_small_radius == 1e-8
+    assert [cv.dist_lo[1][i] for i in range(2)] == [1e-6, 1e-6] and [cv.dist_hi[1][i] for i in range(2)] == [1.0, 100.0]
+    assert all(cv.dist_lo[3][i] == -1.0 and cv.dist_hi[3][i] == 1.0 for i in range(5))
+    cv.kb4_small_radius = 1e-3
+    cv.dist_hi[1][0] = 0.5
+    ctx.set_model_conventions(cv)
+    got = ctx.model_conventions()
+    assert got.kb4_small_radius == 1e-3 and got.dist_hi[1][0] == 0.5
+    bad = ctx.model_conventions(); bad.dist_lo[2][1] = 2.0            # lo > hi
+    with pytest.raises(CcalError):
+        ctx.set_model_conventions(bad)
+    ctx.set_model_conventions(None)                                     # defaults again
+    assert ctx.model_conventions().kb4_small_radius == 1e-8
+    ctx.close()
+
+
+def test_kb4_small_radius_is_a_runtime_convention(oracle):
+    """A point 1e-5 off the optical axis: with the default threshold (1e-8) KB4 takes the atan branch, with 1e-3 the
+    pinhole limit - no kernel is rebuilt.  Both are the same function to O(r^2), the distortion columns differ."""
+    ctx = Context(0)
+    th = np.zeros((1, synth.PMAX)); th[0, :8] = [190.9, 190.9, 255.0, 257.0, 0.3, 0.07, -0.02, 0.002]
+    X = np.array([[1e-5, 0.0, 0.0]], dtype=np.float32)
+    pose = np.array([[0.0, 0.0, 0.3, 0.0, 0.0, 1.0]])      # rotation about the optical axis: the point stays 1e-5 off it
+    d, keep = make_desc(1, [2], [512.0], [512.0], False, 1, [0], [0], [0, 1], X[:, 0], X[:, 1], X[:, 2], [255.0], [257.0], 1.0)
+    gp = Problem(ctx, d, keep)
+    r_a, J_a = gp.eval(th, pose)
+    ro, Jo = oracle.OracleProblem(d, keep).eval(th, pose)
+    np.testing.assert_allclose(r_a, ro, atol=1e-10); np.testing.assert_allclose(J_a, Jo, rtol=1e-9, atol=1e-9)
+    cv = ctx.model_conventions(); cv.kb4_small_radius = 1e-3
+    ctx.set_model_conventions(cv)
+    r_p, J_p = gp.eval(th, pose)
+    J_a = J_a.reshape(2, 14); J_p = J_p.reshape(2, 14)
+    np.testing.assert_allclose(r_p, r_a, atol=1e-7)                     # same projection to O(r^3)
+    assert (J_p[:, 4:8] == 0.0).all() and np.abs(J_a[:, 4:8]).max() > 0.0   # pinhole limit: no distortion derivative
+    ctx.set_model_conventions(None)
+    r_b, J_b = gp.eval(th, pose)
+    np.testing.assert_array_equal(J_b.reshape(2, 14), J_a)
+    gp.close(); ctx.close()
+
+
+def test_distortion_bounds_come_from_the_conventions_table():
+    """ccal_apply_reference_bounds reads the context's table: alpha's upper bound lowered below the optimum clamps the
+    solve there (tiny-solver clamps after every step)."""
+    ctx = Context(0)
+    sp = synth.make_problem(20, "eucm")
+    cv = ctx.model_conventions(); cv.dist_hi[1][0] = 0.6                # EUCM alpha <= 0.6 (ground truth 0.628)
+    ctx.set_model_conventions(cv)
+    gp = Problem.from_synth(ctx, sp)
+    gp.apply_reference_bounds()
+    i0 = sp.intr0.copy(); i0[0, 4] = 0.55
+    intr, _, _, rep = gp.solve(i0, sp.poses0, opts=default_opts(0), raise_on_error=False)
+    assert intr[0, 4] <= 0.6
+    ctx.set_model_conventions(None)
+    gp2 = Problem.from_synth(ctx, sp)
+    gp2.apply_reference_bounds()
+    intr2, _, _, _ = gp2.solve(i0, sp.poses0)
+    assert abs(intr2[0, 4] - sp.intr_gt[0, 4]) < 0.01
+    gp.close(); gp2.close(); ctx.close()

@@ -1,16 +1,66 @@
-"""GPU: the all-reduce hook path of ccal_solve with RCCL (backend "nccl") on a 1-rank group -- the
-device-pointer branch of dist.make_allreduce_hook, stream-ordered on the library's stream.  Multi-rank
-semantics are covered on CPU with gloo (tests/test_dist_cpu.py)."""
+"""GPU: the sharded-solve paths of ccal_solve on the one GPU of the box.
+  * native RCCL inside the library (ccal_set_rccl_comm; communicator created through ccal_rccl_comm_create) on a
+    1-rank communicator: bit-identical to the unsharded solve, groups enqueued ahead like on a single GPU;
+  * the callback path (ccal_set_allreduce) with torch.distributed's RCCL on a 1-rank group: exact collective counts
+    (ONE all-reduce per group, Gauss-Newton and Levenberg-Marquardt alike);
+  * two ranks on the device path (both processes on cuda:0, gloo moving the device buffers).
+RCCL with more than one rank needs more than one GPU: the driver's multi-GPU bench runs that (bench.py --gpus N);
+multi-rank semantics are also covered on CPU with gloo (tests/test_dist_cpu.py)."""
 import os
 import socket
 
 import numpy as np
 import pytest
 
-from camera_intrinsic_calibration_rs_amd import synth
+from camera_intrinsic_calibration_rs_amd import engine, synth
 from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("model,n_cams", [("eucm", 1), ("kb4", 1), ("eucm", 2)])
+def test_native_rccl_single_rank(model, n_cams):
+    """ncclAllReduce issued by the library itself (no Python, no callback in the collective)."""
+    assert engine.rccl_available()
+    ctx = Context(0)
+    comm = ctx.rccl_comm_create(1, 0, engine.rccl_unique_id())
+    try:
+        sp = synth.make_problem(60, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+        gp = Problem.from_synth(ctx, sp)
+        gp.apply_reference_bounds()
+        for method in (0, 1):
+            gp.set_rccl_comm(None)
+            ref = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+            gp.set_rccl_comm(comm)
+            got = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+            assert ref[3].status == got[3].status == 0
+            assert (ref[3].iterations, ref[3].lm_accepted, ref[3].lm_rejected) == (got[3].iterations, got[3].lm_accepted, got[3].lm_rejected)
+            for a, b in zip(ref[:3], got[:3]):          # a 1-rank sum is the identity: bit for bit
+                np.testing.assert_array_equal(a, b)
+            assert ref[3].final_cost == got[3].final_cost
+        gp.set_rccl_comm(None)
+        gp.close()
+    finally:
+        engine.rccl_comm_destroy(comm)
+
+
+def test_native_rccl_empty_shard_takes_the_same_path():
+    """A rank whose shard holds no observation frame still runs the single-camera loop and its collectives (with zeros):
+    with one rank that is a problem without observations - Gauss-Newton has no step (NOT_PD), never a hang or a crash."""
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    from camera_intrinsic_calibration_rs_amd.engine import make_desc
+    ctx = Context(0)
+    comm = ctx.rccl_comm_create(1, 0, engine.rccl_unique_id())
+    try:
+        d, keep = make_desc(1, [1], [512.0], [512.0], False, 3, [], [], [0], [], [], [], [], [], 1.0)
+        gp = Problem(ctx, d, keep)
+        gp.set_rccl_comm(comm)
+        sp = synth.make_problem(3, "eucm")
+        _, _, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(0), raise_on_error=False)
+        assert rep.status in (_ffi.OK, _ffi.ERR_NOT_PD)
+        gp.close()
+    finally:
+        engine.rccl_comm_destroy(comm)
 
 
 def test_solve_with_rccl_hook_single_rank():
@@ -45,17 +95,15 @@ def test_solve_with_rccl_hook_single_rank():
             np.testing.assert_array_equal(ref[1], got[1])
             assert ref[3].iterations == got[3].iterations
             K = gp.K
-            # with a hook no group is enqueued ahead: exactly iterations + 1 evaluations, on every rank
-            groups = got[3].iterations + 1
-            if method == 0:
-                # GN: ONE packed all-reduce per group ([A_dir | Y^T Y | cost | mc], 2 (K+1)^2 + 2 doubles)
-                assert set(calls) == {2 * (K + 1) ** 2 + 2}
-                assert len(calls) == groups
-            else:
-                # LM: per group [cost, model decrease] before the decision and [A_dir | Y^T Y] before the camera solve
-                assert calls.count(2) == groups
-                assert calls.count(2 * (K + 1) ** 2) == groups
-                assert len(calls) == 2 * groups
+            rep = got[3]
+            # with a callback no group is enqueued ahead: the first evaluation, one group per decision and one
+            # re-elimination group per rejected step / missed speculation - and ONE packed all-reduce per group
+            # ([A_dir | Y^T Y | model decrease | failed blocks], 2 (K+1)^2 + 2 doubles), GN and LM alike
+            groups = 1 + rep.iterations + (rep.lm_rejected + rep.lm_spec_misses if method == 1 else 0)
+            assert set(calls) == {2 * (K + 1) ** 2 + 2}
+            assert len(calls) == groups
+            if method == 1:
+                assert rep.lm_spec_hits + rep.lm_spec_misses <= rep.lm_accepted
     finally:
         dist.destroy_process_group()
 

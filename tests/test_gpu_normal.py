@@ -193,19 +193,46 @@ def test_solve_all_lane_mappings(gpu_ctx, oracle, n_frames):
     np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("model,n_cams", [("eucm", 1), ("opencv5", 1), ("eucm", 2)])
 @pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
-def test_solve_fused_tail_opt_in(gpu_ctx, oracle, method, monkeypatch):
-    """CCAL_FUSE_TAIL=1 (last Schur workgroup reduces + decides, opt-in because it measured slower) must
-    follow the same iterates as the split launches."""
-    sp = synth.make_problem(300, "eucm", ragged=True)
-    gp, _ = _pair(gpu_ctx, oracle, sp)
-    ref = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
-    monkeypatch.setenv("CCAL_FUSE_TAIL", "1")
-    out = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
-    assert (out[3].status, out[3].iterations) == (ref[3].status, ref[3].iterations)
-    assert abs(out[3].final_cost - ref[3].final_cost) <= 1e-10 * ref[3].final_cost
-    np.testing.assert_allclose(out[0], ref[0], rtol=1e-9, atol=0)
-    np.testing.assert_allclose(out[1], ref[1], rtol=0, atol=1e-9)
+def test_solve_dev_equals_solve(gpu_ctx, model, n_cams, method):
+    """ccal_solve_dev (parameters uploaded once, result left on the device) is the same loop as ccal_solve without the
+    host staging: bit-identical parameters and report; a second solve_dev continues from the first one's result."""
+    sp = synth.make_problem(300, model, n_cams=n_cams, ragged=True, outlier_frac=0.01)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    gp.apply_reference_bounds()
+    intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+    gp.upload_params(sp.intr0, sp.poses0, sp.extr0)
+    rep_d = gp.solve_dev(default_opts(method))
+    intr_d, poses_d, extr_d = gp.download_params()
+    assert (rep_d.status, rep_d.iterations, rep_d.lm_accepted, rep_d.lm_rejected) == (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected)
+    assert rep_d.final_cost == rep.final_cost and rep_d.initial_cost == rep.initial_cost
+    np.testing.assert_array_equal(intr_d, intr); np.testing.assert_array_equal(poses_d, poses)
+    if n_cams > 1:
+        np.testing.assert_array_equal(extr_d, extr)
+    # continuing from the optimum: converges at once, the cost does not go up
+    rep2 = gp.solve_dev(default_opts(method))
+    assert rep2.status == 0 and rep2.iterations <= 2
+    assert rep2.initial_cost == rep.final_cost and rep2.final_cost <= rep.final_cost * (1 + 1e-12)
+
+
+def test_lm_speculative_elimination_bookkeeping(gpu_ctx, oracle):
+    """LM eliminates the candidate's pose blocks with the damping an accepted step of gain ratio ~1 gets (radius x 3).
+    Well-conditioned start: every accepted step but the last is a hit (one group per step, like GN).  Poor start: misses
+    and rejections are re-eliminated - and the accept / reject sequence is the oracle's either way."""
+    sp = synth.make_problem(400, "eucm", outlier_frac=0.01)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    _, _, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    _, _, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    assert (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected) == (rep_o.status, rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected)
+    assert rep.lm_spec_hits >= 1 and rep.lm_spec_hits + rep.lm_spec_misses <= rep.lm_accepted
+    sp = synth.make_problem(8, "eucm", init_perturb=0.8, outlier_frac=0.05, seed=1)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    gp.apply_reference_bounds(); op.apply_reference_bounds()
+    _, _, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    _, _, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    assert rep.lm_rejected >= 1
+    assert (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected) == (rep_o.status, rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected)
 
 
 @pytest.mark.parametrize("fused", [True, False])
