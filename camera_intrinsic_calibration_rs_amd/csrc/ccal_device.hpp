@@ -70,55 +70,42 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
     c = ((k + 1) & 2) ? -c1 : c1;
 }
 
-// R = exp([w]x) and G_k = dR/dw_k (row-major 3x3 each), series below theta^2 < 0.04.
-// The reference's quaternion path (nalgebra from_scaled_axis) returns the identity as a constant at
-// exactly rvec == 0, i.e. a zero rvec-Jacobian there; we use the true limit dR/dw_k = [e_k]x instead
-// ("rvec = 0").
-__device__ inline void so3_exp_jac(const double w[3], double R[9], double G[27]) {
+// R = exp([w]x) and the left Jacobian of SO(3), J_l(w) = a I + b W + e w w^T with
+//   a = sin t / t,  b = (1 - cos t) / t^2,  e = (t - sin t) / t^3 = (1 - a) / t^2        (series below t^2 < 0.04).
+// d(R X)/dw_k = (k-th column of J_l) x (R X): what forward-mode duals through Rodrigues' formula evaluate to, in
+// closed form (three 3-vectors instead of three 3 x 3 matrices dR/dw_k).
+// The reference's quaternion path (nalgebra from_scaled_axis) returns the identity as a constant at exactly
+// rvec == 0, i.e. a zero rvec-Jacobian there; we use the true limit J_l = I instead ("rvec = 0").
+__device__ inline void so3_exp_ljac(const double w[3], double R[9], double JL[9]) {
     const double wx = w[0], wy = w[1], wz = w[2];
-    const double t2 = wx * wx + wy * wy + wz * wz;
-    double a, b, c, d;
+    const double xx = wx * wx, yy = wy * wy, zz = wz * wz;
+    const double t2 = xx + yy + zz;
+    double a, b, e;
     if (t2 < 0.04) {
         a = 1.0 + t2 * (-1.0 / 6 + t2 * (1.0 / 120 + t2 * (-1.0 / 5040 + t2 * (1.0 / 362880 + t2 * (-1.0 / 39916800 + t2 * (1.0 / 6227020800.0))))));
         b = 0.5 + t2 * (-1.0 / 24 + t2 * (1.0 / 720 + t2 * (-1.0 / 40320 + t2 * (1.0 / 3628800 + t2 * (-1.0 / 479001600 + t2 * (1.0 / 87178291200.0))))));
-        c = -1.0 / 3 + t2 * (1.0 / 30 + t2 * (-1.0 / 840 + t2 * (1.0 / 45360 + t2 * (-1.0 / 3991680 + t2 * (1.0 / 518918400.0)))));
-        d = -1.0 / 12 + t2 * (1.0 / 180 + t2 * (-1.0 / 6720 + t2 * (1.0 / 453600 + t2 * (-1.0 / 47900160 + t2 * (1.0 / 7264857600.0)))));
+        e = 1.0 / 6 + t2 * (-1.0 / 120 + t2 * (1.0 / 5040 + t2 * (-1.0 / 362880 + t2 * (1.0 / 39916800 + t2 * (-1.0 / 6227020800.0 + t2 * (1.0 / 1307674368000.0))))));
     } else {
         double t, it;
         fast_sqrt_rsqrt(t2, t, it);
         double s, co, sh, ch;
         fast_sincos(t, s, co);
         fast_sincos(0.5 * t, sh, ch);
-        (void)ch;
+        (void)ch; (void)co;
         const double it2 = it * it;
         a = s * it;
         b = 2.0 * sh * sh * it2;          // (1 - cos t) / t^2 without cancellation
-        c = (co - a) * it2;
-        d = (a - 2.0 * b) * it2;
+        e = (1.0 - a) * it2;              // t^2 >= 0.04: 1 - a >= 6.6e-3, no harmful cancellation
     }
-    const double xx = wx * wx, yy = wy * wy, zz = wz * wz, xy = wx * wy, xz = wx * wz, yz = wy * wz;
+    const double xy = wx * wy, xz = wx * wz, yz = wy * wz;
     // R = I + a W + b W^2,  W^2 = w w^T - t2 I
     R[0] = 1.0 - b * (yy + zz); R[1] = b * xy - a * wz;     R[2] = b * xz + a * wy;
     R[3] = b * xy + a * wz;     R[4] = 1.0 - b * (xx + zz); R[5] = b * yz - a * wx;
     R[6] = b * xz - a * wy;     R[7] = b * yz + a * wx;     R[8] = 1.0 - b * (xx + yy);
-    // G_k = c w_k W + a E_k + d w_k W^2 + b (E_k W + W E_k)
-    const double W[9] = { 0.0, -wz, wy, wz, 0.0, -wx, -wy, wx, 0.0 };
-    const double W2[9] = { -(yy + zz), xy, xz, xy, -(xx + zz), yz, xz, yz, -(xx + yy) };
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double wk = w[k];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                // E_k[i][j] = -eps_{ijk}
-                const int e = (i == j || j == k || i == k) ? 0 : (((j - i + 3) % 3 == 1) ? 1 : -1);   // eps_{ijk}
-                const double Ek = -(double)e;
-                const double sym = (j == k ? w[i] : 0.0) + (i == k ? w[j] : 0.0) - (i == j ? 2.0 * wk : 0.0);
-                G[k * 9 + i * 3 + j] = c * wk * W[i * 3 + j] + a * Ek + d * wk * W2[i * 3 + j] + b * sym;
-            }
-        }
-    }
+    // J_l = a I + b W + e w w^T  (row-major)
+    JL[0] = a + e * xx;      JL[1] = e * xy - b * wz; JL[2] = e * xz + b * wy;
+    JL[3] = e * xy + b * wz; JL[4] = a + e * yy;      JL[5] = e * yz - b * wx;
+    JL[6] = e * xz - b * wy; JL[7] = e * yz + b * wx; JL[8] = a + e * zz;
 }
 
 __device__ inline void mat3_mul(const double* A, const double* B, double* C) {
@@ -134,26 +121,22 @@ __device__ inline void mat3_vec(const double* A, const double* v, double* o) {
 
 // Fill the frame constants for one observation frame.  pose = rvec,tvec of T_0_b; extr = rvec,tvec
 // of T_c_0 (OTHER only).  Every lane computes the same values; `fc` may be registers or LDS.
-// k-th column of the left Jacobian from the derivative of the rotation: [a_k]x = (dR/dw_k) R^T
-__device__ inline void left_jacobian_col(const double* Gk, const double* R, double* a) {
-    a[0] = Gk[6] * R[3] + Gk[7] * R[4] + Gk[8] * R[5];      // (G R^T)[2][1]
-    a[1] = Gk[0] * R[6] + Gk[1] * R[7] + Gk[2] * R[8];      // (G R^T)[0][2]
-    a[2] = Gk[3] * R[0] + Gk[4] * R[1] + Gk[5] * R[2];      // (G R^T)[1][0]
-}
 template <bool OTHER>
 __device__ inline void frame_setup(const double* pose, const double* extr, double* fc) {
-    double R0[9], G0[27];
-    so3_exp_jac(pose, R0, G0);
+    double R0[9], J0[9];
+    so3_exp_ljac(pose, R0, J0);
     if constexpr (!OTHER) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) fc[FC_RC + i] = R0[i];
 #pragma unroll
         for (int i = 0; i < 3; ++i) fc[FC_TC + i] = pose[3 + i];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) left_jacobian_col(G0 + 9 * k, R0, fc + FC_A + 3 * k);
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fc[FC_A + 3 * k + i] = J0[i * 3 + k];       // a_k = k-th column of J_l
     } else {
-        double R1[9], G1[27], tmp[9], v[3];
-        so3_exp_jac(extr, R1, G1);
+        double R1[9], J1[9], tmp[9], v[3];
+        so3_exp_ljac(extr, R1, J1);
         mat3_mul(R1, R0, tmp);
 #pragma unroll
         for (int i = 0; i < 9; ++i) fc[FC_RC + i] = tmp[i];
@@ -162,10 +145,10 @@ __device__ inline void frame_setup(const double* pose, const double* extr, doubl
         for (int i = 0; i < 3; ++i) fc[FC_TC + i] = v[i] + extr[3 + i];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            double a0[3];
-            left_jacobian_col(G0 + 9 * k, R0, a0);
+            const double a0[3] = { J0[k], J0[3 + k], J0[6 + k] };
             mat3_vec(R1, a0, fc + FC_A + 3 * k);             // R1 (a x b) = (R1 a) x (R1 b)
-            left_jacobian_col(G1 + 9 * k, R1, fc + FC_B + 3 * k);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fc[FC_B + 3 * k + i] = J1[i * 3 + k];
         }
 #pragma unroll
         for (int i = 0; i < 9; ++i) fc[FC_R1 + i] = R1[i];

@@ -28,11 +28,11 @@ __device__ __forceinline__ void wave_lds_sync() {
 #ifndef CCAL_EVAL_NT
 #define CCAL_EVAL_NT 1           // non-temporal stores for the streamed J tile
 #endif
-#ifndef CCAL_EVAL_NTLOAD
-#define CCAL_EVAL_NTLOAD 0
-#endif
 #ifndef CCAL_EVAL_NTR
 #define CCAL_EVAL_NTR 0
+#endif
+#ifndef CCAL_EVAL_PREFETCH
+#define CCAL_EVAL_PREFETCH -1    // -1: chosen per launch (see launch_eval_t); 0 / 1 force one form
 #endif
 #ifndef CCAL_EVAL_PERSIST
 #define CCAL_EVAL_PERSIST 0      // >0: that many workgroups per CU, each wave strides over frames
@@ -41,7 +41,13 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int eval_tile_stride(int D) { return 2 * D + ((D & 1) ? 4 : 2); }
 template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : FC_N0P; }   // padded to keep 16-B alignment
 
-template <int MODEL, bool OF, bool OTHER>
+// PF: request a pass's corner rows one pass ahead (first pass: before the exponential map).  While the inputs of a problem
+// stay in the 256 MiB Infinity Cache from one launch to the next (up to ~46 000 frames x 144 corners), HBM sees a pure
+// write stream and the plain form is 1-2 % faster; beyond that the 8 % of reads queue behind a saturated write stream
+// and their latency, not bandwidth, sets the pace (tools/eval_cliff.py: 40 000 frames run at 6.4 TB/s with warm inputs
+// and at 5.0 TB/s when the inputs are evicted between launches) - there PF hides one memory latency per pass:
+// 50 000 frames 5.4 -> 6.0 TB/s.
+template <int MODEL, bool OF, bool OTHER, bool PF>
 __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int TW = 2 * D;            // doubles per block Jacobian
@@ -65,6 +71,14 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
 
+    // software prefetch: the first pass's corner rows are requested before the (latency-bound) exponential map below,
+    // every later pass one pass ahead - one exposed memory latency per frame instead of one per pass (it is the read
+    // latency under a saturated write stream that limits this kernel once the inputs no longer sit in the Infinity Cache)
+    float pX = 0.f, pY = 0.f, pZ = 0.f, pU = 0.f, pV = 0.f;
+    if constexpr (PF) {
+        const int64_t g0 = start + (lane < n ? lane : 0);
+        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+    }
     {   // frame constants -> LDS (every lane computes, lane 0 stores)
         double pose[6], ex[6];
 #pragma unroll
@@ -87,13 +101,17 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         const int c = base + lane;
         const bool valid = c < n;
         const int64_t g = start + (valid ? c : 0);
-#if CCAL_EVAL_NTLOAD
-        const double X = __builtin_nontemporal_load(a.x + g), Y = __builtin_nontemporal_load(a.y + g),
-                     Z = __builtin_nontemporal_load(a.z + g), uo = __builtin_nontemporal_load(a.u + g),
-                     vo = __builtin_nontemporal_load(a.v + g);
-#else
-        const double X = a.x[g], Y = a.y[g], Z = a.z[g], uo = a.u[g], vo = a.v[g];
-#endif
+        double X, Y, Z, uo, vo;
+        if constexpr (PF) {
+            X = pX; Y = pY; Z = pZ; uo = pU; vo = pV;
+            if (base + 64 < n) {          // wave-uniform: the next pass's rows are in flight while this one computes and stores
+                const int cn = base + 64 + lane;
+                const int64_t gn = start + (cn < n ? cn : 0);
+                pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+            }
+        } else {
+            X = a.x[g]; Y = a.y[g]; Z = a.z[g]; uo = a.u[g]; vo = a.v[g];
+        }
         double ru, rv, J[TW];
         double* Ju = J;
         double* Jv = J + D;
@@ -176,8 +194,8 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
     }
 }
 
-template <int MODEL, bool OF, bool OTHER>
-static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
+template <int MODEL, bool OF, bool OTHER, bool PF>
+static hipError_t launch_eval_pf(const KArgs& a, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int WS = fc_doubles<OTHER>() + 64 * eval_tile_stride(D);
     const size_t lds = sizeof(double) * WS * CCAL_EVAL_WPB;
@@ -185,9 +203,14 @@ static hipError_t launch_eval_t(const KArgs& a, hipStream_t s) {
     if (blocks == 0) return hipSuccess;
     if (CCAL_EVAL_PERSIST > 0) blocks = std::min(blocks, 256 * CCAL_EVAL_PERSIST);
     static DynLdsGuard lds_guard;
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER>), lds, lds_guard); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER, PF>), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER, PF>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
     return hipGetLastError();
+}
+template <int MODEL, bool OF, bool OTHER>
+static hipError_t launch_eval_t(const KArgs& a, bool big_inputs, hipStream_t s) {
+    const bool pf = CCAL_EVAL_PREFETCH < 0 ? big_inputs : CCAL_EVAL_PREFETCH != 0;
+    return pf ? launch_eval_pf<MODEL, OF, OTHER, true>(a, s) : launch_eval_pf<MODEL, OF, OTHER, false>(a, s);
 }
 template <int MODEL, bool OF, bool OTHER>
 static hipError_t launch_err_t(const KArgs& a, hipStream_t s) {
@@ -214,7 +237,10 @@ static hipError_t launch_err_t(const KArgs& a, hipStream_t s) {
     } while (0)
 
 hipError_t launch_eval(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s) {
-    CCAL_DISPATCH(launch_eval_t, p->cams[cam].model, p->one_focal, cam > 0, a, s);
+    // corner rows (20 B each) of the whole problem beyond ~half the Infinity Cache: they will not survive the output
+    // stream from one launch to the next (measured cliff: 46 000 -> 50 000 frames x 144 corners = 132 -> 144 MB)
+    const bool big_inputs = p->n_corners * 20 > (int64_t)120 << 20;
+    CCAL_DISPATCH(launch_eval_t, p->cams[cam].model, p->one_focal, cam > 0, a, big_inputs, s);
 }
 hipError_t launch_reproj_err(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s) {
     CCAL_DISPATCH(launch_err_t, p->cams[cam].model, p->one_focal, cam > 0, a, s);

@@ -29,6 +29,22 @@ def build():
     subprocess.check_call(["make", "-C", _HERE, "-s"])
 
 
+def use_native_build(timeout: float = 300.0) -> str:
+    """Switch this process to a build of the oracle for the host it runs on (-O3 -march=native, oracle/_native/): what
+    bench.py's cpu_baseline leg times.  Returns "native", or "x86-64-v3" when that build is not possible here."""
+    global _lib, LIB_PATH
+    native = os.path.join(_HERE, "_native", "liboracle_ccal.so")
+    try:
+        subprocess.run(["make", "-C", _HERE, "-s", "native"], check=True, timeout=timeout,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:  # noqa: BLE001 - no compiler on this host: keep the portable build
+        return "x86-64-v3"
+    LIB_PATH = native
+    _lib = None
+    load()
+    return "native"
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -59,6 +75,9 @@ def load():
         "oracle_convert_model": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, _u8,
                                            C.POINTER(C.c_int), C.c_void_p]),
         "oracle_hardware_threads": (C.c_int, []),
+        "oracle_usable_cpus": (C.c_int, []),
+        "oracle_eval_timed_heap": (C.c_double, [D, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
+        "oracle_eval_heap": (C.c_int, [D, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -186,13 +205,21 @@ class OracleProblem:
         assert rc == 0
         return r, J
 
-    def eval_timed(self, intr, poses, extr=None, threads=1, reps=1):
-        """Wall seconds for `reps` full evaluations on `threads` threads (cpu_baseline leg of bench.py)."""
+    def eval_timed(self, intr, poses, extr=None, threads=1, reps=1, heap_duals=False):
+        """Wall seconds for `reps` full evaluations on `threads` threads (cpu_baseline leg of bench.py).  heap_duals: the
+        per-corner evaluation with heap-backed dual numbers (the container tiny-solver uses) instead of stack arrays."""
         intr, poses, extr = self._params(intr, poses, extr)
         if not hasattr(self, "_rbuf"):
             self._rbuf = np.empty((self.n_corners, 2)); self._jbuf = np.empty(self.j_len)
-        return float(self.lib.oracle_eval_timed(C.byref(self.desc), _p(intr), _p(poses), _p(extr), threads, reps,
-                                                _p(self._rbuf), _p(self._jbuf)))
+        fn = self.lib.oracle_eval_timed_heap if heap_duals else self.lib.oracle_eval_timed
+        return float(fn(C.byref(self.desc), _p(intr), _p(poses), _p(extr), threads, reps, _p(self._rbuf), _p(self._jbuf)))
+
+    def eval_heap(self, intr, poses, extr=None, apply_loss=False, threads=1):
+        intr, poses, extr = self._params(intr, poses, extr)
+        r = np.empty((self.n_corners, 2)); J = np.empty(self.j_len)
+        rc = self.lib.oracle_eval_heap(C.byref(self.desc), _p(intr), _p(poses), _p(extr), int(apply_loss), threads, _p(r), _p(J))
+        assert rc == 0
+        return r, J
 
     def build_normal(self, intr, poses, extr=None, lam=0.0, min_diag=1e-6, max_diag=1e32, full=False):
         intr, poses, extr = self._params(intr, poses, extr)
@@ -281,3 +308,8 @@ def convert_model(src_model: int, src_params, tgt_model: int, tgt_params, width:
 
 def hardware_threads() -> int:
     return int(load().oracle_hardware_threads())
+
+
+def usable_cpus() -> int:
+    """CPUs this process may run on (affinity mask), not the machine's thread count."""
+    return int(load().oracle_usable_cpus())

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <thread>
 
+#include <sched.h>
+
 namespace oracle {
 
 void factor_jacobian_dyn(int D, int model, bool xy, bool other, int p_eff,
@@ -58,10 +60,11 @@ static void eff_to_full(const Layout& L, int c, const double* eff, double* full)
 // One block (corner k of observation frame o): raw r, J (2 x D, row-major).
 static inline void eval_block(const ccal_problem_desc* d, const Layout& L, int cam, int64_t k,
                               const double* eff, const double* pose0, const double* pose1,
-                              double r[2], double* J) {
+                              double r[2], double* J, bool heap_duals = false) {
     const float p3[3] = { d->p3d_x[k], d->p3d_y[k], d->p3d_z[k] };
     const float p2[2] = { d->p2d_u[k], d->p2d_v[k] };
-    factor_jacobian_dyn(L.D[cam], L.model[cam], L.xy, cam > 0, L.Peff[cam], eff, pose0, pose1, p3, p2, r, J);
+    if (heap_duals) factor_jacobian_heap(L.D[cam], L.model[cam], L.xy, cam > 0, L.Peff[cam], eff, pose0, pose1, p3, p2, r, J);
+    else factor_jacobian_dyn(L.D[cam], L.model[cam], L.xy, cam > 0, L.Peff[cam], eff, pose0, pose1, p3, p2, r, J);
 }
 
 // Dense symmetric Cholesky (lower), in place; returns false if not PD.
@@ -366,7 +369,7 @@ int oracle_pose_apply(const double* a, const double* p, double* out) {
 // model and exp-map rebuilt per corner (src/optimization/factors.rs:152-173).  `threads` static
 // partition over observation frames (tiny-solver evaluates blocks from a rayon pool).
 static int oracle_eval_impl(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
-                            int apply_loss, int threads, int reps, double* r_out, double* J_out) {
+                            int apply_loss, int threads, int reps, double* r_out, double* J_out, bool heap_duals = false) {
     Layout L; if (!make_layout(d, L)) return CCAL_ERR_INVALID_ARG;
     double eff[CCAL_MAX_CAMS][9];
     for (int c = 0; c < L.n_cams; ++c) full_to_eff(L, c, intr + (size_t)c * CCAL_PMAX, eff[c]);
@@ -379,7 +382,7 @@ static int oracle_eval_impl(const ccal_problem_desc* d, const double* intr, cons
             for (int64_t k = d->obs_offsets[o]; k < d->obs_offsets[o + 1]; ++k) {
                 double* r = r_out + 2 * k;
                 double* J = J_out + joff[o] + (k - d->obs_offsets[o]) * 2 * D;
-                eval_block(d, L, cam, k, eff[cam], poses + (size_t)slot * 6, extr ? extr + (size_t)cam * 6 : nullptr, r, J);
+                eval_block(d, L, cam, k, eff[cam], poses + (size_t)slot * 6, extr ? extr + (size_t)cam * 6 : nullptr, r, J, heap_duals);
                 if (apply_loss && d->huber_delta > 0.0) {
                     const double sw = std::sqrt(huber_weight(r[0] * r[0] + r[1] * r[1], d->huber_delta));
                     r[0] *= sw; r[1] *= sw; for (int i = 0; i < 2 * D; ++i) J[i] *= sw;
@@ -408,6 +411,18 @@ double oracle_eval_timed(const ccal_problem_desc* d, const double* intr, const d
     const auto t0 = std::chrono::steady_clock::now();
     if (oracle_eval_impl(d, intr, poses, extr, 0, threads, reps, r_out, J_out) != CCAL_OK) return -1.0;
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// the same with heap-backed duals (DualH, the container tiny-solver instantiates the factors with)
+double oracle_eval_timed_heap(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
+                              int threads, int reps, double* r_out, double* J_out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (oracle_eval_impl(d, intr, poses, extr, 0, threads, reps, r_out, J_out, true) != CCAL_OK) return -1.0;
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+int oracle_eval_heap(const ccal_problem_desc* d, const double* intr, const double* poses, const double* extr,
+                     int apply_loss, int threads, double* r_out, double* J_out) {
+    return oracle_eval_impl(d, intr, poses, extr, apply_loss, threads, 1, r_out, J_out, true);
 }
 
 int oracle_reduced_dim(const ccal_problem_desc* d) { Layout L; return make_layout(d, L) ? L.K : -1; }
@@ -720,5 +735,12 @@ int oracle_convert_model(int src_model, const double* src, int tgt_model, double
 }
 
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
+// CPUs this process may actually run on: the scheduler affinity mask (a container / cgroup cpuset shrinks it)
+int oracle_usable_cpus(void) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return (int)std::thread::hardware_concurrency();
+    return CPU_COUNT(&set);
+}
 
 }  // extern "C"

@@ -39,6 +39,7 @@
 // converged intrinsics: for those items parity is UNPINNED against the Rust
 // crates' rounding and is pinned only against the published math.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -95,6 +96,62 @@ template <int N> inline Dual<N> atan2(const Dual<N>& y, const Dual<N>& x) {
     Dual<N> r; r.re = std::atan2(y.re, x.re); const double d = 1.0 / (x.re * x.re + y.re * y.re);
     for (int i = 0; i < N; ++i) r.eps[i] = (x.re * y.eps[i] - y.re * x.eps[i]) * d; return r; }
 template <int N> inline double real(const Dual<N>& a) { return a.re; }
+// ---------------------------------------------------------------------------
+// The same dual number with a HEAP-backed tangent vector of run-time length: what tiny-solver actually instantiates
+// its factors with (num-dual's DualDVec64: every arithmetic result allocates a fresh nalgebra DVector).  Used only by
+// the cpu_baseline leg of bench.py (kind "port-heap") to bracket the reference's per-corner cost from the other side:
+// Dual<N> above (stack array, loops the compiler unrolls and vectorises) is the optimistic port, this the faithful one.
+// An empty tangent vector is the constant's zero tangent.
+// ---------------------------------------------------------------------------
+struct DualH {
+    double re;
+    std::vector<double> eps;
+    DualH() : re(0.0) {}
+    DualH(double v) : re(v) {}
+    static DualH seed(double v, int k, int n) { DualH d(v); d.eps.assign(n, 0.0); d.eps[k] = 1.0; return d; }
+};
+namespace dualh_detail {
+template <class F> inline DualH map2(double re, const DualH& a, const DualH& b, F f) {   // eps_i = f(a_i, b_i), empty = zeros
+    DualH r(re);
+    const size_t n = std::max(a.eps.size(), b.eps.size());
+    if (n) { r.eps.resize(n); for (size_t i = 0; i < n; ++i) r.eps[i] = f(i < a.eps.size() ? a.eps[i] : 0.0, i < b.eps.size() ? b.eps[i] : 0.0); }
+    return r;
+}
+inline DualH scale(double re, const DualH& a, double d) {
+    DualH r(re);
+    if (!a.eps.empty()) { r.eps.resize(a.eps.size()); for (size_t i = 0; i < a.eps.size(); ++i) r.eps[i] = a.eps[i] * d; }
+    return r;
+}
+}  // namespace dualh_detail
+inline DualH operator+(const DualH& a, const DualH& b) { return dualh_detail::map2(a.re + b.re, a, b, [](double x, double y) { return x + y; }); }
+inline DualH operator-(const DualH& a, const DualH& b) { return dualh_detail::map2(a.re - b.re, a, b, [](double x, double y) { return x - y; }); }
+inline DualH operator-(const DualH& a) { return dualh_detail::scale(-a.re, a, -1.0); }
+inline DualH operator*(const DualH& a, const DualH& b) {
+    const double ar = a.re, br = b.re;
+    return dualh_detail::map2(ar * br, a, b, [ar, br](double x, double y) { return x * br + ar * y; });
+}
+inline DualH operator/(const DualH& a, const DualH& b) {
+    const double inv = 1.0 / b.re, q = a.re * inv;
+    return dualh_detail::map2(q, a, b, [inv, q](double x, double y) { return (x - q * y) * inv; });
+}
+inline DualH operator+(const DualH& a, double b) { DualH r = a; r.re += b; return r; }
+inline DualH operator+(double a, const DualH& b) { return b + a; }
+inline DualH operator-(const DualH& a, double b) { DualH r = a; r.re -= b; return r; }
+inline DualH operator-(double a, const DualH& b) { return (-b) + a; }
+inline DualH operator*(const DualH& a, double b) { return dualh_detail::scale(a.re * b, a, b); }
+inline DualH operator*(double a, const DualH& b) { return b * a; }
+inline DualH operator/(const DualH& a, double b) { return a * (1.0 / b); }
+inline DualH operator/(double a, const DualH& b) { return DualH(a) / b; }
+inline DualH sqrt(const DualH& a) { const double s = std::sqrt(a.re); return dualh_detail::scale(s, a, 0.5 / s); }
+inline DualH sin(const DualH& a) { return dualh_detail::scale(std::sin(a.re), a, std::cos(a.re)); }
+inline DualH cos(const DualH& a) { return dualh_detail::scale(std::cos(a.re), a, -std::sin(a.re)); }
+inline DualH exp(const DualH& a) { const double e = std::exp(a.re); return dualh_detail::scale(e, a, e); }
+inline DualH atan2(const DualH& y, const DualH& x) {
+    const double d = 1.0 / (x.re * x.re + y.re * y.re), xr = x.re, yr = y.re;
+    return dualh_detail::map2(std::atan2(y.re, x.re), y, x, [d, xr, yr](double ye, double xe) { return (xr * ye - yr * xe) * d; });
+}
+inline double real(const DualH& a) { return a.re; }
+
 inline double real(double a) { return a; }
 using std::sqrt; using std::sin; using std::cos; using std::exp; using std::atan2;
 
@@ -347,6 +404,29 @@ inline void factor_jacobian(int model, bool xy_same_focal, bool other_cam, int p
     for (int row = 0; row < 2; ++row) {
         r[row] = rr[row].re;
         for (int c = 0; c < D; ++c) J[row * D + c] = rr[row].eps[c];
+    }
+}
+
+// The same block with heap-backed duals of run-time length D (DualH): the container tiny-solver uses.
+inline void factor_jacobian_heap(int D, int model, bool xy_same_focal, bool other_cam, int p_eff,
+                                 const double* params, const double* pose0, const double* pose1,
+                                 const float p3d[3], const float p2d[2], double r[2], double* J) {
+    DualH pv[9], a0[3], b0[3], a1[3], b1[3];
+    int k = 0;
+    for (int i = 0; i < p_eff; ++i) pv[i] = DualH::seed(params[i], k++, D);
+    for (int i = 0; i < 3; ++i) a0[i] = DualH::seed(pose0[i], k++, D);
+    for (int i = 0; i < 3; ++i) b0[i] = DualH::seed(pose0[3 + i], k++, D);
+    DualH rr[2];
+    if (other_cam) {
+        for (int i = 0; i < 3; ++i) a1[i] = DualH::seed(pose1[i], k++, D);
+        for (int i = 0; i < 3; ++i) b1[i] = DualH::seed(pose1[3 + i], k++, D);
+        other_cam_reprojection_factor<DualH>(model, xy_same_focal, pv, a0, b0, a1, b1, p3d, p2d, rr);
+    } else {
+        reprojection_factor<DualH>(model, xy_same_focal, pv, a0, b0, p3d, p2d, rr);
+    }
+    for (int row = 0; row < 2; ++row) {
+        r[row] = rr[row].re;
+        for (int c = 0; c < D; ++c) J[row * D + c] = c < (int)rr[row].eps.size() ? rr[row].eps[c] : 0.0;
     }
 }
 

@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Developer tool: interleaved A/B timing of mode E for several library builds in ONE process per build is not possible
+(one libccal per process), so: run every (variant, size) in its own subprocess, round-robin, R rounds, report medians."""
+import json, os, subprocess, sys, statistics
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+variants = sys.argv[1].split(",")
+sizes = [int(x) for x in sys.argv[2].split(",")]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+extra = sys.argv[4:] 
+res = {}
+for rd in range(rounds):
+    for F in sizes:
+        for v in variants:
+            env = dict(os.environ)
+            if v != "base": env["CCAL_LIB"] = f"{root}/camera_intrinsic_calibration_rs_amd/lib/variants/libccal_{v}.so"
+            o = subprocess.run([sys.executable, f"{root}/tools/time_kernels.py", "--what", "eval", "--frames", str(F), "--reps", "30"] + extra,
+                               env=env, capture_output=True, text=True).stdout.strip().split("\n")[-1]
+            try: res.setdefault((v, F), []).append(json.loads(o)["eval_GBps"])
+            except Exception as e: print("ERR", v, F, o[-200:])
+for (v, F), xs in sorted(res.items(), key=lambda t: (t[0][1], t[0][0])):
+    print(f"{F:6d} {v:12s} median {statistics.median(xs):7.0f} GB/s  all {[round(x) for x in xs]}")
