@@ -277,7 +277,11 @@ __device__ __forceinline__ void project_uv(const double* th, double x, double y,
 
 // One residual block: r[2] and the two Jacobian rows Ju[D], Jv[D].
 //   th : FULL model parameters (fy == fx when ONE_FOCAL), fc : frame constants.
-template <int MODEL, bool ONE_FOCAL, bool OTHER>
+// PHI (camera-0 blocks of the single-camera Gram kernels): the three rotation columns are taken with respect to a LEFT
+// perturbation phi of the rotation, d(R X) = phi x (R X), i.e. row (R X) x ju - no frame constants a_k, a third of the
+// arithmetic.  d/d rvec = (d/d phi) J_l(rvec) with the frame's 3 x 3 left Jacobian, which the per-frame elimination
+// applies ONCE to the frame's reduced Gram blocks (k_schur1 / k_schur1m) instead of every corner applying it to its rows.
+template <int MODEL, bool ONE_FOCAL, bool OTHER, bool PHI = false>
 __device__ __forceinline__ void corner_block(const double* th, const double* fc,
                                              double X, double Y, double Z, double uo, double vo,
                                              double& ru, double& rv, double* Ju, double* Jv) {
@@ -308,15 +312,22 @@ __device__ __forceinline__ void corner_block(const double* th, const double* fc,
     // d(u,v)/dp
     const double ju[3] = { fx * dmx[0], fx * dmx[1], fx * dmx[2] };
     const double jv[3] = { fy * dmy[0], fy * dmy[1], fy * dmy[2] };
-    // rvec_0_b columns: a_k x (RC X)
+    if constexpr (PHI) {
+        static_assert(!OTHER || !PHI, "the phi basis is used by camera-0 blocks only");
+        // d(u, v) / d phi = (R X) x j
+        Ju[PE + 0] = ry * ju[2] - rz * ju[1]; Ju[PE + 1] = rz * ju[0] - rx * ju[2]; Ju[PE + 2] = rx * ju[1] - ry * ju[0];
+        Jv[PE + 0] = ry * jv[2] - rz * jv[1]; Jv[PE + 1] = rz * jv[0] - rx * jv[2]; Jv[PE + 2] = rx * jv[1] - ry * jv[0];
+    } else {
+        // rvec_0_b columns: a_k x (RC X)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double* A = fc + FC_A + 3 * k;
-        const double qx = A[1] * rz - A[2] * ry;
-        const double qy = A[2] * rx - A[0] * rz;
-        const double qz = A[0] * ry - A[1] * rx;
-        Ju[PE + k] = ju[0] * qx + ju[1] * qy + ju[2] * qz;
-        Jv[PE + k] = jv[0] * qx + jv[1] * qy + jv[2] * qz;
+        for (int k = 0; k < 3; ++k) {
+            const double* A = fc + FC_A + 3 * k;
+            const double qx = A[1] * rz - A[2] * ry;
+            const double qy = A[2] * rx - A[0] * rz;
+            const double qz = A[0] * ry - A[1] * rx;
+            Ju[PE + k] = ju[0] * qx + ju[1] * qy + ju[2] * qz;
+            Jv[PE + k] = jv[0] * qx + jv[1] * qy + jv[2] * qz;
+        }
     }
     if constexpr (!OTHER) {
 #pragma unroll
@@ -341,6 +352,36 @@ __device__ __forceinline__ void corner_block(const double* th, const double* fc,
 #pragma unroll
         for (int k = 0; k < 3; ++k) { Ju[PE + 9 + k] = ju[k]; Jv[PE + 9 + k] = jv[k]; }
     }
+}
+
+// From the phi basis of a frame's reduced Gram blocks to the rvec basis (see corner_block<..., PHI>): T = diag(J_l, I).
+//   C  packed lower 6 x 6 pose block (index i (i + 1) / 2 + j, pose order rvec | tvec), in place
+//   jl the frame's left Jacobian as its three columns a_k: jl[3 k + m] = J_l[m][k]
+__device__ __forceinline__ void phi_to_rvec_C(double* C, const double* jl) {
+    // rows t = 3..5, columns phi: C[t][i] <- sum_m C[t][m] J_l[m][i]
+#pragma unroll
+    for (int t = 3; t < 6; ++t) {
+        const double c0 = C[t * (t + 1) / 2 + 0], c1 = C[t * (t + 1) / 2 + 1], c2 = C[t * (t + 1) / 2 + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) C[t * (t + 1) / 2 + i] = c0 * jl[3 * i + 0] + c1 * jl[3 * i + 1] + c2 * jl[3 * i + 2];
+    }
+    // phi x phi block: J_l^T M J_l with the symmetric M
+    const double M[9] = { C[0], C[1], C[3], C[1], C[2], C[4], C[3], C[4], C[5] };
+    double N[9];                                   // N = M J_l
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) N[r * 3 + i] = M[r * 3 + 0] * jl[3 * i + 0] + M[r * 3 + 1] * jl[3 * i + 1] + M[r * 3 + 2] * jl[3 * i + 2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) C[i * (i + 1) / 2 + j] = jl[3 * i + 0] * N[0 * 3 + j] + jl[3 * i + 1] * N[1 * 3 + j] + jl[3 * i + 2] * N[2 * 3 + j];
+}
+// one column of [B | g] (six pose rows): rows 0..2 <- J_l^T (rows 0..2)
+__device__ __forceinline__ void phi_to_rvec_col(double* b, const double* jl) {
+    const double b0 = b[0], b1 = b[1], b2 = b[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = jl[3 * i + 0] * b0 + jl[3 * i + 1] * b1 + jl[3 * i + 2] * b2;
 }
 
 // Point in the camera frame only (cost / validation kernels).

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        corner_block<MODEL, OF, false, true>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);      // rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         const int nv = min(64, n - base);
 #pragma unroll
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
         rec[21 + 6 * K1 + e] = G[(i < K ? i : D) * 16 + (j < K ? j : D)];
     }
     if (lane == 0) a.cost_f[f] = G[D * 16 + D];
+    if (lane < 9) rec[praw_jl_off(K) + lane] = fc[FC_A + lane];      // the frame's left Jacobian: k_schur1(m) maps phi -> rvec with it
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -269,9 +270,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     const DevState* st = a.st;
     if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int grp = lane / LPF, gl = lane % LPF;
+    // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
+    const bool lane_ok = lane < G * LPF;
+    const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
-    const bool active = f < a.n_obs;
+    const bool active = lane_ok && f < a.n_obs;
     const int fa_ = active ? f : 0;
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         if (active && gl == 0) a.mc_f[f] = mc;
         double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
-        if (gl == 0) {
+        if (gl == 0 && lane_ok) {
 #pragma unroll
             for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
         }
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     // same trip count for the whole wave: the largest frame of the four
     int nmax = n;
 #pragma unroll
-    for (int off = LPF; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    for (int off = ((LPF & (LPF - 1)) == 0 ? LPF : 1); off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
     for (int base = 0; base < nmax; base += LPF) {
         const int c = base + gl;
         const bool valid = c < n;
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        corner_block<MODEL, OF, false, true>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);      // rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -417,6 +420,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             if (e == NE - 1) a.cost_f[ff] = v;                       // the last entry is r x r
         }
     }
+    // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
+    if (active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
 }
 
 // k_gram1w: k_gram1v with two wavefronts per SIMD.  k_gram1v needs 256 VGPRs + 66 AGPRs (91 accumulators and the
@@ -449,9 +454,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const DevState* st = a.st;
     if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int grp = lane / LPF, gl = lane % LPF;
+    // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
+    const bool lane_ok = lane < G * LPF;
+    const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
-    const bool active = f < a.n_obs;
+    const bool active = lane_ok && f < a.n_obs;
     const int fa_ = active ? f : 0;
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
         if (active && gl == 0) a.mc_f[f] = mc;
         double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
-        if (gl == 0) {
+        if (gl == 0 && lane_ok) {
 #pragma unroll
             for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
         }
@@ -527,7 +534,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     // same trip count for the whole wave: the largest frame of the four
     int nmax = n;
 #pragma unroll
-    for (int off = LPF; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+    for (int off = ((LPF & (LPF - 1)) == 0 ? LPF : 1); off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
     for (int base = 0; base < nmax; base += LPF) {
         asm volatile("" ::: "memory");      // frame constants stay in LDS: no 78 registers of hoisted copies
         const int c = base + gl;
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);
+        corner_block<MODEL, OF, false, true>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);      // rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -634,6 +641,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             if (e == NR - 1) a.cost_f[ff] = v;                       // the last entry is r x r
         }
     }
+    // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
+    if (active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
 }
 
 template <int MODEL, bool OF, int LPF, bool W>
@@ -652,6 +661,21 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
+// Lanes per frame.  Two wavefronts fit a SIMD (2 048 slots on the chip) and a wavefront's life is the same whether the
+// chip is full or not, so what a launch costs is ROUNDS x (corner passes per lane x pass + per-wavefront set-up and
+// reduction): few lanes per frame = many corner passes per lane but fewer wavefronts and the set-up / reduction
+// amortised over more corners.  10 000 frames at 16 lanes per frame are 2 500 wavefronts = one full round and a second
+// one for the last 452 (36 us); at 12 lanes (5 frames per wavefront, 4 lanes idle) 2 000 wavefronts = ONE round.
+// The table below is the measured optimum of the whole build (tools/sweep_lpf.py); CCAL_GRAMV_LPF overrides.
+static int gram_lanes_per_frame(int n_obs) {
+    static const int lpf_env = [] { const char* e = std::getenv("CCAL_GRAMV_LPF"); return e ? std::atoi(e) : 0; }();
+    if (lpf_env) return lpf_env;
+    if (n_obs <= 1024) return 64;
+    if (n_obs <= 4096) return 32;
+    if (n_obs <= 8192) return 16;
+    if (n_obs <= 10240) return 12;
+    return 8;
+}
 template <int MODEL, bool OF>
 static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // More wavefronts than SIMDs (>= 2000 frames): k_gram1w, two wavefronts per SIMD (10 000 frames: 40 vs 53 us).
@@ -661,19 +685,13 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     constexpr int NCt = block_dim(MODEL, OF, false) + 1;
     // larger triangles (KB4) do not fit two wavefronts per SIMD without scratch: k_gram1v there
     const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 105);
-    static const int lpf_env = [] { const char* e = std::getenv("CCAL_GRAMV_LPF"); return e ? std::atoi(e) : 0; }();
-    // measured optimum of the whole build (tools/time_kernels.py --what normal, CCAL_GRAMV_LPF sweep): a wavefront per
-    // frame up to one wavefront per SIMD (1 024 frames), 32 lanes per frame up to ~4 800 frames (<= 2 400 wavefronts on
-    // 2 048 slots), 16 beyond
-    const int lpf = lpf_env ? lpf_env : (a.n_obs > 4800 ? 16 : a.n_obs > 1024 ? 32 : 64);
-    if (w) {
-        if (lpf == 16) return launch_gram1v_l<MODEL, OF, 16, true>(a, s);
-        if (lpf == 32) return launch_gram1v_l<MODEL, OF, 32, true>(a, s);
-        return launch_gram1v_l<MODEL, OF, 64, true>(a, s);
+    const int lpf = gram_lanes_per_frame(a.n_obs);
+#define CCAL_LPF_CASE(L) case L: return w ? launch_gram1v_l<MODEL, OF, L, true>(a, s) : launch_gram1v_l<MODEL, OF, L, false>(a, s);
+    switch (lpf) {
+        CCAL_LPF_CASE(8) CCAL_LPF_CASE(12) CCAL_LPF_CASE(16) CCAL_LPF_CASE(32)
+        default: return w ? launch_gram1v_l<MODEL, OF, 64, true>(a, s) : launch_gram1v_l<MODEL, OF, 64, false>(a, s);
     }
-    if (lpf == 16) return launch_gram1v_l<MODEL, OF, 16, false>(a, s);
-    if (lpf == 32) return launch_gram1v_l<MODEL, OF, 32, false>(a, s);
-    return launch_gram1v_l<MODEL, OF, 64, false>(a, s);
+#undef CCAL_LPF_CASE
 }
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
@@ -754,22 +772,29 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
     for (int f = gw; f < a.n_obs; f += a.n_pw) {
         const int slot = a.obs_slot[f];
         const double* rec = a.praw[set] + (int64_t)f * a.PRAW;
-        if (lane < 21) { const double v = rec[lane]; Cm[li * 6 + lr] = v; Cm[lr * 6 + li] = v; }
+        if (lane < 21) Cm[lane] = rec[lane];                                   // packed lower triangle, phi basis
+        if (lane >= 32 && lane < 41) Cm[21 + lane - 32] = rec[praw_jl_off(K) + lane - 32];   // the frame's left Jacobian
         for (int e = lane; e < 6 * K1; e += 64) Bm[e] = rec[21 + e];
         double adir[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) { const int e = lane + 64 * q; adir[q] = e < NA ? rec[21 + 6 * K1 + e] : 0.0; }
         acc_mc += a.mc_f[f];
         wsync();
-        // 6x6 Cholesky of C + lambda clamp(diag C): every lane runs the same factorisation (diag inverted)
+        // phi -> rvec, then the 6x6 Cholesky of C + lambda clamp(diag C): every lane runs the same factorisation (diag inverted)
+        double Cr[21], jl[9];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Cr[i] = Cm[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) jl[i] = Cm[21 + i];
+        phi_to_rvec_C(Cr, jl);
         double L[21], dC[6];
         bool ok = true;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            dC[i] = Cm[i * 6 + i];
+            dC[i] = Cr[i * (i + 1) / 2 + i];
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                double t = Cm[i * 6 + j];
+                double t = Cr[i * (i + 1) / 2 + j];
                 if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
 #pragma unroll
                 for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
@@ -790,15 +815,22 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
             for (int e = lane; e < 6 * K1; e += 64) Ym[e] = 0.0;
         } else {
             if (lane < K1) {
-                double y[6];
+                double bc[6], y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + lane];
+                phi_to_rvec_col(bc, jl);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    double t = Bm[i * K1 + lane];
+                    double t = bc[i];
 #pragma unroll
                     for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
                     y[i] = t * L[i * (i + 1) / 2 + i];
                     Ym[i * K1 + lane] = y[i];
                     pf[21 + i * K1 + lane] = y[i];
+                }
+                if (lane == K) {                   // g_p in the rvec basis
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
                 }
             }
             {   // lane i stores L[i], lane i the damping diagonal dC[i]: a select chain over static register indices (no
@@ -809,7 +841,7 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
 #pragma unroll
                 for (int i = 1; i < 6; ++i) dv = lane == i ? dC[i] : dv;
                 if (lane < 21) pf[lane] = lv;
-                if (lane < 6) { pf[21 + 6 * K1 + lane] = Bm[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dv; }
+                if (lane < 6) pf[21 + 6 * K1 + 6 + lane] = dv;
             }
         }
         wsync();
@@ -848,7 +880,7 @@ template <int K>
 __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
     constexpr int K1 = K + 1, NA = K1 * K1;
     constexpr int NQ = (NA + 15) / 16;                    // A / Y^T Y entries per lane
-    constexpr int REC = 21 + 6 * K1 + NA;                 // C (21) | [B|g] (6 x K1) | A (K1 x K1)
+    constexpr int REC = 21 + 6 * K1 + NA + 9;             // C (21) | [B|g] (6 x K1) | A (K1 x K1) | J_l (9)
     constexpr int GS = (REC + 6 * K1 + 1) & ~1;           // per frame in LDS: record | Y (6 x K1)
     __shared__ double smem[16 * GS];
     __shared__ double blk[16][2 * NA + 2];
@@ -875,14 +907,21 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
     wsync();
     bool ok = true;
     if (active) {
-        // 6x6 Cholesky of C + lambda clamp(diag C) from the packed lower triangle; every lane of the frame's 16 runs it
+        // phi -> rvec, then the 6x6 Cholesky of C + lambda clamp(diag C) from the packed lower triangle; every lane of
+        // the frame's 16 runs it
+        double Cr[21], jl[9];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Cr[i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) jl[i] = R[praw_jl_off(K) + i];
+        phi_to_rvec_C(Cr, jl);
         double L[21], dC[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            dC[i] = R[i * (i + 1) / 2 + i];
+            dC[i] = Cr[i * (i + 1) / 2 + i];
 #pragma unroll
             for (int j = 0; j <= i; ++j) {
-                double t = R[i * (i + 1) / 2 + j];
+                double t = Cr[i * (i + 1) / 2 + j];
                 if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
 #pragma unroll
                 for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
@@ -903,15 +942,22 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
             for (int e = gl; e < 6 * K1; e += 16) Ym[e] = 0.0;
         } else {
             if (gl < K1) {
-                double y[6];
+                double bc[6], y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + gl];
+                phi_to_rvec_col(bc, jl);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    double t = Bm[i * K1 + gl];
+                    double t = bc[i];
 #pragma unroll
                     for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
                     y[i] = t * L[i * (i + 1) / 2 + i];
                     Ym[i * K1 + gl] = y[i];
                     pf[21 + i * K1 + gl] = y[i];
+                }
+                if (gl == K) {                     // g_p in the rvec basis
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
                 }
             }
             {   // lane gl stores L[gl] and L[16 + gl], dC[gl]: select chains over static register indices, coalesced stores
@@ -924,7 +970,7 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
                 for (int i = 1; i < 6; ++i) dv = gl == i ? dC[i] : dv;
                 pf[gl] = l0;
                 if (gl < 5) pf[16 + gl] = l1;
-                if (gl < 6) { pf[21 + 6 * K1 + gl] = Bm[gl * K1 + K]; pf[21 + 6 * K1 + 6 + gl] = dv; }
+                if (gl < 6) pf[21 + 6 * K1 + 6 + gl] = dv;
             }
         }
     }

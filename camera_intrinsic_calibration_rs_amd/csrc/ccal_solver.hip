@@ -74,7 +74,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     FusedWs* f = new FusedWs();
     w->fws = f;
     const int K1 = p->K + 1;
-    f->PRAW = (21 + 6 * K1 + K1 * K1 + 1) & ~1;
+    f->PRAW = praw_size(p->K);
     f->RB1 = fused_red_size(p->K);
     const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
     int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 16384);   // 4 workgroups of 4 waves per CU

@@ -302,6 +302,40 @@ def test_frames_of_any_size(gpu_ctx, oracle, n_corners, n_frames):
     assert (np.abs(intr[0, :6] - intr_o[0, :6]) / np.abs(intr_o[0, :6])).max() <= 1e-6
 
 
+_LPF_SCRIPT = """
+import numpy as np, sys
+sys.path.insert(0, {root!r})
+from camera_intrinsic_calibration_rs_amd import _ffi, synth
+from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
+from oracle import binding as ob
+ctx = Context(0)
+for n_frames, model in ((300, "eucm"), (2600, "eucm"), (2600, "ucm"), (700, "kb4")):
+    sp = synth.make_problem(n_frames, model, ragged=True, outlier_frac=0.01)
+    gp = Problem.from_synth(ctx, sp); op = ob.OracleProblem.from_synth(sp)
+    S, b, c = gp.build_normal(sp.intr0, sp.poses0, lam=1e-3); So, bo, co = op.build_normal(sp.intr0, sp.poses0, lam=1e-3)
+    assert abs(c - co) <= 1e-12 * co and np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+    for m in (0, 1):
+        i, p, _, r = gp.solve(sp.intr0, sp.poses0, opts=default_opts(m)); io, po, _, ro = op.solve(sp.intr0, sp.poses0, opts=default_opts(m))
+        assert (r.status, r.iterations) == (ro.status, ro.iterations), (r.status, r.iterations, ro.status, ro.iterations)
+        P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+        assert (np.abs(i[0, :P] - io[0, :P]) / np.maximum(np.abs(io[0, :P]), 1e-3)).max() <= 1e-6
+        assert np.abs(p - po).max() <= 1e-7
+print("LPF-OK")
+"""
+
+
+@pytest.mark.parametrize("lpf", [8, 12, 16, 32, 64])
+def test_gram_lanes_per_frame_every_mapping(lpf):
+    """Every lanes-per-frame mapping of the register Gram kernels (8, 12 - five frames per wavefront, four lanes idle -,
+    16, 32, 64) forced through CCAL_GRAMV_LPF (read once per process, hence the subprocess), ragged frames, with damping
+    (the per-frame phi -> rvec map only shows under damping: the undamped Schur complement is basis invariant)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CCAL_GRAMV_LPF=str(lpf))
+    out = subprocess.run([sys.executable, "-c", _LPF_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=600)
+    assert "LPF-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
 def _tile(sp, rep):
     """`rep` copies of a single-camera synthetic problem, frames renumbered (a large problem without regenerating it)."""
     import dataclasses
