@@ -40,7 +40,13 @@ _MODEL_KEYS = {
     "kb4": ["fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4"],
     "opencv5": ["fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3"],
 }
+# serde tags of GenericModel's variants.  UCM / EUCM / KannalaBrandt4 appear in the reference (data/eucm.json,
+# examples/convert_model.rs:14,19); "OpenCVModel5" is this build's ASSUMPTION about the absent crate (one string to flip).
 _JSON_NAMES = {"ucm": "UCM", "eucm": "EUCM", "kb4": "KannalaBrandt4", "opencv5": "OpenCVModel5"}
+# EUCMT ("Extended Unified with Tangential", README.md:78): a PARAMETER CONTAINER here - target of the closed-form
+# UCM -> EUCMT conversion (src/util.rs:236-243).  Its projection and its JSON field names live only in the absent crate.
+MODEL_EUCMT = 4
+_CONTAINER_KINDS = {"eucmt": (MODEL_EUCMT, 8)}
 
 
 @dataclasses.dataclass
@@ -87,9 +93,9 @@ class GenericModel:
 
     def __init__(self, kind: str, params: Sequence[float], width: float, height: float):
         kind = kind.lower()
-        if kind not in MODEL_NAMES:
+        if kind not in MODEL_NAMES and kind not in _CONTAINER_KINDS:
             raise ValueError(f"unsupported model {kind}")
-        if len(params) != MODEL_NPARAMS[MODEL_NAMES[kind]]:
+        if len(params) != (_CONTAINER_KINDS[kind][1] if kind in _CONTAINER_KINDS else MODEL_NPARAMS[MODEL_NAMES[kind]]):
             raise ValueError("wrong number of parameters")
         self.kind = kind
         self._params = np.asarray(params, dtype=np.float64).copy()
@@ -97,7 +103,7 @@ class GenericModel:
 
     @property
     def model_id(self) -> int:
-        return MODEL_NAMES[self.kind]
+        return _CONTAINER_KINDS[self.kind][0] if self.kind in _CONTAINER_KINDS else MODEL_NAMES[self.kind]
 
     def params(self) -> np.ndarray:
         return self._params.copy()
@@ -116,6 +122,8 @@ class GenericModel:
 
     # cam{i}.json: {"EUCM": {"fx":..,"fy":..,"cx":..,"cy":..,"alpha":..,"beta":..,"width":..,"height":..}} (data/eucm.json)
     def to_json_obj(self) -> dict:
+        if self.kind in _CONTAINER_KINDS:
+            raise NotImplementedError(f"{self.kind}: the JSON field names are defined only in the absent camera-intrinsic-model crate")
         d = {k: float(v) for k, v in zip(_MODEL_KEYS[self.kind], self._params)}
         d["width"] = int(round(self._w)); d["height"] = int(round(self._h))
         return {_JSON_NAMES[self.kind]: d}
@@ -262,13 +270,10 @@ def calib_camera(frame_feature_list: Sequence[Optional[FrameFeature]], generic_c
         prob.close()
 
 
-def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0: Sequence[RvecTvec],
-                                     cam_rtvecs: Sequence[Dict[int, RvecTvec]],
-                                     cams_detected_feature_frames: Sequence[Sequence[Optional[FrameFeature]]],
-                                     xy_same_focal: bool, disabled_distortions: int, cam0_fixed_focal: bool,
-                                     ctx: Optional[Context] = None, opts: Optional[_ffi.SolverOpts] = None
-                                     ) -> Optional[Tuple[List[GenericModel], List[RvecTvec], Dict[int, RvecTvec]]]:
-    """util::calib_all_camera_with_extrinsics (src/util.rs:567-715): joint intrinsics + extrinsics."""
+def _joint_problem_inputs(cameras, t_cam_i_0, cam_rtvecs, cams_detected_feature_frames, xy_same_focal):
+    """Problem description and starting point of the joint problem exactly as src/util.rs:576-651 lays it out (the tests
+    hand the same arrays to the oracle): slots = sorted union of the frame indices with a pose, T_0_b per slot = cam0's
+    pose when it saw the frame, else T_c0^-1 * T_cb of the first camera that did (`.entry().or_insert()` in camera order)."""
     n_cams = len(cameras)
     use = [sorted(cam_rtvecs[c].keys()) for c in range(n_cams)]
     slots, obs_cam, obs_slot, offs, X, U = _flatten(cams_detected_feature_frames, use)
@@ -277,21 +282,34 @@ def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0:
     d, keep = make_desc(n_cams, [m.model_id for m in cameras], [m.width() for m in cameras],
                         [m.height() for m in cameras], xy_same_focal, len(slots), obs_cam, obs_slot, offs,
                         X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
+    intr = _intr_matrix(cameras)
+    extr = np.zeros((n_cams, 6))
+    for c in range(1, n_cams):
+        extr[c] = t_cam_i_0[c].as6()
+    poses = np.zeros((len(slots), 6))
+    for s, fi in enumerate(slots):
+        for c in range(n_cams):
+            if fi in cam_rtvecs[c]:
+                rt = cam_rtvecs[c][fi]
+                poses[s] = (rt if c == 0 else t_cam_i_0[c].inverse().compose(rt)).as6()
+                break
+    return d, keep, slots, intr, poses, extr
+
+
+def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0: Sequence[RvecTvec],
+                                     cam_rtvecs: Sequence[Dict[int, RvecTvec]],
+                                     cams_detected_feature_frames: Sequence[Sequence[Optional[FrameFeature]]],
+                                     xy_same_focal: bool, disabled_distortions: int, cam0_fixed_focal: bool,
+                                     ctx: Optional[Context] = None, opts: Optional[_ffi.SolverOpts] = None
+                                     ) -> Optional[Tuple[List[GenericModel], List[RvecTvec], Dict[int, RvecTvec]]]:
+    """util::calib_all_camera_with_extrinsics (src/util.rs:567-715): joint intrinsics + extrinsics."""
+    n_cams = len(cameras)
+    built = _joint_problem_inputs(cameras, t_cam_i_0, cam_rtvecs, cams_detected_feature_frames, xy_same_focal)
+    if built is None:
+        return None
+    d, keep, slots, intr, poses, extr = built
     prob = Problem(_ctx(ctx), d, keep)
     try:
-        intr = _intr_matrix(cameras)
-        extr = np.zeros((n_cams, 6))
-        for c in range(1, n_cams):
-            extr[c] = t_cam_i_0[c].as6()
-        # T_0_b per slot: cam0's pose when it saw the frame, else T_c0^-1 * T_cb of the first camera that did
-        # (`.entry().or_insert()` in camera order, src/util.rs:633-651)
-        poses = np.zeros((len(slots), 6))
-        for s, fi in enumerate(slots):
-            for c in range(n_cams):
-                if fi in cam_rtvecs[c]:
-                    rt = cam_rtvecs[c][fi]
-                    poses[s] = (rt if c == 0 else t_cam_i_0[c].inverse().compose(rt)).as6()
-                    break
         prob.apply_reference_bounds()
         prob.disable_distortions(disabled_distortions, intr)
         if cam0_fixed_focal:
@@ -343,6 +361,11 @@ def convert_model(source_model: GenericModel, target_model: GenericModel, disabl
     if source_model.kind == "ucm" and target_model.kind == "eucm":                   # closed form: no device needed
         target_model.set_params(list(source_model.params()) + [1.0])
         return target_model
+    if source_model.kind == "ucm" and target_model.kind == "eucmt":                  # src/util.rs:236-243
+        target_model.set_params(list(source_model.params()) + [1.0, 0.0, 0.0])
+        return target_model
+    if source_model.kind in _CONTAINER_KINDS or target_model.kind in _CONTAINER_KINDS:
+        raise CcalError(_ffi.ERR_UNSUPPORTED, "convert_model", "EUCMT can only be the target of the closed-form UCM conversion")
     lib = _ffi.load()
     c = _ctx(ctx)
     src = np.ascontiguousarray(source_model.params(), dtype=np.float64)

@@ -58,7 +58,7 @@ int ccal_set_model_conventions(ccal_ctx* ctx, const ccal_model_conventions* in) 
 }
 
 const char* ccal_version(void) { return "ccal-mi355x 0.2.0 (gfx950)"; }
-int ccal_model_num_params(int model) { return (model >= 0 && model < kNumModels) ? model_np(model) : -1; }
+int ccal_model_num_params(int model) { return (model >= 0 && model < kNumModels) ? model_np(model) : model == CCAL_MODEL_EUCMT ? 8 : -1; }
 
 int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
     if (!out) return CCAL_ERR_INVALID_ARG;
@@ -118,6 +118,7 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     for (int c = 0; c < d->n_cams; ++c) {
         CamLayout& cl = p->cams[c];
         cl.model = d->model[c];
+        if (cl.model == CCAL_MODEL_EUCMT) return fail(ctx, CCAL_ERR_UNSUPPORTED, "EUCMT is a parameter container in this build (its projection is only in the absent camera-intrinsic-model crate)");
         if (cl.model < 0 || cl.model >= kNumModels) return fail(ctx, CCAL_ERR_INVALID_ARG, "unknown camera model");
         cl.P = model_np(cl.model); cl.Peff = cl.P - (p->one_focal ? 1 : 0);
         cl.D = cl.Peff + (c == 0 ? 6 : 12);

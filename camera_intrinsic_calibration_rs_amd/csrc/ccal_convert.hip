@@ -206,6 +206,7 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
                                   double* tgt_params_io, double width, double height, int disabled_distortions,
                                   const ccal_solver_opts* opts, ccal_report* rep) {
     if (!ctx) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
     const int PS = ccal_model_num_params(src_model), P = ccal_model_num_params(tgt_model);
     if (PS < 0 || P < 0 || !src_params || !tgt_params_io || disabled_distortions < 0 || disabled_distortions > P - 4 ||
         !(width >= 1.0) || !(height >= 1.0)) { ctx->err = "ccal_convert_model: invalid argument"; return CCAL_ERR_INVALID_ARG; }
@@ -215,6 +216,17 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
         tgt_params_io[5] = 1.0;
         if (rep) *rep = R;
         return CCAL_OK;
+    }
+    if (src_model == kUCM && tgt_model == CCAL_MODEL_EUCMT) {      // src/util.rs:236-243: beta = 1, both tangential terms 0
+        for (int i = 0; i < 5; ++i) tgt_params_io[i] = src_params[i];
+        tgt_params_io[5] = 1.0; tgt_params_io[6] = 0.0; tgt_params_io[7] = 0.0;
+        if (rep) *rep = R;
+        return CCAL_OK;
+    }
+    if (src_model >= kNumModels || tgt_model >= kNumModels) {
+        // EUCMT is a parameter container here: its projection lives only in the absent camera-intrinsic-model crate
+        ctx->err = "ccal_convert_model: EUCMT can only be the target of the closed-form UCM conversion";
+        return CCAL_ERR_UNSUPPORTED;
     }
     ccal_solver_opts o;
     if (opts) o = *opts; else ccal_set_defaults(&o);
@@ -298,4 +310,5 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
     if (status == CCAL_OK || status == CCAL_ERR_NO_CONVERGENCE) for (int i = 0; i < P; ++i) tgt_params_io[i] = th[i];
     if (status != CCAL_OK && ctx->err.empty()) ctx->err = "ccal_convert_model: solve failed";
     return status;
+    CCAL_API_CATCH(ctx)
 }

@@ -3,8 +3,11 @@
 // (src/optimization/factors.rs:234-272): residual = [scaled_axis(R_diff), t_diff] of
 // T_diff = T_i_b^-1 * T_i_0 * T_0_b, HuberLoss(0.5), Gauss-Newton with tiny-solver's defaults, started
 // from T_i_b * T_0_b^-1 of the first common frame.  SURVEY 8(f) rank 4: a 6-unknown problem with a few
-// hundred residuals -- host code of the library, not a GPU kernel; the Jacobian (a 6 x 6 block per frame)
-// is taken by central differences of the residual.
+// hundred residuals -- host code of the library, not a GPU kernel.  The 6 x 6 block Jacobian is analytic (what the
+// reference's dual numbers evaluate to): with w = rvec, R = exp([w]x), J_l the left Jacobian of SO(3),
+//   R_d = R_ib^T R R_0b                       a step d in rvec is the left perturbation psi = R_ib^T J_l(w) d of R_d
+//   r_rot = log(R_d)                          d r_rot / d rvec = J_l^-1(r_rot) R_ib^T J_l(w),   d r_rot / d tvec = 0
+//   r_t   = R_ib^T (R t_0b + tvec - t_ib)     d r_t / d rvec = R_ib^T [ a_k x (R t_0b) ]_k,      d r_t / d tvec = R_ib^T
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -51,6 +54,57 @@ void se3_residual(const Iso& t_0_b, const Iso& t_i_b_inv, const double* x, doubl
     iso_to6(d, r);
 }
 
+void quat_to_mat(const Q& q, double* R) {
+    const double e0[3] = { 1, 0, 0 }, e1[3] = { 0, 1, 0 }, e2[3] = { 0, 0, 1 };
+    double c0[3], c1[3], c2[3];
+    rot(q, e0, c0); rot(q, e1, c1); rot(q, e2, c2);
+    for (int i = 0; i < 3; ++i) { R[i * 3 + 0] = c0[i]; R[i * 3 + 1] = c1[i]; R[i * 3 + 2] = c2[i]; }
+}
+// left Jacobian of SO(3) and its inverse at w (row-major 3 x 3); series near 0
+void so3_left_jacobian(const double* w, double* J, bool inverse) {
+    const double t2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    double b, e;                 // J = I + b W + e W^2  (inverse: b = -1/2)
+    if (!inverse) {
+        if (t2 < 1e-8) { b = 0.5 - t2 / 24.0; e = 1.0 / 6.0 - t2 / 120.0; }
+        else { const double t = std::sqrt(t2); b = (1.0 - std::cos(t)) / t2; e = (t - std::sin(t)) / (t2 * t); }
+    } else {
+        b = -0.5;
+        if (t2 < 1e-8) e = 1.0 / 12.0 + t2 / 720.0;
+        else { const double t = std::sqrt(t2); e = 1.0 / t2 - (1.0 + std::cos(t)) / (2.0 * t * std::sin(t)); }
+    }
+    const double W[9] = { 0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0 };
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double w2 = 0; for (int k = 0; k < 3; ++k) w2 += W[i * 3 + k] * W[k * 3 + j];
+        J[i * 3 + j] = (i == j ? 1.0 : 0.0) + b * W[i * 3 + j] + e * w2;
+    }
+}
+// residual and its analytic 6 x 6 Jacobian (columns rvec, tvec)
+void se3_residual_jac(const Iso& t_0_b, const Iso& t_i_b_inv, const double* x, double* r, double J[6][6]) {
+    se3_residual(t_0_b, t_i_b_inv, x, r);
+    double Rib_t[9], Jl[9], Jinv[9];
+    quat_to_mat(t_i_b_inv.q, Rib_t);                       // rotation of T_i_b^-1 = R_ib^T
+    so3_left_jacobian(x, Jl, false);
+    so3_left_jacobian(r, Jinv, true);
+    double M[9];                                           // R_ib^T J_l(w)
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double t = 0; for (int k = 0; k < 3; ++k) t += Rib_t[i * 3 + k] * Jl[k * 3 + j]; M[i * 3 + j] = t; }
+    double Rt0[3];
+    rot(quat_from_rvec(x), t_0_b.t, Rt0);                  // R t_0b
+    // nalgebra's scaled_axis() returns the CONSTANT zero vector when the rotation has no axis (|imag q| <= eps): with
+    // dual numbers the rotation rows of such a block have a zero Jacobian - which happens in the reference's first
+    // iteration for the frame the start value was built from (src/util.rs:530).  Reproduced for parity.
+    const Iso d = iso_mul(iso_mul(t_i_b_inv, iso_from6(x)), t_0_b);
+    const bool no_axis = std::sqrt(d.q.x * d.q.x + d.q.y * d.q.y + d.q.z * d.q.z) <= 2.220446049250313e-16;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+        double t = 0; for (int k = 0; k < 3; ++k) t += Jinv[i * 3 + k] * M[k * 3 + j];
+        J[i][j] = no_axis ? 0.0 : t; J[i][3 + j] = 0.0; J[3 + i][3 + j] = Rib_t[i * 3 + j];
+    }
+    for (int k = 0; k < 3; ++k) {                           // a_k x (R t_0b), a_k = k-th column of J_l
+        const double a[3] = { Jl[0 * 3 + k], Jl[1 * 3 + k], Jl[2 * 3 + k] };
+        const double c[3] = { a[1] * Rt0[2] - a[2] * Rt0[1], a[2] * Rt0[0] - a[0] * Rt0[2], a[0] * Rt0[1] - a[1] * Rt0[0] };
+        for (int i = 0; i < 3; ++i) J[3 + i][k] = Rib_t[i * 3 + 0] * c[0] + Rib_t[i * 3 + 1] * c[1] + Rib_t[i * 3 + 2] * c[2];
+    }
+}
+
 double cost(const std::vector<Iso>& a, const std::vector<Iso>& binv, const double* x, double delta) {
     double c = 0;
     for (size_t k = 0; k < a.size(); ++k) {
@@ -63,9 +117,18 @@ double cost(const std::vector<Iso>& a, const std::vector<Iso>& binv, const doubl
 
 }  // namespace
 
+// developer / test hook (not in include/ccal.h): one SE3Factor block, residual r[6] and Jacobian J[6][6] row-major
+extern "C" int ccal_debug_se3_factor(const double* pose_0_b, const double* pose_i_b, const double* x, double* r, double* J) {
+    double Jm[6][6];
+    se3_residual_jac(iso_from6(pose_0_b), iso_inv(iso_from6(pose_i_b)), x, r, Jm);
+    std::memcpy(J, Jm, sizeof Jm);
+    return CCAL_OK;
+}
+
 extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common, double* t_i_0_io,
                                           int use_initial, ccal_report* rep) {
     if (!poses_cam0 || !poses_cami || n_common < 1 || !t_i_0_io) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
     const double delta = 0.5;                                   // HuberLoss::new(0.5), src/util.rs:539
     std::vector<Iso> a(n_common), binv(n_common);
     for (int k = 0; k < n_common; ++k) { a[k] = iso_from6(poses_cam0 + 6 * k); binv[k] = iso_inv(iso_from6(poses_cami + 6 * k)); }
@@ -81,15 +144,7 @@ extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double
         double H[36] = { 0 }, g[6] = { 0 };
         for (int k = 0; k < n_common; ++k) {
             double r[6], J[6][6];
-            se3_residual(a[k], binv[k], x, r);
-            for (int c = 0; c < 6; ++c) {
-                const double h = 1e-6;
-                double xp[6], xm[6], rp[6], rm[6];
-                std::memcpy(xp, x, sizeof xp); std::memcpy(xm, x, sizeof xm);
-                xp[c] += h; xm[c] -= h;
-                se3_residual(a[k], binv[k], xp, rp); se3_residual(a[k], binv[k], xm, rm);
-                for (int i = 0; i < 6; ++i) J[i][c] = (rp[i] - rm[i]) / (2 * h);
-            }
+            se3_residual_jac(a[k], binv[k], x, r, J);
             double s = 0; for (int i = 0; i < 6; ++i) s += r[i] * r[i];
             const double w = s <= delta * delta ? 1.0 : delta / std::sqrt(s);
             for (int i = 0; i < 6; ++i) for (int c = 0; c < 6; ++c) {
@@ -122,4 +177,5 @@ extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double
     if (rep) *rep = R;
     if (status == CCAL_OK) std::memcpy(t_i_0_io, x, sizeof x);
     return status;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
 }

@@ -683,8 +683,9 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // CCAL_GRAMV_LDSACC=0|1 forces one or the other.
     static const int force = [] { const char* e = std::getenv("CCAL_GRAMV_LDSACC"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     constexpr int NCt = block_dim(MODEL, OF, false) + 1;
-    // larger triangles (KB4) do not fit two wavefronts per SIMD without scratch: k_gram1v there
-    const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 105);
+    // larger triangles (KB4: 105 / 120 entries, OPENCV5: 120 / 136) do not fit two wavefronts per SIMD without scratch
+    // (one-focal KB4 through k_gram1w: 124 us instead of 64 at 10 000 frames): k_gram1v there
+    const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 91);
     const int lpf = gram_lanes_per_frame(a.n_obs);
 #define CCAL_LPF_CASE(L) case L: return w ? launch_gram1v_l<MODEL, OF, L, true>(a, s) : launch_gram1v_l<MODEL, OF, L, false>(a, s);
     switch (lpf) {

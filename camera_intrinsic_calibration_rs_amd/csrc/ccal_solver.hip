@@ -253,14 +253,14 @@ static bool fused_use_schur1m(const ccal_problem* p, FusedArgs& fa) {
     fa.n_pw = n_pw;
     return true;
 }
-// register-resident Gram when the triangle of [J|r]^T[J|r] fits the VGPR/AGPR file next to the row math
-// (measured at 10 000 frames, GN solve: KB4 0.58 vs 0.60 ms, OPENCV5 0.59 vs 0.55 ms); matrix-core Gram
-// otherwise.  CCAL_GRAM=mfma|valu overrides.
+// Register-resident (VALU) Gram for every model: with the rotation columns in the phi basis it beats the matrix-core
+// kernel also for the 120 / 136-entry triangles of OPENCV5 (10 000 frames, whole build: 70.0 vs 71.8 us two-focal, 59.9 vs
+// 66.1 us one-focal; KB4 64.3 vs 74.0) - f64 MFMA shares the FP64 datapath with the VALU and a 16 x 16 tile computes
+// 256 products where the triangle needs <= 136.  CCAL_GRAM=mfma selects the matrix-core kernel (k_gram1).
 static bool fused_use_valu_gram(const ccal_problem* p) {
-    const int ncols = p->cams[0].D + 1;
-    bool v = ncols * (ncols + 1) / 2 <= 120;      // UCM, EUCM, KB4; OPENCV5 (136 entries) is faster on the matrix cores
-    if (const char* g = std::getenv("CCAL_GRAM")) v = (g[0] == 'v') && ncols * (ncols + 1) / 2 <= 136;
-    return v;
+    (void)p;
+    if (const char* g = std::getenv("CCAL_GRAM")) return g[0] != 'm';
+    return true;
 }
 // Gram + elimination + reduce of one group on the single-camera path (everything but the collective and the decision)
 static hipError_t enqueue_fused_system(const ccal_problem* p, const FusedArgs& fa, bool schur_m, hipStream_t st) {

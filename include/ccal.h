@@ -75,7 +75,10 @@ typedef enum {                    /* camera-intrinsic-model GenericModel variant
     CCAL_MODEL_UCM = 0,           /* [fx,fy,cx,cy,alpha]              tests/optimization_test.rs:41 */
     CCAL_MODEL_EUCM = 1,          /* [fx,fy,cx,cy,alpha,beta]         data/eucm.json              */
     CCAL_MODEL_KB4 = 2,           /* [fx,fy,cx,cy,k1,k2,k3,k4]                                     */
-    CCAL_MODEL_OPENCV5 = 3        /* [fx,fy,cx,cy,k1,k2,p1,p2,k3]                                  */
+    CCAL_MODEL_OPENCV5 = 3,       /* [fx,fy,cx,cy,k1,k2,p1,p2,k3]                                  */
+    CCAL_MODEL_EUCMT = 4          /* [fx,fy,cx,cy,alpha,beta,t1,t2]: PARAMETER CONTAINER ONLY - the target of the closed-form
+                                     UCM -> EUCMT conversion (src/util.rs:236-243); its projection exists only in the absent
+                                     crate, so problems with it are refused with CCAL_ERR_UNSUPPORTED */
 } ccal_model;
 
 /* What this build assumes about the crate camera-intrinsic-model 0.8 (Cargo.toml:25; its source is not part of the
@@ -157,7 +160,7 @@ int ccal_ctx_create(int device_id, void* hip_stream /* hipStream_t or NULL = own
 void ccal_ctx_destroy(ccal_ctx* ctx);
 const char* ccal_last_error(const ccal_ctx* ctx);
 const char* ccal_version(void);
-int ccal_model_num_params(int model);            /* 5 / 6 / 8 / 9, -1 if unknown */
+int ccal_model_num_params(int model);            /* 5 / 6 / 8 / 9 (/ 8 for the EUCMT container), -1 if unknown */
 /* Conventions of a context: read them, change a field, set them (in == NULL restores the defaults).  They apply to
  * everything the context evaluates afterwards (kernels receive the threshold as an argument) and to later
  * ccal_apply_reference_bounds / ccal_convert_model calls. */
@@ -240,7 +243,7 @@ int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cam
  * rays the source model unprojects from rows/cols edge = max(w,h)/100 .. in steps of max(w,h)/30, 10000 where a
  * projection is undefined, HuberLoss(1.0) on the whole block; Gauss-Newton on all target intrinsics with the
  * reference's parameter bounds, the last `disabled_distortions` parameters fixed at 0; UCM -> EUCM is the closed
- * form beta = 1 (util.rs:229-235).  tgt_params_io: in = the target's current parameters (its first four are
+ * form beta = 1 (util.rs:229-235), UCM -> EUCMT the closed form beta = 1, t1 = t2 = 0 (util.rs:236-243).  tgt_params_io: in = the target's current parameters (its first four are
  * replaced by the source's fx, fy, cx, cy: util.rs:256-258), out = the fitted parameters.  opts NULL = the
  * reference's Gauss-Newton defaults.  Rays and the per-iteration Gram run on the device; the <= 9 x 9 solve
  * on the host. */

@@ -14,6 +14,7 @@
 //   util::init_camera_extrinsic         src/util.rs:511-561         init_camera_extrinsic
 //   util::validation                    src/util.rs:721-795         validation
 //   util::convert_model                 src/util.rs:224-282         convert_model
+//   io::object_to_json / write_report   src/io.rs, src/types.rs     model_to_json / poses_to_json / extrinsics_to_json / report_text (+ *_from_json)
 //
 // `None` of the reference == std::nullopt here; nothing falls back to a CPU implementation: every
 // numeric call goes through libccal_hip.so.  Corner order inside a frame is by corner id (std::map), the
@@ -22,9 +23,13 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
 #include <map>
 #include <optional>
 #include <set>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -260,6 +265,13 @@ inline std::vector<RvecTvec> init_camera_extrinsic(const std::vector<std::map<si
 inline void convert_model(const GenericModel& source_model, GenericModel& target_model, size_t disabled_distortions, int device = 0) {
     if ((uint32_t)std::lround(source_model.width()) != (uint32_t)std::lround(target_model.width())) throw std::invalid_argument("source width and target width are not the same.");      // factors.rs:29-33: panic!
     if ((uint32_t)std::lround(source_model.height()) != (uint32_t)std::lround(target_model.height())) throw std::invalid_argument("source height and target height are not the same.");
+    if (source_model.model_id() == CCAL_MODEL_UCM && (target_model.model_id() == CCAL_MODEL_EUCM || target_model.model_id() == CCAL_MODEL_EUCMT)) {
+        std::vector<double> t = source_model.params();                    // closed forms, src/util.rs:229-243: no device needed
+        t.push_back(1.0);
+        if (target_model.model_id() == CCAL_MODEL_EUCMT) { t.push_back(0.0); t.push_back(0.0); }
+        target_model.set_params(t);
+        return;
+    }
     detail::Ctx ctx(device);
     std::vector<double> t = target_model.params();
     const int rc = ccal_convert_model(ctx.h, source_model.model_id(), source_model.params().data(), target_model.model_id(), t.data(),
@@ -318,5 +330,175 @@ public:
     using ReprojectionFactor::ReprojectionFactor;
     std::array<double, 2> residual_func(const std::vector<std::vector<double>>& params, std::vector<double>* J = nullptr) const { return eval(params, true, J); }
 };
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wire formats: what `ccrs` writes next to a calibration, so that results can be diffed against a
+// run of the reference made elsewhere and fed back in as initial values.
+//   cam{i}.json        {"EUCM": {"fx":..,"fy":..,"cx":..,"cy":..,"alpha":..,"beta":..,"width":..,"height":..}}   data/eucm.json:1-11
+//   cam{i}_poses.json  {"<frame index>": {"rvec":[3],"tvec":[3]}, ...}      src/types.rs:13-17, src/bin/camera_calibration.rs:288-293
+//   extrinsics.json    {"rtvecs":[{"rvec":[3],"tvec":[3]}, ...]}            src/types.rs:41-44
+//   report.txt         src/io.rs:21-31
+// serde tags of the model variants: UCM / EUCM / KannalaBrandt4 appear in the reference (data/eucm.json,
+// examples/convert_model.rs:14,19); "OpenCVModel5" is this build's assumption about the absent crate (one string).
+// ---------------------------------------------------------------------------------------------------------------
+namespace json {
+
+struct Value {                               // a JSON value: just enough for the three shapes above
+    enum Kind { Null, Number, String, Array, Object } kind = Null;
+    double num = 0.0;
+    std::string str;
+    std::vector<Value> arr;
+    std::vector<std::pair<std::string, Value>> obj;       // insertion order kept
+    const Value& at(const std::string& k) const {
+        for (auto& kv : obj) if (kv.first == k) return kv.second;
+        throw std::runtime_error("json: missing key " + k);
+    }
+};
+
+class Parser {
+public:
+    explicit Parser(const std::string& s) : s_(s) {}
+    Value parse() { Value v = value(); ws(); if (i_ != s_.size()) fail("trailing characters"); return v; }
+private:
+    const std::string& s_; size_t i_ = 0;
+    [[noreturn]] void fail(const char* m) const { throw std::runtime_error(std::string("json: ") + m + " at offset " + std::to_string(i_)); }
+    void ws() { while (i_ < s_.size() && (s_[i_] == ' ' || s_[i_] == '\n' || s_[i_] == '\t' || s_[i_] == '\r')) ++i_; }
+    Value value() {
+        ws();
+        if (i_ >= s_.size()) fail("unexpected end");
+        const char c = s_[i_];
+        Value v;
+        if (c == '{') {
+            v.kind = Value::Object; ++i_; ws();
+            if (i_ < s_.size() && s_[i_] == '}') { ++i_; return v; }
+            for (;;) {
+                ws(); if (i_ >= s_.size() || s_[i_] != '"') fail("expected a key");
+                std::string k = string();
+                ws(); if (i_ >= s_.size() || s_[i_] != ':') fail("expected ':'");
+                ++i_;
+                v.obj.emplace_back(std::move(k), value());
+                ws(); if (i_ < s_.size() && s_[i_] == ',') { ++i_; continue; }
+                if (i_ < s_.size() && s_[i_] == '}') { ++i_; return v; }
+                fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            v.kind = Value::Array; ++i_; ws();
+            if (i_ < s_.size() && s_[i_] == ']') { ++i_; return v; }
+            for (;;) {
+                v.arr.push_back(value());
+                ws(); if (i_ < s_.size() && s_[i_] == ',') { ++i_; continue; }
+                if (i_ < s_.size() && s_[i_] == ']') { ++i_; return v; }
+                fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { v.kind = Value::String; v.str = string(); return v; }
+        if (s_.compare(i_, 4, "null") == 0) { i_ += 4; return v; }
+        char* end = nullptr;
+        v.num = std::strtod(s_.c_str() + i_, &end);
+        if (end == s_.c_str() + i_) fail("expected a value");
+        v.kind = Value::Number; i_ = (size_t)(end - s_.c_str());
+        return v;
+    }
+    std::string string() {
+        std::string o; ++i_;
+        while (i_ < s_.size() && s_[i_] != '"') {
+            if (s_[i_] == '\\' && i_ + 1 < s_.size()) { ++i_; const char e = s_[i_]; o.push_back(e == 'n' ? '\n' : e == 't' ? '\t' : e); }
+            else o.push_back(s_[i_]);
+            ++i_;
+        }
+        if (i_ >= s_.size()) fail("unterminated string");
+        ++i_;
+        return o;
+    }
+};
+inline Value parse(const std::string& text) { return Parser(text).parse(); }
+inline std::string number(double v) { char b[40]; std::snprintf(b, sizeof b, "%.17g", v); return b; }    // round-trips an f64
+inline std::string vec3(const std::array<double, 3>& v) { return "[" + number(v[0]) + "," + number(v[1]) + "," + number(v[2]) + "]"; }
+inline std::string read_file(const std::string& path) {
+    std::ifstream f(path); if (!f) throw std::runtime_error("cannot open " + path);
+    std::stringstream ss; ss << f.rdbuf(); return ss.str();
+}
+inline void write_file(const std::string& path, const std::string& text) {
+    std::ofstream f(path); if (!f) throw std::runtime_error("cannot write " + path);
+    f << text;
+}
+
+}  // namespace json
+
+namespace detail {
+struct ModelJson { int model; const char* tag; std::vector<const char*> keys; };
+inline const std::vector<ModelJson>& model_json_table() {
+    static const std::vector<ModelJson> t = {
+        {CCAL_MODEL_UCM, "UCM", {"fx", "fy", "cx", "cy", "alpha"}},
+        {CCAL_MODEL_EUCM, "EUCM", {"fx", "fy", "cx", "cy", "alpha", "beta"}},
+        {CCAL_MODEL_KB4, "KannalaBrandt4", {"fx", "fy", "cx", "cy", "k1", "k2", "k3", "k4"}},
+        {CCAL_MODEL_OPENCV5, "OpenCVModel5", {"fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3"}},
+    };
+    return t;
+}
+inline RvecTvec rtvec_from(const json::Value& v) {
+    RvecTvec r;
+    const auto& a = v.at("rvec").arr; const auto& b = v.at("tvec").arr;
+    if (a.size() != 3 || b.size() != 3) throw std::runtime_error("json: rvec / tvec must have three entries");
+    for (int i = 0; i < 3; ++i) { r.rvec[i] = a[i].num; r.tvec[i] = b[i].num; }
+    return r;
+}
+inline std::string rtvec_to(const RvecTvec& r) { return "{\"rvec\":" + json::vec3(r.rvec) + ",\"tvec\":" + json::vec3(r.tvec) + "}"; }
+}  // namespace detail
+
+inline std::string model_to_json(const GenericModel& m) {
+    for (auto& e : detail::model_json_table()) if (e.model == m.model_id()) {
+        std::string s = std::string("{\n  \"") + e.tag + "\": {\n";
+        for (size_t i = 0; i < e.keys.size(); ++i) s += std::string("    \"") + e.keys[i] + "\": " + json::number(m.params()[i]) + ",\n";
+        s += "    \"width\": " + std::to_string((long)std::lround(m.width())) + ",\n    \"height\": " + std::to_string((long)std::lround(m.height())) + "\n  }\n}";
+        return s;
+    }
+    throw std::invalid_argument("model_to_json: this model's JSON field names are defined only in the absent camera-intrinsic-model crate");
+}
+inline GenericModel model_from_json(const std::string& text) {
+    const json::Value v = json::parse(text);
+    if (v.kind != json::Value::Object || v.obj.size() != 1) throw std::runtime_error("json: expected {\"<Model>\": {...}}");
+    for (auto& e : detail::model_json_table()) if (v.obj[0].first == e.tag) {
+        std::vector<double> p;
+        for (auto k : e.keys) p.push_back(v.obj[0].second.at(k).num);
+        return GenericModel(e.model, p, v.obj[0].second.at("width").num, v.obj[0].second.at("height").num);
+    }
+    throw std::runtime_error("json: unknown camera model " + v.obj[0].first);
+}
+inline std::string poses_to_json(const std::map<size_t, RvecTvec>& poses) {            // BTreeMap order = std::map order
+    std::string s = "{";
+    bool first = true;
+    for (auto& kv : poses) { s += (first ? "\n  \"" : ",\n  \"") + std::to_string(kv.first) + "\": " + detail::rtvec_to(kv.second); first = false; }
+    return s + "\n}";
+}
+inline std::map<size_t, RvecTvec> poses_from_json(const std::string& text) {
+    std::map<size_t, RvecTvec> out;
+    const json::Value doc = json::parse(text);
+    for (auto& kv : doc.obj) out[(size_t)std::stoull(kv.first)] = detail::rtvec_from(kv.second);
+    return out;
+}
+inline std::string extrinsics_to_json(const std::vector<RvecTvec>& rtvecs) {
+    std::string s = "{\n  \"rtvecs\": [";
+    for (size_t i = 0; i < rtvecs.size(); ++i) s += (i ? ",\n    " : "\n    ") + detail::rtvec_to(rtvecs[i]);
+    return s + "\n  ]\n}";
+}
+inline std::vector<RvecTvec> extrinsics_from_json(const std::string& text) {
+    std::vector<RvecTvec> out;
+    const json::Value doc = json::parse(text);
+    for (auto& v : doc.at("rtvecs").arr) out.push_back(detail::rtvec_from(v));
+    return out;
+}
+// write_report (src/io.rs:21-31), byte for byte
+inline std::string report_text(bool with_extrinsic, const std::vector<std::pair<double, double>>& rep_rms) {
+    std::string s = std::string("Calibrate with extrinsics: ") + (with_extrinsic ? "true" : "false") + "\n\n";
+    char b[160];
+    for (size_t i = 0; i < rep_rms.size(); ++i) {
+        std::snprintf(b, sizeof b, "cam%zu:\n    average reprojection error: %.5f px\n    median  reprojection error: %.5f px\n\n", i, rep_rms[i].first, rep_rms[i].second);
+        s += b;
+    }
+    return s;
+}
 
 }  // namespace ccal

@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.dirname(_HERE))
 from camera_intrinsic_calibration_rs_amd import _ffi as F  # noqa: E402  (struct definitions only)
 from camera_intrinsic_calibration_rs_amd.engine import desc_from_synth, make_desc  # noqa: E402,F401
 
-LIB_PATH = os.path.join(_HERE, "liboracle_ccal.so")
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle_ccal.so")     # ORACLE_LIB: the sanitizer build (tests/test_sanitizers_cpu.py)
 PMAX = F.PMAX
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -72,6 +72,7 @@ def load():
         "oracle_reprojection_errors": (C.c_int, [D, _dp, _dp, _dp, _dp]),
         "oracle_validation_stats": (C.c_int, [_dp, C.c_int64, _dp, _dp]),
         "oracle_init_camera_extrinsic": (C.c_int, [_dp, _dp, C.c_int, _dp, C.POINTER(C.c_int)]),
+        "oracle_se3_factor": (C.c_int, [_dp, _dp, _dp, _dp, _dp]),
         "oracle_convert_model": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, _u8,
                                            C.POINTER(C.c_int), C.c_void_p]),
         "oracle_hardware_threads": (C.c_int, []),
@@ -280,6 +281,14 @@ class OracleProblem:
         sel = np.ascontiguousarray(sel)
         assert self.lib.oracle_validation_stats(_p(sel), len(sel), C.byref(a), C.byref(m)) == 0
         return a.value, m.value
+
+
+def se3_factor(pose_0_b, pose_i_b, x):
+    """SE3Factor::residual_func with dual numbers (src/optimization/factors.rs:248-271): r[6], J[6, 6]."""
+    a = _f64(pose_0_b); b = _f64(pose_i_b); xx = _f64(x)
+    r = np.empty(6); J = np.empty((6, 6))
+    assert load().oracle_se3_factor(_p(a), _p(b), _p(xx), _p(r), _p(J)) == 0
+    return r, J
 
 
 def init_camera_extrinsic(poses0, posesi):

@@ -613,6 +613,15 @@ int oracle_validation_stats(const double* err, int64_t n, double* avg_99, double
     return CCAL_OK;
 }
 
+// One SE3Factor block with forward-mode duals: r[6] and J[6][6] (row-major, columns rvec | tvec)
+int oracle_se3_factor(const double* pose_0_b, const double* pose_i_b, const double* x, double* r, double* J) {
+    using DT = Dual<6>;
+    DT xv[6]; for (int i = 0; i < 6; ++i) xv[i] = DT::seed(x[i], i);
+    DT rr[6]; se3_factor<DT>(pose_0_b, pose_i_b, xv, xv + 3, rr);
+    for (int i = 0; i < 6; ++i) { r[i] = rr[i].re; for (int c = 0; c < 6; ++c) J[i * 6 + c] = rr[i].eps[c]; }
+    return CCAL_OK;
+}
+
 // init_camera_extrinsic (src/util.rs:511-561): SE3Factor per common frame, HuberLoss(0.5), Gauss-Newton
 // with dual-number Jacobians and tiny-solver's default thresholds, from t_i_b[0] * t_0_b[0]^-1.
 int oracle_init_camera_extrinsic(const double* poses0, const double* posesi, int n, double* out6, int* iters) {

@@ -157,6 +157,8 @@ def gen_reference_tests():
         test_rvec_tvec_conversion=dict(rvec=[0.1, 0.2, 0.3], tvec=[1.0, 2.0, 3.0], tol=1e-6),  # tests/types_test.rs:5-20
         test_convert_model=dict(ucm=[500.0, 500.0, 320.0, 240.0, 0.5], eucm_expected=[500.0, 500.0, 320.0, 240.0, 0.5, 1.0]),
         test_board_init=dict(n_ids=144, tag_size=0.088, tag0=[[0, 0, 0], [0.088, 0, 0], [0.088, -0.088, 0], [0, -0.088, 0]]),
+        # the reference's sample model file data/eucm.json (a data file: examples/convert_model.rs:13 loads it), as data
+        data_eucm_json=json.load(open("/root/reference/data/eucm.json")),
     )
     with open(os.path.join(OUT, "reference_tests.json"), "w") as f:
         json.dump(data, f, indent=1)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     lib = _ffi.load()
     assert lib.ccal_version().startswith(b"ccal-mi355x")
-    assert [lib.ccal_model_num_params(m) for m in range(5)] == [5, 6, 8, 9, -1]
+    assert [lib.ccal_model_num_params(m) for m in range(6)] == [5, 6, 8, 9, 8, -1]      # 4 = the EUCMT parameter container
     o = _ffi.SolverOpts()
     assert lib.ccal_set_defaults(ctypes.byref(o)) == 0
     # tiny-solver OptimizerOptions::default() as restated in SURVEY 3.3

@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 
 from camera_intrinsic_calibration_rs_amd import api
 
@@ -49,9 +50,34 @@ def test_rvec_tvec_algebra_matches_oracle(oracle):
     np.testing.assert_allclose(a.inverse().inverse().as6(), a.as6(), atol=1e-13)
 
 
+def test_se3_factor_analytic_jacobian_matches_dual_numbers(oracle):
+    """SE3Factor (src/optimization/factors.rs:248-271): the library's closed-form 6 x 6 block Jacobian (inverse left
+    Jacobian of SO(3) at the residual rotation, left Jacobian at rvec) against the oracle's forward-mode duals through the
+    quaternion path nalgebra takes - random poses, small and large rotations, residual rotations up to ~2.5 rad."""
+    import ctypes as C
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    lib = _ffi.load()
+    fn = lib.ccal_debug_se3_factor
+    dp = C.POINTER(C.c_double)
+    fn.restype = C.c_int; fn.argtypes = [dp, dp, dp, dp, dp]
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for k in range(200):
+        scale = [1e-4, 0.3, 1.2][k % 3]
+        a = np.concatenate([rng.normal(0, 1.0, 3), rng.normal(0, 1.0, 3)])
+        x = np.concatenate([rng.normal(0, scale, 3), rng.normal(0, 0.5, 3)])
+        b = np.asarray(api.RvecTvec.from6(x).compose(api.RvecTvec.from6(a)).as6()) + np.concatenate([rng.normal(0, scale, 3), rng.normal(0, 0.1, 3)])
+        r = np.empty(6); J = np.empty((6, 6))
+        assert fn(a.ctypes.data_as(dp), b.ctypes.data_as(dp), x.ctypes.data_as(dp), r.ctypes.data_as(dp), J.ctypes.data_as(dp)) == 0
+        ro, Jo = oracle.se3_factor(a, b, x)
+        np.testing.assert_allclose(r, ro, rtol=0, atol=1e-12)
+        worst = max(worst, np.abs(J - Jo).max())
+    assert worst <= 1e-9, worst
+
+
 def test_init_camera_extrinsic_matches_oracle_and_truth(oracle):
     """util::init_camera_extrinsic (src/util.rs:511-561) -- SE3Factor + HuberLoss(0.5) + GN.  The library's
-    host implementation (central-difference Jacobian) against the oracle's dual-number one and against the
+    host implementation (analytic Jacobian) against the oracle's dual-number one and against the
     transform the poses were generated with; one gross outlier frame is absorbed by the Huber loss."""
     rng = np.random.default_rng(3)
     t_i_0 = api.RvecTvec((0.01, -0.02, 0.005), (-0.101, 0.002, 0.001))
@@ -67,10 +93,26 @@ def test_init_camera_extrinsic_matches_oracle_and_truth(oracle):
     assert out[0].as6().tolist() == [0.0] * 6
     keys = sorted(set(cam0) & set(cam1))
     ref, iters = oracle.init_camera_extrinsic([cam0[k].as6() for k in keys], [cam1[k].as6() for k in keys])
-    np.testing.assert_allclose(out[1].as6(), ref, rtol=0, atol=1e-6)       # both stop on the 1e-5 cost thresholds
+    np.testing.assert_allclose(out[1].as6(), ref, rtol=0, atol=1e-10)      # same Jacobian to rounding: the same iterates
     # Huber bounds the outlier's pull to ~delta / n = 0.5 / 40 per component
     np.testing.assert_allclose(out[1].as6(), t_i_0.as6(), rtol=0, atol=1.5e-2)
     assert 1 <= iters <= 20
+
+
+def test_convert_model_ucm_to_eucmt_closed_form():
+    """src/util.rs:236-243: UCM -> EUCMT inserts beta = 1 and two zero tangential terms; through the Python mirror and
+    through the C ABI (a host-only path of ccal_convert_model, no GPU needed); everything else with EUCMT is refused."""
+    import ctypes as C
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    from camera_intrinsic_calibration_rs_amd.engine import CcalError
+    ucm = api.GenericModel("ucm", [500.0, 510.0, 320.0, 240.0, 0.55], 640, 480)
+    t = api.GenericModel("eucmt", [0.0] * 8, 640, 480)
+    assert api.convert_model(ucm, t).params().tolist() == [500.0, 510.0, 320.0, 240.0, 0.55, 1.0, 0.0, 0.0]
+    assert t.model_id == 4 and _ffi.load().ccal_model_num_params(4) == 8
+    with pytest.raises(NotImplementedError):
+        t.to_json_obj()
+    with pytest.raises(CcalError):
+        api.convert_model(api.GenericModel("eucm", [1, 1, 1, 1, 0.5, 1.0], 640, 480), api.GenericModel("eucmt", [0.0] * 8, 640, 480))
 
 
 def test_convert_model_closed_form():

@@ -18,6 +18,46 @@ def test_header_compiles_as_plain_cxx17():
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "ccal.h")])
 
 
+def test_cpp_wire_formats_roundtrip_with_python_mirror(tmp_path):
+    """cam{i}.json / cam{i}_poses.json / extrinsics.json / report.txt: files written by the Python mirror are read and
+    re-written by include/ccal.hpp; both mirrors read each other's output to the last bit; the reference's sample model
+    file (data/eucm.json, a fixture under tests/golden/) parses.  Host code only: runs without a GPU."""
+    from camera_intrinsic_calibration_rs_amd import api, synth
+    exe = str(tmp_path / "test_ccal_json")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_ccal_json.cpp"), "-o", exe,
+                           "-L", LIBDIR, "-lccal_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"])
+    d = tmp_path
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_tests.json")))
+    with open(d / "eucm_reference.json", "w") as f:
+        json.dump(golden["data_eucm_json"], f, indent=2)
+    rng = np.random.default_rng(2)
+    models = {}
+    for name in ("ucm", "eucm", "kb4", "opencv5"):
+        P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[name]]
+        models[name] = api.GenericModel(name, np.asarray(synth.GT_PARAMS[synth.MODEL_NAMES[name]]) * (1 + rng.normal(0, 1e-3, P)), 512, 512)
+        api.model_to_json(str(d / f"cam_{name}.json"), models[name])
+    poses = {int(k): api.RvecTvec.from6(rng.normal(0, 1, 6)) for k in (0, 3, 17, 250)}
+    api.poses_to_json(str(d / "cam0_poses.json"), poses)
+    ext = [api.RvecTvec.from6(np.zeros(6)), api.RvecTvec.from6(rng.normal(0, 0.1, 6))]
+    api.extrinsics_to_json(str(d / "extrinsics.json"), ext)
+    out = subprocess.check_output([exe, str(d)], env=dict(os.environ, LD_LIBRARY_PATH=LIBDIR + ":/opt/rocm/lib")).decode()
+    assert "JSON-OK 4 2" in out
+    for name, m in models.items():
+        back = api.model_from_json(str(d / f"cpp_cam_{name}.json"))
+        assert back.kind == name and back.width() == 512 and back.height() == 512
+        np.testing.assert_array_equal(back.params(), m.params())
+    back = api.poses_from_json(str(d / "cpp_cam0_poses.json"))
+    assert sorted(back) == sorted(poses)
+    for k in poses:
+        np.testing.assert_array_equal(back[k].as6(), poses[k].as6())
+    back = api.extrinsics_from_json(str(d / "cpp_extrinsics.json"))
+    for a, b in zip(back, ext):
+        np.testing.assert_array_equal(a.as6(), b.as6())
+    api.write_report(str(d / "py_report.txt"), True, [(0.0912345678, 0.0801), (0.1, 0.123456789)])
+    assert open(d / "py_report.txt").read() == open(d / "cpp_report.txt").read()
+
+
 @pytest.mark.gpu
 def test_cpp_calib_camera_matches_python_binding(tmp_path, gpu_ctx):
     from camera_intrinsic_calibration_rs_amd import api, synth

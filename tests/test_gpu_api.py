@@ -94,6 +94,17 @@ def test_calib_all_camera_with_extrinsics(gpu_ctx, oracle):
     models, t_out, board = res
     assert sorted(board.keys()) == list(range(16))
     assert t_out[0].as6().tolist() == [0.0] * 6
+    # the oracle through the same steps: same problem description and starting point (src/util.rs:576-651), the
+    # reference's bounds, Gauss-Newton
+    d, keep, slots, intr0, poses0, extr0 = api._joint_problem_inputs(cams, t_i_0, [rt0, rt1], [f0, f1], False)
+    op = oracle.OracleProblem(d, keep)
+    op.apply_reference_bounds()
+    intr_o, poses_o, extr_o, rep_o = op.solve(intr0, poses0, extr0)
+    assert rep_o.status == 0
+    for c in range(2):
+        assert np.abs(models[c].params() / intr_o[c, :6] - 1).max() <= 1e-6
+    np.testing.assert_allclose(t_out[1].as6(), extr_o[1], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(np.stack([board[i].as6() for i in slots]), poses_o, rtol=0, atol=1e-7)
     # ground truth is recovered within noise: baseline 101 mm to < 0.5 mm, focal to 0.5 %
     assert np.abs(np.array(t_out[1].tvec) - sp.extr_gt[1, 3:]).max() < 5e-4
     for c in range(2):
@@ -115,9 +126,10 @@ def test_validation_matches_oracle(gpu_ctx, oracle):
     assert abs(a - ao) < 1e-11 and abs(m - mo) < 1e-11
 
 
-def test_init_ucm_two_frames(gpu_ctx):
+def test_init_ucm_two_frames(gpu_ctx, oracle):
     """util::init_ucm (src/util.rs:287-378): [f, alpha] + two poses from two frames, principal point pinned at
-    the image centre, then calib_camera(xy_same_focal = true) on the same two frames."""
+    the image centre, then calib_camera(xy_same_focal = true) on the same two frames - against ground truth and against
+    the oracle driven through the same two solves."""
     sp = synth.make_problem(2, "ucm", seed=77)
     frames = api.frames_from_synth(sp)
     gt = sp.intr_gt[0]
@@ -128,6 +140,25 @@ def test_init_ucm_two_frames(gpu_ctx):
     assert p[0] == p[1]
     assert abs(p[0] / gt[0] - 1) < 0.03 and abs(p[4] - gt[4]) < 0.05         # two frames only: a few percent
     assert abs(p[2] - gt[2]) < 5 and abs(p[3] - gt[3]) < 5
+    # oracle, the same recipe: (1) UCM, one focal, cx / cy fixed at the image centre, f in [f0/3, 3 f0], alpha in [1e-6, 1]
+    # (src/util.rs:305-348); (2) calib_camera(xy_same_focal = true) on the two frames with the reference's bounds (:365-371)
+    import dataclasses
+    f0 = gt[0] * 1.3
+    sub = dataclasses.replace(sp, xy_same_focal=True)
+    op = oracle.OracleProblem.from_synth(sub)
+    op.fix_param(0, 1); op.fix_param(0, 2)
+    op.set_bounds(0, 0, f0 / 3.0, f0 * 3.0); op.set_bounds(0, 3, 1e-6, 1.0)
+    i0 = np.zeros((1, synth.PMAX)); i0[0, :5] = [f0, f0, 256.0, 256.0, 0.4]
+    i1, p1, _, r1 = op.solve(i0, sp.poses0[:2])
+    assert r1.status == 0
+    op2 = oracle.OracleProblem.from_synth(sub)
+    op2.apply_reference_bounds()
+    i1[0, 1] = i1[0, 0]; i1[0, 2:4] = 256.0
+    # calib_camera initialises the poses itself (src/util.rs:418-436): the same device initialisation for both sides
+    init = api.init_frame_poses(frames, api.GenericModel("ucm", i1[0, :5], 512, 512), ctx=gpu_ctx)
+    i2, _, _, r2 = op2.solve(i1, np.stack([init[0].as6(), init[1].as6()]))
+    assert r2.status == 0
+    assert np.abs(p / i2[0, :5] - 1).max() <= 1e-6
 
 
 def test_multi_camera_pipeline_from_detections(gpu_ctx):

@@ -1,0 +1,105 @@
+"""CPU: AddressSanitizer + UndefinedBehaviorSanitizer runs of the code that can run without a GPU (GPU sanitizers are
+not available on this pool): the oracle (gcc, `make -C oracle asan`) through its whole ctypes surface, and the
+library's host-only translation unit (ccal_extrinsic.hip: init_camera_extrinsic / SE3Factor, built with hipcc's host
+ASan, device code untouched).  Each runs in its own subprocess with its own sanitizer runtime preloaded; any report
+aborts the subprocess (halt_on_error)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_ORACLE_DRIVER = r"""
+import sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from camera_intrinsic_calibration_rs_amd import synth
+from camera_intrinsic_calibration_rs_amd.engine import default_opts
+from oracle import binding as ob
+ob.load()
+for model, n_cams, of in (("eucm", 1, False), ("kb4", 2, True), ("opencv5", 1, False), ("ucm", 3, True)):
+    sp = synth.make_problem(7, model, n_cams=n_cams, xy_same_focal=of, ragged=True, outlier_frac=0.03)
+    op = ob.OracleProblem.from_synth(sp)
+    op.apply_reference_bounds()
+    r, J = op.eval(sp.intr0, sp.poses0, sp.extr0, apply_loss=True, threads=3)
+    rh, Jh = op.eval_heap(sp.intr0, sp.poses0, sp.extr0, apply_loss=True, threads=2)
+    assert np.array_equal(r, rh) and np.array_equal(J, Jh)
+    op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=1e-3)
+    for m in (0, 1):
+        op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(m))
+    op.gn_step_dense(sp.intr0, sp.poses0, sp.extr0)
+    for c in range(n_cams):
+        op.validation(c, sp.intr_gt, sp.poses_gt, sp.extr_gt)
+    op.eval_timed(sp.intr0, sp.poses0, sp.extr0, threads=2, reps=2)
+# degenerate inputs: one corner per frame (rank-deficient pose blocks), an empty problem
+from camera_intrinsic_calibration_rs_amd.engine import make_desc
+sp = synth.make_problem(3, "eucm")
+idx = sp.obs_offsets[:-1]
+d, keep = make_desc(1, [1], [512.0], [512.0], False, 3, [0] * 3, [0, 1, 2], np.arange(4, dtype=np.int64),
+                    sp.p3d[idx, 0], sp.p3d[idx, 1], sp.p3d[idx, 2], sp.p2d[idx, 0], sp.p2d[idx, 1], 1.0)
+ob.OracleProblem(d, keep).solve(sp.intr0, sp.poses0)
+d, keep = make_desc(1, [1], [512.0], [512.0], False, 0, [], [], [0], [], [], [], [], [], 1.0)
+ob.OracleProblem(d, keep)
+rng = np.random.default_rng(0)
+p0 = rng.normal(0, 1, (9, 6)); pi = p0 + rng.normal(0, 1e-3, (9, 6))
+ob.init_camera_extrinsic(p0, pi)
+ob.se3_factor(p0[0], pi[0], np.zeros(6))
+ob.convert_model(1, synth.GT_PARAMS[1], 2, [0.0] * 8, 512, 512, 0, [0, 0, 0, 0, -1, -1, -1, -1], [1e4, 1e4, 512, 512, 1, 1, 1, 1])
+ob.convert_model(2, synth.GT_PARAMS[2], 3, [0.0] * 9, 512, 512, 1)
+ob.project(3, synth.GT_PARAMS[3], rng.normal(0, 1, (50, 3)) + [0, 0, 3])
+print("SAN-OK")
+"""
+
+_HOST_DRIVER = r"""
+import ctypes as C, sys
+import numpy as np
+lib = C.CDLL({lib!r})
+dp = C.POINTER(C.c_double)
+class Report(C.Structure):
+    _fields_ = [("status", C.c_int32), ("iterations", C.c_int32), ("lm_accepted", C.c_int32), ("lm_rejected", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms", C.c_double), ("h", C.c_int32), ("m", C.c_int32)]
+lib.ccal_init_camera_extrinsic.argtypes = [dp, dp, C.c_int, dp, C.c_int, C.POINTER(Report)]
+lib.ccal_debug_se3_factor.argtypes = [dp] * 5
+rng = np.random.default_rng(1)
+for n in (1, 2, 40):
+    p0 = np.ascontiguousarray(rng.normal(0, 1, (n, 6))); pi = np.ascontiguousarray(p0 + rng.normal(0, 1e-2, (n, 6)))
+    x = np.zeros(6); rep = Report()
+    rc = lib.ccal_init_camera_extrinsic(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, x.ctypes.data_as(dp), 0, C.byref(rep))
+    assert rc in (0, 4), rc
+    x2 = x.copy()
+    lib.ccal_init_camera_extrinsic(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, x2.ctypes.data_as(dp), 1, None)
+    r = np.empty(6); J = np.empty((6, 6))
+    lib.ccal_debug_se3_factor(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), x.ctypes.data_as(dp), r.ctypes.data_as(dp), J.ctypes.data_as(dp))
+assert lib.ccal_init_camera_extrinsic(None, None, 0, None, 0, None) == 1
+print("SAN-OK")
+"""
+
+
+def _run(code, preload, extra_env=None):
+    env = dict(os.environ, LD_PRELOAD=preload, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1", PYTHONMALLOC="malloc", **(extra_env or {}))
+    return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_oracle_under_asan_ubsan():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "asan"])
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"]).decode().strip()
+    if not os.path.isabs(asan):
+        pytest.skip("gcc has no libasan here")
+    out = _run(_ORACLE_DRIVER.format(root=ROOT), asan, {"ORACLE_LIB": os.path.join(ROOT, "oracle", "liboracle_ccal_asan.so")})
+    assert out.returncode == 0 and "SAN-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-6000:])
+
+
+def test_library_host_code_under_asan_ubsan(tmp_path):
+    hipcc = "/opt/rocm/bin/hipcc"
+    rt = subprocess.check_output([hipcc, "-print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip()
+    if not os.path.isabs(rt) or not os.path.exists(rt):
+        pytest.skip("no clang ASan runtime in this image")
+    so = str(tmp_path / "libccal_host_asan.so")
+    src = os.path.join(ROOT, "camera_intrinsic_calibration_rs_amd", "csrc", "ccal_extrinsic.hip")
+    subprocess.check_call([hipcc, "-O1", "-g", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fsanitize=address,undefined",
+                           "-fno-gpu-sanitize", "-fno-sanitize-recover=undefined", "-shared", src, "-o", so], stderr=subprocess.DEVNULL)
+    out = _run(_HOST_DRIVER.format(lib=so), rt)
+    assert out.returncode == 0 and "SAN-OK" in out.stdout, (out.stdout[-2000:], out.stderr[-6000:])
