@@ -42,16 +42,13 @@ def _latest_profile_file(name):
 
 
 def _gram_kernel_key(model, one_focal, frames):
-    """Which Gram kernel ccal_solver.hip / launch_gram1v_t pick for a single camera, as a key of profiles/*/flops.json."""
+    """Which Gram kernel launch_gram1v_t (ccal_kernels_fused.hip) picks for a single camera, as a key of profiles/*/flops.json:
+    the register Gram for every model; its two-wavefronts-per-SIMD form (k_gram1w) from 2 000 frames up when the triangle
+    of [J | r]^T [J | r] has at most 91 entries (UCM, EUCM)."""
     of = "one-focal" if one_focal else "two-focal"
-    if model == "opencv5":
-        return f"k_gram1<OPENCV5,{of}>"
-    if model == "kb4":
-        return f"k_gram1v<KB4,{of},16>"
-    name = model.upper()
-    if frames >= 2000:
-        return f"k_gram1w<{name},{of},16 lanes/frame>" if (model == "eucm" and not one_focal) else f"k_gram1w<{name},{of},16>"
-    return f"k_gram1v<{name},{of},64>"
+    ncols = {"ucm": 5, "eucm": 6, "kb4": 8, "opencv5": 9}[model] - (1 if one_focal else 0) + 7
+    w = frames >= 2000 and ncols * (ncols + 1) // 2 <= 91
+    return f"{'k_gram1w' if w else 'k_gram1v'}<{model.upper()},{of}>"
 
 
 def main():

@@ -80,16 +80,15 @@ def main():
     out = {"source": "gfx950 ISA of ccal_kernels_fused.hip (hipcc -O3 -ffp-contract=fast), counted by tools/count_flops.py",
            "fp64_vector_peak_tflops": 78.6, "kernels": {}}
     # model ids: 0 UCM 1 EUCM 2 KB4 3 OPENCV5; k_gram1w<MODEL, OF, LPF>, k_gram1v<...>, k_gram1<MODEL, OF>, k_schur1m<K>
-    want = {
-        "k_gram1w<EUCM,two-focal,16 lanes/frame>": "k_gram1wILi1ELb0ELi16EE",
-        "k_gram1w<EUCM,one-focal,16>": "k_gram1wILi1ELb1ELi16EE",
-        "k_gram1w<UCM,two-focal,16>": "k_gram1wILi0ELb0ELi16EE",
-        "k_gram1v<EUCM,two-focal,64>": "k_gram1vILi1ELb0ELi64EE",
-        "k_gram1v<KB4,two-focal,16>": "k_gram1vILi2ELb0ELi16EE",
-        "k_gram1v<KB4,one-focal,16>": "k_gram1vILi2ELb1ELi16EE",
-        "k_gram1<OPENCV5,two-focal>": "k_gram1ILi3ELb0EE",
-        "k_gram1<OPENCV5,one-focal>": "k_gram1ILi3ELb1EE",
-    }
+    names = {0: "UCM", 1: "EUCM", 2: "KB4", 3: "OPENCV5"}
+    want = {}
+    for m, nm in names.items():
+        for of in (0, 1):
+            focal = "one-focal" if of else "two-focal"
+            # the per-corner count does not depend on the lanes-per-frame instantiation: read it off the 12-lane one
+            want[f"k_gram1w<{nm},{focal}>"] = f"k_gram1wILi{m}ELb{of}ELi12EE"
+            want[f"k_gram1v<{nm},{focal}>"] = f"k_gram1vILi{m}ELb{of}ELi12EE"
+            want[f"k_gram1<{nm},{focal}>"] = f"k_gram1ILi{m}ELb{of}EE"
     for name, key in want.items():
         hits = [k for k in bodies if key in k]
         if not hits:
