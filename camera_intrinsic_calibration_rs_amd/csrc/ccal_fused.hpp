@@ -154,6 +154,9 @@ struct FusedArgs {
     double* fcbuf; double* mc_f; double* cost_f;
     const double* dc; const DevState* st;
     double* partial; double* red;
+    // general (multi-camera) loop, camera-0 blocks through the register Gram kernels: the camera's observation frames
+    // and where each frame's record goes inside the Gram buffer praw[set] (doubles)
+    const int32_t* list; const int64_t* rec_off;
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:
@@ -178,7 +181,8 @@ struct UnpackArgs {               // staging block (doubles): [intr CCAL_PMAX | 
 };
 hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
-hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // VALU Gram (<= 105 triangle entries)
+hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
+hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
 hipError_t launch_schur1(const FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size)
 hipError_t launch_schur1m(const FusedArgs& a, hipStream_t s);   // four frames per wavefront; needs a.n_pw = 4 ceil(n_obs / 16)
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s);

@@ -255,7 +255,10 @@ template <bool OF> __device__ constexpr bool nz_u(int i) { return OF ? (i != 2) 
 template <bool OF> __device__ constexpr bool nz_v(int i) { return OF ? (i != 1) : (i != 0 && i != 2); }
 
 // LPF = lanes per frame (16, 32 or 64): small problems spread a frame over more lanes so that the chip still fills.
-template <int MODEL, bool OF, int LPF>
+// GEN: the general (multi-camera) loop's camera-0 blocks - the frames are those of a.list, the evaluated pose is read as it
+// stands (k_backsub has formed it), the rotation columns stay in the rvec basis (k_schur mixes cameras), and the record
+// goes to the observation frame's slot of the Gram buffer (a.rec_off), where k_schur reads it through its table.
+template <int MODEL, bool OF, int LPF, bool GEN>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedArgs a) {
     constexpr int G = 64 / LPF;                     // frames per wavefront
     constexpr int D = block_dim(MODEL, OF, false);
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
     const bool active = lane_ok && f < a.n_obs;
-    const int fa_ = active ? f : 0;
+    const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
     double* red = fcw + G * FC_N0P;
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         const int slot = a.obs_slot[fa_];
         double pose[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[GEN ? es : cur][(int64_t)slot * 6 + i];     // GEN: k_backsub has formed the candidate
         double mc = 0.0;
-        if (!first) {
+        if (!GEN && !first) {
             const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
             if (pf[0] != 0.0) {
                 double dp[6];
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
                 for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
             }
         }
-        if (active && gl == 0) a.mc_f[f] = mc;
+        if (!GEN && active && gl == 0) a.mc_f[f] = mc;
         double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
         if (gl == 0 && lane_ok) {
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false, true>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);      // rotation columns in the phi basis
+        corner_block<MODEL, OF, false, !GEN>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);       // fused loop: rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -414,14 +417,14 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             if (e >= NE || ff >= a.n_obs) continue;
             const uint32_t m = g_recmap<K, 0>.d[e];
             const double v = res[h][q];
-            double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
+            double* rec = a.praw[es] + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
             rec[m & 0xffff] = v;
             if ((m >> 16) != 0xffff) rec[m >> 16] = v;
-            if (e == NE - 1) a.cost_f[ff] = v;                       // the last entry is r x r
+            if (!GEN && e == NE - 1) a.cost_f[ff] = v;               // the last entry is r x r
         }
     }
     // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
-    if (active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+    if (!GEN && active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
 }
 
 // k_gram1w: k_gram1v with two wavefronts per SIMD.  k_gram1v needs 256 VGPRs + 66 AGPRs (91 accumulators and the
@@ -429,7 +432,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
 // Here the 6 K camera x pose accumulators of every lane live in LDS ([entry][lane], stride 65: conflict-free both
 // for the lane-private ds_add_f64 of the corner loop - fire and forget, nothing waits on it - and for the column
 // sums afterwards), and the frame constants are re-read from LDS every corner instead of being hoisted.
-template <int MODEL, bool OF, int LPF>
+template <int MODEL, bool OF, int LPF, bool GEN>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedArgs a) {
     constexpr int G = 64 / LPF;                     // frames per wavefront
     constexpr int D = block_dim(MODEL, OF, false);
@@ -459,7 +462,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
     const bool active = lane_ok && f < a.n_obs;
-    const int fa_ = active ? f : 0;
+    const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
     double* red = fcw + G * FC_N0P;
@@ -481,9 +484,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
         const int slot = a.obs_slot[fa_];
         double pose[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[GEN ? es : cur][(int64_t)slot * 6 + i];     // GEN: k_backsub has formed the candidate
         double mc = 0.0;
-        if (!first) {
+        if (!GEN && !first) {
             const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
             if (pf[0] != 0.0) {
                 double dp[6];
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
                 for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
             }
         }
-        if (active && gl == 0) a.mc_f[f] = mc;
+        if (!GEN && active && gl == 0) a.mc_f[f] = mc;
         double fcr[FC_N0];
         frame_setup<false>(pose, nullptr, fcr);
         if (gl == 0 && lane_ok) {
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false, true>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);      // rotation columns in the phi basis
+        corner_block<MODEL, OF, false, !GEN>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);       // fused loop: rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const int ff = fbase + g;
             if (ff >= a.n_obs) continue;
             const int i = t / 6, jp = t - 6 * i;
-            a.praw[es][(int64_t)ff * a.PRAW + 21 + jp * K1 + i] = resa[q];
+            a.praw[es][(GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW) + 21 + jp * K1 + i] = resa[q];
         }
     }
 
@@ -635,17 +638,17 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             if (e >= NR || ff >= a.n_obs) continue;
             const uint32_t m = g_recmap<K, NLC>.d[e];
             const double v = res[h][q];
-            double* rec = a.praw[es] + (int64_t)ff * a.PRAW;
+            double* rec = a.praw[es] + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
             rec[m & 0xffff] = v;
             if ((m >> 16) != 0xffff) rec[m >> 16] = v;
-            if (e == NR - 1) a.cost_f[ff] = v;                       // the last entry is r x r
+            if (!GEN && e == NR - 1) a.cost_f[ff] = v;               // the last entry is r x r
         }
     }
     // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
-    if (active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+    if (!GEN && active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
 }
 
-template <int MODEL, bool OF, int LPF, bool W>
+template <int MODEL, bool OF, int LPF, bool W, bool GEN>
 static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int G = 64 / LPF;
     constexpr int NC = block_dim(MODEL, OF, false) + 1;
@@ -654,10 +657,11 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int RED = (W && NL * 65 > 64 * (HALF | 1)) ? NL * 65 : 64 * (HALF | 1);
     constexpr int WSL = G * FC_N0P + RED;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
-    auto kern = W ? k_gram1w<MODEL, OF, LPF> : k_gram1v<MODEL, OF, LPF>;
+    auto kern = W ? k_gram1w<MODEL, OF, LPF, GEN> : k_gram1v<MODEL, OF, LPF, GEN>;
     static DynLdsGuard lds_guard;
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
     const int fpb = G * CCAL_GRAMV_WPB;
+    if (a.n_obs <= 0) return hipSuccess;
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
@@ -676,7 +680,7 @@ static int gram_lanes_per_frame(int n_obs) {
     if (n_obs <= 10240) return 12;
     return 8;
 }
-template <int MODEL, bool OF>
+template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // More wavefronts than SIMDs (>= 2000 frames): k_gram1w, two wavefronts per SIMD (10 000 frames: 40 vs 53 us).
     // Below that every wavefront has a SIMD to itself and k_gram1v's all-register accumulators are a little faster.
@@ -687,27 +691,30 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // (one-focal KB4 through k_gram1w: 124 us instead of 64 at 10 000 frames): k_gram1v there
     const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 91);
     const int lpf = gram_lanes_per_frame(a.n_obs);
-#define CCAL_LPF_CASE(L) case L: return w ? launch_gram1v_l<MODEL, OF, L, true>(a, s) : launch_gram1v_l<MODEL, OF, L, false>(a, s);
+#define CCAL_LPF_CASE(L) case L: return w ? launch_gram1v_l<MODEL, OF, L, true, GEN>(a, s) : launch_gram1v_l<MODEL, OF, L, false, GEN>(a, s);
     switch (lpf) {
         CCAL_LPF_CASE(8) CCAL_LPF_CASE(12) CCAL_LPF_CASE(16) CCAL_LPF_CASE(32)
-        default: return w ? launch_gram1v_l<MODEL, OF, 64, true>(a, s) : launch_gram1v_l<MODEL, OF, 64, false>(a, s);
+        default: return w ? launch_gram1v_l<MODEL, OF, 64, true, GEN>(a, s) : launch_gram1v_l<MODEL, OF, 64, false, GEN>(a, s);
     }
 #undef CCAL_LPF_CASE
 }
-hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
+template <bool GEN>
+static hipError_t launch_gram1v_m(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
-        case 0: return launch_gram1v_t<kUCM, false>(a, s);
-        case 1: return launch_gram1v_t<kUCM, true>(a, s);
-        case 2: return launch_gram1v_t<kEUCM, false>(a, s);
-        case 3: return launch_gram1v_t<kEUCM, true>(a, s);
-        case 4: return launch_gram1v_t<kKB4, false>(a, s);
-        case 5: return launch_gram1v_t<kKB4, true>(a, s);
-        case 6: return launch_gram1v_t<kOCV5, false>(a, s);
-        case 7: return launch_gram1v_t<kOCV5, true>(a, s);
+        case 0: return launch_gram1v_t<kUCM, false, GEN>(a, s);
+        case 1: return launch_gram1v_t<kUCM, true, GEN>(a, s);
+        case 2: return launch_gram1v_t<kEUCM, false, GEN>(a, s);
+        case 3: return launch_gram1v_t<kEUCM, true, GEN>(a, s);
+        case 4: return launch_gram1v_t<kKB4, false, GEN>(a, s);
+        case 5: return launch_gram1v_t<kKB4, true, GEN>(a, s);
+        case 6: return launch_gram1v_t<kOCV5, false, GEN>(a, s);
+        case 7: return launch_gram1v_t<kOCV5, true, GEN>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
-
+hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) { return launch_gram1v_m<false>(model, one_focal, a, s); }
+// camera-0 blocks of a multi-camera problem: a.list / a.rec_off / a.n_obs = that camera's observation frames
+hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s) { return launch_gram1v_m<true>(model, one_focal, a, s); }
 template <int MODEL, bool OF>
 static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
     constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * 34;

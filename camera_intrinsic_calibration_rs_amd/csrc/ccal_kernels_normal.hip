@@ -251,6 +251,19 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
 // device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1])
 hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s) {
     const NormalWs* w = p->nws;
+    if (cam == 0 && w->cam0_register_gram) {
+        // camera-0 blocks (6 + P_eff + 1 columns: a triangle of <= 136 entries) through the register Gram kernels of the
+        // single-camera loop, record format; k_schur's table reads it (caminfo NCP = 0).  10 000 frames: 50 -> ~30 us
+        FusedArgs fa = {};
+        fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
+        fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
+        fa.list = p->cams[0].d_obs; fa.n_obs = (int32_t)p->cams[0].obs.size(); fa.rec_off = w->d_goff;
+        fa.K = p->cams[0].Peff; fa.huber_delta = p->huber_delta; fa.kb4_eps = p->ctx->conv.kb4_small_radius;
+        fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
+        fa.praw[0] = w->G[w->cur]; fa.praw[1] = w->G[w->cur ^ 1];
+        fa.st = st;
+        return launch_gram1v_general(p->cams[0].model, p->one_focal, fa, s);
+    }
     GramArgs ga = {};
     KArgs& a = ga.k;
     a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
@@ -323,7 +336,16 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 } else {
                     off = RB + 6 * K1 + ii * 6 + jj;                                   // Cm
                 }
-                const int src = (i >= 16 && j < 16) ? j * NCP + i : i * NCP + j;
+                int src = (i >= 16 && j < 16) ? j * NCP + i : i * NCP + j;
+                if (NCP == 0) {
+                    // camera 0 through the register Gram kernels (k_gram1v / k_gram1w, GEN): the frame's record is
+                    // C = H_pp packed lower (21) | [B | g] (6 x K1c) | A (K1c x K1c) with K1c = Pe + 1 (r is column Pe)
+                    const int K1c = Pe + 1, ci = i < Pe ? i : Pe, cj = j < Pe ? j : Pe;
+                    if (ki == 1 && kj == 1) { const int hi = ii > jj ? ii : jj, lo = ii > jj ? jj : ii; src = hi * (hi + 1) / 2 + lo; }
+                    else if (ki == 1) src = 21 + ii * K1c + cj;
+                    else if (kj == 1) src = 21 + jj * K1c + ci;
+                    else src = 21 + 6 * K1c + ci * K1c + cj;
+                }
                 tab[base + e] = (int64_t)src | ((int64_t)(off + 1) << 16) | ((int64_t)(xoff + 1) << 32);
             }
             base += NC * NC;
@@ -502,14 +524,31 @@ struct SolveArgs {
 __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     SolveArgs a = a0;
     __shared__ int go;
+    __shared__ DevState S0;            // the optimizer state is staged in LDS: the decision touches ~20 fields one after the
+                                       // other, each a global round trip for a single lane otherwise (k_solve 19 -> ~9 us)
     const int lane = threadIdx.x;
+    DevState* const gst = a0.st;
     if (a.st) {
-        if (a.st->done) { if (lane == 0) publish_host_status(a.hs, a.st, a.seq); return; }
-        if (lane == 0) go = optimizer_decide(a.st, a.red[a.RB - 3], a.red[a.RB - 2], a.red[a.RB - 1] > 0.0, a.seq) ? 1 : 0;
+        {
+            const double* src = reinterpret_cast<const double*>(gst);
+            double* dst = reinterpret_cast<double*>(&S0);
+            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+        }
         __syncthreads();
-        if (!go) { if (lane == 0) publish_host_status(a.hs, a.st, a.seq); return; }
-        a.lambda = a.st->lambda;
-        if (a.st->cur) { a.intr = a0.intr_c; a.extr = a0.extr_c; a.intr_c = const_cast<double*>(a0.intr); a.extr_c = const_cast<double*>(a0.extr); }
+        a.st = &S0;
+        if (S0.done) { if (lane == 0) publish_host_status(a.hs, &S0, a.seq); return; }
+        if (lane == 0) go = optimizer_decide(&S0, a.red[a.RB - 3], a.red[a.RB - 2], a.red[a.RB - 1] > 0.0, a.seq) ? 1 : 0;
+        __syncthreads();
+        if (!go) {
+            const double* src = reinterpret_cast<const double*>(&S0);
+            double* dst = reinterpret_cast<double*>(gst);
+            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+            __syncthreads();
+            if (lane == 0) publish_host_status(a.hs, &S0, a.seq);
+            return;
+        }
+        a.lambda = S0.lambda;
+        if (S0.cur) { a.intr = a0.intr_c; a.extr = a0.extr_c; a.intr_c = const_cast<double*>(a0.intr); a.extr_c = const_cast<double*>(a0.extr); }
     }
     __shared__ double S[CCAL_KMAX * (CCAL_KMAX + 1)];
     __shared__ double x[CCAL_KMAX];
@@ -566,10 +605,17 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
                 if (a.st->method != CCAL_METHOD_LM) { a.st->done = CCAL_ERR_NOT_PD + 1; if (!a.st->done_seq) a.st->done_seq = a.seq; }
                 else a.st->cam_failed = 1;
                 a.st->mc_cam = 0.0; a.st->lambda_solve = a.lambda;
-                publish_host_status(a.hs, a.st, a.seq);
             }
         }
         if (lane < K) a.dc[lane] = 0.0;
+        __syncthreads();
+        if (a.st) {
+            const double* src = reinterpret_cast<const double*>(&S0);
+            double* dst = reinterpret_cast<double*>(gst);
+            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+            __syncthreads();
+            if (lane == 0) publish_host_status(a.hs, &S0, a.seq);
+        }
         return;
     }
     {   // two triangular solves: lane i owns x_i, the finished component travels by shuffle
@@ -605,7 +651,15 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
     if (lane == 0) {
         a.scal[2] = mc;
-        if (a.st) { a.st->mc_cam = mc; a.st->lambda_solve = a.lambda; publish_host_status(a.hs, a.st, a.seq); }
+        if (a.st) { a.st->mc_cam = mc; a.st->lambda_solve = a.lambda; }
+    }
+    __syncthreads();
+    if (a.st) {
+        const double* src = reinterpret_cast<const double*>(&S0);
+        double* dst = reinterpret_cast<double*>(gst);
+        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+        __syncthreads();
+        if (lane == 0) publish_host_status(a.hs, &S0, a.seq);
     }
 }
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st,

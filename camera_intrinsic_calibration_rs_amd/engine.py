@@ -5,6 +5,7 @@ Nothing here computes; every method forwards to the HIP library through ctypes.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -42,6 +43,7 @@ class Context:
             raise CcalError(rc, "ccal_ctx_create", "no usable HIP device" if rc == _ffi.ERR_HIP else "")
         self.handle = h
         self.device = device
+        self._problems = weakref.WeakSet()        # closed before the context: a ccal_problem holds its ccal_ctx
 
     def last_error(self) -> str:
         return (self.lib.ccal_last_error(self.handle) or b"").decode()
@@ -77,6 +79,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            for p in list(getattr(self, "_problems", ())):     # whatever order the garbage collector picks: problems first
+                p.close()
             self.lib.ccal_ctx_destroy(self.handle)
             self.handle = None
 
@@ -156,6 +160,7 @@ class Problem:
         if rc != _ffi.OK:
             raise CcalError(rc, "ccal_problem_create", ctx.last_error())
         self.handle = h
+        ctx._problems.add(self)
         self.n_cams = desc.n_cams
         self.n_slots = desc.n_slots
         self.n_obs = int(desc.n_obs)

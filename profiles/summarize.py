@@ -3,6 +3,8 @@
 committed under profiles/<tag>/:
 
   kernel_stats_bench_steps50.csv   rocprofv3 --kernel-trace --stats summary of `bench.py --steps 50 --warmup 5`
+  kernel_stats_two_camera.csv      the same for tools/time_kernels.py --cams 2 (2 x 10 000 frames, EUCM) + two_camera.json
+  kernel_stats_kb4 / _opencv5.csv  the same for --model kb4 / opencv5 (10 000 frames) + model_*.json
   pmc_summary.json                 per-kernel means of the --pmc passes + the HBM bytes per k_eval launch that
                                    bench.py reports as roofline.traffic
   bench_full.json                  the default `python bench.py` line of the same box
@@ -40,7 +42,18 @@ def main() -> None:
     bench = json.loads(line)
 
     counters = defaultdict(lambda: defaultdict(list))
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for extra_dir, name in (("stats2", "kernel_stats_two_camera.csv"), ("stats_kb4", "kernel_stats_kb4.csv"), ("stats_opencv5", "kernel_stats_opencv5.csv")):
+        f = os.path.join(src, extra_dir, "stats_kernel_stats.csv")
+        if os.path.exists(f):
+            shutil.copyfile(f, os.path.join(dst, name))
+    for jf in ("two_camera.json", "model_kb4.json", "model_opencv5.json"):
+        f = os.path.join(src, jf)
+        if os.path.exists(f):
+            lines = [l for l in open(f) if l.startswith("{")]
+            if lines:
+                with open(os.path.join(dst, jf), "w") as o:
+                    o.write(lines[-1])
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
         path = os.path.join(src, sub, "pmc_counter_collection.csv")
         if not os.path.exists(path):
             continue
