@@ -78,10 +78,14 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
     *out = c;
     return CCAL_OK;
 }
+static void ctx_free(ccal_ctx* ctx) {
+    if (ctx->own_stream && ctx->stream) { (void)hipSetDevice(ctx->device); (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
 void ccal_ctx_destroy(ccal_ctx* ctx) {
     if (!ctx) return;
-    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
+    if (ctx->n_problems > 0) { ctx->destroy_requested = true; return; }     // freed by its last problem
+    ctx_free(ctx);
 }
 const char* ccal_last_error(const ccal_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 int ccal_sync(ccal_ctx* ctx) {
@@ -174,6 +178,8 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     }
     p->lo.assign(ni, 0.0); p->hi.assign(ni, 0.0); p->has_bound.assign(ni, 0); p->fixed.assign(ni, 0);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, CCAL_ERR_HIP, "upload failed");
+    p->counted = true;
+    ctx->n_problems += 1;
     *out = hold.release();
     return CCAL_OK;
     CCAL_API_CATCH(ctx)
@@ -186,7 +192,10 @@ void ccal_problem_destroy(ccal_problem* p) {
     for (void* q : ptrs) if (q) (void)hipFree(q);
     for (auto& c : p->cams) if (c.d_obs) (void)hipFree(c.d_obs);
     normal_ws_destroy(p);
+    ccal_ctx* ctx = p->ctx;
+    const bool counted = p->counted;
     delete p;
+    if (ctx && counted && --ctx->n_problems == 0 && ctx->destroy_requested) ctx_free(ctx);
 }
 
 int64_t ccal_num_corners(const ccal_problem* p) { return p ? p->n_corners : -1; }

@@ -54,6 +54,10 @@ struct ccal_ctx {
     bool own_stream = false;
     std::string err;
     ccal_model_conventions conv;   // run-time model conventions (defaults: ccal_models.hpp)
+    // a problem holds its context: ccal_ctx_destroy with problems still alive only marks it, the last
+    // ccal_problem_destroy frees it (bindings with a garbage collector destroy in any order)
+    int n_problems = 0;
+    bool destroy_requested = false;
 };
 
 struct ccal_problem {
@@ -82,6 +86,7 @@ struct ccal_problem {
     ccal_allreduce_fn allreduce = nullptr;     // callback form of the step's collective (tests over gloo)
     void* allreduce_user = nullptr;
     void* rccl_comm = nullptr;                 // ncclComm_t: the library issues ncclAllReduce itself (ccal_set_rccl_comm)
+    bool counted = false;                      // registered in ctx->n_problems (creation succeeded)
     bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
 };
 

@@ -41,10 +41,14 @@ namespace ccal {
 void normal_ws_destroy(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (!w) return;
-    // early-exit groups of the last solve (or of a solve that ended in an error) may still be queued: they publish into
-    // the pinned status words freed below
-    (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
+    // early-exit groups of the last solve (or of a solve that ended in an error: every such exit sets tail_pending) may
+    // still be queued: they publish into the pinned status words freed below.  The whole device is drained rather than
+    // the stream: the stream may be the caller's own (ccal_ctx_create with a stream) and already destroyed when a
+    // binding's garbage collector gets here.
+    if (w->tail_pending || (w->fws && w->fws->tail_pending)) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipDeviceSynchronize();
+    }
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
                      w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc };
     for (void* q : ptrs) if (q) (void)hipFree(q);

@@ -155,7 +155,9 @@ typedef struct {
 typedef int (*ccal_allreduce_fn)(void* user, double* device_buf, size_t count, void* hip_stream);
 #define CCAL_RCCL_UNIQUE_ID_BYTES 128
 
-/* ---- context ---------------------------------------------------------------------------- */
+/* ---- context ----------------------------------------------------------------------------
+ * A problem holds its context: ccal_ctx_destroy with problems still alive is deferred to the last ccal_problem_destroy
+ * (any destruction order is safe); a caller-provided stream must stay alive while work is enqueued on it. */
 int ccal_ctx_create(int device_id, void* hip_stream /* hipStream_t or NULL = own stream */, ccal_ctx** out);
 void ccal_ctx_destroy(ccal_ctx* ctx);
 const char* ccal_last_error(const ccal_ctx* ctx);

@@ -121,3 +121,25 @@ def test_distortion_bounds_come_from_the_conventions_table():
     intr2, _, _, _ = gp2.solve(i0, sp.poses0)
     assert abs(intr2[0, 4] - sp.intr_gt[0, 4]) < 0.01
     gp.close(); gp2.close(); ctx.close()
+
+
+def test_context_destroyed_before_its_problem():
+    """A binding with a garbage collector destroys in any order: ccal_ctx_destroy with a live problem is deferred to the
+    last ccal_problem_destroy.  Raw C ABI calls (the Python wrapper orders them itself)."""
+    lib = _ffi.load()
+    h = C.c_void_p()
+    assert lib.ccal_ctx_create(0, None, C.byref(h)) == 0
+    sp = synth.make_problem(30, "eucm")
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, sp.n_slots, sp.obs_cam, sp.obs_slot, sp.obs_offsets, *sp.soa(), 1.0)
+    ph = C.c_void_p(); ph2 = C.c_void_p()
+    assert lib.ccal_problem_create(h, C.byref(d), C.byref(ph)) == 0
+    assert lib.ccal_problem_create(h, C.byref(d), C.byref(ph2)) == 0
+    intr = np.ascontiguousarray(sp.intr0); poses = np.ascontiguousarray(sp.poses0)
+    o = default_opts(1); rep = _ffi.Report()
+    assert lib.ccal_solve(ph, C.byref(o), intr.ctypes.data_as(_dp), poses.ctypes.data_as(_dp), None, C.byref(rep)) == 0
+    lib.ccal_ctx_destroy(h)                      # deferred: two problems hold it
+    intr2 = np.ascontiguousarray(sp.intr0); poses2 = np.ascontiguousarray(sp.poses0)
+    assert lib.ccal_solve(ph2, C.byref(o), intr2.ctypes.data_as(_dp), poses2.ctypes.data_as(_dp), None, C.byref(rep)) == 0
+    np.testing.assert_array_equal(intr, intr2)
+    lib.ccal_problem_destroy(ph)
+    lib.ccal_problem_destroy(ph2)                # frees the context too
