@@ -39,12 +39,22 @@ struct DevState {                 // lives in device memory; updated by the deci
 static_assert(sizeof(DevState) % 8 == 0, "DevState is staged as doubles");
 
 struct HostStatus {               // pinned, host-coherent; written at the end of a decision kernel
-    volatile int32_t seq;
-    volatile int32_t done, iter, cur, lm_accepted, lm_rejected;
-    volatile int32_t done_seq;    // which step finished the solve: the host acts on `done` only once it has waited for that step
+    // what the polling host needs after EVERY group, in one 8-byte store (no fence, no second word to order against):
+    // bits 0-23 sequence number of the group, 24-31 `done` (0 = running, else ccal_status + 1), 32-55 the sequence number
+    // of the step that set `done` - the host acts on `done` only once it has waited for that step
+    volatile uint64_t word;
+    // the rest is published (behind a system-scope fence, before `word`) only by the group that finishes the solve
+    volatile int32_t iter, cur, lm_accepted, lm_rejected;
     volatile int32_t spec_hits, spec_misses;
     volatile double cur_cost, initial_cost, radius;
 };
+constexpr int kMaxGroups = (1 << 23);             // sequence numbers fit the 24-bit fields of HostStatus::word
+__host__ __device__ inline uint64_t status_word(int seq, int done, int done_seq) {
+    return (uint64_t)(uint32_t)seq | ((uint64_t)(uint32_t)(done & 0xff) << 24) | ((uint64_t)(uint32_t)done_seq << 32);
+}
+__host__ __device__ inline int status_seq(uint64_t w) { return (int)(w & 0xffffff); }
+__host__ __device__ inline int status_done(uint64_t w) { return (int)((w >> 24) & 0xff); }
+__host__ __device__ inline int status_done_seq(uint64_t w) { return (int)((w >> 32) & 0xffffff); }
 
 // What an accepted LM step whose gain ratio is near 1 does to the radius: the rule's cap.  The same expression as in
 // optimizer_decide, so that a hit is a bitwise comparison.
@@ -128,13 +138,41 @@ __device__ inline bool optimizer_decide(DevState* st, double cost, double mc_pos
     return solve && !done;
 }
 
-__device__ inline void publish_host_status(HostStatus* hs, const DevState* s, int seq) {
-    hs->done = s->done; hs->done_seq = s->done_seq; hs->iter = s->iter; hs->cur = s->cur;
-    hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
-    hs->spec_hits = s->spec_hits; hs->spec_misses = s->spec_misses;
-    hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
-    __threadfence_system();
-    hs->seq = seq;                   // the host polls this word; kernel completion flushes it at the latest
+// `full`: publish the whole report (the finishing group always does; verbose solves do after every group).  Otherwise one
+// 8-byte store: a system-scope fence costs ~3 us of a 10-us single-wavefront kernel.
+__device__ inline void publish_host_status(HostStatus* hs, const DevState* s, int seq, bool full = false) {
+    if (full || s->done) {
+        hs->iter = s->iter; hs->cur = s->cur;
+        hs->lm_accepted = s->lm_accepted; hs->lm_rejected = s->lm_rejected;
+        hs->spec_hits = s->spec_hits; hs->spec_misses = s->spec_misses;
+        hs->cur_cost = s->cur_cost; hs->initial_cost = s->initial_cost; hs->radius = s->radius;
+        __threadfence_system();
+    }
+    hs->word = status_word(seq, s->done, s->done_seq);      // the host polls this word; kernel completion flushes it at the latest
+}
+
+// Deterministic sum of the elimination kernel's per-workgroup partial sums, laid out [workgroup][entry]: a 256-thread
+// workgroup sums 64 consecutive entries - lane = entry (coalesced rows, every load independent of the last), the four
+// wavefronts take the four contiguous quarters of the rows (four interleaved accumulators each), combined in LDS in a
+// fixed order.  The same function - hence the same order, bit for bit - whether k_reduce1 runs it (one workgroup per 64
+// entries; the sharded loop all-reduces its result) or k_head does before it decides (single-GPU loop: one launch less).
+__device__ __forceinline__ double reduce_partial_rows(const double* partial, int n_part, int rb, int e, double (*sh)[64]) {
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (n_part + 3) >> 2, r0 = wv * per, r1 = min(n_part, r0 + per);
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+    if (e < rb) {
+        const double* src = partial + e;
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            v0 += src[(int64_t)r * rb]; v1 += src[(int64_t)(r + 1) * rb]; v2 += src[(int64_t)(r + 2) * rb]; v3 += src[(int64_t)(r + 3) * rb];
+        }
+        for (; r < r1; ++r) v0 += src[(int64_t)r * rb];
+    }
+    sh[wv][lane] = (v0 + v1) + (v2 + v3);
+    __syncthreads();
+    const double t = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    __syncthreads();
+    return t;                                     // every wavefront holds the sum of entry e in lane (e & 63)
 }
 
 // Which parameter / record set a group's kernels work on, and with which damping.
@@ -148,6 +186,7 @@ struct FusedArgs {
     const float* x; const float* y; const float* z; const float* u; const float* v;
     const int64_t* obs_off; const int32_t* obs_slot;
     int32_t n_obs, K, PF, PRAW, n_pw;
+    int32_t n_part;                // workgroups of the elimination kernel = partial sums per entry (set by the launcher)
     double huber_delta, min_diag, max_diag;
     double kb4_eps;                // ccal_model_conventions.kb4_small_radius of the context
     double* intr[2]; double* poses[2]; double* pf[2]; double* praw[2];
@@ -171,6 +210,10 @@ struct HeadArgs {
     double* intr[2]; double* dc;
     int32_t K, seq;
     double min_diag, max_diag;
+    // single-GPU loop: the head reduces the elimination kernel's partial sums itself (no k_reduce1 launch);
+    // partial == NULL: `red` holds the (all-)reduced sums
+    const double* partial; int32_t n_part;
+    int32_t publish_all;           // verbose solves: the whole report after every group
 };
 
 struct UnpackArgs {               // staging block (doubles): [intr CCAL_PMAX | DevState | ColInfo x CCAL_KMAX | poses np6]
@@ -183,8 +226,8 @@ hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
-hipError_t launch_schur1(const FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size)
-hipError_t launch_schur1m(const FusedArgs& a, hipStream_t s);   // four frames per wavefront; needs a.n_pw = 4 ceil(n_obs / 16)
+hipError_t launch_schur1(FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size); sets a.n_part
+hipError_t launch_schur1m(FusedArgs& a, hipStream_t s);   // four frames per wavefront, 32 per workgroup, one pass; sets a.n_part
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s);     // state := "first evaluation of set 0 with this lambda"

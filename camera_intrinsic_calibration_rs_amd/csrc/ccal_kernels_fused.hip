@@ -538,8 +538,24 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     int nmax = n;
 #pragma unroll
     for (int off = ((LPF & (LPF - 1)) == 0 ? LPF : 1); off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+#ifndef CCAL_GRAMW_HOIST
+#define CCAL_GRAMW_HOIST 1      // measured: 10 000 frames 42.5 -> 41.7 us per build, 20 000: 72.7 -> 70.6 (244 VGPRs, still two wavefronts per SIMD)
+#endif
+#if CCAL_GRAMW_HOIST
+    // phi basis: a corner needs R and t only (12 doubles): in registers, no LDS read (and no wait for one) per corner
+    double fcl[GEN ? 1 : 12];
+    if constexpr (!GEN) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fcl[i] = fc[i];
+    }
+    const double* fcp = GEN ? fc : fcl;
+#else
+    const double* fcp = fc;
+#endif
     for (int base = 0; base < nmax; base += LPF) {
+#if !CCAL_GRAMW_HOIST
         asm volatile("" ::: "memory");      // frame constants stay in LDS: no 78 registers of hoisted copies
+#endif
         const int c = base + gl;
         const bool valid = c < n;
         const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false, !GEN>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);       // fused loop: rotation columns in the phi basis
+        corner_block<MODEL, OF, false, !GEN>(th, fcp, X, Y, Z, uo, vo, ru, rv, J, J + D);      // fused loop: rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -876,27 +892,29 @@ __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
     }
     if (lane == 0) { blk[wave][2 * NA] = acc_mc; blk[wave][2 * NA + 1] = acc_fail; }
     __syncthreads();
-    const int nblk = a.n_pw / WAVES_PER_BLOCK;      // [entry][workgroup]: k_reduce1 sums one entry per workgroup
+    // [workgroup][entry]: k_reduce1 / k_head sum the rows (reduce_partial_rows)
     for (int e = threadIdx.x; e < 2 * NA + 2; e += 256)
-        a.partial[(int64_t)e * nblk + blockIdx.x] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
+        a.partial[(int64_t)blockIdx.x * (2 * NA + 2) + e] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
 }
 // k_schur1m: the same elimination with FOUR frames per wavefront (16 lanes each) - k_schur1 keeps 64 lanes busy with
 // one frame's 7 columns and 49 sums, so a 10 000-frame problem is 10 000 latency-bound wavefronts (381 vector + 520
 // scalar instructions each, 46 % of the time waiting); here the same instruction stream serves four frames.
 // One pass per wavefront: the grid covers all frames (n_pw = 4 ceil(n_obs / 16)).
+constexpr int SCHUR1M_WAVES = 8;          // 32 frames per workgroup: a quarter of the partial sums k_head / k_reduce1 have to add up
 template <int K>
-__global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
+__global__ __launch_bounds__(64 * SCHUR1M_WAVES) void k_schur1m(const FusedArgs a) {
     constexpr int K1 = K + 1, NA = K1 * K1;
     constexpr int NQ = (NA + 15) / 16;                    // A / Y^T Y entries per lane
     constexpr int REC = 21 + 6 * K1 + NA + 9;             // C (21) | [B|g] (6 x K1) | A (K1 x K1) | J_l (9)
-    constexpr int GS = (REC + 6 * K1 + 1) & ~1;           // per frame in LDS: record | Y (6 x K1)
-    __shared__ double smem[16 * GS];
-    __shared__ double blk[16][2 * NA + 2];
+    constexpr int GS = (REC + 6 * K1 + 1) & ~1;           // per frame in LDS: record | Y (6 x K1); later the frame's sums
+    constexpr int NF = 4 * SCHUR1M_WAVES;                 // frames per workgroup
+    static_assert(2 * NA + 2 <= GS, "a frame's sums reuse its record row");
+    __shared__ double smem[NF * GS];
     const DevState* st = a.st;
     if (st->done) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 4, gl = lane & 15;
-    const int f = (blockIdx.x * WAVES_PER_BLOCK + wave) * 4 + grp;
+    const int f = (blockIdx.x * SCHUR1M_WAVES + wave) * 4 + grp;
     const bool active = f < a.n_obs;
     double* R = smem + (wave * 4 + grp) * GS;
     double* Ym = R + REC;
@@ -997,24 +1015,25 @@ __global__ __launch_bounds__(256) void k_schur1m(const FusedArgs a) {
             }
         }
     }
-    // the sixteen frames of the workgroup combine in LDS (fixed order), one flush per workgroup
+    // the frames of the workgroup combine in LDS (fixed order), one flush per workgroup; a frame's sums reuse its row
+    wsync();
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int e = gl + 16 * q;
-        if (e < NA) { blk[wave * 4 + grp][e] = accA[q]; blk[wave * 4 + grp][NA + e] = accY[q]; }
+        if (e < NA) { R[e] = accA[q]; R[NA + e] = accY[q]; }
     }
-    if (gl == 0) { blk[wave * 4 + grp][2 * NA] = mcv; blk[wave * 4 + grp][2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
+    if (gl == 0) { R[2 * NA] = mcv; R[2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
     __syncthreads();
-    const int nblk = a.n_pw / WAVES_PER_BLOCK;
-    for (int e = threadIdx.x; e < 2 * NA + 2; e += 256) {
+    for (int e = threadIdx.x; e < 2 * NA + 2; e += 64 * SCHUR1M_WAVES) {
         double t = 0.0;
 #pragma unroll
-        for (int g = 0; g < 16; ++g) t += blk[g][e];
-        a.partial[(int64_t)e * nblk + blockIdx.x] = t;
+        for (int g = 0; g < NF; ++g) t += smem[g * GS + e];
+        a.partial[(int64_t)blockIdx.x * (2 * NA + 2) + e] = t;
     }
 }
-hipError_t launch_schur1m(const FusedArgs& a, hipStream_t s) {
-    const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
+hipError_t launch_schur1m(FusedArgs& a, hipStream_t s) {
+    const dim3 grid((a.n_obs + 4 * SCHUR1M_WAVES - 1) / (4 * SCHUR1M_WAVES)), blk(64 * SCHUR1M_WAVES);
+    a.n_part = (int32_t)grid.x;
     if (grid.x == 0) return hipSuccess;
     switch (a.K) {
         case 4: hipLaunchKernelGGL(k_schur1m<4>, grid, blk, 0, s, a); break;
@@ -1028,8 +1047,9 @@ hipError_t launch_schur1m(const FusedArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_schur1(const FusedArgs& a, hipStream_t s) {
+hipError_t launch_schur1(FusedArgs& a, hipStream_t s) {
     const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
+    a.n_part = (int32_t)grid.x;
     if (grid.x == 0) return hipSuccess;
     switch (a.K) {
         case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a); break;
@@ -1044,30 +1064,18 @@ hipError_t launch_schur1(const FusedArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_reduce1: red[b] = sum_w partial[b][w], one workgroup per entry, fixed order (no atomics: bitwise reproducible)
+// k_reduce1: red[e] = sum over workgroups of partial[w][e], fixed order (no atomics: bitwise reproducible)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ double block_sum(double v, double* sh) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double t = 0.0;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
-    return t;
-}
-__global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_pw, double* red, const DevState* st) {
+__global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_part, int rb, double* red, const DevState* st) {
     if (st->done) return;
-    __shared__ double sh[4];
-    const double* src = partial + (int64_t)blockIdx.x * n_pw;
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-    int i = threadIdx.x;
-    for (; i + 768 < n_pw; i += 1024) { v0 += src[i]; v1 += src[i + 256]; v2 += src[i + 512]; v3 += src[i + 768]; }
-    for (; i < n_pw; i += 256) v0 += src[i];
-    const double t = block_sum((v0 + v1) + (v2 + v3), sh);
-    if (threadIdx.x == 0) red[blockIdx.x] = t;
+    __shared__ double sh[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+    const double t = reduce_partial_rows(partial, n_part, rb, e, sh);
+    if (threadIdx.x < 64 && e < rb) red[e] = t;
 }
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce1, dim3(fused_red_size(a.K)), dim3(256), 0, s, a.partial, a.n_pw / WAVES_PER_BLOCK, a.red, a.st);
+    const int rb = fused_red_size(a.K);
+    hipLaunchKernelGGL(k_reduce1, dim3((rb + 63) / 64), dim3(256), 0, s, a.partial, a.n_part, rb, a.red, a.st);
     return hipGetLastError();
 }
 
@@ -1126,11 +1134,25 @@ __device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
     return ok;
 }
 
-__global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
+__global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
     __shared__ HeadShared hs;
     DevState& S0 = hs.S0;
     double* red = hs.red; double* S = hs.S; double* x = hs.x; int& bad = hs.bad;
     const int K = a.K, K1 = K + 1;
+    if (a.partial) {
+        // single-GPU loop: the partial sums of the elimination kernel are added up here in k_reduce1's order (a launch and a
+        // kernel boundary less per group); then wavefront 0 goes on alone
+        if (a.st->done) { if (threadIdx.x == 0) publish_host_status(a.hs, a.st, a.seq, a.publish_all != 0); return; }
+        __shared__ double shr[4][64];
+        const int rb = fused_red_size(K);
+        for (int e0 = 0; e0 < rb; e0 += 64) {
+            const int e = e0 + (threadIdx.x & 63);
+            const double t = reduce_partial_rows(a.partial, a.n_part, rb, e, shr);
+            if (threadIdx.x < 64 && e < rb) red[e] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x >= 64) return;
+    }
     const int lane = threadIdx.x;
     // everything the solve needs from global memory is requested up front, next to the state: one memory latency
     // instead of a chain of three (state -> column info -> intrinsics)
@@ -1142,12 +1164,12 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
         const double* src = reinterpret_cast<const double*>(a.st);
         double* dst = reinterpret_cast<double*>(&S0);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
-        for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red[e];
+        if (!a.partial) for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red[e];
         if (lane < K) hs.fx[lane] = ci.fixed;
     }
     __syncthreads();
     DevState* st = &S0;
-    if (st->done) { if (lane == 0) publish_host_status(a.hs, st, a.seq); return; }     // the host still waits for this group's number
+    if (st->done) { if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0); return; }     // the host still waits for this group's number
     const double* Ad = red;
     const double* Yt = red + K1 * K1;
     const bool lm = st->method == CCAL_METHOD_LM;
@@ -1221,7 +1243,7 @@ __global__ __launch_bounds__(64) void k_head(const HeadArgs a) {
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
     }
     __syncthreads();
-    if (lane == 0) publish_host_status(a.hs, st, a.seq);
+    if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
 }
 // ccal_build_normal_dev on a single camera: evaluate set 0 as a first evaluation (no pose update) with this damping
 __global__ void k_state_eval(DevState* st, double lambda) {
@@ -1234,7 +1256,7 @@ hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_head, dim3(1), dim3(a.partial ? 256 : 64), 0, s, a);
     return hipGetLastError();
 }
 

@@ -519,7 +519,7 @@ struct SolveArgs {
     const double* intr; const double* extr; double* intr_c; double* extr_c; int32_t n_intr, n_extr;
     double* dc; double* scal; int32_t* flags;
     DevState* st;                  // device-resident loop: current set = st->cur (0: intr/extr, 1: intr_c/extr_c), lambda from the state
-    HostStatus* hs; int32_t seq;
+    HostStatus* hs; int32_t seq, publish_all;
 };
 __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     SolveArgs a = a0;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         }
         __syncthreads();
         a.st = &S0;
-        if (S0.done) { if (lane == 0) publish_host_status(a.hs, &S0, a.seq); return; }
+        if (S0.done) { if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0); return; }
         if (lane == 0) go = optimizer_decide(&S0, a.red[a.RB - 3], a.red[a.RB - 2], a.red[a.RB - 1] > 0.0, a.seq) ? 1 : 0;
         __syncthreads();
         if (!go) {
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
             double* dst = reinterpret_cast<double*>(gst);
             for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
             __syncthreads();
-            if (lane == 0) publish_host_status(a.hs, &S0, a.seq);
+            if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0);
             return;
         }
         a.lambda = S0.lambda;
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
             double* dst = reinterpret_cast<double*>(gst);
             for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
             __syncthreads();
-            if (lane == 0) publish_host_status(a.hs, &S0, a.seq);
+            if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0);
         }
         return;
     }
@@ -659,14 +659,14 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         double* dst = reinterpret_cast<double*>(gst);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
         __syncthreads();
-        if (lane == 0) publish_host_status(a.hs, &S0, a.seq);
+        if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0);
     }
 }
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st,
-                        HostStatus* hs, int seq) {
+                        HostStatus* hs, int seq, bool publish_all) {
     const NormalWs* w = p->nws;
     SolveArgs a = {};
-    a.st = st; a.hs = hs; a.seq = seq;
+    a.st = st; a.hs = hs; a.seq = seq; a.publish_all = publish_all ? 1 : 0;
     a.red = w->red; a.cols = w->cols; a.K = w->K; a.RB = w->RB; a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
     a.intr = p->d_intr; a.extr = p->d_extr; a.intr_c = p->d_intr_c; a.extr_c = p->d_extr_c;
     a.n_intr = p->n_cams * CCAL_PMAX; a.n_extr = p->n_cams * 6;

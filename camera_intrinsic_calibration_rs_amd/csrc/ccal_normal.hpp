@@ -98,7 +98,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
                         const DevState* st = nullptr);
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st = nullptr);
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st = nullptr,
-                        HostStatus* hs = nullptr, int seq = 0);
+                        HostStatus* hs = nullptr, int seq = 0, bool publish_all = false);
 hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, const DevState* st = nullptr);
 
 }  // namespace ccal

@@ -77,7 +77,6 @@ static int fused_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     FusedWs* f = new FusedWs();
     w->fws = f;
-    const int K1 = p->K + 1;
     f->PRAW = praw_size(p->K);
     f->RB1 = fused_red_size(p->K);
     const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
@@ -280,15 +279,17 @@ static bool fused_use_valu_gram(const ccal_problem* p) {
     if (const char* g = std::getenv("CCAL_GRAM")) return g[0] != 'm';
     return true;
 }
-// Gram + elimination + reduce of one group on the single-camera path (everything but the collective and the decision)
-static hipError_t enqueue_fused_system(const ccal_problem* p, const FusedArgs& fa, bool schur_m, hipStream_t st) {
-    hipError_t e = hipSuccess;
-    if (p->n_obs > 0) {            // a rank whose shard is empty still takes part in the collective, with zeros
-        e = fused_use_valu_gram(p) ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
-        if (e != hipSuccess) return e;
-        e = schur_m ? launch_schur1m(fa, st) : launch_schur1(fa, st);
-        if (e != hipSuccess) return e;
-    }
+// Gram + elimination of one group on the single-camera path (fa.n_part = the number of partial sums per entry)
+static hipError_t enqueue_fused_gram_schur(const ccal_problem* p, FusedArgs& fa, bool schur_m, hipStream_t st) {
+    fa.n_part = 0;
+    if (p->n_obs <= 0) return hipSuccess;      // a rank whose shard is empty still takes part in the collective, with zeros
+    hipError_t e = fused_use_valu_gram(p) ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
+    if (e != hipSuccess) return e;
+    return schur_m ? launch_schur1m(fa, st) : launch_schur1(fa, st);
+}
+// ... + k_reduce1: the reduced sums in fws->red (the all-reduce buffer of sharded solves; ccal_build_normal_dev)
+static hipError_t enqueue_fused_system(const ccal_problem* p, FusedArgs& fa, bool schur_m, hipStream_t st) {
+    if (hipError_t e = enqueue_fused_gram_schur(p, fa, schur_m, st); e != hipSuccess) return e;
     return launch_reduce1(fa, st);
 }
 
@@ -296,17 +297,17 @@ static hipError_t enqueue_fused_system(const ccal_problem* p, const FusedArgs& f
 static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const DevState* d_state, int target) {
     const auto tw = std::chrono::steady_clock::now();
     long spins = 0;
-    while (hst->seq < target) {
+    while (status_seq(hst->word) < target) {
         if ((++spins & 0xFFF) == 0) {
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-            if (el > 0.002 && hipStreamQuery(st) == hipSuccess && hst->seq < target) {
+            if (el > 0.002 && hipStreamQuery(st) == hipSuccess && status_seq(hst->word) < target) {
                 // stream drained but the word did not arrive: fall back to an explicit copy
                 DevState ds;
                 HIP_TRY(ctx, hipMemcpy(&ds, d_state, sizeof ds, hipMemcpyDeviceToHost));
-                hst->done = ds.done; hst->done_seq = ds.done_seq; hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
+                hst->iter = ds.iter; hst->cur = ds.cur; hst->lm_accepted = ds.lm_accepted;
                 hst->lm_rejected = ds.lm_rejected; hst->cur_cost = ds.cur_cost; hst->initial_cost = ds.initial_cost;
                 hst->spec_hits = ds.spec_hits; hst->spec_misses = ds.spec_misses;
-                hst->seq = target;
+                hst->word = status_word(target, ds.done, ds.done_seq);
                 break;
             }
             if (el > 30.0) { ctx->err = "device-resident solve timed out"; return CCAL_ERR_HIP; }
@@ -326,7 +327,8 @@ static void init_state(DevState* s, const ccal_solver_opts* o) {
 }
 // Groups the host may enqueue at most: one per decision plus one re-elimination group per LM decision, plus the first.
 static int max_groups_for(const ccal_solver_opts* o) {
-    return (o->method == CCAL_METHOD_LM ? 2 : 1) * std::max(o->max_iterations, 0) + 2;
+    const int64_t n = (int64_t)(o->method == CCAL_METHOD_LM ? 2 : 1) * std::max(o->max_iterations, 0) + 2;
+    return (int)std::min<int64_t>(n, kMaxGroups);      // sequence numbers travel in 24 bits of the status word
 }
 // How many groups are kept in flight ahead of the one the host waits for.  With native RCCL the collective is just
 // another stream operation, so sharded solves run ahead like single-GPU ones; a callback is host code - the loop waits
@@ -381,7 +383,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
         HIP_TRY(ctx, launch_unpack1(ua, st));
     }
     HostStatus* hst = f->h_status;
-    hst->seq = 0; hst->done = 0; hst->done_seq = 0;
+    hst->word = 0;
 
     FusedArgs fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
     const bool schur_m = fused_use_schur1m(p, fa);
@@ -393,9 +395,24 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
     // after the first enqueue an error exit leaves kernels in flight that publish into the pinned status word:
     // the next solve / the destructor must drain the stream first
     auto fail_enqueued = [&](int code) -> int { f->tail_pending = true; return code; };
+    ha.publish_all = o->verbose ? 1 : 0;
+    const bool sharded = p->sharded();
+    static const int head_reduce_max_rows = [] { const char* e = std::getenv("CCAL_HEAD_REDUCE_ROWS"); return e ? std::atoi(e) : 40; }();
     auto enqueue = [&]() -> int {         // one group: evaluation + elimination + ONE collective + decision/solve; returns its seq
-        HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));
-        if (int e = allreduce(p, f->red, (size_t)f->RB1); e != CCAL_OK) return -e;
+        if (sharded) {
+            // Gram -> elimination -> reduce -> all-reduce of the packed sums -> head
+            HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));
+            if (int e = allreduce(p, f->red, (size_t)f->RB1); e != CCAL_OK) return -e;
+            ha.partial = nullptr; ha.n_part = 0;
+        } else {
+            // single GPU: for session-sized problems (<= 40 rows of partial sums = 1 280 frames) the head adds them up itself,
+            // three launches per group (600 / 1 000 frames: 23.6 / 24.4 -> 23.2 / 23.5 us per group); beyond ~3 000 frames one
+            // workgroup reading all rows costs more than the reduce launch it replaces (10 000 frames: 58.6 vs 52.6 us).
+            // Same sums bit for bit either way (reduce_partial_rows).
+            HIP_TRYN(ctx, enqueue_fused_gram_schur(p, fa, schur_m, st));
+            if (fa.n_part <= head_reduce_max_rows) { ha.partial = f->partial; ha.n_part = fa.n_part; }
+            else { HIP_TRYN(ctx, launch_reduce1(fa, st)); ha.partial = nullptr; ha.n_part = 0; }
+        }
         ha.seq = ++seq;
         HIP_TRYN(ctx, launch_head(ha, st));
         return seq;
@@ -426,17 +443,18 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
         // act on `done` only when it was set by a step this thread has waited for: a later group may already have
         // published it, and how many groups get enqueued must not depend on that race (sharded ranks would issue
         // different numbers of collectives)
-        if (hst->done && hst->done_seq <= waited) { status = hst->done - 1; finished = true; }
+        const uint64_t wd = hst->word;
+        if (status_done(wd) && status_done_seq(wd) <= waited) { status = status_done(wd) - 1; finished = true; }
         else if (o->verbose) std::printf("[ccal fused %s] iter %d cost %.12g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost);
     }
     // hst->done was published by the last instruction of the deciding k_head (after a system-scope fence): everything
     // the result depends on is complete.  A download goes through a side stream so that it does not queue behind
     // the early-exit groups still in the main stream; the next solve drains those before it starts.
     hipStream_t dl = st;
-    if (hst->done && !pending.empty()) { dl = f->side; f->tail_pending = true; }
+    if (status_done(hst->word) && !pending.empty()) { dl = f->side; f->tail_pending = true; }
     else HIP_TRY(ctx, hipStreamSynchronize(st));
     struct { int done, iter, cur, acc, rej, hits, misses; double cur_cost, initial_cost; } ds =
-        { hst->done, hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->spec_hits, hst->spec_misses, hst->cur_cost, hst->initial_cost };
+        { status_done(hst->word), hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->spec_hits, hst->spec_misses, hst->cur_cost, hst->initial_cost };
     if (!ds.done) { status = CCAL_ERR_NO_CONVERGENCE; }
     else status = ds.done - 1;
     if (ds.cur == 1) { std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); }
@@ -483,7 +501,7 @@ static int solve_general(ccal_problem* p, const ccal_solver_opts* o, bool host_i
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
     if (p->n_slots) HIP_TRY(ctx, hipMemsetAsync(w->mc_slot, 0, (size_t)p->n_slots * sizeof(double), st));
     HostStatus* hst = w->h_gstatus;
-    hst->seq = 0; hst->done = 0; hst->done_seq = 0;
+    hst->word = 0;
     DevState* ds = w->d_gstate;
     int seq = 0;
     auto fail_enqueued = [&](int code) -> int { w->tail_pending = true; return code; };
@@ -492,7 +510,7 @@ static int solve_general(ccal_problem* p, const ccal_solver_opts* o, bool host_i
         HIP_TRYN(ctx, launch_schur(p, w->cur, 0.0, min_d, max_d, st, ds));
         HIP_TRYN(ctx, launch_reduce(p, st, ds));
         if (int e = allreduce(p, w->red, (size_t)w->RB); e != CCAL_OK) return -e;
-        HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds, hst, ++seq));
+        HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds, hst, ++seq, o->verbose != 0));
         HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
         return seq;
     };
@@ -514,14 +532,14 @@ static int solve_general(ccal_problem* p, const ccal_solver_opts* o, bool host_i
         if ((rc = wait_status(ctx, st, hst, w->d_gstate, waited)) != CCAL_OK) return fail_enqueued(rc);
         pending.erase(pending.begin());
         if (o->verbose) std::printf("[ccal %s] iter %d cost %.12g radius %.3g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost, hst->radius);
-        if (hst->done && hst->done_seq <= waited) finished = true;     // see solve_fused: no dependence on publication races
+        if (status_done(hst->word) && status_done_seq(hst->word) <= waited) finished = true;     // see solve_fused: no dependence on publication races
     }
     // the deciding k_solve published after a system-scope fence: the result is complete; it is downloaded through a
     // side stream so that it does not queue behind the early-exit group enqueued ahead (drained before the next solve)
     hipStream_t dl = st;
-    if (hst->done && !pending.empty()) { dl = w->side; w->tail_pending = true; }
+    if (status_done(hst->word) && !pending.empty()) { dl = w->side; w->tail_pending = true; }
     else HIP_TRY(ctx, hipStreamSynchronize(st));
-    int status = hst->done ? hst->done - 1 : CCAL_ERR_NO_CONVERGENCE;
+    int status = status_done(hst->word) ? status_done(hst->word) - 1 : CCAL_ERR_NO_CONVERGENCE;
     if (hst->cur == 1) {             // the accepted point lives in set 1: make it set 0 for whoever comes next
         std::swap(p->d_intr, p->d_intr_c); std::swap(p->d_poses, p->d_poses_c); std::swap(p->d_extr, p->d_extr_c);
         w->cur ^= 1;
