@@ -277,12 +277,14 @@ def main():
     # library itself on its own RCCL communicator.  Every rank solves its shard of a (frames x world)-frame problem.
     # A collective that never completes must not take the headline line down with it, and must not look like success:
     # a watchdog prints the line (rank 0) and exits NON-ZERO on every rank that hangs.
-    if world > 1 and not args.no_extra:
+    force_sharded = os.environ.get("CCAL_BENCH_FORCE_SHARDED") == "1"     # developer switch: the sharded leg on a 1-rank communicator
+    if (world > 1 or force_sharded) and not args.no_extra:
         import threading
         result = {}
         # one shared camera: every rank starts from rank 0's initial intrinsics (each rank's frames are its own)
         intr_shared = torch.from_numpy(np.ascontiguousarray(sp.intr0)).to(dev)
-        dist.broadcast(intr_shared, src=0)
+        if world > 1:
+            dist.broadcast(intr_shared, src=0)
         start = synth.dataclasses.replace(sp, intr0=intr_shared.cpu().numpy())
         native = backend == "nccl" and engine.rccl_available()
         comm = None
@@ -291,7 +293,8 @@ def main():
             idt = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:
                 idt = torch.tensor(list(engine.rccl_unique_id()), dtype=torch.uint8, device=dev)
-            dist.broadcast(idt, src=0)
+            if world > 1:
+                dist.broadcast(idt, src=0)
             uid = bytes(idt.cpu().tolist())
 
         def sharded():
@@ -314,7 +317,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 result["error"] = repr(e)
             finally:
-                prob.set_rccl_comm(None)
+                prob.set_rccl_comm(None)            # drains the early-exit groups (and their collectives) still queued
                 prob.set_allreduce(None)
 
         th = threading.Thread(target=sharded, daemon=True)

@@ -258,6 +258,7 @@ int ccal_disable_distortions(ccal_problem* p, int n_disabled, double* intr_io) {
 }
 int ccal_set_allreduce(ccal_problem* p, ccal_allreduce_fn fn, void* user) {
     if (!p) return CCAL_ERR_INVALID_ARG;
+    if (p->allreduce != fn || p->allreduce_user != user) { const int rc = drain_pending_groups(p); if (rc != CCAL_OK) return rc; }
     p->allreduce = fn; p->allreduce_user = user;
     return CCAL_OK;
 }

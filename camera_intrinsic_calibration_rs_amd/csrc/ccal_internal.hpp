@@ -110,6 +110,8 @@ hipError_t launch_eval(const ccal_problem* p, int cam, const KArgs& a, hipStream
 hipError_t launch_reproj_err(const ccal_problem* p, int cam, const KArgs& a, hipStream_t s);
 // ccal_rccl.hip: in-place sum over the ranks of an ncclComm_t, ordered on the stream; returns a ccal_status
 int rccl_allreduce_sum(ccal_ctx* ctx, void* comm, double* buf, size_t count, hipStream_t st);
+// ccal_solver.hip: wait for the early-exit groups a finished solve left in the stream (no-op if there are none)
+int drain_pending_groups(ccal_problem* p);
 // ccal_kernels_stats.hip
 hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
 // ccal_kernels_init.hip

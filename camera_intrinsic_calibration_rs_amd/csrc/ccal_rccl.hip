@@ -123,6 +123,12 @@ int ccal_rccl_comm_destroy(void* comm) {
 int ccal_set_rccl_comm(ccal_problem* p, void* nccl_comm) {
     if (!p) return CCAL_ERR_INVALID_ARG;
     if (nccl_comm && !rccl()) { note_error(p->ctx, "RCCL is not available (librccl.so.1 not found)"); return CCAL_ERR_UNSUPPORTED; }
+    // early-exit groups of the last solve (each with its collective on the old communicator) may still be queued: they
+    // must have run before the caller may destroy that communicator
+    if (p->rccl_comm != nccl_comm) {
+        int rc = drain_pending_groups(p);
+        if (rc != CCAL_OK) return rc;
+    }
     p->rccl_comm = nccl_comm;
     return CCAL_OK;
 }

@@ -70,6 +70,17 @@ void normal_ws_destroy(ccal_problem* p) {
     p->nws = nullptr;
 }
 
+int drain_pending_groups(ccal_problem* p) {
+    NormalWs* w = p->nws;
+    if (!w || !(w->tail_pending || (w->fws && w->fws->tail_pending))) return CCAL_OK;
+    ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    w->tail_pending = false;
+    if (w->fws) w->fws->tail_pending = false;
+    return CCAL_OK;
+}
+
 static int fused_ws_ensure(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (w->fws) return CCAL_OK;
