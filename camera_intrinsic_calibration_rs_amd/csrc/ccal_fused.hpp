@@ -202,6 +202,8 @@ struct FusedArgs {
 //   C = H_pp packed lower (21) | [B = H_pc | g_p] (6 x (K+1)) | A = [J_c | r]^T W [J_c | r] ((K+1)^2) | J_l, the frame's left Jacobian (9)
 __host__ __device__ constexpr int praw_jl_off(int K) { return 21 + 6 * (K + 1) + (K + 1) * (K + 1); }
 __host__ __device__ constexpr int praw_size(int K) { return (praw_jl_off(K) + 9 + 1) & ~1; }
+// rows of partial sums up to which k_head adds them up itself (session-sized problems: <= 1 280 frames); see solve_fused
+constexpr int kHeadReduceRows = 40;
 // red / partial rows of the single-camera path: [A_dir (K1 x K1) | Y^T Y (K1 x K1) | mc_pose | failed pose blocks]
 __host__ __device__ constexpr int fused_red_size(int K) { return 2 * (K + 1) * (K + 1) + 2; }
 

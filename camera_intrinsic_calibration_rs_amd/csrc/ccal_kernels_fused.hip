@@ -1073,9 +1073,29 @@ __global__ __launch_bounds__(256) void k_reduce1(const double* partial, int n_pa
     const double t = reduce_partial_rows(partial, n_part, rb, e, sh);
     if (threadIdx.x < 64 && e < rb) red[e] = t;
 }
+// Many rows (> kHeadReduceRows, where k_head never reduces itself): one workgroup per entry, 256 threads over the rows,
+// shuffle tree + four wavefront sums - the parallel form (10 000 frames = 313 rows: 4.4 us instead of 7.8)
+__global__ __launch_bounds__(256) void k_reduce1_wide(const double* partial, int n_part, int rb, double* red, const DevState* st) {
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double* src = partial + blockIdx.x;
+    double v0 = 0.0, v1 = 0.0;
+    int r = threadIdx.x;
+    for (; r + 256 < n_part; r += 512) { v0 += src[(int64_t)r * rb]; v1 += src[(int64_t)(r + 256) * rb]; }
+    if (r < n_part) v0 += src[(int64_t)r * rb];
+    double v = v0 + v1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) red[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s) {
     const int rb = fused_red_size(a.K);
-    hipLaunchKernelGGL(k_reduce1, dim3((rb + 63) / 64), dim3(256), 0, s, a.partial, a.n_part, rb, a.red, a.st);
+    // up to kHeadReduceRows rows the order must be k_head's own (reduce_partial_rows): sharded and single-GPU solves of the
+    // same frames then agree bit for bit; beyond, both go through the wide form
+    if (a.n_part <= kHeadReduceRows) hipLaunchKernelGGL(k_reduce1, dim3((rb + 63) / 64), dim3(256), 0, s, a.partial, a.n_part, rb, a.red, a.st);
+    else hipLaunchKernelGGL(k_reduce1_wide, dim3(rb), dim3(256), 0, s, a.partial, a.n_part, rb, a.red, a.st);
     return hipGetLastError();
 }
 

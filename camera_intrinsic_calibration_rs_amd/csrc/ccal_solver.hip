@@ -408,7 +408,8 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
     auto fail_enqueued = [&](int code) -> int { f->tail_pending = true; return code; };
     ha.publish_all = o->verbose ? 1 : 0;
     const bool sharded = p->sharded();
-    static const int head_reduce_max_rows = [] { const char* e = std::getenv("CCAL_HEAD_REDUCE_ROWS"); return e ? std::atoi(e) : 40; }();
+    // CCAL_HEAD_REDUCE_ROWS=0 (developer switch): always the separate reduce launch
+    static const int head_reduce_max_rows = [] { const char* e = std::getenv("CCAL_HEAD_REDUCE_ROWS"); return e ? std::min(std::atoi(e), kHeadReduceRows) : kHeadReduceRows; }();
     auto enqueue = [&]() -> int {         // one group: evaluation + elimination + ONE collective + decision/solve; returns its seq
         if (sharded) {
             // Gram -> elimination -> reduce -> all-reduce of the packed sums -> head
