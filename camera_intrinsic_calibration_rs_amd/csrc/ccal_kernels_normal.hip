@@ -455,7 +455,12 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
         }
         wave_sync_lds();
     }
-    for (int e = lane; e < RB; e += 64) a.partial[(int64_t)e * a.n_pw + gw] = acc[e];
+    // the four wavefronts of the workgroup combine in LDS (fixed order): a quarter of the partial sums to write and for
+    // k_reduce to read (4 096 wavefronts x 367 doubles were 12 MB per group for two EUCM cameras)
+    __syncthreads();
+    const int nblk = a.n_pw / WAVES_PER_BLOCK;
+    for (int e = threadIdx.x; e < RB; e += 256)
+        a.partial[(int64_t)e * nblk + blockIdx.x] = (smem[e] + smem[WS + e]) + (smem[2 * WS + e] + smem[3 * WS + e]);
 }
 
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw,
 }
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw, w->red, st);
+    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw / WAVES_PER_BLOCK, w->red, st);
     return hipGetLastError();
 }
 
