@@ -196,6 +196,7 @@ struct FusedArgs {
     // general (multi-camera) loop, camera-0 blocks through the register Gram kernels: the camera's observation frames
     // and where each frame's record goes inside the Gram buffer praw[set] (doubles)
     const int32_t* list; const int64_t* rec_off;
+    int32_t avg_corners;           // corners per observation frame on average (lanes-per-frame choice of the Gram launchers)
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:

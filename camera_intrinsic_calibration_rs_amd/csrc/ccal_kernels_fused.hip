@@ -681,20 +681,29 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
-// Lanes per frame.  Two wavefronts fit a SIMD (2 048 slots on the chip) and a wavefront's life is the same whether the
-// chip is full or not, so what a launch costs is ROUNDS x (corner passes per lane x pass + per-wavefront set-up and
-// reduction): few lanes per frame = many corner passes per lane but fewer wavefronts and the set-up / reduction
-// amortised over more corners.  10 000 frames at 16 lanes per frame are 2 500 wavefronts = one full round and a second
-// one for the last 452 (36 us); at 12 lanes (5 frames per wavefront, 4 lanes idle) 2 000 wavefronts = ONE round.
-// The table below is the measured optimum of the whole build (tools/sweep_lpf.py); CCAL_GRAMV_LPF overrides.
-static int gram_lanes_per_frame(int n_obs) {
+// Lanes per frame.  A wavefront's life is the same whether the chip is full or not, so what a launch costs is
+//     ROUNDS of wavefronts x (per-wavefront set-up and reduction + corner passes per lane x one pass)
+// with `slots` wavefronts per round (k_gram1w: two per SIMD = 2 048, k_gram1v: one = 1 024): few lanes per frame = many
+// passes per lane but fewer wavefronts and the set-up / reduction amortised over more corners.  10 000 frames: k_gram1w at
+// 16 lanes (2 500 wavefronts) = one full round and a second one for the last 452, at 12 lanes (five frames per wavefront,
+// four lanes idle) 2 000 wavefronts = ONE round; k_gram1v at 6 lanes (ten frames per wavefront) 1 000 wavefronts = one
+// round of 24 passes beats two rounds of 12.  The model (set-up + reduction = 3.5 passes) reproduces the measured order of
+// every point of tools/sweep_lpf.py and tools/gram_models.sh; CCAL_GRAMV_LPF overrides.
+static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots) {
     static const int lpf_env = [] { const char* e = std::getenv("CCAL_GRAMV_LPF"); return e ? std::atoi(e) : 0; }();
     if (lpf_env) return lpf_env;
-    if (n_obs <= 1024) return 64;
-    if (n_obs <= 4096) return 32;
-    if (n_obs <= 8192) return 16;
-    if (n_obs <= 10240) return 12;
-    return 8;
+    static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
+    int best = 64;
+    double best_cost = 1e300;
+    for (int i = 0; i < 6; ++i) {
+        const int lpf = cand[i], g = 64 / lpf;
+        const int64_t waves = ((int64_t)n_obs + g - 1) / g;
+        const int64_t rounds = (waves + slots - 1) / slots;
+        const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
+        const double cost = (double)rounds * (3.5 + passes);
+        if (cost < best_cost) { best_cost = cost; best = lpf; }        // ties: the wider mapping (listed first)
+    }
+    return best;
 }
 template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
@@ -706,10 +715,10 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     // larger triangles (KB4: 105 / 120 entries, OPENCV5: 120 / 136) do not fit two wavefronts per SIMD without scratch
     // (one-focal KB4 through k_gram1w: 124 us instead of 64 at 10 000 frames): k_gram1v there
     const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 91);
-    const int lpf = gram_lanes_per_frame(a.n_obs);
+    const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024);
 #define CCAL_LPF_CASE(L) case L: return w ? launch_gram1v_l<MODEL, OF, L, true, GEN>(a, s) : launch_gram1v_l<MODEL, OF, L, false, GEN>(a, s);
     switch (lpf) {
-        CCAL_LPF_CASE(8) CCAL_LPF_CASE(12) CCAL_LPF_CASE(16) CCAL_LPF_CASE(32)
+        CCAL_LPF_CASE(6) CCAL_LPF_CASE(8) CCAL_LPF_CASE(12) CCAL_LPF_CASE(16) CCAL_LPF_CASE(32)
         default: return w ? launch_gram1v_l<MODEL, OF, 64, true, GEN>(a, s) : launch_gram1v_l<MODEL, OF, 64, false, GEN>(a, s);
     }
 #undef CCAL_LPF_CASE

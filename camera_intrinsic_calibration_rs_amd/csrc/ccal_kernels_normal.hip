@@ -2,6 +2,8 @@
 // Schur complement, deterministic reductions, the small camera-system solve and the pose
 // back-substitution.  Replaces tiny-solver's sparse J^T J assembly + sparse Cholesky (call sites
 // src/util.rs:455, 670) by the exact arrow-structure elimination described in SURVEY 8(e).
+#include <algorithm>
+
 #include "ccal_device.hpp"
 #include "ccal_fused.hpp"
 
@@ -262,6 +264,7 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
         fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
         fa.praw[0] = w->G[w->cur]; fa.praw[1] = w->G[w->cur ^ 1];
         fa.st = st;
+        fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
         return launch_gram1v_general(p->cams[0].model, p->one_focal, fa, s);
     }
     GramArgs ga = {};

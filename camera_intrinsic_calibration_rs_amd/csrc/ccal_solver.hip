@@ -271,6 +271,7 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
     fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
+    fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
     return fa;
 }
 // Per-frame elimination with four frames per wavefront (k_schur1m) when one pass covers the problem; sets fa.n_pw.

@@ -324,10 +324,10 @@ print("LPF-OK")
 """
 
 
-@pytest.mark.parametrize("lpf", [8, 12, 16, 32, 64])
+@pytest.mark.parametrize("lpf", [6, 8, 12, 16, 32, 64])
 def test_gram_lanes_per_frame_every_mapping(lpf):
-    """Every lanes-per-frame mapping of the register Gram kernels (8, 12 - five frames per wavefront, four lanes idle -,
-    16, 32, 64) forced through CCAL_GRAMV_LPF (read once per process, hence the subprocess), ragged frames, with damping
+    """Every lanes-per-frame mapping of the register Gram kernels (6 and 12 - ten / five frames per wavefront, four lanes
+    idle -, 8, 16, 32, 64) forced through CCAL_GRAMV_LPF (read once per process, hence the subprocess), ragged frames, with damping
     (the per-frame phi -> rvec map only shows under damping: the undamped Schur complement is basis invariant)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
