@@ -158,6 +158,58 @@ __device__ inline void frame_setup(const double* pose, const double* extr, doubl
     }
 }
 
+// General (multi-camera) loop, register Gram kernels: every camera's blocks are evaluated at the COMPOSED pose
+//   T_cb = T_c0 o T_0b  (camera 0: T_0b),   R = R_c0 R_0b,  t = R_c0 t_0b + t_c0,
+// with corner_block<..., PHI>: six pose columns j [-(R X)x | I] in the split left-perturbation basis (phi_cb, delta_cb) of the
+// composed pose - the same 6 + P_eff + 1 columns and the same kernel for every camera.  The block's twelve reference
+// columns (rvec_0_b, tvec_0_b, rvec_c_0, tvec_c_0: src/optimization/factors.rs:212-218) are per-frame constant linear
+// combinations of those six:
+//   (phi_cb, delta_cb) = [ R_c0 J_l(rvec_0b)   0    |  J_l(rvec_c0)                      0 ] (d rvec_0b, d tvec_0b, d rvec_c0, d tvec_c0)
+//                        [ 0                   R_c0 |  -[R_c0 t_0b]x J_l(rvec_c0)        I ]
+// so the per-slot elimination (k_schur) expands a frame's 13-column Gram with that 6 x 12 matrix E once per frame instead
+// of every corner carrying 19 columns.  fc12 = R | t; ept = E transposed, dense: ept[6 b + m] = E[m][b], b < 12
+// (camera 0: R_c0 = I, the extrinsics columns b >= 6 are never read).
+constexpr int GEN_EPT = 72;
+__device__ inline void frame_setup_composed(const double* pose, const double* extr, double* fc12, double* ept) {
+    double R0[9], J0[9];
+    so3_exp_ljac(pose, R0, J0);
+#pragma unroll
+    for (int i = 0; i < GEN_EPT; ++i) ept[i] = 0.0;
+    if (!extr) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fc12[i] = R0[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fc12[9 + i] = pose[3 + i];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) ept[6 * b + m] = J0[m * 3 + b];
+            ept[6 * (3 + b) + 3 + b] = 1.0;
+        }
+    } else {
+        double R1[9], J1[9], v[3], RJ[9], SJ[9];
+        so3_exp_ljac(extr, R1, J1);
+        mat3_mul(R1, R0, fc12);
+        mat3_vec(R1, pose + 3, v);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fc12[9 + i] = v[i] + extr[3 + i];
+        mat3_mul(R1, J0, RJ);
+        const double S[9] = { 0.0, v[2], -v[1], -v[2], 0.0, v[0], v[1], -v[0], 0.0 };      // -[v]x
+        mat3_mul(S, J1, SJ);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                ept[6 * b + m] = RJ[m * 3 + b];                 // rvec_0_b -> phi
+                ept[6 * (3 + b) + 3 + m] = R1[m * 3 + b];       // tvec_0_b -> delta
+                ept[6 * (6 + b) + m] = J1[m * 3 + b];           // rvec_c_0 -> phi
+                ept[6 * (6 + b) + 3 + m] = SJ[m * 3 + b];       // rvec_c_0 -> delta
+            }
+            ept[6 * (9 + b) + 3 + b] = 1.0;                     // tvec_c_0 -> delta
+        }
+    }
+}
+
 // Intrinsics of one camera as the kernels hold them: th[0 .. P) = FULL model parameters (fy := fx with ONE_FOCAL)
 // and th[P] = the run-time convention slot (KB4: the small-radius threshold of project_one, dead for the others).
 template <int MODEL> __host__ __device__ constexpr int th_len() { return model_np(MODEL) + 1; }
@@ -313,7 +365,7 @@ __device__ __forceinline__ void corner_block(const double* th, const double* fc,
     const double ju[3] = { fx * dmx[0], fx * dmx[1], fx * dmx[2] };
     const double jv[3] = { fy * dmy[0], fy * dmy[1], fy * dmy[2] };
     if constexpr (PHI) {
-        static_assert(!OTHER || !PHI, "the phi basis is used by camera-0 blocks only");
+        static_assert(!OTHER || !PHI, "the phi basis takes one (possibly composed) pose: OTHER blocks go through frame_setup_composed");
         // d(u, v) / d phi = (R X) x j
         Ju[PE + 0] = ry * ju[2] - rz * ju[1]; Ju[PE + 1] = rz * ju[0] - rx * ju[2]; Ju[PE + 2] = rx * ju[1] - ry * ju[0];
         Jv[PE + 0] = ry * jv[2] - rz * jv[1]; Jv[PE + 1] = rz * jv[0] - rx * jv[2]; Jv[PE + 2] = rx * jv[1] - ry * jv[0];

@@ -193,9 +193,10 @@ struct FusedArgs {
     double* fcbuf; double* mc_f; double* cost_f;
     const double* dc; const DevState* st;
     double* partial; double* red;
-    // general (multi-camera) loop, camera-0 blocks through the register Gram kernels: the camera's observation frames
-    // and where each frame's record goes inside the Gram buffer praw[set] (doubles)
+    // general (multi-camera) loop, one camera's blocks through the register Gram kernels (GEN): the camera's observation
+    // frames, where each frame's record goes inside the Gram buffer praw[set] (doubles), the camera and the extrinsics sets
     const int32_t* list; const int64_t* rec_off;
+    int32_t cam; const double* extr[2];
     int32_t avg_corners;           // corners per observation frame on average (lanes-per-frame choice of the Gram launchers)
 };
 
@@ -203,6 +204,12 @@ struct FusedArgs {
 //   C = H_pp packed lower (21) | [B = H_pc | g_p] (6 x (K+1)) | A = [J_c | r]^T W [J_c | r] ((K+1)^2) | J_l, the frame's left Jacobian (9)
 __host__ __device__ constexpr int praw_jl_off(int K) { return 21 + 6 * (K + 1) + (K + 1) * (K + 1); }
 __host__ __device__ constexpr int praw_size(int K) { return (praw_jl_off(K) + 9 + 1) & ~1; }
+// GEN record of one observation frame (general loop), laid out for k_schur's expansion: every row it multiplies with E is
+// six contiguous doubles:  C (6 x 6, full symmetric) | [B|g]^T (K1 x 6: row = camera column, r last) | A (K1 x K1) |
+// E^T dense (12 x 6, frame_setup_composed);  K = the camera's P_eff
+__host__ __device__ constexpr int gen_a_off(int K) { return 36 + 6 * (K + 1); }
+__host__ __device__ constexpr int gen_e_off(int K) { return (36 + 6 * (K + 1) + (K + 1) * (K + 1) + 1) & ~1; }    // 16-byte aligned rows
+__host__ __device__ constexpr int gen_rec_size(int K) { return gen_e_off(K) + 72; }
 // rows of partial sums up to which k_head adds them up itself (session-sized problems: <= 1 280 frames); see solve_fused
 constexpr int kHeadReduceRows = 40;
 // red / partial rows of the single-camera path: [A_dir (K1 x K1) | Y^T Y (K1 x K1) | mc_pose | failed pose blocks]

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
 // C (21) | [B|g] (6 x K1) | A (K1 x K1, both halves), worked out at compile time: dst | mirror << 16 (0xffff = none).
 // W = number of leading camera columns whose products with the pose columns are left out (k_gram1w keeps those in LDS
 // and writes them separately).
-template <int K, int W>
+template <int K, int W, bool GEN = false>
 struct RecMap {
     static constexpr int D = K + 6, NC = D + 1, K1 = K + 1;
     static constexpr int N = NC * (NC + 1) / 2 - 6 * W;
@@ -237,15 +237,22 @@ struct RecMap {
                 if (!ip && jp && i < W) continue;
                 const int ci = i < K ? i : K, cj = j < K ? j : K;           // camera-block index (r -> K)
                 uint32_t a = 0, b = 0xffff;
-                if (ip && jp) a = (j - K) * (j - K + 1) / 2 + (i - K);
-                else if (!ip && jp) a = 21 + (j - K) * K1 + ci;             // i camera, j pose
-                else if (ip && !jp) a = 21 + (i - K) * K1 + K;              // i pose, j = r
-                else { a = 21 + 6 * K1 + ci * K1 + cj; b = 21 + 6 * K1 + cj * K1 + ci; }
+                if (!GEN) {
+                    if (ip && jp) a = (j - K) * (j - K + 1) / 2 + (i - K);
+                    else if (!ip && jp) a = 21 + (j - K) * K1 + ci;             // i camera, j pose
+                    else if (ip && !jp) a = 21 + (i - K) * K1 + K;              // i pose, j = r
+                    else { a = 21 + 6 * K1 + ci * K1 + cj; b = 21 + 6 * K1 + cj * K1 + ci; }
+                } else {                                                        // GEN record (ccal_fused.hpp)
+                    if (ip && jp) { a = (i - K) * 6 + (j - K); if (i != j) b = (j - K) * 6 + (i - K); }
+                    else if (!ip && jp) a = 36 + ci * 6 + (j - K);
+                    else if (ip && !jp) a = 36 + K * 6 + (i - K);
+                    else { a = gen_a_off(K) + ci * K1 + cj; b = gen_a_off(K) + cj * K1 + ci; }
+                }
                 d[r++] = a | (b << 16);
             }
     }
 };
-template <int K, int W> __device__ const RecMap<K, W> g_recmap = RecMap<K, W>();
+template <int K, int W, bool GEN = false> __device__ const RecMap<K, W, GEN> g_recmap = RecMap<K, W, GEN>();
 
 #ifndef CCAL_GRAMV_WPB
 #define CCAL_GRAMV_WPB 2          // wavefronts per workgroup (4 frames each)
@@ -255,9 +262,10 @@ template <bool OF> __device__ constexpr bool nz_u(int i) { return OF ? (i != 2) 
 template <bool OF> __device__ constexpr bool nz_v(int i) { return OF ? (i != 1) : (i != 0 && i != 2); }
 
 // LPF = lanes per frame (16, 32 or 64): small problems spread a frame over more lanes so that the chip still fills.
-// GEN: the general (multi-camera) loop's camera-0 blocks - the frames are those of a.list, the evaluated pose is read as it
-// stands (k_backsub has formed it), the rotation columns stay in the rvec basis (k_schur mixes cameras), and the record
-// goes to the observation frame's slot of the Gram buffer (a.rec_off), where k_schur reads it through its table.
+// GEN: one camera's blocks of the general (multi-camera) loop - the frames are those of a.list, the slot pose is read as it
+// stands (k_backsub has formed it) and composed with the camera's extrinsics (frame_setup_composed): the six pose columns
+// are those of the COMPOSED pose, in the phi basis, for every camera; the record goes to the observation frame's place in
+// the Gram buffer (a.rec_off) together with the blocks of the matrix that expands it to the block's reference columns.
 template <int MODEL, bool OF, int LPF, bool GEN>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedArgs a) {
     constexpr int G = 64 / LPF;                     // frames per wavefront
@@ -336,11 +344,30 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             }
         }
         if (!GEN && active && gl == 0) a.mc_f[f] = mc;
-        double fcr[FC_N0];
-        frame_setup<false>(pose, nullptr, fcr);
-        if (gl == 0 && lane_ok) {
+        if constexpr (GEN) {
+            // composed pose T_c0 o T_0b and the 6 x 12 expansion matrix E (frame_setup_composed); E^T goes straight into
+            // the frame's record, where k_schur finds it
+            const bool other = a.cam > 0;
+            double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
-            for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
+            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
+            frame_setup_composed(pose, other ? ex : nullptr, fcr, ept);
+            if (gl == 0 && lane_ok) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
+            }
+            if (gl == 0 && active) {
+                double2* rec = reinterpret_cast<double2*>(a.praw[es] + a.rec_off[fa_] + gen_e_off(K));
+#pragma unroll
+                for (int i = 0; i < GEN_EPT / 2; ++i) rec[i] = make_double2(ept[2 * i], ept[2 * i + 1]);
+            }
+        } else {
+            double fcr[FC_N0];
+            frame_setup<false>(pose, nullptr, fcr);
+            if (gl == 0 && lane_ok) {
+#pragma unroll
+                for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
+            }
         }
     }
     wsync();
@@ -362,7 +389,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false, !GEN>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);       // fused loop: rotation columns in the phi basis
+        corner_block<MODEL, OF, false, true>(th, fc, X, Y, Z, uo, vo, ru, rv, J, J + D);       // rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -415,7 +442,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
             const int ff = fbase + g;
             if (e >= NE || ff >= a.n_obs) continue;
-            const uint32_t m = g_recmap<K, 0>.d[e];
+            const uint32_t m = g_recmap<K, 0, GEN>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
             rec[m & 0xffff] = v;
@@ -520,11 +547,30 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             }
         }
         if (!GEN && active && gl == 0) a.mc_f[f] = mc;
-        double fcr[FC_N0];
-        frame_setup<false>(pose, nullptr, fcr);
-        if (gl == 0 && lane_ok) {
+        if constexpr (GEN) {
+            // composed pose T_c0 o T_0b and the 6 x 12 expansion matrix E (frame_setup_composed); E^T goes straight into
+            // the frame's record, where k_schur finds it
+            const bool other = a.cam > 0;
+            double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
-            for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
+            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
+            frame_setup_composed(pose, other ? ex : nullptr, fcr, ept);
+            if (gl == 0 && lane_ok) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
+            }
+            if (gl == 0 && active) {
+                double2* rec = reinterpret_cast<double2*>(a.praw[es] + a.rec_off[fa_] + gen_e_off(K));
+#pragma unroll
+                for (int i = 0; i < GEN_EPT / 2; ++i) rec[i] = make_double2(ept[2 * i], ept[2 * i + 1]);
+            }
+        } else {
+            double fcr[FC_N0];
+            frame_setup<false>(pose, nullptr, fcr);
+            if (gl == 0 && lane_ok) {
+#pragma unroll
+                for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
+            }
         }
     }
     wsync();
@@ -543,12 +589,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
 #endif
 #if CCAL_GRAMW_HOIST
     // phi basis: a corner needs R and t only (12 doubles): in registers, no LDS read (and no wait for one) per corner
-    double fcl[GEN ? 1 : 12];
-    if constexpr (!GEN) {
+    double fcl[12];
 #pragma unroll
-        for (int i = 0; i < 12; ++i) fcl[i] = fc[i];
-    }
-    const double* fcp = GEN ? fc : fcl;
+    for (int i = 0; i < 12; ++i) fcl[i] = fc[i];
+    const double* fcp = fcl;
 #else
     const double* fcp = fc;
 #endif
@@ -565,7 +609,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
         double ru, rv, J[2 * D];
-        corner_block<MODEL, OF, false, !GEN>(th, fcp, X, Y, Z, uo, vo, ru, rv, J, J + D);      // fused loop: rotation columns in the phi basis
+        corner_block<MODEL, OF, false, true>(th, fcp, X, Y, Z, uo, vo, ru, rv, J, J + D);      // rotation columns in the phi basis
         const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
         // sqrt(w)-scaled rows (only the structurally non-zero entries are ever touched)
         double su[NC], sv[NC];
@@ -617,7 +661,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const int ff = fbase + g;
             if (ff >= a.n_obs) continue;
             const int i = t / 6, jp = t - 6 * i;
-            a.praw[es][(GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW) + 21 + jp * K1 + i] = resa[q];
+            a.praw[es][GEN ? a.rec_off[a.list[ff]] + 36 + i * 6 + jp : (int64_t)ff * a.PRAW + 21 + jp * K1 + i] = resa[q];
         }
     }
 
@@ -652,7 +696,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const int g = idx / HALF, t = idx - g * HALF, e = h * HALF + t;
             const int ff = fbase + g;
             if (e >= NR || ff >= a.n_obs) continue;
-            const uint32_t m = g_recmap<K, NLC>.d[e];
+            const uint32_t m = g_recmap<K, NLC, GEN>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
             rec[m & 0xffff] = v;

@@ -253,19 +253,22 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
 // device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1])
 hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s) {
     const NormalWs* w = p->nws;
-    if (cam == 0 && w->cam0_register_gram) {
-        // camera-0 blocks (6 + P_eff + 1 columns: a triangle of <= 136 entries) through the register Gram kernels of the
-        // single-camera loop, record format; k_schur's table reads it (caminfo NCP = 0).  10 000 frames: 50 -> ~30 us
+    if (w->register_gram) {
+        // every camera's blocks (6 + P_eff + 1 columns at the composed pose: a triangle of <= 136 entries) through the
+        // register Gram kernels of the single-camera loop, record format; k_schur expands the records (caminfo NCP = 0).
+        // Two EUCM cameras x 10 000 frames: 32 + 60 us (matrix-core kernel for camera 1, 19 columns) -> 2 x ~32 us
         FusedArgs fa = {};
         fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
         fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
-        fa.list = p->cams[0].d_obs; fa.n_obs = (int32_t)p->cams[0].obs.size(); fa.rec_off = w->d_goff;
-        fa.K = p->cams[0].Peff; fa.huber_delta = p->huber_delta; fa.kb4_eps = p->ctx->conv.kb4_small_radius;
-        fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
+        fa.list = p->cams[cam].d_obs; fa.n_obs = (int32_t)p->cams[cam].obs.size(); fa.rec_off = w->d_goff;
+        fa.K = p->cams[cam].Peff; fa.huber_delta = p->huber_delta; fa.kb4_eps = p->ctx->conv.kb4_small_radius;
+        fa.intr[0] = p->d_intr + cam * CCAL_PMAX; fa.intr[1] = p->d_intr_c + cam * CCAL_PMAX;
+        fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
+        fa.extr[0] = p->d_extr; fa.extr[1] = p->d_extr_c; fa.cam = cam;
         fa.praw[0] = w->G[w->cur]; fa.praw[1] = w->G[w->cur ^ 1];
         fa.st = st;
         fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
-        return launch_gram1v_general(p->cams[0].model, p->one_focal, fa, s);
+        return launch_gram1v_general(p->cams[cam].model, p->one_focal, fa, s);
     }
     GramArgs ga = {};
     KArgs& a = ga.k;
@@ -289,6 +292,7 @@ struct SchurArgs {
     const int64_t* slot_desc;      // per (slot, observation) in slot order: goff * 8 + camera - one load instead of three
     const int32_t* slot_off; const int32_t* caminfo; int32_t n_cams;
     int32_t n_slots, K, RB, PF, n_pw;
+    int32_t STG;                   // per-wavefront staging (doubles) for record-format observations, 0 = none
     double lambda, min_diag, max_diag;
     double* partial; double* pf; const double* mc_slot;
     const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
@@ -296,29 +300,33 @@ struct SchurArgs {
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
-__global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
-    extern __shared__ double smem[];
+template <bool REC>
+__global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // four wavefronts per SIMD: <= 128 VGPRs
+    extern __shared__ __attribute__((aligned(16))) double smem[];
     const int K = a.K, K1 = a.K + 1, RB = a.RB;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
-    // per-wave LDS: acc[RB] | Baug[6][K1] | C[36] | Y[6][K1]
-    const int WS = ((RB + 12 * K1 + 36) + 1) & ~1;
+    // per-wave LDS: acc[RB] | Baug[6][K1] | C[36] | Y[6][K1] | record staging [STG]
+    const int WS = ((RB + 12 * K1 + 36 + 1) & ~1) + a.STG;
     double* acc = smem + wave * WS;
     double* Baug = acc + RB;
     double* Cm = Baug + 6 * K1;
     double* Ym = Cm + 36;
+    double* stg = acc + ((RB + 12 * K1 + 36 + 1) & ~1);        // 16-byte aligned rows
     // Scatter table, built once per workgroup: for every entry e of a camera's (D+1) x (D+1) Gram block where it is
     // read from (k_gram leaves the whole 16 x 16 tile or the block-upper three tiles of a 32-stride block) and which
     // LDS accumulator(s) receive it - packed src | (dst + 1) << 16 | (extra + 1) << 32.  The per-slot loop is then
     // load, load, ds_add: the index arithmetic and its divergent branches cost as many scalar as vector
     // instructions before (SQ_INSTS_SALU = SQ_INSTS_VALU = 5 k per wavefront).
-    __shared__ int32_t cbase[CCAL_MAX_CAMS + 1], cnc2[CCAL_MAX_CAMS];
+    __shared__ int32_t cbase[CCAL_MAX_CAMS + 1], cnc2[CCAL_MAX_CAMS], cinfo[CCAL_MAX_CAMS][4];
+    if (threadIdx.x < a.n_cams * 4) cinfo[threadIdx.x >> 2][threadIdx.x & 3] = a.caminfo[threadIdx.x];
     int64_t* tab = reinterpret_cast<int64_t*>(smem + WAVES_PER_BLOCK * WS);
-    {
+    if constexpr (!REC) {
         int base = 0;
         for (int c = 0; c < a.n_cams; ++c) {
             const int Pe = a.caminfo[c * 4 + 0], ct = a.caminfo[c * 4 + 1], ce = a.caminfo[c * 4 + 2], NCP = a.caminfo[c * 4 + 3];
             const int D = Pe + (c > 0 ? 12 : 6), NC = D + 1;
+            if (NCP == 0) continue;                 // record format: expanded in the slot loop, no table
             if (threadIdx.x == 0) { cbase[c] = base; cnc2[c] = NC * NC; }
             for (int e = threadIdx.x; e < NC * NC; e += 256) {
                 const int i = e / NC, j = e - i * NC;
@@ -340,15 +348,6 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                     off = RB + 6 * K1 + ii * 6 + jj;                                   // Cm
                 }
                 int src = (i >= 16 && j < 16) ? j * NCP + i : i * NCP + j;
-                if (NCP == 0) {
-                    // camera 0 through the register Gram kernels (k_gram1v / k_gram1w, GEN): the frame's record is
-                    // C = H_pp packed lower (21) | [B | g] (6 x K1c) | A (K1c x K1c) with K1c = Pe + 1 (r is column Pe)
-                    const int K1c = Pe + 1, ci = i < Pe ? i : Pe, cj = j < Pe ? j : Pe;
-                    if (ki == 1 && kj == 1) { const int hi = ii > jj ? ii : jj, lo = ii > jj ? jj : ii; src = hi * (hi + 1) / 2 + lo; }
-                    else if (ki == 1) src = 21 + ii * K1c + cj;
-                    else if (kj == 1) src = 21 + jj * K1c + ci;
-                    else src = 21 + 6 * K1c + ci * K1c + cj;
-                }
                 tab[base + e] = (int64_t)src | ((int64_t)(off + 1) << 16) | ((int64_t)(xoff + 1) << 32);
             }
             base += NC * NC;
@@ -376,6 +375,75 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
             const int64_t desc = a.slot_desc[oi];
             const int cam = (int)(desc & 7);
             const double* Go = p_G + (desc >> 3);
+            if constexpr (REC) {
+                // Record of the register Gram kernels (GEN, layout in ccal_fused.hpp): the 6 + Pe + 1 column Gram at the
+                // COMPOSED pose - C (pose x pose, 6 x 6) | [B|g]^T (K1c rows of 6, r last) | A (K1c x K1c) - and E^T (12 x 6),
+                // the matrix that turns the composed pose's (phi, delta) into the block's reference columns
+                // rvec_0_b, tvec_0_b | rvec_c_0, tvec_c_0 (frame_setup_composed):
+                //   pose x pose, pose x extrinsics, extrinsics x extrinsics = E^T C E;   (camera | r) x those = [B|g]^T E.
+                // Every row that meets E is six contiguous doubles (three ds_read_b128), lanes = (row or column group, b)
+                // without a division; each accumulator receives one addend per observation frame (ordered sums).
+                const int Pe = cinfo[cam][0], ct = cinfo[cam][1], ce = cinfo[cam][2];
+                const int K1c = Pe + 1, EO = gen_e_off(Pe), NEc = cam > 0 ? 12 : 6;
+                const double* ept = stg + EO;             // E^T, 12 x 6
+                double* wvt = stg + EO + 72;              // (C E)^T, 12 x 6
+                {   // all loads first (one memory latency per record), then the LDS image
+                    constexpr int RV = (gen_rec_size(9) + 63) / 64;        // P_eff <= 9 (OPENCV5)
+                    double rv[RV];
+#pragma unroll
+                    for (int t = 0; t < RV; ++t) rv[t] = (lane + 64 * t) < EO + 72 ? Go[lane + 64 * t] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < RV; ++t) if ((lane + 64 * t) < EO + 72) stg[lane + 64 * t] = rv[t];
+                }
+                wave_sync_lds();
+                const int b = lane & 15, rg = lane >> 4;
+                const bool b_ok = b < NEc;
+                double2 eb0 = { 0, 0 }, eb1 = { 0, 0 }, eb2 = { 0, 0 };
+                if (b_ok) { const double2* er = reinterpret_cast<const double2*>(ept + 6 * b); eb0 = er[0]; eb1 = er[1]; eb2 = er[2]; }
+                // the camera | r block needs nothing: straight into the system (+ hdiag, g_c, cost)
+                for (int i = rg; i < K1c; i += 4) {
+                    if (b >= K1c) continue;
+                    const int j = b, ii = i < Pe ? ct + i : K, jj = j < Pe ? ct + j : K;
+                    const double v = stg[gen_a_off(Pe) + i * K1c + j];
+                    __hip_atomic_fetch_add(acc + ii * K1 + jj, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int x = i == j ? (i < Pe ? K1 * K1 + ii : K1 * K1 + 2 * K) : ((j == Pe) ? K1 * K1 + K + ii : -1);
+                    if (x >= 0) __hip_atomic_fetch_add(acc + x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                // rows 0..5: C E (kept, transposed, for the second product); rows 6..: [B|g]^T E (final: scattered at once)
+                for (int row = rg; row < 6 + K1c; row += 4) {
+                    if (!b_ok) continue;
+                    const double2* rr = reinterpret_cast<const double2*>(stg + 6 * row);
+                    const double2 r0 = rr[0], r1 = rr[1], r2 = rr[2];
+                    const double t = ((r0.x * eb0.x + r0.y * eb0.y) + (r1.x * eb1.x + r1.y * eb1.y)) + (r2.x * eb2.x + r2.y * eb2.y);
+                    if (row < 6) { wvt[6 * b + row] = t; continue; }
+                    const int i = row - 6, ci = i < Pe ? ct + i : K;
+                    if (b < 6) {
+                        __hip_atomic_fetch_add(Baug + b * K1 + ci, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        const int cj = ce + (b - 6);
+                        __hip_atomic_fetch_add(acc + ci * K1 + cj, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(acc + cj * K1 + ci, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (i == Pe) __hip_atomic_fetch_add(acc + K1 * K1 + K + cj, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                wave_sync_lds();
+                double2 w0 = { 0, 0 }, w1 = { 0, 0 }, w2 = { 0, 0 };
+                if (b_ok) { const double2* wr = reinterpret_cast<const double2*>(wvt + 6 * b); w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; }
+                for (int aa = rg; aa < NEc; aa += 4) {
+                    if (!b_ok || (aa >= 6 && b < 6)) continue;                         // extrinsics x pose: its transpose is taken
+                    const double2* ar = reinterpret_cast<const double2*>(ept + 6 * aa);
+                    const double2 a0 = ar[0], a1 = ar[1], a2 = ar[2];
+                    const double t = ((a0.x * w0.x + a0.y * w0.y) + (a1.x * w1.x + a1.y * w1.y)) + (a2.x * w2.x + a2.y * w2.y);
+                    if (aa < 6) {
+                        double* dst = b < 6 ? Cm + aa * 6 + b : Baug + aa * K1 + ce + (b - 6);
+                        __hip_atomic_fetch_add(dst, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        __hip_atomic_fetch_add(acc + (ce + aa - 6) * K1 + ce + (b - 6), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (aa == b) __hip_atomic_fetch_add(acc + K1 * K1 + ce + aa - 6, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                wave_sync_lds();
+            } else {
             const int64_t* tb = tab + cbase[cam];
             const int nc2 = cnc2[cam];
             // table entries, then all of this lane's Gram entries (NC <= 22: at most 8 per lane; one memory latency per
@@ -395,6 +463,7 @@ __global__ __launch_bounds__(256) void k_schur(const SchurArgs a) {
                 if (xoff >= 0) __hip_atomic_fetch_add(acc + xoff, gv[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             wave_sync_lds();
+            }
         }
         // Cholesky of C + lambda clamp(diag C): every lane runs the same 6x6 factorisation
         double L[21], dC[6];
@@ -477,14 +546,25 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
     a.partial = w->partial; a.pf = w->pf; a.mc_slot = w->mc_slot;
     const int K1 = w->K + 1;
-    const int WS = ((w->RB + 12 * K1 + 36) + 1) & ~1;
+    // record-format cameras: staging for the largest record (with E^T) + (C E)^T (72)
+    int stg = 0;
+    if (w->register_gram)
+        for (int c = 0; c < p->n_cams; ++c) stg = std::max(stg, gen_rec_size(p->cams[c].Peff) + 72);
+    a.STG = stg;
+    const int WS = ((w->RB + 12 * K1 + 36 + 1) & ~1) + stg;
     int tab_entries = 0;
-    for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
+    if (!w->register_gram) for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
     const size_t lds = sizeof(double) * ((size_t)WS * WAVES_PER_BLOCK + tab_entries);
     static DynLdsGuard lds_guard;
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur), lds, lds_guard); e != hipSuccess) return e;
     const int blocks = (w->n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    hipLaunchKernelGGL(k_schur, dim3(blocks), dim3(256), lds, s, a);
+    if (w->register_gram) {
+        static DynLdsGuard lds_guard_rec;
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<true>), lds, lds_guard_rec); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_schur<true>, dim3(blocks), dim3(256), lds, s, a);
+        return hipGetLastError();
+    }
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<false>), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_schur<false>, dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -56,7 +56,7 @@ struct NormalWs {
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
     bool red_fused = false;                    // the last ccal_build_normal_dev left its sums in fws->red (single camera)
-    bool cam0_register_gram = false;           // general loop: camera 0's blocks come from k_gram1v / k_gram1w (record format, caminfo NCP = 0)
+    bool register_gram = false;                // general loop: every camera's blocks come from k_gram1v / k_gram1w (GEN record format, caminfo NCP = 0)
     int64_t g_len = 0;
     struct DevState* d_gstate = nullptr;       // general loop: optimizer state on the device,
     struct HostStatus* h_gstatus = nullptr;    //   its published copy (pinned, host-coherent)

@@ -140,16 +140,21 @@ int normal_ws_ensure(ccal_problem* p) {
     std::vector<int64_t> goff(p->n_obs);
     std::vector<int32_t> caminfo(p->n_cams * 4);
     int64_t gl = 0;
-    // camera 0 of the device-resident general loop: register Gram kernels + record format (CCAL_GENERAL_GRAM0=mfma: the
-    // matrix-core kernel and its 16 x 16 tile, as for the other cameras)
-    { const char* e = std::getenv("CCAL_GENERAL_GRAM0"); w->cam0_register_gram = !(e && e[0] == 'm'); }
+    // Register Gram kernels + record format for every camera (k_gram1v / k_gram1w, GEN; k_schur expands the records).
+    // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
+    // blocks), kept as the independent second implementation the tests compare against.
+    { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm'); }
     std::vector<int> ncp_of(p->n_cams);
     for (int c = 0; c < p->n_cams; ++c) {
         ncp_of[c] = (p->cams[c].D + 1) <= 16 ? 16 : 32;
         caminfo[c * 4 + 0] = p->cams[c].Peff; caminfo[c * 4 + 1] = p->cams[c].col_theta;
-        caminfo[c * 4 + 2] = p->cams[c].col_extr; caminfo[c * 4 + 3] = (c == 0 && w->cam0_register_gram) ? 0 : ncp_of[c];
+        caminfo[c * 4 + 2] = p->cams[c].col_extr; caminfo[c * 4 + 3] = w->register_gram ? 0 : ncp_of[c];
     }
-    for (int o = 0; o < p->n_obs; ++o) { goff[o] = gl; const int ncp = ncp_of[p->h_obs_cam[o]]; gl += (int64_t)ncp * ncp; }
+    for (int o = 0; o < p->n_obs; ++o) {
+        goff[o] = gl;
+        const int c = p->h_obs_cam[o];
+        gl += w->register_gram ? (int64_t)gen_rec_size(p->cams[c].Peff) : (int64_t)ncp_of[c] * ncp_of[c];
+    }
     w->g_len = gl;
     std::vector<int32_t> slot_off(p->n_slots + 1, 0), slot_obs(p->n_obs);
     for (int o = 0; o < p->n_obs; ++o) slot_off[p->h_obs_slot[o] + 1]++;
@@ -227,16 +232,14 @@ int normal_upload_cols(ccal_problem* p) {
 static int enqueue_gram(ccal_problem* p, bool cand, int gbuf) {
     ccal_ctx* ctx = p->ctx;
     NormalWs* w = p->nws;
-    for (int c = 0; c < p->n_cams; ++c) {
-        if (c == 0 && w->cam0_register_gram && !cand && gbuf == w->cur) {
-            // camera 0 in record format (what k_schur's table expects): the device loop's launcher with the state set to
-            // "first evaluation of set 0"
-            HIP_TRY(ctx, launch_state_eval(w->d_gstate, 0.0, ctx->stream));
-            HIP_TRY(ctx, launch_gram_dev(p, 0, w->d_gstate, ctx->stream));
-        } else {
-            HIP_TRY(ctx, launch_gram(p, c, cand, gbuf, ctx->stream));
-        }
+    if (w->register_gram && !cand && gbuf == w->cur) {
+        // record format (what k_schur expects): the device loop's launcher with the state set to "first evaluation of set 0"
+        HIP_TRY(ctx, launch_state_eval(w->d_gstate, 0.0, ctx->stream));
+        for (int c = 0; c < p->n_cams; ++c) HIP_TRY(ctx, launch_gram_dev(p, c, w->d_gstate, ctx->stream));
+        return CCAL_OK;
     }
+    if (w->register_gram) { ctx->err = "enqueue_gram: candidate sets go through the device loop"; return CCAL_ERR_UNSUPPORTED; }
+    for (int c = 0; c < p->n_cams; ++c) HIP_TRY(ctx, launch_gram(p, c, cand, gbuf, ctx->stream));
     return CCAL_OK;
 }
 
