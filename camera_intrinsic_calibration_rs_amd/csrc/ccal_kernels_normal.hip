@@ -304,7 +304,7 @@ template <bool REC>
 __global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // four wavefronts per SIMD: <= 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int K = a.K, K1 = a.K + 1, RB = a.RB;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave-uniform values in SGPRs
     const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
     // per-wave LDS: acc[RB] | Baug[6][K1] | C[36] | Y[6][K1] | record staging [STG]
     const int WS = ((RB + 12 * K1 + 36 + 1) & ~1) + a.STG;
@@ -321,6 +321,13 @@ __global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // f
     __shared__ int32_t cbase[CCAL_MAX_CAMS + 1], cnc2[CCAL_MAX_CAMS], cinfo[CCAL_MAX_CAMS][4];
     if (threadIdx.x < a.n_cams * 4) cinfo[threadIdx.x >> 2][threadIdx.x & 3] = a.caminfo[threadIdx.x];
     int64_t* tab = reinterpret_cast<int64_t*>(smem + WAVES_PER_BLOCK * WS);
+    __shared__ uint16_t tri[REC ? (CCAL_KMAX + 1) * (CCAL_KMAX + 2) / 2 : 1];      // lower-triangle entry -> i | j << 8
+    if constexpr (REC) {
+        for (int e = threadIdx.x; e < K1 * K1; e += 256) {
+            const int i = e / K1, j = e - i * K1;
+            if (j <= i) tri[i * (i + 1) / 2 + j] = (uint16_t)(i | (j << 8));
+        }
+    }
     if constexpr (!REC) {
         int base = 0;
         for (int c = 0; c < a.n_cams; ++c) {
@@ -396,21 +403,26 @@ __global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // f
                     for (int t = 0; t < RV; ++t) if ((lane + 64 * t) < EO + 72) stg[lane + 64 * t] = rv[t];
                 }
                 wave_sync_lds();
-                const int b = lane & 15, rg = lane >> 4;
+                // (row group, column b) of the two products: 4 x 16 lanes for twelve columns, 8 x 8 for camera 0's six
+                const int sh = cam > 0 ? 4 : 3, b = lane & ((1 << sh) - 1), rg = lane >> sh, rstep = 64 >> sh;
                 const bool b_ok = b < NEc;
                 double2 eb0 = { 0, 0 }, eb1 = { 0, 0 }, eb2 = { 0, 0 };
                 if (b_ok) { const double2* er = reinterpret_cast<const double2*>(ept + 6 * b); eb0 = er[0]; eb1 = er[1]; eb2 = er[2]; }
-                // the camera | r block needs nothing: straight into the system (+ hdiag, g_c, cost)
-                for (int i = rg; i < K1c; i += 4) {
-                    if (b >= K1c) continue;
-                    const int j = b, ii = i < Pe ? ct + i : K, jj = j < Pe ? ct + j : K;
-                    const double v = stg[gen_a_off(Pe) + i * K1c + j];
-                    __hip_atomic_fetch_add(acc + ii * K1 + jj, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    const int x = i == j ? (i < Pe ? K1 * K1 + ii : K1 * K1 + 2 * K) : ((j == Pe) ? K1 * K1 + K + ii : -1);
-                    if (x >= 0) __hip_atomic_fetch_add(acc + x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // Only the LOWER triangle of the (K + 1) x (K + 1) system is kept (r = row K: b^T, cost): k_solve and
+                // ccal_build_normal read nothing else.  The camera | r block needs no product: straight in (+ hdiag, g_c, cost)
+                {
+                    const int j = lane & 15;
+                    for (int i = lane >> 4; i < K1c; i += 4) {
+                        if (j > i) continue;
+                        const int ii = i < Pe ? ct + i : K, jj = j < Pe ? ct + j : K;
+                        const double v = stg[gen_a_off(Pe) + i * K1c + j];
+                        __hip_atomic_fetch_add(acc + ii * K1 + jj, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int x = i == j ? (i < Pe ? K1 * K1 + ii : K1 * K1 + 2 * K) : ((i == Pe) ? K1 * K1 + K + jj : -1);
+                        if (x >= 0) __hip_atomic_fetch_add(acc + x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
                 // rows 0..5: C E (kept, transposed, for the second product); rows 6..: [B|g]^T E (final: scattered at once)
-                for (int row = rg; row < 6 + K1c; row += 4) {
+                for (int row = rg; row < 6 + K1c; row += rstep) {
                     if (!b_ok) continue;
                     const double2* rr = reinterpret_cast<const double2*>(stg + 6 * row);
                     const double2 r0 = rr[0], r1 = rr[1], r2 = rr[2];
@@ -420,17 +432,17 @@ __global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // f
                     if (b < 6) {
                         __hip_atomic_fetch_add(Baug + b * K1 + ci, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
-                        const int cj = ce + (b - 6);
-                        __hip_atomic_fetch_add(acc + ci * K1 + cj, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_fetch_add(acc + cj * K1 + ci, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const int cj = ce + (b - 6), hi = ci > cj ? ci : cj, lo = ci > cj ? cj : ci;
+                        __hip_atomic_fetch_add(acc + hi * K1 + lo, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         if (i == Pe) __hip_atomic_fetch_add(acc + K1 * K1 + K + cj, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 wave_sync_lds();
                 double2 w0 = { 0, 0 }, w1 = { 0, 0 }, w2 = { 0, 0 };
                 if (b_ok) { const double2* wr = reinterpret_cast<const double2*>(wvt + 6 * b); w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; }
-                for (int aa = rg; aa < NEc; aa += 4) {
-                    if (!b_ok || (aa >= 6 && b < 6)) continue;                         // extrinsics x pose: its transpose is taken
+                for (int aa = rg; aa < NEc; aa += rstep) {
+                    // pose x pose and extrinsics x extrinsics: lower triangle; pose x extrinsics: all of it
+                    if (!b_ok || ((aa < 6) == (b < 6) ? b > aa : aa >= 6)) continue;
                     const double2* ar = reinterpret_cast<const double2*>(ept + 6 * aa);
                     const double2 a0 = ar[0], a1 = ar[1], a2 = ar[2];
                     const double t = ((a0.x * w0.x + a0.y * w0.y) + (a1.x * w1.x + a1.y * w1.y)) + (a2.x * w2.x + a2.y * w2.y);
@@ -506,24 +518,36 @@ __global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // f
                 pf[21 + i * K1 + j] = y[i];
             }
         }
-        {   // lane i stores L[i] / dC[i]: select chains over static register indices (no scratch), coalesced stores
-            double lv = L[0], dv = dC[0];
+        // L and diag C to the slot's record: every lane holds them; lane 0 parks them in the (now dead) C block, 21 + 6
+        // lanes store (two ds_write / ds_read pairs instead of 27 three-instruction select chains)
+        if (lane == 0) {
 #pragma unroll
-            for (int i = 1; i < 21; ++i) lv = lane == i ? L[i] : lv;
+            for (int i = 0; i < 21; ++i) Cm[i] = L[i];
 #pragma unroll
-            for (int i = 1; i < 6; ++i) dv = lane == i ? dC[i] : dv;
-            if (lane < 21) pf[lane] = lv;
-            if (lane < 6) { pf[21 + 6 * K1 + lane] = Baug[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = dv; }
+            for (int i = 0; i < 6; ++i) Cm[21 + i] = dC[i];
         }
         wave_sync_lds();
-        // A -= Y^T Y
-        const float rk1 = 1.0f / (float)K1;
-        for (int e = lane; e < K1 * K1; e += 64) {
-            const int i = (int)(((float)e + 0.5f) * rk1), j = e - i * K1;
-            double t = 0.0;
+        if (lane < 21) pf[lane] = Cm[lane];
+        if (lane < 6) { pf[21 + 6 * K1 + lane] = Baug[lane * K1 + K]; pf[21 + 6 * K1 + 6 + lane] = Cm[21 + lane]; }
+        // A -= Y^T Y  (record mode: lower triangle only, (i, j) from the workgroup's table)
+        if constexpr (REC) {
+            const int NT = K1 * (K1 + 1) / 2;
+            for (int e = lane; e < NT; e += 64) {
+                const int ij = tri[e], i = ij & 255, j = ij >> 8;
+                double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
-            __hip_atomic_fetch_add(acc + e, -t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+                __hip_atomic_fetch_add(acc + i * K1 + j, -t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            const float rk1 = 1.0f / (float)K1;
+            for (int e = lane; e < K1 * K1; e += 64) {
+                const int i = (int)(((float)e + 0.5f) * rk1), j = e - i * K1;
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+                __hip_atomic_fetch_add(acc + e, -t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
         wave_sync_lds();
     }
@@ -650,14 +674,14 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     if (lane == 0) bad = 0;
     for (int e = lane; e < a.n_intr; e += 64) a.intr_c[e] = a.intr[e];
     for (int e = lane; e < a.n_extr; e += 64) a.extr_c[e] = a.extr[e];
-    const double rhs = lane < K ? a.red[lane * K1 + K] : 0.0;
+    const double rhs = lane < K ? a.red[K * K1 + lane] : 0.0;          // the system is kept as its lower triangle (row K = b^T)
     const double hd = lane < K ? hdiag[lane] : 0.0, gcl = lane < K ? gc[lane] : 0.0;
     const double xsrc = lane < K ? (ci.is_extr ? a.extr : a.intr)[ci.dst] : 0.0;
     __syncthreads();
 #pragma unroll 4
     for (int e = lane; e < K * K; e += 64) {
         const int i = e / K, j = e - i * K;
-        double v = a.red[i * K1 + j];
+        double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
         if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
         S[i * (CCAL_KMAX + 1) + j] = v;
     }

@@ -652,12 +652,13 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
         HIP_TRY(ctx, hipMemcpyAsync(h, w->red, w->RB * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const double* hd = h + K1 * K1;
+        // the general path keeps the lower triangle of the (K + 1) x (K + 1) system (row K = b^T)
         if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
-            double v = h[i * K1 + j];
+            double v = h[i >= j ? i * K1 + j : j * K1 + i];
             if (i == j && lambda > 0.0) v += lambda * std::min(std::max(hd[i], 1e-6), 1e32);
             S[i * K + j] = v;
         }
-        if (b) for (int i = 0; i < K; ++i) b[i] = h[i * K1 + K];
+        if (b) for (int i = 0; i < K; ++i) b[i] = h[K * K1 + i];
         if (cost) *cost = h[w->RB - 3];
         failed = h[w->RB - 1];
     }
