@@ -308,3 +308,60 @@ def make_problem(n_frames: int, model: str | int = "eucm", n_cams: int = 1, seed
         obs_cam=obs_cam, obs_slot=obs_slot, obs_offsets=offs,
         p3d=board[ids].astype(np.float32), p2d=uv.astype(np.float32), huber_delta=huber_delta,
         intr_gt=intr_gt, poses_gt=poses_gt, extr_gt=extr_gt, intr0=intr0, poses0=poses0, extr0=extr0)
+
+
+def make_rig(n_frames: int, models, extr_gt, seed: int = 0xC0FFEE, noise_px: float = 0.1, xy_same_focal: bool = False,
+             min_corners: int = 24, drop_frac: float = 0.2, init_perturb: float = 0.02, ragged: bool = True) -> SynthProblem:
+    """A rig of DIFFERENT cameras: one model per camera, arbitrary (large) extrinsic rotations, and every camera seeing its
+    own subset of the frame slots with only the corners that fall inside its image (`ragged`: a random subset of those,
+    in random order; >= `min_corners`, the reference's minimum: src/data_loader.rs:15) - the general form of calib_all_camera_with_extrinsics' input (src/util.rs:567-651:
+    cameras paired by frame index, frames seen by one camera only).  Observation frames are ordered by slot, cameras
+    within a slot in index order; a slot that no camera keeps still exists (a pose without residual blocks)."""
+    ms = [MODEL_NAMES[m] if isinstance(m, str) else int(m) for m in models]
+    n_cams = len(ms)
+    extr_gt = np.asarray(extr_gt, dtype=np.float64).reshape(n_cams, 6)
+    assert not extr_gt[0].any()
+    board = default_board()
+    nb = board.shape[0]
+    W, H = GT_SIZE
+    Rc = rodrigues(extr_gt[:, :3])
+    narrow = any(m == MODEL_OPENCV5 for m in ms)
+    R, t = _gen_poses(seed, n_frames, (0.75, 1.3) if narrow else (0.4, 1.2), 0.12 if narrow else 0.25)
+    poses_gt = np.concatenate([rotmat_to_rvec(R), t], axis=-1)
+    pc0 = np.einsum("nij,kj->nki", R, board.astype(np.float64)) + t[:, None, :]
+    drop = uniform01(seed, n_frames * n_cams, stream=11).reshape(n_frames, n_cams) < drop_frac
+    obs_cam, obs_slot, offs, ids, uvs = [], [], [0], [], []
+    for s in range(n_frames):
+        for c in range(n_cams):
+            pc = pc0[s] @ Rc[c].T + extr_gt[c, 3:]
+            uv = project(ms[c], GT_PARAMS[ms[c]], pc)
+            vis = (pc[:, 2] > 0.05) & (uv[:, 0] >= 0) & (uv[:, 0] <= W) & (uv[:, 1] >= 0) & (uv[:, 1] <= H)
+            if drop[s, c] or vis.sum() < min_corners:
+                continue
+            k = np.nonzero(vis)[0]
+            if ragged:
+                key = uniform01(seed + 31 * s + c, nb + 1, stream=12)
+                k = k[np.argsort(key[:len(k)])][:min_corners + int(key[nb] * (len(k) - min_corners + 1))]
+            obs_cam.append(c); obs_slot.append(s); offs.append(offs[-1] + len(k)); ids.append(k); uvs.append(uv[k])
+    ids = np.concatenate(ids); uv = np.concatenate(uvs)
+    ntot = len(ids)
+    uv = uv + noise_px * normal01(seed, 2 * ntot, stream=4).reshape(ntot, 2)
+    intr_gt = np.zeros((n_cams, PMAX))
+    for c, m in enumerate(ms):
+        intr_gt[c, :MODEL_NPARAMS[m]] = GT_PARAMS[m]
+    pert = (2.0 * uniform01(seed, n_cams * PMAX, stream=7).reshape(n_cams, PMAX) - 1.0) * init_perturb
+    intr0 = intr_gt * (1.0 + pert)
+    if xy_same_focal:
+        intr0[:, 1] = intr0[:, 0]
+    scale = init_perturb / 0.05
+    dp = 2.0 * uniform01(seed, n_frames * 6, stream=8).reshape(n_frames, 6) - 1.0
+    poses0 = poses_gt + dp * np.array([0.02, 0.02, 0.02, 0.01, 0.01, 0.01]) * scale
+    de = 2.0 * uniform01(seed, n_cams * 6, stream=9).reshape(n_cams, 6) - 1.0
+    extr0 = extr_gt + de * np.array([0.005, 0.005, 0.005, 0.003, 0.003, 0.003]) * scale
+    extr0[0] = 0.0
+    return SynthProblem(
+        n_cams=n_cams, model=np.asarray(ms, dtype=np.int32), width=np.full(n_cams, W), height=np.full(n_cams, H),
+        xy_same_focal=xy_same_focal, n_slots=n_frames, obs_cam=np.asarray(obs_cam, dtype=np.int32),
+        obs_slot=np.asarray(obs_slot, dtype=np.int32), obs_offsets=np.asarray(offs, dtype=np.int64),
+        p3d=board[ids].astype(np.float32), p2d=uv.astype(np.float32), huber_delta=1.0,
+        intr_gt=intr_gt, poses_gt=poses_gt, extr_gt=extr_gt, intr0=intr0, poses0=poses0, extr0=extr0)

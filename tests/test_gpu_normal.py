@@ -394,3 +394,53 @@ def test_two_camera_rig_at_scale(gpu_ctx):
     assert np.abs(e_gn[1, 3:] - sp.extr_gt[1, 3:]).max() < 2e-4            # metres
     assert np.abs(e_gn[1, :3] - sp.extr_gt[1, :3]).max() < 5e-4            # radians
     assert 0.015 < r_gn.final_cost / gp.n_corners < 0.025
+
+
+RIG_EXTR = {3: [[0.0] * 6, [0.3, -0.25, 0.2, -0.1, 0.02, 0.01], [-0.2, 0.35, -0.15, 0.1, -0.03, 0.02]],
+            2: [[0.0] * 6, [0.12, -0.1, 0.3, -0.1, 0.02, 0.01]]}
+
+
+@pytest.mark.parametrize("models", [("eucm", "kb4", "ucm"), ("opencv5", "opencv5"), ("kb4", "eucm")])
+@pytest.mark.parametrize("one_focal", [False, True])
+def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatch):
+    """calib_all_camera_with_extrinsics' general input (src/util.rs:567-651): a different model per camera, LARGE extrinsic
+    rotations (0.3-0.5 rad: R_c0, J_l(rvec_c0) and -[R_c0 t_0b]x of the record expansion are far from I / 0), cameras
+    that see different subsets of the frame slots (slots without camera 0, slots seen by one camera only) and ragged
+    corner sets.  Normal equations, GN and LM against the oracle; and the matrix-core implementation (19-column Gram
+    per corner, CCAL_GENERAL_GRAM=mfma) against the register one (13 columns at the composed pose + expansion)."""
+    sp = synth.make_rig(48, models, RIG_EXTR[len(models)], xy_same_focal=one_focal, seed=0xBEEF + len(models))
+    seen = np.zeros((sp.n_slots, sp.n_cams), bool)
+    seen[sp.obs_slot, sp.obs_cam] = True
+    assert (~seen[:, 0]).any() and (seen.sum(1) == 1).any()            # the cases the test is about are present
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    monkeypatch.setenv("CCAL_GENERAL_GRAM", "mfma")
+    gm = Problem.from_synth(gpu_ctx, sp)
+    gm.build_normal(sp.intr0, sp.poses0, sp.extr0)                      # workspace (and the choice) made under the switch
+    monkeypatch.delenv("CCAL_GENERAL_GRAM")
+    for lam in (0.0, 1e-3):
+        S, b, cost = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        Sm, bm, costm = gm.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        for (S_, b_, c_) in ((S, b, cost), (Sm, bm, costm)):
+            assert abs(c_ - costo) <= 1e-12 * costo
+            assert np.abs(S_ - So).max() <= 1e-9 * np.abs(So).max()
+            assert np.abs(b_ - bo).max() <= 1e-9 * np.abs(bo).max()
+        assert np.abs(S - S.T).max() == 0.0                             # mirrored from the lower triangle the engine keeps
+        dc, dco = np.linalg.solve(S, -b), np.linalg.solve(So, -bo)
+        assert np.abs(dc - dco).max() <= 1e-6 * np.abs(dco).max()
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        gp.apply_reference_bounds(); op.apply_reference_bounds(); gm.apply_reference_bounds()
+        intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        intr_m, poses_m, extr_m, rep_m = gm.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        assert rep.status == rep_m.status == rep_o.status == 0
+        assert rep.iterations == rep_m.iterations == rep_o.iterations
+        assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+        assert abs(rep_m.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+        scale = np.maximum(np.abs(intr_o), 1e-3)
+        assert (np.abs(intr - intr_o) / scale).max() <= 1e-6
+        np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(extr_m, extr_o, rtol=0, atol=1e-7)
+        assert np.abs(extr - sp.extr_gt).max() < 5e-3                   # and the rig is recovered
+    gm.close()
