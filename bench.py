@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--model", default="eucm", choices=["ucm", "eucm", "kb4", "opencv5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (mode N / solver) measurements")
+    ap.add_argument("--no-rig", action="store_true", help="skip the two-camera leg of the secondary measurements")
     args = ap.parse_args()
 
     import numpy as np
@@ -269,6 +270,28 @@ def main():
                     "gn": solve_stats(sprob, sub, 0, False), "lm": solve_stats(sprob, sub, 1, False),
                     "gn_device_resident": solve_stats(sprob, sub, 0, True), "lm_device_resident": solve_stats(sprob, sub, 1, True)}
                 sprob.close()
+            # BASELINE configs[4] shape: a two-camera rig with extrinsics (calib_all_camera_with_extrinsics, src/util.rs:567),
+            # both cameras seeing every frame slot - the general loop: 13-column Gram per camera at the composed pose,
+            # per-slot expansion + elimination, K = 2 P_eff + 6
+            if not args.no_rig:
+                sp2 = synth.make_problem(args.frames, args.model, n_cams=2)
+                p2 = Problem.from_synth(ctx, sp2)
+                p2.upload_params(sp2.intr0, sp2.poses0, sp2.extr0)
+                with torch.cuda.stream(stream):
+                    for _ in range(10):
+                        p2.build_normal_dev(0.0)
+                    torch.cuda.synchronize()
+                    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                    a.record(stream)
+                    for _ in range(100):
+                        p2.build_normal_dev(0.0)
+                    b.record(stream)
+                    torch.cuda.synchronize()
+                extra["two_cameras"] = {
+                    "frames": sp2.n_slots, "corners": sp2.n_corners, "K": p2.K, "build_ms": a.elapsed_time(b) / 100,
+                    "gn": solve_stats(p2, sp2, 0, False), "lm": solve_stats(p2, sp2, 1, False),
+                    "gn_device_resident": solve_stats(p2, sp2, 0, True), "lm_device_resident": solve_stats(p2, sp2, 1, True)}
+                p2.close()
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)
         out["extra"] = extra

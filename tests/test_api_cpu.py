@@ -121,3 +121,22 @@ def test_convert_model_closed_form():
     eucm = api.GenericModel("eucm", [400.0, 400.0, 320.0, 240.0, 0.0, 1.0], 640, 480)
     p = api.convert_model(ucm, eucm).params()
     assert abs(p[0] - 500.0) < 1e-6 and abs(p[4] - 0.5) < 1e-6 and abs(p[5] - 1.0) < 1e-6
+
+
+def test_bench_mode_n_roofline_inputs_present():
+    """bench.py's extra.mode_N_roofline reads the ISA operation counts of the kernels it times from the latest
+    profiles/rNN/flops.json (tools/count_flops.py): every key the default workloads ask for must be there."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    path = bench._latest_profile_file("flops.json")
+    assert path is not None
+    kernels = json.load(open(path))["kernels"]
+    for model, K in (("ucm", 5), ("eucm", 6), ("kb4", 8), ("opencv5", 9)):
+        for frames in (1000, 10000):
+            gk = bench._gram_kernel_key(model, False, frames)
+            assert kernels[gk]["per_corner"]["flops"] > 200, gk
+        assert kernels[f"k_schur1m<K={K}>"]["per_lane_whole_kernel"]["per_frame_flops_16_lanes"] > 1000

@@ -86,8 +86,8 @@ def main():
         for of in (0, 1):
             focal = "one-focal" if of else "two-focal"
             # the per-corner count does not depend on the lanes-per-frame instantiation: read it off the 12-lane one
-            want[f"k_gram1w<{nm},{focal}>"] = f"k_gram1wILi{m}ELb{of}ELi12EE"
-            want[f"k_gram1v<{nm},{focal}>"] = f"k_gram1vILi{m}ELb{of}ELi12EE"
+            want[f"k_gram1w<{nm},{focal}>"] = f"k_gram1wILi{m}ELb{of}ELi12ELb0EE"
+            want[f"k_gram1v<{nm},{focal}>"] = f"k_gram1vILi{m}ELb{of}ELi12ELb0EE"
             want[f"k_gram1<{nm},{focal}>"] = f"k_gram1ILi{m}ELb{of}EE"
     for name, key in want.items():
         hits = [k for k in bodies if key in k]

@@ -24,6 +24,18 @@ while time.time() - t0 < args.seconds:
     kw = dict(n_cams=n_cams, seed=int(rng.integers(1, 1 << 30)), ragged=bool(rng.integers(0, 2)),
               xy_same_focal=bool(rng.integers(0, 2)), outlier_frac=float(rng.choice([0.0, 0.01, 0.05])))
     sp = synth.make_problem(frames, model, **kw)
+    if n_cams > 1 and rng.random() < 0.5:
+        # a rig of different cameras: random model per camera, extrinsic rotations up to ~0.45 rad, uneven visibility
+        models = [str(rng.choice(["ucm", "eucm", "kb4", "opencv5"])) for _ in range(n_cams)]
+        ext = np.zeros((n_cams, 6))
+        narrow = "opencv5" in models
+        ext[1:, :3] = rng.uniform(-0.26, 0.26, (n_cams - 1, 3)) * (0.4 if narrow else 1.0)
+        ext[1:, 3:] = rng.uniform(-0.12, 0.12, (n_cams - 1, 3))
+        sp = synth.make_rig(frames * 2, models, ext, seed=kw["seed"], xy_same_focal=kw["xy_same_focal"],
+                            ragged=kw["ragged"], drop_frac=float(rng.choice([0.0, 0.2, 0.4])))
+        if np.bincount(sp.obs_cam, minlength=n_cams).min() < 3:
+            continue
+        kw = dict(kw, rig=models, ext=ext[1:].round(3).tolist())
     gp = Problem.from_synth(ctx, sp); op = ob.OracleProblem.from_synth(sp)
     case = dict(model=str(model), frames=frames, **kw)
     try:
