@@ -51,7 +51,31 @@ def _gram_kernel_key(model, one_focal, frames):
     return f"{'k_gram1w' if w else 'k_gram1v'}<{model.upper()},{of}>"
 
 
+_REAL_STDOUT = None
+
+
+def _stdout_for_the_line_only():
+    """The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner when its first
+    communicator comes up: 'RCCL version : ... Librccl path : ...'), so file descriptor 1 is pointed at stderr for the
+    whole run and the line is written to the saved descriptor at the end."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _emit(out):
+    line = (json.dumps(out) + "\n").encode()
+    sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.write(_REAL_STDOUT, line)
+    else:
+        os.write(1, line)
+
+
 def main():
+    _stdout_for_the_line_only()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
@@ -351,7 +375,7 @@ def main():
             out.setdefault("extra", {})["sharded_solve"] = result
         if th.is_alive():
             if rank == 0:
-                print(json.dumps(out), flush=True)
+                _emit(out)
             os._exit(3)                     # a hung collective in a process that has touched the GPU is a failure
         if comm:
             engine.rccl_comm_destroy(comm)
@@ -421,7 +445,7 @@ def main():
                 out["extra"]["cpu_oracle_gn"] = {"error": repr(e)}
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

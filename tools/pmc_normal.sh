@@ -11,7 +11,7 @@ d=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$R/gpurun_out/pmcn_*/p_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         k=row['Kernel_Name'].split('(')[0]
-        if 'k_gram' in k or 'k_schur' in k or 'k_solve' in k or 'k_head' in k: d[k][row['Counter_Name']].append(float(row['Counter_Value']))
+        if any(t in k for t in ('k_gram', 'k_schur', 'k_solve', 'k_head', 'k_eval', 'k_backsub')): d[k][row['Counter_Name']].append(float(row['Counter_Value']))
 for k,v in d.items():
     print(k)
     for c,x in sorted(v.items()): print('   %-28s %14.0f' % (c, sum(x)/len(x)))
