@@ -348,20 +348,33 @@ def _tile(sp, rep):
         poses_gt=np.tile(sp.poses_gt, (rep, 1)), poses0=np.tile(sp.poses0, (rep, 1)))
 
 
-def test_config4_size_properties(gpu_ctx):
-    """BASELINE configs[3] size on ONE GPU: 50 000 frames x 144 corners (7.2 M blocks, 1.5 GB of r and J).  Size-independent
-    properties: the squared norm of the loss-weighted residual (mode E) is the cost the normal-equation builder reports
-    (mode N); the cost is additive over frame shards; five copies of a 10 000-frame problem have five times its cost
-    and the same optimum."""
+def test_config4_size_properties(gpu_ctx, oracle):
+    """BASELINE configs[3] size on ONE GPU: 50 000 frames x 144 corners (7.2 M blocks, 1.5 GB of r and J).  Against the
+    oracle: sampled frames of the mode-E pass (every part of the launch: first, last, the chunk boundaries of the tiling)
+    and the normal equations of ALL 50 000 frames (a second of CPU).  Size-independent properties: the squared norm of
+    the loss-weighted residual (mode E) is the cost the normal-equation builder reports (mode N); the cost is additive
+    over frame shards; five copies of a 10 000-frame problem have five times its cost and the same optimum."""
     base = synth.make_problem(10000, "eucm")
     sp = _tile(base, 5)
     gp = Problem.from_synth(gpu_ctx, sp)
     assert gp.n_corners == 50000 * 144
+    r, J = gp.eval(sp.intr0, sp.poses0)
+    Jb = J.reshape(-1, 2, 12)
+    for f in (0, 9999, 10000, 25000, 39999, 40001, 49999):
+        sub = base.shard(f % 10000, 10000)
+        ro, Jo = oracle.OracleProblem.from_synth(sub).eval(sp.intr0, sub.poses0)
+        sl = slice(f * 144, (f + 1) * 144)
+        assert np.abs(r[sl] - ro).max() <= 1e-10
+        assert (np.abs(Jb[sl].ravel() - Jo) / np.maximum(1.0, np.abs(Jo))).max() <= 1e-11
+    del r, J, Jb
     r, J = gp.eval(sp.intr0, sp.poses0, apply_loss=True)
     assert np.isfinite(r).all() and np.isfinite(J).all()
     S, b, cost = gp.build_normal(sp.intr0, sp.poses0)
     assert abs(float((r * r).sum()) - cost) <= 1e-11 * cost
     del r, J
+    So, bo, costo = oracle.OracleProblem.from_synth(sp).build_normal(sp.intr0, sp.poses0)
+    assert abs(cost - costo) <= 1e-12 * costo
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
     gb = Problem.from_synth(gpu_ctx, base)
     Sb, bb, cost_b = gb.build_normal(base.intr0, base.poses0)
     assert abs(cost - 5.0 * cost_b) <= 1e-11 * cost
