@@ -484,6 +484,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const DevState* st = a.st;
     if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifdef CCAL_STAMPS          // diagnostic build (tools/stamps_gram.py): start / end time of every wavefront into the per-frame scratch
+    const long long t_start = wall_clock64();
+#endif
     // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
     const bool lane_ok = lane < G * LPF;
     const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
@@ -706,6 +709,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     }
     // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
     if (!GEN && active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+#ifdef CCAL_STAMPS
+    if (!GEN && lane == 0) { const int wg = blockIdx.x * CCAL_GRAMV_WPB + wave; a.fcbuf[2 * wg] = (double)t_start; a.fcbuf[2 * wg + 1] = (double)wall_clock64(); }
+#endif
 }
 
 template <int MODEL, bool OF, int LPF, bool W, bool GEN>

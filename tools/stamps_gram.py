@@ -1,3 +1,6 @@
+"""Developer tool: start / end time of every wavefront of k_gram1w (10 ns clock), from a library built with
+-DCCAL_STAMPS (tools/build_variants.sh "stamps:-DCCAL_STAMPS", CCAL_LIB=.../libccal_stamps.so).  WPBV = wavefronts per
+workgroup of that build (CCAL_GRAMV_WPB, default 2)."""
 import os, sys, ctypes as C, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
