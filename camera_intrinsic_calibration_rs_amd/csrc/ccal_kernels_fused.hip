@@ -599,6 +599,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
 #else
     const double* fcp = fc;
 #endif
+#ifdef CCAL_STAMPS
+    const long long t_loop = wall_clock64();
+#endif
     for (int base = 0; base < nmax; base += LPF) {
 #if !CCAL_GRAMW_HOIST
         asm volatile("" ::: "memory");      // frame constants stay in LDS: no 78 registers of hoisted copies
@@ -639,6 +642,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             }
         }
     }
+#ifdef CCAL_STAMPS
+    const long long t_after = wall_clock64();
+#endif
     const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
     // camera x pose: LPF lane-private LDS sums per frame -> record  [B|g][pose j][camera i]
     wsync();
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
     if (!GEN && active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
 #ifdef CCAL_STAMPS
-    if (!GEN && lane == 0) { const int wg = blockIdx.x * CCAL_GRAMV_WPB + wave; a.fcbuf[2 * wg] = (double)t_start; a.fcbuf[2 * wg + 1] = (double)wall_clock64(); }
+    if (!GEN && lane == 0) { const int wg = blockIdx.x * CCAL_GRAMV_WPB + wave; a.fcbuf[2 * wg] = (double)t_start; a.fcbuf[2 * wg + 1] = (double)wall_clock64(); a.fcbuf[8192 + 2 * wg] = (double)t_loop; a.fcbuf[8192 + 2 * wg + 1] = (double)t_after; }
 #endif
 }
 

@@ -1,3 +1,5 @@
+"""Developer tool: prologue / corner loop / epilogue times of k_gram1w's wavefronts (10 000 frames, EUCM) from a library
+built with -DCCAL_STAMPS (tools/build_variants.sh "stamps:-DCCAL_STAMPS"; CCAL_LIB selects it)."""
 import os, sys, ctypes as C, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
