@@ -168,45 +168,33 @@ __device__ inline void frame_setup(const double* pose, const double* extr, doubl
 //                        [ 0                   R_c0 |  -[R_c0 t_0b]x J_l(rvec_c0)        I ]
 // so the per-slot elimination (k_schur) expands a frame's 13-column Gram with that 6 x 12 matrix E once per frame instead
 // of every corner carrying 19 columns.  fc12 = R | t; ept = E transposed, dense: ept[6 b + m] = E[m][b], b < 12
-// (camera 0: R_c0 = I, the extrinsics columns b >= 6 are never read).
+// (camera 0: extr = 0, i.e. R_c0 = I; its extrinsics columns b >= 6 are never read).
 constexpr int GEN_EPT = 72;
 __device__ inline void frame_setup_composed(const double* pose, const double* extr, double* fc12, double* ept) {
-    double R0[9], J0[9];
+    // camera 0 passes extr = 0: R_c0 = I and J_l = I come out exactly, the products below reproduce R_0b, t_0b, J_l(rvec_0b)
+    // bit for bit - one code path, no merge of two 72-value results
+    double R0[9], J0[9], R1[9], J1[9], v[3], RJ[9], SJ[9];
     so3_exp_ljac(pose, R0, J0);
+    so3_exp_ljac(extr, R1, J1);
+    mat3_mul(R1, R0, fc12);
+    mat3_vec(R1, pose + 3, v);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) fc12[9 + i] = v[i] + extr[3 + i];
+    mat3_mul(R1, J0, RJ);
+    const double S[9] = { 0.0, v[2], -v[1], -v[2], 0.0, v[0], v[1], -v[0], 0.0 };      // -[v]x
+    mat3_mul(S, J1, SJ);
 #pragma unroll
     for (int i = 0; i < GEN_EPT; ++i) ept[i] = 0.0;
-    if (!extr) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) fc12[i] = R0[i];
+    for (int b = 0; b < 3; ++b) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) fc12[9 + i] = pose[3 + i];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) ept[6 * b + m] = J0[m * 3 + b];
-            ept[6 * (3 + b) + 3 + b] = 1.0;
+        for (int m = 0; m < 3; ++m) {
+            ept[6 * b + m] = RJ[m * 3 + b];                 // rvec_0_b -> phi
+            ept[6 * (3 + b) + 3 + m] = R1[m * 3 + b];       // tvec_0_b -> delta
+            ept[6 * (6 + b) + m] = J1[m * 3 + b];           // rvec_c_0 -> phi
+            ept[6 * (6 + b) + 3 + m] = SJ[m * 3 + b];       // rvec_c_0 -> delta
         }
-    } else {
-        double R1[9], J1[9], v[3], RJ[9], SJ[9];
-        so3_exp_ljac(extr, R1, J1);
-        mat3_mul(R1, R0, fc12);
-        mat3_vec(R1, pose + 3, v);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) fc12[9 + i] = v[i] + extr[3 + i];
-        mat3_mul(R1, J0, RJ);
-        const double S[9] = { 0.0, v[2], -v[1], -v[2], 0.0, v[0], v[1], -v[0], 0.0 };      // -[v]x
-        mat3_mul(S, J1, SJ);
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                ept[6 * b + m] = RJ[m * 3 + b];                 // rvec_0_b -> phi
-                ept[6 * (3 + b) + 3 + m] = R1[m * 3 + b];       // tvec_0_b -> delta
-                ept[6 * (6 + b) + m] = J1[m * 3 + b];           // rvec_c_0 -> phi
-                ept[6 * (6 + b) + 3 + m] = SJ[m * 3 + b];       // rvec_c_0 -> delta
-            }
-            ept[6 * (9 + b) + 3 + b] = 1.0;                     // tvec_c_0 -> delta
-        }
+        ept[6 * (9 + b) + 3 + b] = 1.0;                     // tvec_c_0 -> delta
     }
 }
 

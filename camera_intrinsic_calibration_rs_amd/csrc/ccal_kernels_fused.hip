@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
             for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
-            frame_setup_composed(pose, other ? ex : nullptr, fcr, ept);
+            frame_setup_composed(pose, ex, fcr, ept);
             if (gl == 0 && lane_ok) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
             for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
-            frame_setup_composed(pose, other ? ex : nullptr, fcr, ept);
+            frame_setup_composed(pose, ex, fcr, ept);
             if (gl == 0 && lane_ok) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
