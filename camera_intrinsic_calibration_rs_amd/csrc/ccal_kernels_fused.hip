@@ -729,7 +729,8 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     constexpr int RED = (W && NL * 65 > 64 * (HALF | 1)) ? NL * 65 : 64 * (HALF | 1);
     constexpr int WSL = G * FC_N0P + RED;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
-    auto kern = W ? k_gram1w<MODEL, OF, LPF, GEN> : k_gram1v<MODEL, OF, LPF, GEN>;
+    void (*kern)(const FusedArgs);
+    if constexpr (W) kern = k_gram1w<MODEL, OF, LPF, GEN>; else kern = k_gram1v<MODEL, OF, LPF, GEN>;
     static DynLdsGuard lds_guard;
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
     const int fpb = G * CCAL_GRAMV_WPB;
@@ -770,12 +771,14 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     constexpr int NCt = block_dim(MODEL, OF, false) + 1;
     // larger triangles (KB4: 105 / 120 entries, OPENCV5: 120 / 136) do not fit two wavefronts per SIMD without scratch
     // (one-focal KB4 through k_gram1w: 124 us instead of 64 at 10 000 frames): k_gram1v there
-    const bool w = force >= 0 ? force == 1 : (a.n_obs >= 2000 && NCt * (NCt + 1) / 2 <= 91);
+    // (k_gram1w is not even instantiated for them: CCAL_GRAMV_LDSACC=1 has no effect there)
+    constexpr bool W_OK = NCt * (NCt + 1) / 2 <= 91;
+    const bool w = W_OK && (force >= 0 ? force == 1 : a.n_obs >= 2000);
     const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024);
-#define CCAL_LPF_CASE(L) case L: return w ? launch_gram1v_l<MODEL, OF, L, true, GEN>(a, s) : launch_gram1v_l<MODEL, OF, L, false, GEN>(a, s);
+#define CCAL_LPF_CASE(L) case L: if constexpr (W_OK) { if (w) return launch_gram1v_l<MODEL, OF, L, true, GEN>(a, s); } return launch_gram1v_l<MODEL, OF, L, false, GEN>(a, s);
     switch (lpf) {
         CCAL_LPF_CASE(6) CCAL_LPF_CASE(8) CCAL_LPF_CASE(12) CCAL_LPF_CASE(16) CCAL_LPF_CASE(32)
-        default: return w ? launch_gram1v_l<MODEL, OF, 64, true, GEN>(a, s) : launch_gram1v_l<MODEL, OF, 64, false, GEN>(a, s);
+        default: if constexpr (W_OK) { if (w) return launch_gram1v_l<MODEL, OF, 64, true, GEN>(a, s); } return launch_gram1v_l<MODEL, OF, 64, false, GEN>(a, s);
     }
 #undef CCAL_LPF_CASE
 }
