@@ -32,6 +32,105 @@ __device__ __forceinline__ void wsync() {
 }
 __device__ __forceinline__ double clampd1(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+// Exact elimination of ONE frame's pose block, LPE lanes per frame (all wavefront lanes call it; `active` marks the lanes
+// of frames that exist).  R = the frame's record in LDS: C (21, phi basis) | [B|g] (6 x K1) | A (K1 x K1) | J_l (9);
+// Ym = 6 x K1 doubles of LDS behind it.  phi -> rvec map of C and [B|g], C + lambda clamp(diag C) = L L^T (every lane of the
+// frame runs the same 6 x 6 factorisation), Y = L^-1 [B|g]; the slot's record pf = L (inverted diagonal) | Y | g_p | diag C.
+// Returns this lane's entries e = gl + LPE q of A (accA) and of Y^T Y (accY), and whether the block was positive definite.
+template <int K, int LPE>
+__device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int gl, const bool active, const double lambda,
+                                                const double min_diag, const double max_diag, double* pf, const int PF,
+                                                double* accA, double* accY) {
+    constexpr int K1 = K + 1, NA = K1 * K1;
+    constexpr int NQ = (NA + LPE - 1) / LPE;
+    bool ok = true;
+    if (active) {
+        double Cr[21], jl[9];
+#pragma unroll
+        for (int i = 0; i < 21; ++i) Cr[i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) jl[i] = R[praw_jl_off(K) + i];
+        phi_to_rvec_C(Cr, jl);
+        double L[21], dC[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dC[i] = Cr[i * (i + 1) / 2 + i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = Cr[i * (i + 1) / 2 + j];
+                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], min_diag, max_diag);
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) {
+                    ok = ok && (t > 0.0) && (t < 1.7e308);
+                    double sq, rsq;
+                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
+                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;
+                } else {
+                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
+                }
+            }
+        }
+        const double* Bm = R + 21;
+        if (!ok) {
+            for (int e = gl; e < PF; e += LPE) pf[e] = 0.0;
+            for (int e = gl; e < 6 * K1; e += LPE) Ym[e] = 0.0;
+        } else {
+            for (int c = gl; c < K1; c += LPE) {
+                double bc[6], y[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + c];
+                phi_to_rvec_col(bc, jl);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double t = bc[i];
+#pragma unroll
+                    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
+                    y[i] = t * L[i * (i + 1) / 2 + i];
+                    Ym[i * K1 + c] = y[i];
+                    pf[21 + i * K1 + c] = y[i];
+                }
+                if (c == K) {                      // g_p in the rvec basis
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
+                }
+            }
+            // L and diag C: every lane holds them; lane 0 of the frame parks them in the record's C | B area (read above,
+            // dead now), the frame's lanes store them coalesced after the fence below
+            if (gl == 0) {
+#pragma unroll
+                for (int i = 0; i < 21; ++i) R[i] = L[i];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) R[21 + i] = dC[i];
+            }
+        }
+    }
+    wsync();
+    if (active && ok) {
+        for (int e = gl; e < 21; e += LPE) pf[e] = R[e];
+        for (int e = gl; e < 6; e += LPE) pf[21 + 6 * K1 + 6 + e] = R[21 + e];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = gl + LPE * q;
+            if (e < NA) {
+                const int i = e / K1, j = e - i * K1;
+                double t = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+                accY[q] = t;
+                accA[q] = R[21 + 6 * K1 + e];
+            }
+        }
+    } else if (active) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = gl + LPE * q;
+            if (e < NA) { accY[q] = 0.0; accA[q] = R[21 + 6 * K1 + e]; }
+        }
+    }
+    return ok;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_unpack1: the whole starting point arrives as ONE host-to-device copy of the staging block
 // [intr | DevState | ColInfo x KMAX | poses]; this kernel distributes it (both parameter sets start from the
@@ -999,90 +1098,8 @@ __global__ __launch_bounds__(64 * SCHUR1M_WAVES) void k_schur1m(const FusedArgs 
     }
     const int slot = active ? a.obs_slot[f] : 0;
     wsync();
-    bool ok = true;
-    if (active) {
-        // phi -> rvec, then the 6x6 Cholesky of C + lambda clamp(diag C) from the packed lower triangle; every lane of
-        // the frame's 16 runs it
-        double Cr[21], jl[9];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) Cr[i] = R[i];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) jl[i] = R[praw_jl_off(K) + i];
-        phi_to_rvec_C(Cr, jl);
-        double L[21], dC[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            dC[i] = Cr[i * (i + 1) / 2 + i];
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double t = Cr[i * (i + 1) / 2 + j];
-                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
-#pragma unroll
-                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-                if (i == j) {
-                    ok = ok && (t > 0.0) && (t < 1.7e308);
-                    double sq, rsq;
-                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
-                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;
-                } else {
-                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
-                }
-            }
-        }
-        double* pf = a.pf[set] + (int64_t)slot * a.PF;
-        const double* Bm = R + 21;
-        if (!ok) {
-            for (int e = gl; e < a.PF; e += 16) pf[e] = 0.0;
-            for (int e = gl; e < 6 * K1; e += 16) Ym[e] = 0.0;
-        } else {
-            if (gl < K1) {
-                double bc[6], y[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + gl];
-                phi_to_rvec_col(bc, jl);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    double t = bc[i];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
-                    y[i] = t * L[i * (i + 1) / 2 + i];
-                    Ym[i * K1 + gl] = y[i];
-                    pf[21 + i * K1 + gl] = y[i];
-                }
-                if (gl == K) {                     // g_p in the rvec basis
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
-                }
-            }
-            {   // lane gl stores L[gl] and L[16 + gl], dC[gl]: select chains over static register indices, coalesced stores
-                double l0 = L[0], l1 = L[16], dv = dC[0];
-#pragma unroll
-                for (int i = 1; i < 16; ++i) l0 = gl == i ? L[i] : l0;
-#pragma unroll
-                for (int i = 17; i < 21; ++i) l1 = gl == i - 16 ? L[i] : l1;
-#pragma unroll
-                for (int i = 1; i < 6; ++i) dv = gl == i ? dC[i] : dv;
-                pf[gl] = l0;
-                if (gl < 5) pf[16 + gl] = l1;
-                if (gl < 6) pf[21 + 6 * K1 + 6 + gl] = dv;
-            }
-        }
-    }
-    wsync();
-    if (active) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = gl + 16 * q;
-            if (e < NA) {
-                const int i = e / K1, j = e - i * K1;
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
-                accY[q] = t;
-                accA[q] = R[21 + 6 * K1 + e];
-            }
-        }
-    }
+    const bool ok = eliminate_frame<K, 16>(R, Ym, gl, active, lambda, a.min_diag, a.max_diag,
+                                          a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY);
     // the frames of the workgroup combine in LDS (fixed order), one flush per workgroup; a frame's sums reuse its row
     wsync();
 #pragma unroll
