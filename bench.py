@@ -242,7 +242,8 @@ def main():
             extra["mode_N_build_ms"] = ms
             extra["mode_N_evals_per_s"] = n_corners / (ms * 1e-3)
             extra["mode_N_note"] = ("ccal_build_normal_dev: reduced normal equations [S | b | cost] from resident parameters "
-                                   "(single camera: Gram kernel + k_schur1m + k_reduce1, one launch each)")
+                                   "(single camera, >= 2 000 frames: k_gram1w with the per-frame elimination fused into its tail "
+                                   "+ k_reduce1; below: Gram kernel + k_schur1m + k_reduce1)")
             # mode-N roofline (both rooflines; the FP64 one binds): exact FP64 operation counts read off the
             # kernels' ISA (tools/count_flops.py -> profiles/<round>/flops.json), time = the three launches together
             try:
@@ -260,7 +261,7 @@ def main():
                 pf = 21 + 6 * K1 + 12
                 hbm = n_corners * 20 + sp.n_slots * (48 + 8 * (2 * rec + pf))          # inputs + record written, read back, pose factor written
                 extra["mode_N_roofline"] = {
-                    "kernels": f"{gk} + k_schur1m<K={K}> + k_reduce1",
+                    "kernels": f"{gk} (+ fused elimination = the body of k_schur1m<K={K}>) + k_reduce1",
                     "flops_per_corner_gram": flops_corner, "flops_per_frame_elimination": schur,
                     "flops_per_corner": flops / n_corners,
                     "achieved_tflops": flops / (ms * 1e-3) / 1e12, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
@@ -268,7 +269,8 @@ def main():
                     "hbm_bytes": hbm, "achieved_GBps": hbm / (ms * 1e-3) / 1e9, "frac_hbm": hbm / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "bound": "fp64 issue (VALU + LDS), not HBM",
                     "counted": "FP64 fma x2 + mul + add + LDS adds per corner in the Gram kernel's corner loop (inlier path) and "
-                               "the elimination kernel's whole body x 16 lanes per frame, from the gfx950 ISA",
+                               "the elimination body (eliminate_frame, counted on k_schur1m: x 16 lanes per frame; the fused tail runs it "
+                               "with the Gram kernel's lanes per frame) from the gfx950 ISA",
                 }
             except Exception as e:  # noqa: BLE001
                 extra["mode_N_roofline"] = {"error": repr(e)}

@@ -198,6 +198,10 @@ struct FusedArgs {
     const int32_t* list; const int64_t* rec_off;
     int32_t cam; const double* extr[2];
     int32_t avg_corners;           // corners per observation frame on average (lanes-per-frame choice of the Gram launchers)
+    // single-camera loop: k_gram1w eliminates the pose blocks of its frames itself (gram_fused_tail): no k_schur1m launch,
+    // one row of partial sums per wavefront.  Set by launch_gram1v when the kernel it picks supports it (elim_fused = 1)
+    int32_t fuse_elim, elim_fused;
+    int32_t part_cap;              // rows the partial-sum buffer holds
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:
@@ -234,7 +238,7 @@ struct UnpackArgs {               // staging block (doubles): [intr CCAL_PMAX | 
 };
 hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
-hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
+hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
 hipError_t launch_schur1(FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size); sets a.n_part
 hipError_t launch_schur1m(FusedArgs& a, hipStream_t s);   // four frames per wavefront, 32 per workgroup, one pass; sets a.n_part

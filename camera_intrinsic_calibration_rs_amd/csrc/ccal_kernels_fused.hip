@@ -353,6 +353,42 @@ struct RecMap {
 };
 template <int K, int W, bool GEN = false> __device__ const RecMap<K, W, GEN> g_recmap = RecMap<K, W, GEN>();
 
+// Fused elimination (single-camera loop, k_gram1w): the wavefront that built G frames' Grams eliminates their pose blocks
+// itself - records in LDS at red + g GS (what k_schur1m loads from HBM), LPF lanes per frame - and writes ONE row of
+// partial sums per wavefront, [A_dir | Y^T Y | model decrease | failed blocks], frames added in a fixed order.
+template <int K, int LPF>
+__device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const DevState* st, double* red, const int wave_global,
+                                                const int grp, const int gl, const bool lane_ok, const bool active, const int slot,
+                                                const int set, const double mcv) {
+    constexpr int G = 64 / LPF, K1 = K + 1, NA = K1 * K1;
+    constexpr int REC = praw_jl_off(K) + 9, GS = (REC + 6 * K1 + 1) & ~1, NQ = (NA + LPF - 1) / LPF;
+    static_assert(2 * NA + 2 <= GS, "a frame's sums reuse its record row");
+    double* R = red + grp * GS;
+    double* Ym = R + REC;
+    double accA[NQ], accY[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
+    const bool ok = eliminate_frame<K, LPF>(R, Ym, gl, active, schur_lambda(st), a.min_diag, a.max_diag,
+                                           a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY);
+    wsync();
+    if (lane_ok) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = gl + LPF * q;
+            if (e < NA) { R[e] = accA[q]; R[NA + e] = accY[q]; }
+        }
+        if (gl == 0) { R[2 * NA] = active ? mcv : 0.0; R[2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
+    }
+    wsync();
+    const int lane = threadIdx.x & 63;
+    for (int e = lane; e < 2 * NA + 2; e += 64) {
+        double t = 0.0;
+#pragma unroll
+        for (int g = 0; g < G; ++g) t += red[g * GS + e];
+        a.partial[(int64_t)wave_global * (2 * NA + 2) + e] = t;
+    }
+}
+
 #ifndef CCAL_GRAMV_WPB
 #define CCAL_GRAMV_WPB 2          // wavefronts per workgroup (4 frames each)
 #endif
@@ -581,7 +617,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     constexpr int NQA = (G * NL + 63) / 64;
     extern __shared__ double smem[];
     const DevState* st = a.st;
-    if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
+    // fused elimination (launch_gram1v_t decides): no separate elimination launch; a re-elimination group then runs here too
+    const bool fuse = !GEN && a.fuse_elim != 0;
+    // the records in HBM are what a re-elimination group reads: Gauss-Newton never has one, so a fused GN group skips the stores
+    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
+    if (st->done || (st->redo && !fuse)) return;            // finished, or a re-elimination group without fusion (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #ifdef CCAL_STAMPS          // diagnostic build (tools/stamps_gram.py): start / end time of every wavefront into the per-frame scratch
     const long long t_start = wall_clock64();
@@ -597,6 +637,25 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     double* red = fcw + G * FC_N0P;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
+    if constexpr (!GEN) {
+        constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
+        static_assert(G * GS_ <= RED, "the frames' records fit the reduction buffer");
+        if (st->redo) {
+            // re-elimination group (LM: rejected step or missed speculation): the accepted set's stored records, new damping
+            double* R = red + grp * GS_;
+            double mcv = 0.0;
+            int slot_r = 0;
+            if (active) {
+                const double* rec = a.praw[cur] + (int64_t)f * a.PRAW;
+                slot_r = a.obs_slot[f];
+                for (int e = gl; e < REC_; e += LPF) R[e] = rec[e];
+                if (gl == 0) mcv = a.mc_f[f];
+            }
+            wsync();
+            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_r, cur, mcv);
+            return;
+        }
+    }
     const double* th_g = a.intr[es];
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
@@ -745,10 +804,16 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const long long t_after = wall_clock64();
 #endif
     const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
+    // fused elimination: what its tail needs from memory is requested now, behind the reductions
+    int slot_t = 0;
+    double mc_t = 0.0;
+    if constexpr (!GEN) {
+        if (fuse && active) { slot_t = a.obs_slot[f]; if (gl == 0) mc_t = a.mc_f[f]; }
+    }
     // camera x pose: LPF lane-private LDS sums per frame -> record  [B|g][pose j][camera i]
     wsync();
+    double resa[NQA];
     {
-        double resa[NQA];
 #pragma unroll
         for (int q = 0; q < NQA; ++q) {
             const int idx = lane + 64 * q;
@@ -769,7 +834,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const int ff = fbase + g;
             if (ff >= a.n_obs) continue;
             const int i = t / 6, jp = t - 6 * i;
-            a.praw[es][GEN ? a.rec_off[a.list[ff]] + 36 + i * 6 + jp : (int64_t)ff * a.PRAW + 21 + jp * K1 + i] = resa[q];
+            if (keep_rec) a.praw[es][GEN ? a.rec_off[a.list[ff]] + 36 + i * 6 + jp : (int64_t)ff * a.PRAW + 21 + jp * K1 + i] = resa[q];
         }
     }
 
@@ -807,13 +872,42 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             const uint32_t m = g_recmap<K, NLC, GEN>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
-            rec[m & 0xffff] = v;
-            if ((m >> 16) != 0xffff) rec[m >> 16] = v;
-            if (!GEN && e == NR - 1) a.cost_f[ff] = v;               // the last entry is r x r
+            if (keep_rec) {
+                rec[m & 0xffff] = v;
+                if ((m >> 16) != 0xffff) rec[m >> 16] = v;
+                if (!GEN && e == NR - 1) a.cost_f[ff] = v;               // the last entry is r x r
+            }
+            if constexpr (!GEN) {
+                if (fuse) {                                          // fused elimination: the same record in LDS (red is free: every sum is in registers)
+                    constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+                    red[g * GS_ + (m & 0xffff)] = v;
+                    if ((m >> 16) != 0xffff) red[g * GS_ + (m >> 16)] = v;
+                }
+            }
         }
     }
     // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
-    if (!GEN && active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+    if (!GEN && active && keep_rec) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+    if constexpr (!GEN) {
+        if (fuse) {
+            constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+#pragma unroll
+            for (int q = 0; q < NQA; ++q) {
+                const int idx = lane + 64 * q;
+                if (idx >= G * NL) continue;
+                const int g = idx / NL, t = idx - g * NL, ci = t / 6, jp = t - 6 * ci;
+                red[g * GS_ + 21 + jp * K1 + ci] = resa[q];
+            }
+            if (lane_ok) for (int e = gl; e < 9; e += LPF) red[grp * GS_ + praw_jl_off(K) + e] = fc[FC_A + e];
+        }
+    }
+    if constexpr (!GEN) {
+        if (fuse) {
+            // the records are in LDS as well (written along with the global stores above): the elimination right here
+            wsync();
+            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_t, es, mc_t);
+        }
+    }
 #ifdef CCAL_STAMPS
     if (!GEN && lane == 0) { const int wg = blockIdx.x * CCAL_GRAMV_WPB + wave; a.fcbuf[2 * wg] = (double)t_start; a.fcbuf[2 * wg + 1] = (double)wall_clock64(); a.fcbuf[8192 + 2 * wg] = (double)t_loop; a.fcbuf[8192 + 2 * wg + 1] = (double)t_after; }
 #endif
@@ -862,7 +956,7 @@ static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots) {
     return best;
 }
 template <int MODEL, bool OF, bool GEN>
-static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
+static hipError_t launch_gram1v_t(FusedArgs& a, hipStream_t s) {
     // More wavefronts than SIMDs (>= 2000 frames): k_gram1w, two wavefronts per SIMD (10 000 frames: 40 vs 53 us).
     // Below that every wavefront has a SIMD to itself and k_gram1v's all-register accumulators are a little faster.
     // CCAL_GRAMV_LDSACC=0|1 forces one or the other.
@@ -874,6 +968,12 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
     constexpr bool W_OK = NCt * (NCt + 1) / 2 <= 91;
     const bool w = W_OK && (force >= 0 ? force == 1 : a.n_obs >= 2000);
     const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024);
+    // fused elimination (single-camera loop, k_gram1w only): one row of partial sums per wavefront
+    const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
+    const bool fuse = !GEN && w && a.fuse_elim != 0 && waves <= a.part_cap;
+    a.fuse_elim = fuse ? 1 : 0;
+    a.elim_fused = fuse ? 1 : 0;
+    if (fuse) a.n_part = waves;
 #define CCAL_LPF_CASE(L) case L: if constexpr (W_OK) { if (w) return launch_gram1v_l<MODEL, OF, L, true, GEN>(a, s); } return launch_gram1v_l<MODEL, OF, L, false, GEN>(a, s);
     switch (lpf) {
         CCAL_LPF_CASE(6) CCAL_LPF_CASE(8) CCAL_LPF_CASE(12) CCAL_LPF_CASE(16) CCAL_LPF_CASE(32)
@@ -882,7 +982,7 @@ static hipError_t launch_gram1v_t(const FusedArgs& a, hipStream_t s) {
 #undef CCAL_LPF_CASE
 }
 template <bool GEN>
-static hipError_t launch_gram1v_m(int model, bool one_focal, const FusedArgs& a, hipStream_t s) {
+static hipError_t launch_gram1v_m(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
         case 0: return launch_gram1v_t<kUCM, false, GEN>(a, s);
         case 1: return launch_gram1v_t<kUCM, true, GEN>(a, s);
@@ -895,9 +995,10 @@ static hipError_t launch_gram1v_m(int model, bool one_focal, const FusedArgs& a,
         default: return hipErrorInvalidValue;
     }
 }
-hipError_t launch_gram1v(int model, bool one_focal, const FusedArgs& a, hipStream_t s) { return launch_gram1v_m<false>(model, one_focal, a, s); }
-// camera-0 blocks of a multi-camera problem: a.list / a.rec_off / a.n_obs = that camera's observation frames
-hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s) { return launch_gram1v_m<true>(model, one_focal, a, s); }
+// single-camera loop; a.fuse_elim in: fusion allowed, out: fusion done (then a.n_part = rows of partial sums, a.elim_fused = 1)
+hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s) { return launch_gram1v_m<false>(model, one_focal, a, s); }
+// one camera's blocks of a multi-camera problem: a.list / a.rec_off / a.n_obs = that camera's observation frames
+hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a0, hipStream_t s) { FusedArgs a = a0; a.fuse_elim = 0; return launch_gram1v_m<true>(model, one_focal, a, s); }
 template <int MODEL, bool OF>
 static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
     constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * 34;

@@ -275,6 +275,7 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
     fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
     fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
+    fa.part_cap = f->n_pw;
     return fa;
 }
 // Per-frame elimination with four frames per wavefront (k_schur1m) when one pass covers the problem; sets fa.n_pw.
@@ -298,8 +299,13 @@ static bool fused_use_valu_gram(const ccal_problem* p) {
 static hipError_t enqueue_fused_gram_schur(const ccal_problem* p, FusedArgs& fa, bool schur_m, hipStream_t st) {
     fa.n_part = 0;
     if (p->n_obs <= 0) return hipSuccess;      // a rank whose shard is empty still takes part in the collective, with zeros
-    hipError_t e = fused_use_valu_gram(p) ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
+    // CCAL_FUSE_ELIM=0 (developer switch): always the separate elimination launch
+    static const bool fuse_ok = [] { const char* e = std::getenv("CCAL_FUSE_ELIM"); return !(e && e[0] == '0'); }();
+    const bool valu = fused_use_valu_gram(p);
+    fa.fuse_elim = (fuse_ok && valu) ? 1 : 0; fa.elim_fused = 0;
+    hipError_t e = valu ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
     if (e != hipSuccess) return e;
+    if (fa.elim_fused) return hipSuccess;      // k_gram1w eliminated its frames' pose blocks itself: fa.n_part rows of partial sums
     return schur_m ? launch_schur1m(fa, st) : launch_schur1(fa, st);
 }
 // ... + k_reduce1: the reduced sums in fws->red (the all-reduce buffer of sharded solves; ccal_build_normal_dev)
