@@ -414,7 +414,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
     extern __shared__ double smem[];
     const DevState* st = a.st;
-    if (st->done || st->redo) return;            // finished, or a re-elimination group (no evaluation)
+    // fused elimination (launch_gram1v_t decides): no separate elimination launch; a re-elimination group then runs here too
+    const bool fuse = !GEN && a.fuse_elim != 0;
+    // the records in HBM are what a re-elimination group reads: Gauss-Newton never has one, so a fused GN group skips the stores
+    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
+    if (st->done || (st->redo && !fuse)) return;            // finished, or a re-elimination group without fusion (no evaluation)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
     const bool lane_ok = lane < G * LPF;
@@ -427,6 +431,25 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     double* red = fcw + G * FC_N0P;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
+    if constexpr (!GEN) {
+        constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
+        static_assert(G * GS_ <= 64 * LS, "the frames' records fit the reduction buffer");
+        if (st->redo) {
+            // re-elimination group (LM: rejected step or missed speculation): the accepted set's stored records, new damping
+            double* R = red + grp * GS_;
+            double mcv = 0.0;
+            int slot_r = 0;
+            if (active) {
+                const double* rec = a.praw[cur] + (int64_t)f * a.PRAW;
+                slot_r = a.obs_slot[f];
+                for (int e = gl; e < REC_; e += LPF) R[e] = rec[e];
+                if (gl == 0) mcv = a.mc_f[f];
+            }
+            wsync();
+            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_r, cur, mcv);
+            return;
+        }
+    }
     const double* th_g = a.intr[es];
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
@@ -568,6 +591,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     }
     // scatter the upper triangle into the compact record  C (21) | [B|g] (6 x K1) | A (K1 x K1)
     const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
+    // fused elimination: what its tail needs from memory is requested now, behind the reductions
+    int slot_t = 0;
+    double mc_t = 0.0;
+    if constexpr (!GEN) {
+        if (fuse && active) { slot_t = a.obs_slot[f]; if (gl == 0) mc_t = a.mc_f[f]; }
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -580,13 +609,30 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             const uint32_t m = g_recmap<K, 0, GEN>.d[e];
             const double v = res[h][q];
             double* rec = a.praw[es] + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
-            rec[m & 0xffff] = v;
-            if ((m >> 16) != 0xffff) rec[m >> 16] = v;
-            if (!GEN && e == NE - 1) a.cost_f[ff] = v;               // the last entry is r x r
+            if (keep_rec) {
+                rec[m & 0xffff] = v;
+                if ((m >> 16) != 0xffff) rec[m >> 16] = v;
+                if (!GEN && e == NE - 1) a.cost_f[ff] = v;               // the last entry is r x r
+            }
+            if constexpr (!GEN) {
+                if (fuse) {                                          // fused elimination: the same record in LDS (red is free: every sum is in registers)
+                    constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+                    red[g * GS_ + (m & 0xffff)] = v;
+                    if ((m >> 16) != 0xffff) red[g * GS_ + (m >> 16)] = v;
+                }
+            }
         }
     }
     // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
-    if (!GEN && active) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+    if (!GEN && active && keep_rec) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
+    if constexpr (!GEN) {
+        if (fuse) {
+            constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+            if (lane_ok) for (int e = gl; e < 9; e += LPF) red[grp * GS_ + praw_jl_off(K) + e] = fc[FC_A + e];
+            wsync();
+            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_t, es, mc_t);
+        }
+    }
 }
 
 // k_gram1w: k_gram1v with two wavefronts per SIMD.  k_gram1v needs 256 VGPRs + 66 AGPRs (91 accumulators and the
@@ -970,7 +1016,10 @@ static hipError_t launch_gram1v_t(FusedArgs& a, hipStream_t s) {
     const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024);
     // fused elimination (single-camera loop, k_gram1w only): one row of partial sums per wavefront
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
-    const bool fuse = !GEN && w && a.fuse_elim != 0 && waves <= a.part_cap;
+    // (every size: 300 / 625 / 1 000 / 1 280 frames GN 0.135-0.155 ms fused against 0.145-0.172 with k_schur1m and the head's own
+    // reduction of its <= 40 rows; CCAL_FUSE_MIN = fewest frames that fuse, CCAL_FUSE_ELIM=0 never)
+    static const int fuse_min = [] { const char* e = std::getenv("CCAL_FUSE_MIN"); return e ? std::atoi(e) : 1; }();
+    const bool fuse = !GEN && a.n_obs >= fuse_min && a.fuse_elim != 0 && waves <= a.part_cap;
     a.fuse_elim = fuse ? 1 : 0;
     a.elim_fused = fuse ? 1 : 0;
     if (fuse) a.n_part = waves;
