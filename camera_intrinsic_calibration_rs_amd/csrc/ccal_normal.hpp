@@ -76,6 +76,7 @@ struct FusedWs {
     double* mc_f = nullptr;                    // [n_obs] model decrease of each pose block
     double* cost_f = nullptr;                  // [n_obs] cost of each frame
     struct DevState* d_state = nullptr;
+    bool fuse_elim = true;                     // the Gram kernels eliminate their frames' pose blocks in their tail (CCAL_FUSE_ELIM=0: separate launch)
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
     double* h_stage = nullptr;                 // pinned staging [intr | state | cols | poses]
     double* d_stage = nullptr;                 // its device image (one copy per solve, k_unpack1 distributes it)

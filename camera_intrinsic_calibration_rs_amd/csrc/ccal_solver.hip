@@ -89,6 +89,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     FusedWs* f = new FusedWs();
     w->fws = f;
     f->PRAW = praw_size(p->K);
+    { const char* e = std::getenv("CCAL_FUSE_ELIM"); f->fuse_elim = !(e && e[0] == '0'); }
     f->RB1 = fused_red_size(p->K);
     const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
     int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 16384);   // 4 workgroups of 4 waves per CU
@@ -299,10 +300,9 @@ static bool fused_use_valu_gram(const ccal_problem* p) {
 static hipError_t enqueue_fused_gram_schur(const ccal_problem* p, FusedArgs& fa, bool schur_m, hipStream_t st) {
     fa.n_part = 0;
     if (p->n_obs <= 0) return hipSuccess;      // a rank whose shard is empty still takes part in the collective, with zeros
-    // CCAL_FUSE_ELIM=0 (developer switch): always the separate elimination launch
-    static const bool fuse_ok = [] { const char* e = std::getenv("CCAL_FUSE_ELIM"); return !(e && e[0] == '0'); }();
+    // CCAL_FUSE_ELIM=0 (developer switch, read when the problem's workspace is created): always the separate elimination launch
     const bool valu = fused_use_valu_gram(p);
-    fa.fuse_elim = (fuse_ok && valu) ? 1 : 0; fa.elim_fused = 0;
+    fa.fuse_elim = (p->nws->fws->fuse_elim && valu) ? 1 : 0; fa.elim_fused = 0;
     hipError_t e = valu ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
     if (e != hipSuccess) return e;
     if (fa.elim_fused) return hipSuccess;      // k_gram1w eliminated its frames' pose blocks itself: fa.n_part rows of partial sums

@@ -457,3 +457,44 @@ def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatc
         np.testing.assert_allclose(extr_m, extr_o, rtol=0, atol=1e-7)
         assert np.abs(extr - sp.extr_gt).max() < 5e-3                   # and the rig is recovered
     gm.close()
+
+
+@pytest.mark.parametrize("model,frames", [("eucm", 2600), ("kb4", 2100), ("eucm", 300)])
+def test_fused_elimination_equals_separate_launch(gpu_ctx, oracle, model, frames, monkeypatch):
+    """The Gram kernels eliminate their frames' pose blocks in their own tail (k_gram1w from 2 000 frames up for UCM / EUCM,
+    k_gram1v otherwise; re-elimination groups of LM run there too).  Against the separate elimination launch
+    (CCAL_FUSE_ELIM=0: k_schur1m) and the oracle, from a poor start that makes LM reject steps and miss speculations."""
+    sp = synth.make_problem(frames, model, init_perturb=0.6, outlier_frac=0.03, seed=5, ragged=True)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    monkeypatch.setenv("CCAL_FUSE_ELIM", "0")
+    gs = Problem.from_synth(gpu_ctx, sp)
+    gs.build_normal(sp.intr0, sp.poses0)                    # workspace (and the choice) made under the switch
+    monkeypatch.delenv("CCAL_FUSE_ELIM")
+    for p_ in (gp, gs, op):
+        p_.apply_reference_bounds()
+    for lam in (0.0, 1e-2):
+        S, b, c = gp.build_normal(sp.intr0, sp.poses0, lam=lam)
+        S2, b2, c2 = gs.build_normal(sp.intr0, sp.poses0, lam=lam)
+        So, bo, co = op.build_normal(sp.intr0, sp.poses0, lam=lam)
+        for (S_, b_, c_) in ((S, b, c), (S2, b2, c2)):
+            assert abs(c_ - co) <= 1e-12 * co
+            assert np.abs(S_ - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b_ - bo).max() <= 1e-9 * np.abs(bo).max()
+    rejected = 0
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        o = default_opts(method)
+        intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=o, raise_on_error=False)
+        intr2, poses2, _, rep2 = gs.solve(sp.intr0, sp.poses0, opts=o, raise_on_error=False)
+        intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=o)
+        sig = lambda r: (r.status, r.iterations, r.lm_accepted, r.lm_rejected)
+        assert sig(rep) == sig(rep2) == sig(rep_o)
+        if rep_o.status == 0:
+            assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+            assert abs(rep2.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+            np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(poses2, poses_o, rtol=0, atol=1e-7)
+        if method == _ffi.METHOD_LM:
+            assert (rep.lm_spec_hits, rep.lm_spec_misses) == (rep2.lm_spec_hits, rep2.lm_spec_misses)
+            rejected = rep.lm_rejected + rep.lm_spec_misses
+    if (model, frames) == ("eucm", 2600):
+        assert rejected >= 1                                 # the re-elimination path of k_gram1w did run
+    gs.close()
