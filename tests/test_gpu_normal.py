@@ -498,3 +498,22 @@ def test_fused_elimination_equals_separate_launch(gpu_ctx, oracle, model, frames
     if (model, frames) == ("eucm", 2600):
         assert rejected >= 1                                 # the re-elimination path of k_gram1w did run
     gs.close()
+
+
+@pytest.mark.parametrize("model,one_focal,frames", [("eucm", False, 150), ("kb4", True, 150), ("opencv5", False, 2300)])
+def test_matrix_core_gram_switch(gpu_ctx, oracle, model, one_focal, frames, monkeypatch):
+    """CCAL_GRAM=mfma: the single-camera loop through the matrix-core Gram kernel (k_gram1: v_mfma_f64_16x16x4_f64 on LDS-staged
+    rows) and the separate elimination launch - the second implementation behind the developer switch stays correct."""
+    sp = synth.make_problem(frames, model, xy_same_focal=one_focal, ragged=True, outlier_frac=0.02)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    monkeypatch.setenv("CCAL_GRAM", "mfma")
+    S, b, c = gp.build_normal(sp.intr0, sp.poses0, lam=1e-3)
+    So, bo, co = op.build_normal(sp.intr0, sp.poses0, lam=1e-3)
+    assert abs(c - co) <= 1e-12 * co
+    assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+        intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+        assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations) and rep.status == 0
+        assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+        np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
