@@ -977,14 +977,17 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
-// Lanes per frame.  A wavefront's life is the same whether the chip is full or not, so what a launch costs is
-//     ROUNDS of wavefronts x (per-wavefront set-up and reduction + corner passes per lane x one pass)
-// with `slots` wavefronts per round (k_gram1w: two per SIMD = 2 048, k_gram1v: one = 1 024): few lanes per frame = many
-// passes per lane but fewer wavefronts and the set-up / reduction amortised over more corners.  10 000 frames: k_gram1w at
-// 16 lanes (2 500 wavefronts) = one full round and a second one for the last 452, at 12 lanes (five frames per wavefront,
-// four lanes idle) 2 000 wavefronts = ONE round; k_gram1v at 6 lanes (ten frames per wavefront) 1 000 wavefronts = one
-// round of 24 passes beats two rounds of 12.  The model (set-up + reduction = 3.5 passes) reproduces the measured order of
-// every point of tools/sweep_lpf.py and tools/gram_models.sh; CCAL_GRAMV_LPF overrides.
+// Lanes per frame: few lanes = many corner passes per lane but fewer wavefronts, and a wavefront's prologue, reductions and
+// (fused) elimination amortised over more corners.  Cost of a launch in units of one corner pass (~1.75 us):
+//   k_gram1v (one wavefront per SIMD):   rounds x (c0 + passes),   rounds = ceil(wavefronts / 1 024)
+//   k_gram1w (two wavefronts per SIMD):  g(n) x (c0 + passes),     n = wavefronts / 1 024 SIMDs,
+//     g = 1 (n <= 1: every wavefront alone on its SIMD), 1 + 0.3 (n - 1) up to n = 2 (the younger partner runs at ~0.57 of
+//     the solo speed until it is alone), 0.65 + 0.43 n beyond (wavefronts past 2 048 wait for a slot: a step at n = 2, then
+//     pipelined) - fitted to tools/sweep_lpf.py with the fused elimination (6 / 8 / 12 / 16 / 32 / 64 lanes, 1 500-50 000 frames;
+//     EUCM us per build, best in brackets: 5 000 frames 37.4 40.2 33.7 [31.2] 37.2 50.7; 10 000: 52.9 45.8 [40.8] 45.7 58.3 82.4;
+//     20 000: 85.2 [67.6] 72.1 74.6 98.0 117; 50 000: 159 [138] 151 154 191 267;  KB4 (k_gram1v) 10 000: [54.6] 78.1 63.4 74.3
+//     88.4 138; 20 000: [99.4] 115 116 120 168 214).  c0 = 6 passes' worth of prologue + epilogue (6 lanes: 8).
+// CCAL_GRAMV_LPF overrides.
 static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots) {
     static const int lpf_env = [] { const char* e = std::getenv("CCAL_GRAMV_LPF"); return e ? std::atoi(e) : 0; }();
     if (lpf_env) return lpf_env;
@@ -994,9 +997,16 @@ static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots) {
     for (int i = 0; i < 6; ++i) {
         const int lpf = cand[i], g = 64 / lpf;
         const int64_t waves = ((int64_t)n_obs + g - 1) / g;
-        const int64_t rounds = (waves + slots - 1) / slots;
         const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
-        const double cost = (double)rounds * (3.5 + passes);
+        const double c0 = lpf == 6 ? 8.0 : 6.0;
+        double occ;
+        if (slots > 1024) {
+            const double n = (double)waves / 1024.0;
+            occ = n <= 1.0 ? 1.0 : (n <= 2.0 ? 1.0 + 0.3 * (n - 1.0) : 0.65 + 0.43 * n);
+        } else {
+            occ = (double)((waves + 1023) / 1024);
+        }
+        const double cost = occ * (c0 + passes);
         if (cost < best_cost) { best_cost = cost; best = lpf; }        // ties: the wider mapping (listed first)
     }
     return best;
