@@ -56,6 +56,7 @@ struct NormalWs {
     double* h_pinned = nullptr;                // pinned staging (RB + 16 doubles)
     int cur = 0;                               // which G buffer holds the current point
     bool red_fused = false;                    // the last ccal_build_normal_dev left its sums in fws->red (single camera)
+    bool gstate_is_eval = false;               // d_gstate already says "first evaluation of set 0" (ccal_build_normal)
     bool register_gram = false;                // general loop: every camera's blocks come from k_gram1v / k_gram1w (GEN record format, caminfo NCP = 0)
     int64_t g_len = 0;
     struct DevState* d_gstate = nullptr;       // general loop: optimizer state on the device,
@@ -76,6 +77,7 @@ struct FusedWs {
     double* mc_f = nullptr;                    // [n_obs] model decrease of each pose block
     double* cost_f = nullptr;                  // [n_obs] cost of each frame
     struct DevState* d_state = nullptr;
+    bool state_is_eval = false; double state_eval_lambda = 0.0;     // d_state already says "first evaluation of set 0" with this damping
     bool fuse_elim = true;                     // the Gram kernels eliminate their frames' pose blocks in their tail (CCAL_FUSE_ELIM=0: separate launch)
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
     double* h_stage = nullptr;                 // pinned staging [intr | state | cols | poses]

@@ -235,7 +235,10 @@ static int enqueue_gram(ccal_problem* p, bool cand, int gbuf) {
     NormalWs* w = p->nws;
     if (w->register_gram && !cand && gbuf == w->cur) {
         // record format (what k_schur expects): the device loop's launcher with the state set to "first evaluation of set 0"
-        HIP_TRY(ctx, launch_state_eval(w->d_gstate, 0.0, ctx->stream));
+        if (!w->gstate_is_eval) {      // as in the single-camera build: set once, valid until a solve rewrites the state
+            HIP_TRY(ctx, launch_state_eval(w->d_gstate, 0.0, ctx->stream));
+            w->gstate_is_eval = true;
+        }
         for (int c = 0; c < p->n_cams; ++c) HIP_TRY(ctx, launch_gram_dev(p, c, w->d_gstate, ctx->stream));
         return CCAL_OK;
     }
@@ -401,6 +404,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
     {
         UnpackArgs ua = { f->d_stage, (int64_t)small_doubles, (int64_t)np6, host_io ? 0 : 1, p->d_intr, p->d_intr_c, p->d_poses, p->d_poses_c,
                           f->d_state, w->cols };
+        f->state_is_eval = false;
         HIP_TRY(ctx, launch_unpack1(ua, st));
     }
     HostStatus* hst = f->h_status;
@@ -518,6 +522,7 @@ static int solve_general(ccal_problem* p, const ccal_solver_opts* o, bool host_i
     if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
     const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
     const auto t0 = std::chrono::steady_clock::now();
+    w->gstate_is_eval = false;
     init_state(w->h_gstate, o);
     HIP_TRY(ctx, hipMemcpyAsync(w->d_gstate, w->h_gstate, sizeof(DevState), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), st));
@@ -616,7 +621,12 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda) {
         if (f->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); f->tail_pending = false; }
         FusedArgs fa = make_fused_args(p, 1e-6, 1e32);
         const bool schur_m = fused_use_schur1m(p, fa);
-        HIP_TRY(ctx, launch_state_eval(f->d_state, lambda, st));
+        // the device state only has to say "first evaluation of set 0 with this damping" - it still does after a build
+        // (nothing decides), so back-to-back builds set it once; a solve invalidates the note
+        if (!(f->state_is_eval && f->state_eval_lambda == lambda)) {
+            HIP_TRY(ctx, launch_state_eval(f->d_state, lambda, st));
+            f->state_is_eval = true; f->state_eval_lambda = lambda;
+        }
         HIP_TRY(ctx, enqueue_fused_system(p, fa, schur_m, st));
         w->red_fused = true;
         return CCAL_OK;
