@@ -662,7 +662,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         a.lambda = S0.lambda;
         if (S0.cur) { a.intr = a0.intr_c; a.extr = a0.extr_c; a.intr_c = const_cast<double*>(a0.intr); a.extr_c = const_cast<double*>(a0.extr); }
     }
-    __shared__ double S[CCAL_KMAX * (CCAL_KMAX + 1)];
+    __shared__ double S[(CCAL_KMAX + 1) * (CCAL_KMAX + 1)];       // rows 0..K-1: the system, row K: the right-hand side
     __shared__ double x[CCAL_KMAX];
     __shared__ int bad;
     const int K = a.K, K1 = K + 1;
@@ -678,16 +678,21 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     const double hd = lane < K ? hdiag[lane] : 0.0, gcl = lane < K ? gc[lane] : 0.0;
     const double xsrc = lane < K ? (ci.is_extr ? a.extr : a.intr)[ci.dst] : 0.0;
     __syncthreads();
+    {
+        const float rk = 1.0f / (float)K;
 #pragma unroll 4
-    for (int e = lane; e < K * K; e += 64) {
-        const int i = e / K, j = e - i * K;
-        double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
-        if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
-        S[i * (CCAL_KMAX + 1) + j] = v;
+        for (int e = lane; e < K * K; e += 64) {
+            const int i = (int)(((float)e + 0.5f) * rk), j = e - i * K;
+            double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
+            if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
+            S[i * (CCAL_KMAX + 1) + j] = v;
+        }
     }
     __syncthreads();
     if (lane < K && !ci.fixed && a.lambda > 0.0) S[lane * (CCAL_KMAX + 1) + lane] += a.lambda * clampd(hd, a.min_diag, a.max_diag);
-    if (lane < K) x[lane] = ci.fixed ? 0.0 : -rhs;
+    // the right-hand side rides along as row K of the matrix: the factorisation's own recurrence turns it into L^-1 rhs
+    // (the forward substitution costs nothing extra: lane K is one more row)
+    if (lane < K) S[K * (CCAL_KMAX + 1) + lane] = ci.fixed ? 0.0 : -rhs;
     __syncthreads();
     // left-looking Cholesky, lane i owns row i: t = S[i][j] - sum_{k<j} L[i][k] L[j][k] (no stores inside the sum,
     // so the LDS reads pipeline), the pivot travels by shuffle; one barrier per column.  Same operation order as
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     constexpr int LD = CCAL_KMAX + 1;
     for (int j = 0; j < K; ++j) {
         double t = 0.0;
-        if (lane >= j && lane < K) {
+        if (lane >= j && lane <= K) {
             t = S[lane * LD + j];
 #pragma unroll 4
             for (int k = 0; k < j; ++k) t -= S[lane * LD + k] * S[j * LD + k];
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         double sq, inv;
         fast_sqrt_rsqrt(piv, sq, inv);                    // hardware seed + Newton steps (<= 2 ulp), not the IEEE sqrt + division expansions
         if (lane == j) S[j * LD + j] = inv;               // the diagonal is kept inverted: the solves below multiply
-        else if (lane > j && lane < K) S[lane * LD + j] = t * inv;
+        else if (lane > j && lane <= K) S[lane * LD + j] = t * inv;
         __syncthreads();
     }
     __syncthreads();
@@ -730,13 +735,8 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         }
         return;
     }
-    {   // two triangular solves: lane i owns x_i, the finished component travels by shuffle
-        double xi = lane < K ? x[lane] : 0.0;
-        for (int j = 0; j < K; ++j) {
-            if (lane == j) xi = xi * S[j * LD + j];
-            const double xj = __shfl(xi, j, 64);
-            if (lane > j && lane < K) xi -= S[lane * LD + j] * xj;
-        }
+    {   // back substitution on y = L^-1 rhs (row K): lane i owns x_i, the finished component travels by shuffle
+        double xi = lane < K ? S[K * LD + lane] : 0.0;
         for (int j = K - 1; j >= 0; --j) {
             if (lane == j) xi = xi * S[j * LD + j];
             const double xj = __shfl(xi, j, 64);
