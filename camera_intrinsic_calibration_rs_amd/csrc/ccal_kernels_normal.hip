@@ -641,6 +641,8 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     const int lane = threadIdx.x;
     DevState* const gst = a0.st;
     if (a.st) {
+        // the three sums the decision needs are requested together with the state (one memory latency, not two)
+        const double d_cost = a.red[a.RB - 3], d_mc = a.red[a.RB - 2], d_fail = a.red[a.RB - 1];
         {
             const double* src = reinterpret_cast<const double*>(gst);
             double* dst = reinterpret_cast<double*>(&S0);
@@ -649,7 +651,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         __syncthreads();
         a.st = &S0;
         if (S0.done) { if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0); return; }
-        if (lane == 0) go = optimizer_decide(&S0, a.red[a.RB - 3], a.red[a.RB - 2], a.red[a.RB - 1] > 0.0, a.seq) ? 1 : 0;
+        if (lane == 0) go = optimizer_decide(&S0, d_cost, d_mc, d_fail > 0.0, a.seq) ? 1 : 0;
         __syncthreads();
         if (!go) {
             const double* src = reinterpret_cast<const double*>(&S0);
