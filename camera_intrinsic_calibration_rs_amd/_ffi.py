@@ -37,7 +37,7 @@ class SolverOpts(C.Structure):
         ("method", C.c_int32), ("max_iterations", C.c_int32),
         ("min_abs_error_decrease", C.c_double), ("min_rel_error_decrease", C.c_double), ("min_error", C.c_double),
         ("lm_initial_radius", C.c_double), ("lm_min_diagonal", C.c_double), ("lm_max_diagonal", C.c_double),
-        ("verbose", C.c_int32), ("reserved", C.c_int32),
+        ("verbose", C.c_int32), ("timeout_s", C.c_int32),
     ]
 
 

@@ -21,15 +21,25 @@ using namespace ccal;
         }                                                                                          \
     } while (0)
 
+// the context stream has just been synchronised: whatever early-exit groups a finished solve left in it are gone
+static void stream_synced(ccal_problem* p) {
+    if (!p->nws) return;
+    p->nws->tail_pending = false;
+    if (p->nws->fws) p->nws->fws->tail_pending = false;
+}
+
 static int fail(ccal_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
     return code;
 }
 
+// One element of slack behind every array: the Gram / eval kernels request a frame's first corner row before they look at
+// its corner count (software prefetch), which for an EMPTY last frame is index n - one past the data, inside the allocation.
 template <class T>
 static int upload(ccal_ctx* ctx, T** dst, const T* src, size_t n) {
-    HIP_TRY(ctx, hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
+    HIP_TRY(ctx, hipMalloc((void**)dst, (n + 1) * sizeof(T)));
     if (n) HIP_TRY(ctx, hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(*dst + n, 0, sizeof(T), ctx->stream));
     return CCAL_OK;
 }
 
@@ -100,7 +110,7 @@ int ccal_set_defaults(ccal_solver_opts* o) {
     o->method = CCAL_METHOD_GN; o->max_iterations = 100;
     o->min_abs_error_decrease = 1e-5; o->min_rel_error_decrease = 1e-5; o->min_error = 1e-10;
     o->lm_initial_radius = 1e4; o->lm_min_diagonal = 1e-6; o->lm_max_diagonal = 1e32;
-    o->verbose = 0; o->reserved = 0;
+    o->verbose = 0; o->timeout_s = 0;
     return CCAL_OK;
 }
 
@@ -187,6 +197,14 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
 
 void ccal_problem_destroy(ccal_problem* p) {
     if (!p) return;
+    // early-exit groups of the last solve may still be queued and hold these pointers: drain them BEFORE anything is freed
+    // (normal_ws_destroy would, but only after the parameter and input buffers are gone)
+    if (p->nws && p->ctx && (p->nws->tail_pending || (p->nws->fws && p->nws->fws->tail_pending))) {
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipDeviceSynchronize();
+        p->nws->tail_pending = false;
+        if (p->nws->fws) p->nws->fws->tail_pending = false;
+    }
     void* ptrs[] = { p->d_x, p->d_y, p->d_z, p->d_u, p->d_v, p->d_obs_off, p->d_joff, p->d_obs_cam, p->d_obs_slot,
                      p->d_intr, p->d_poses, p->d_extr, p->d_intr_c, p->d_poses_c, p->d_extr_c, p->d_r, p->d_J, p->d_err };
     for (void* q : ptrs) if (q) (void)hipFree(q);
@@ -271,6 +289,7 @@ int ccal_upload_params(ccal_problem* p, const double* intr, const double* poses,
     if (poses && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(p->d_poses, poses, sizeof(double) * p->n_slots * 6, hipMemcpyHostToDevice, ctx->stream));
     if (extr) HIP_TRY(ctx, hipMemcpyAsync(p->d_extr, extr, sizeof(double) * p->n_cams * 6, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused by the caller
+    stream_synced(p);
     return CCAL_OK;
 }
 int ccal_download_params(ccal_problem* p, double* intr, double* poses, double* extr) {
@@ -281,6 +300,7 @@ int ccal_download_params(ccal_problem* p, double* intr, double* poses, double* e
     if (poses && p->n_slots) HIP_TRY(ctx, hipMemcpyAsync(poses, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToHost, ctx->stream));
     if (extr) HIP_TRY(ctx, hipMemcpyAsync(extr, p->d_extr, sizeof(double) * p->n_cams * 6, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    stream_synced(p);
     if (intr && p->one_focal) for (int c = 0; c < p->n_cams; ++c) intr[c * CCAL_PMAX + 1] = intr[c * CCAL_PMAX];   // fy = f (src/util.rs:467-470)
     return CCAL_OK;
 }

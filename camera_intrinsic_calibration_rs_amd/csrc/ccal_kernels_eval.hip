@@ -2,7 +2,7 @@
 // Factor::residual_func evaluated with dual numbers per block, src/optimization/factors.rs:152-173,
 // 204-228), plus the residual-only reprojection-error kernel behind validation() (src/util.rs:733-745).
 //
-// Mapping: one wavefront per observation frame, 4 frames per 256-thread workgroup.  The frame's
+// Mapping: one wavefront per observation frame, CCAL_EVAL_WPB (2) frames per 128-thread workgroup.  The frame's
 // pose-dependent constants are computed once per wave and staged in LDS; corner rows are read as
 // coalesced f32 SoA streams; every lane produces one block (r[2], J[2][D]).  The block Jacobians of
 // 64 consecutive corners form one contiguous 64*2*D*8-byte tile of J_out, so they are transposed
@@ -76,8 +76,10 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     // latency under a saturated write stream that limits this kernel once the inputs no longer sit in the Infinity Cache)
     float pX = 0.f, pY = 0.f, pZ = 0.f, pU = 0.f, pV = 0.f;
     if constexpr (PF) {
-        const int64_t g0 = start + (lane < n ? lane : 0);
-        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+        if (n > 0) {                      // an empty last frame has start == n_corners: nothing to read there
+            const int64_t g0 = start + (lane < n ? lane : 0);
+            pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+        }
     }
     {   // frame constants -> LDS (every lane computes, lane 0 stores)
         double pose[6], ex[6];

@@ -989,9 +989,16 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
 //     88.4 138; 20 000: [99.4] 115 116 120 168 214).  c0 = 6 passes' worth of prologue + epilogue (6 lanes: 8).
 // CCAL_GRAMV_LPF overrides.
 static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots) {
-    static const int lpf_env = [] { const char* e = std::getenv("CCAL_GRAMV_LPF"); return e ? std::atoi(e) : 0; }();
-    if (lpf_env) return lpf_env;
     static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
+    // developer override: only the instantiated mappings (anything else would make the launcher's wavefront count and the
+    // kernel it falls back to disagree)
+    static const int lpf_env = [] {
+        const char* e = std::getenv("CCAL_GRAMV_LPF");
+        const int v = e ? std::atoi(e) : 0;
+        for (int c : cand) if (v == c) return v;
+        return 0;
+    }();
+    if (lpf_env) return lpf_env;
     int best = 64;
     double best_cost = 1e300;
     for (int i = 0; i < 6; ++i) {
@@ -1416,7 +1423,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             if (threadIdx.x < 64 && e < rb) red[e] = t;
         }
         __syncthreads();
-        if (threadIdx.x >= 64) return;
+        if (threadIdx.x >= 64) return;          // from here on ONE wavefront is left: wave-level hand-offs (wsync), no workgroup barrier
     }
     const int lane = threadIdx.x;
     // everything the solve needs from global memory is requested up front, next to the state: one memory latency
@@ -1432,14 +1439,14 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
         if (!a.partial) for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red[e];
         if (lane < K) hs.fx[lane] = ci.fixed;
     }
-    __syncthreads();
+    wsync();
     DevState* st = &S0;
     if (st->done) { if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0); return; }     // the host still waits for this group's number
     const double* Ad = red;
     const double* Yt = red + K1 * K1;
     const bool lm = st->method == CCAL_METHOD_LM;
     if (lane == 0) hs.solve = optimizer_decide(st, Ad[K * K1 + K], red[2 * K1 * K1], red[2 * K1 * K1 + 1] > 0.0, a.seq) ? 1 : 0;
-    __syncthreads();
+    wsync();
     if (hs.solve) {
         const double lambda = st->lambda;
         const int cur = st->cur;
@@ -1453,7 +1460,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             S[i * 11 + j] = v;
         }
         if (lane < K) x[lane] = ci.fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
-        __syncthreads();
+        wsync();
         // K <= 9: Cholesky + both triangular solves in registers (every lane the same wave-uniform work, no
         // LDS round trips or barriers inside the factorisation)
         {
@@ -1468,7 +1475,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             }
             if (lane == 0 && !okc) bad = 1;
         }
-        __syncthreads();
+        wsync();
         if (bad) {
             if (lane == 0) {
                 if (!lm) { st->done = CCAL_ERR_NOT_PD + 1; if (!st->done_seq) st->done_seq = a.seq; }
@@ -1482,7 +1489,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             double* dst = a.intr[cur ^ 1];
             const double keep = cur ? intr_b : intr_a;          // current intrinsics, full layout, element `lane`
             if (lane < CCAL_PMAX) { dst[lane] = keep; hs.cur_intr[lane] = keep; }
-            __syncthreads();
+            wsync();
             double mc = 0.0;
             if (lane < K && !bad) {
                 const double d = x[lane];
@@ -1501,13 +1508,13 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             if (lane == 0 && !bad) { st->mc_cam = mc; st->lambda_solve = lambda; }
         }
     }
-    __syncthreads();
+    wsync();
     {   // write the state back, then publish
         const double* src = reinterpret_cast<const double*>(&S0);
         double* dst = reinterpret_cast<double*>(a.st);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
     }
-    __syncthreads();
+    wsync();
     if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
 }
 // ccal_build_normal_dev on a single camera: evaluate set 0 as a first evaluation (no pose update) with this damping

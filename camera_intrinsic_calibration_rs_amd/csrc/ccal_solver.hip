@@ -318,13 +318,20 @@ static hipError_t enqueue_fused_system(const ccal_problem* p, FusedArgs& fa, boo
 }
 
 // Host side of the device-resident loops: spin on the status word a decision kernel publishes to pinned memory.
-static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const DevState* d_state, int target) {
+// timeout_s: seconds without the awaited step completing before the wait gives up; <= 0 = never (sharded solves: a late
+// peer is waited for - an asymmetric give-up would leave the other ranks inside a collective with no partner)
+static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const DevState* d_state, int target, double timeout_s) {
     const auto tw = std::chrono::steady_clock::now();
     long spins = 0;
     while (status_seq(hst->word) < target) {
         if ((++spins & 0xFFF) == 0) {
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - tw).count();
-            if (el > 0.002 && hipStreamQuery(st) == hipSuccess && status_seq(hst->word) < target) {
+            const hipError_t q = el > 0.002 ? hipStreamQuery(st) : hipErrorNotReady;
+            if (q != hipSuccess && q != hipErrorNotReady) {      // the stream itself failed (a fault, a lost device): no step will ever publish
+                ctx->err = std::string("device-resident solve: ") + hipGetErrorString(q);
+                return CCAL_ERR_HIP;
+            }
+            if (q == hipSuccess && status_seq(hst->word) < target) {
                 // stream drained but the word did not arrive: fall back to an explicit copy
                 DevState ds;
                 HIP_TRY(ctx, hipMemcpy(&ds, d_state, sizeof ds, hipMemcpyDeviceToHost));
@@ -334,12 +341,16 @@ static int wait_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const Dev
                 hst->word = status_word(target, ds.done, ds.done_seq);
                 break;
             }
-            if (el > 30.0) { ctx->err = "device-resident solve timed out"; return CCAL_ERR_HIP; }
+            if (timeout_s > 0.0 && el > timeout_s) { ctx->err = "device-resident solve timed out"; return CCAL_ERR_HIP; }
         }
     }
     return CCAL_OK;
 }
 
+static double wait_timeout(const ccal_problem* p, const ccal_solver_opts* o) {
+    if (o->timeout_s > 0) return (double)o->timeout_s;
+    return p->sharded() ? 0.0 : 30.0;
+}
 static void init_state(DevState* s, const ccal_solver_opts* o) {
     std::memset(s, 0, sizeof *s);
     const bool lm = o->method == CCAL_METHOD_LM;
@@ -463,7 +474,7 @@ static int solve_fused(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
         }
         if (pending.empty()) break;
         const int waited = pending.front();
-        rc = wait_status(ctx, st, hst, f->d_state, waited);
+        rc = wait_status(ctx, st, hst, f->d_state, waited, wait_timeout(p, o));
         if (rc != CCAL_OK) return fail_enqueued(rc);
         pending.erase(pending.begin());
         // act on `done` only when it was set by a step this thread has waited for: a later group may already have
@@ -556,7 +567,7 @@ static int solve_general(ccal_problem* p, const ccal_solver_opts* o, bool host_i
         }
         if (pending.empty()) break;
         const int waited = pending.front();
-        if ((rc = wait_status(ctx, st, hst, w->d_gstate, waited)) != CCAL_OK) return fail_enqueued(rc);
+        if ((rc = wait_status(ctx, st, hst, w->d_gstate, waited, wait_timeout(p, o))) != CCAL_OK) return fail_enqueued(rc);
         pending.erase(pending.begin());
         if (o->verbose) std::printf("[ccal %s] iter %d cost %.12g radius %.3g\n", lm ? "LM" : "GN", hst->iter, hst->cur_cost, hst->radius);
         if (status_done(hst->word) && status_done_seq(hst->word) <= waited) finished = true;     // see solve_fused: no dependence on publication races

@@ -129,7 +129,12 @@ typedef struct {
     double lm_min_diagonal;        /* 1e-6 */
     double lm_max_diagonal;        /* 1e32 */
     int32_t verbose;
-    int32_t reserved;
+    int32_t timeout_s;             /* host-side watchdog of the device-resident loop, seconds without a step completing.
+                                      0 = default: 30 s on a single GPU; NONE in a sharded solve (a communicator or an
+                                      all-reduce callback is set): a step that waits for a peer - still uploading, still
+                                      setting up RCCL channels - is waited for, the wait ends when the stream does.  Give
+                                      every rank the same value: a rank that gives up (CCAL_ERR_HIP, "timed out") leaves
+                                      the shared sequence of collectives while its peers are inside ncclAllReduce */
 } ccal_solver_opts;
 
 typedef struct {
@@ -151,7 +156,12 @@ typedef struct {
  *                        stream-ordered, and keeps enqueueing steps ahead of the host.  The production path.
  *   ccal_set_allreduce   a callback does the sum (ordered on `hip_stream`) - for transports other than RCCL
  *                        (the tests use gloo); the loop then waits for every step before it enqueues the next.
- * Neither set = single GPU. */
+ * Neither set = single GPU.
+ * Errors: every rank issues the same sequence of collectives by construction (one per step, decisions taken from
+ * all-reduced sums).  If a sharded ccal_solve nevertheless returns an error other than the solver's own verdicts
+ * (NONFINITE / NOT_PD / NO_CONVERGENCE, which all ranks reach together), collectives of this rank may still be queued
+ * with no partner: treat the communicator as INVALID - abort it (ncclCommAbort) or exit the process; do not reuse it and
+ * do not wait for the stream. */
 typedef int (*ccal_allreduce_fn)(void* user, double* device_buf, size_t count, void* hip_stream);
 #define CCAL_RCCL_UNIQUE_ID_BYTES 128
 

@@ -1,5 +1,6 @@
 """GPU parity at the sizes BASELINE.json names.
 
+configs[1]  "Synthetic 1 000 frames x 144 corners, EUCM" and
 configs[2]  "Same synthetic set [1 000 frames x 144 corners], KB4 and OPENCV5 models": mode E on EVERY corner,
             the reduced normal equations, and the GN / LM solves against the oracle, both focal modes; plus sampled
             frames of a 10 000-frame mode-E pass.
@@ -23,7 +24,8 @@ from camera_intrinsic_calibration_rs_amd.engine import Problem, default_opts
 
 pytestmark = pytest.mark.gpu
 
-_CFG2 = [("kb4", False), ("kb4", True), ("opencv5", False), ("opencv5", True)]
+# configs[1] as written (1 000 x 144, EUCM: every corner + normal equations + solves) and configs[2] (KB4, OPENCV5)
+_CFG2 = [("eucm", False), ("eucm", True), ("kb4", False), ("kb4", True), ("opencv5", False), ("opencv5", True)]
 
 
 @pytest.fixture(scope="module")
@@ -56,7 +58,7 @@ def test_config2_mode_e_every_corner(gpu_ctx, oracle, cfg2_problems, model, one_
 @pytest.mark.parametrize("model,one_focal", _CFG2)
 @pytest.mark.parametrize("lam", [0.0, 1e-3])
 def test_config2_build_normal(gpu_ctx, oracle, cfg2_problems, model, one_focal, lam):
-    """The matrix-core Gram (OPENCV5, two-focal KB4) and the register Gram (one-focal KB4) at 1 000 frames."""
+    """The register Gram kernels (the default for every model) with the elimination fused into their tail, 1 000 frames."""
     sp = cfg2_problems(model, one_focal)
     gp = Problem.from_synth(gpu_ctx, sp)
     op = oracle.OracleProblem.from_synth(sp)
