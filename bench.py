@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Headline benchmark: corner residual+Jacobian evals/s (mode E) on synthetic calib frames.
 
-    python bench.py --gpus N --steps K --warmup W [--frames F] [--model eucm]
+    python bench.py --gpus N --steps K --warmup W [--frames F | --frames-total F] [--model eucm]
 
 One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  A "step" is one pass
 of the hot path over one batch: every rank evaluates r[2] + J[2 x D] for all corners of its frame
 shard (F frames x 144 corners per GPU -- weak scaling; mode E needs no collective).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+`--frames-total F` instead splits ONE F-frame problem over the ranks by contiguous slot range (strong scaling:
+`--gpus 8 --frames-total 50000` is BASELINE.json configs[3] as written); without it a multi-GPU run still carries that
+split 50 000-frame solve as `extra.config3_split` next to the weak-scaling numbers.
 
 The workload defaults to the north-star headline (10 000 frames x 144 corners, EUCM, per GPU);
 `--frames 1000` is BASELINE.json configs[1].  PyTorch is used only for the process group, the
@@ -81,6 +84,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=500)
     ap.add_argument("--frames", type=int, default=10000, help="frames per GPU (144 corners each)")
+    ap.add_argument("--frames-total", type=int, default=0,
+                    help="strong scaling: ONE problem of this many frames, every rank takes its slot range (overrides --frames)")
     ap.add_argument("--model", default="eucm", choices=["ucm", "eucm", "kb4", "opencv5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (mode N / solver) measurements")
@@ -113,7 +118,15 @@ def main():
     from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
 
     # ---- synthetic calib frames for this rank (weak scaling: F frames per GPU) -------------------
-    sp = synth.make_problem(args.frames, args.model, seed=0xC0FFEE + 1000003 * rank)
+    strong = args.frames_total > 0
+    if strong:
+        # ONE problem, generated identically on every rank (positional PRNG), of which the rank keeps its slot range
+        sp = synth.make_problem(args.frames_total, args.model, seed=0xC0FFEE)
+        if world > 1:
+            sp = sp.shard(rank, world)
+        args.frames = sp.n_slots
+    else:
+        sp = synth.make_problem(args.frames, args.model, seed=0xC0FFEE + 1000003 * rank)
     stream = torch.cuda.Stream(device=dev)
     ctx = Context(dev_index, stream=stream.cuda_stream)
     prob = Problem.from_synth(ctx, sp)
@@ -175,12 +188,15 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command/workload
         # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/<round>/pmc_summary.json); null otherwise
-        traffic = None
+        traffic, traffic_source = None, None
         try:
-            with open(_latest_profile_file("pmc_summary.json")) as f:
+            pmc_path = _latest_profile_file("pmc_summary.json")
+            with open(pmc_path) as f:
                 pmc = json.load(f)
             if pmc.get("k_eval_algorithmic_bytes_per_launch") == algo_bytes:
                 traffic = pmc["k_eval_hbm_traffic_bytes_per_launch"]
+                # not measured by THIS run: the committed PMC passes of the same command and workload
+                traffic_source = os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes of this command, committed)"
         except Exception:  # noqa: BLE001
             traffic = None
         out = {
@@ -189,15 +205,17 @@ def main():
             "unit": "corner residual+Jacobian evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.frames} frames x 144 corners per GPU, {args.model.upper()}, "
-                                   f"mode E (r[2] + J[2x{D}] per corner materialised in HBM), 6x6 AprilGrid",
-                       "frames_per_gpu": args.frames, "corners_per_frame": 144, "model": args.model,
+            "config": {"workload": (f"synthetic {args.frames_total} frames x 144 corners split over {world} GPU(s) by slot range, "
+                                    if strong else f"synthetic {args.frames} frames x 144 corners per GPU, ") +
+                                   f"{args.model.upper()}, mode E (r[2] + J[2x{D}] per corner materialised in HBM), 6x6 AprilGrid",
+                       "frames_per_gpu": args.frames, "frames_total": args.frames_total if strong else args.frames * world,
+                       "corners_per_frame": 144, "model": args.model,
                        "block_jacobian_cols": D, "sharding": "frames" if world > 1 else "none",
                        "clock_ramp_s": CLOCK_RAMP_S, "clock_ramp_untimed_launches": ramp_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_eval", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
         }
 
@@ -346,28 +364,56 @@ def main():
                 dist.broadcast(idt, src=0)
             uid = bytes(idt.cpu().tolist())
 
+        # BASELINE configs[3] as written - 50 000 frames x 144 corners SPLIT over the ranks - next to the weak-scaling
+        # solves of a default multi-GPU run (with --frames-total the main problem already is the split one).  Generated
+        # here, outside the watchdog: pure host work, identical on every rank, of which the rank keeps its slot range
+        split, split_sp, result3 = None, None, {}
+        if not strong and (world > 1 or os.environ.get("CCAL_BENCH_CONFIG3") == "1"):
+            split_total = int(os.environ.get("CCAL_BENCH_CONFIG3_FRAMES", "50000"))
+            split_sp = synth.make_problem(split_total, args.model, seed=0xC0FFEE)
+            if world > 1:
+                split_sp = split_sp.shard(rank, world)
+            split = Problem.from_synth(ctx, split_sp)
+
+        def attach(pr):
+            if native:
+                pr.set_rccl_comm(comm)
+            else:
+                from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
+                pr.set_allreduce(make_allreduce_hook(device=dev))
+
+        def sharded_solves(pr, st_sp, res, total):
+            with torch.cuda.stream(stream):
+                for name, method in (("gn", 0), ("lm", 1)):
+                    res[name] = solve_stats(pr, st_sp, method, False)
+                    res[name + "_device_resident"] = solve_stats(pr, st_sp, method, True)
+            res["frames_total"] = total
+            res["frames_this_rank"] = st_sp.n_slots
+            res["collective"] = ("ncclAllReduce issued by libccal_hip.so (ccal_set_rccl_comm), one per optimizer step"
+                                 if native else "callback (torch.distributed, developer switch)")
+            res["rccl_version"] = engine._ffi.load().ccal_rccl_version() if native else None
+
         def sharded():
             nonlocal comm
             try:
                 if native:
                     comm = ctx.rccl_comm_create(world, rank, uid)
-                    prob.set_rccl_comm(comm)
-                else:
-                    from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
-                    prob.set_allreduce(make_allreduce_hook(device=dev))
-                with torch.cuda.stream(stream):
-                    for name, method in (("gn", 0), ("lm", 1)):
-                        result[name] = solve_stats(prob, start, method, False)
-                        result[name + "_device_resident"] = solve_stats(prob, start, method, True)
-                result["frames_total"] = args.frames * world
-                result["collective"] = ("ncclAllReduce issued by libccal_hip.so (ccal_set_rccl_comm), one per optimizer step"
-                                        if native else "callback (torch.distributed, developer switch)")
-                result["rccl_version"] = engine._ffi.load().ccal_rccl_version() if native else None
+                attach(prob)
+                sharded_solves(prob, start, result, args.frames_total if strong else args.frames * world)
             except Exception as e:  # noqa: BLE001
                 result["error"] = repr(e)
             finally:
                 prob.set_rccl_comm(None)            # drains the early-exit groups (and their collectives) still queued
                 prob.set_allreduce(None)
+            if split is not None and "error" not in result:
+                try:
+                    attach(split)
+                    sharded_solves(split, split_sp, result3, split_total)
+                except Exception as e:  # noqa: BLE001
+                    result3["error"] = repr(e)
+                finally:
+                    split.set_rccl_comm(None)
+                    split.set_allreduce(None)
 
         th = threading.Thread(target=sharded, daemon=True)
         th.start(); th.join(timeout=180.0)
@@ -375,6 +421,8 @@ def main():
             result = {"error": "timeout (180 s) in the sharded solve"}
         if rank == 0:
             out.setdefault("extra", {})["sharded_solve"] = result
+            if split is not None:
+                out["extra"]["config3_split"] = result3 or {"error": "not reached"}
         if th.is_alive():
             if rank == 0:
                 _emit(out)

@@ -240,6 +240,9 @@ hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
+// ccal_kernels_gram2.hip: a corner's two rows on two lanes (row-local columns), same records, same fused tail
+hipError_t launch_gram2(int model, bool one_focal, FusedArgs& a, hipStream_t s);
+hipError_t launch_gram2_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);
 hipError_t launch_schur1(FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size); sets a.n_part
 hipError_t launch_schur1m(FusedArgs& a, hipStream_t s);   // four frames per wavefront, 32 per workgroup, one pass; sets a.n_part
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s);

@@ -20,116 +20,9 @@
 
 #include "ccal_device.hpp"
 #include "ccal_fused.hpp"
+#include "ccal_gram_common.hpp"
 
 namespace ccal {
-
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void wsync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-__device__ __forceinline__ double clampd1(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
-
-// Exact elimination of ONE frame's pose block, LPE lanes per frame (all wavefront lanes call it; `active` marks the lanes
-// of frames that exist).  R = the frame's record in LDS: C (21, phi basis) | [B|g] (6 x K1) | A (K1 x K1) | J_l (9);
-// Ym = 6 x K1 doubles of LDS behind it.  phi -> rvec map of C and [B|g], C + lambda clamp(diag C) = L L^T (every lane of the
-// frame runs the same 6 x 6 factorisation), Y = L^-1 [B|g]; the slot's record pf = L (inverted diagonal) | Y | g_p | diag C.
-// Returns this lane's entries e = gl + LPE q of A (accA) and of Y^T Y (accY), and whether the block was positive definite.
-template <int K, int LPE>
-__device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int gl, const bool active, const double lambda,
-                                                const double min_diag, const double max_diag, double* pf, const int PF,
-                                                double* accA, double* accY) {
-    constexpr int K1 = K + 1, NA = K1 * K1;
-    constexpr int NQ = (NA + LPE - 1) / LPE;
-    bool ok = true;
-    if (active) {
-        double Cr[21], jl[9];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) Cr[i] = R[i];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) jl[i] = R[praw_jl_off(K) + i];
-        phi_to_rvec_C(Cr, jl);
-        double L[21], dC[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            dC[i] = Cr[i * (i + 1) / 2 + i];
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double t = Cr[i * (i + 1) / 2 + j];
-                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], min_diag, max_diag);
-#pragma unroll
-                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-                if (i == j) {
-                    ok = ok && (t > 0.0) && (t < 1.7e308);
-                    double sq, rsq;
-                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
-                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;
-                } else {
-                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
-                }
-            }
-        }
-        const double* Bm = R + 21;
-        if (!ok) {
-            for (int e = gl; e < PF; e += LPE) pf[e] = 0.0;
-            for (int e = gl; e < 6 * K1; e += LPE) Ym[e] = 0.0;
-        } else {
-            for (int c = gl; c < K1; c += LPE) {
-                double bc[6], y[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + c];
-                phi_to_rvec_col(bc, jl);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    double t = bc[i];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
-                    y[i] = t * L[i * (i + 1) / 2 + i];
-                    Ym[i * K1 + c] = y[i];
-                    pf[21 + i * K1 + c] = y[i];
-                }
-                if (c == K) {                      // g_p in the rvec basis
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
-                }
-            }
-            // L and diag C: every lane holds them; lane 0 of the frame parks them in the record's C | B area (read above,
-            // dead now), the frame's lanes store them coalesced after the fence below
-            if (gl == 0) {
-#pragma unroll
-                for (int i = 0; i < 21; ++i) R[i] = L[i];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) R[21 + i] = dC[i];
-            }
-        }
-    }
-    wsync();
-    if (active && ok) {
-        for (int e = gl; e < 21; e += LPE) pf[e] = R[e];
-        for (int e = gl; e < 6; e += LPE) pf[21 + 6 * K1 + 6 + e] = R[21 + e];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = gl + LPE * q;
-            if (e < NA) {
-                const int i = e / K1, j = e - i * K1;
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
-                accY[q] = t;
-                accA[q] = R[21 + 6 * K1 + e];
-            }
-        }
-    } else if (active) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = gl + LPE * q;
-            if (e < NA) { accY[q] = 0.0; accA[q] = R[21 + 6 * K1 + e]; }
-        }
-    }
-    return ok;
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_unpack1: the whole starting point arrives as ONE host-to-device copy of the staging block
@@ -352,42 +245,6 @@ struct RecMap {
     }
 };
 template <int K, int W, bool GEN = false> __device__ const RecMap<K, W, GEN> g_recmap = RecMap<K, W, GEN>();
-
-// Fused elimination (single-camera loop, k_gram1w): the wavefront that built G frames' Grams eliminates their pose blocks
-// itself - records in LDS at red + g GS (what k_schur1m loads from HBM), LPF lanes per frame - and writes ONE row of
-// partial sums per wavefront, [A_dir | Y^T Y | model decrease | failed blocks], frames added in a fixed order.
-template <int K, int LPF>
-__device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const DevState* st, double* red, const int wave_global,
-                                                const int grp, const int gl, const bool lane_ok, const bool active, const int slot,
-                                                const int set, const double mcv) {
-    constexpr int G = 64 / LPF, K1 = K + 1, NA = K1 * K1;
-    constexpr int REC = praw_jl_off(K) + 9, GS = (REC + 6 * K1 + 1) & ~1, NQ = (NA + LPF - 1) / LPF;
-    static_assert(2 * NA + 2 <= GS, "a frame's sums reuse its record row");
-    double* R = red + grp * GS;
-    double* Ym = R + REC;
-    double accA[NQ], accY[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
-    const bool ok = eliminate_frame<K, LPF>(R, Ym, gl, active, schur_lambda(st), a.min_diag, a.max_diag,
-                                           a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY);
-    wsync();
-    if (lane_ok) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = gl + LPF * q;
-            if (e < NA) { R[e] = accA[q]; R[NA + e] = accY[q]; }
-        }
-        if (gl == 0) { R[2 * NA] = active ? mcv : 0.0; R[2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
-    }
-    wsync();
-    const int lane = threadIdx.x & 63;
-    for (int e = lane; e < 2 * NA + 2; e += 64) {
-        double t = 0.0;
-#pragma unroll
-        for (int g = 0; g < G; ++g) t += red[g * GS + e];
-        a.partial[(int64_t)wave_global * (2 * NA + 2) + e] = t;
-    }
-}
 
 #ifndef CCAL_GRAMV_WPB
 #define CCAL_GRAMV_WPB 2          // wavefronts per workgroup (4 frames each)
@@ -1062,9 +919,25 @@ static hipError_t launch_gram1v_m(int model, bool one_focal, FusedArgs& a, hipSt
     }
 }
 // single-camera loop; a.fuse_elim in: fusion allowed, out: fusion done (then a.n_part = rows of partial sums, a.elim_fused = 1)
-hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s) { return launch_gram1v_m<false>(model, one_focal, a, s); }
+// Which register Gram kernel.  k_gram2 (the block's rows traded between lane halves, ccal_kernels_gram2.hip) where it
+// measured faster (10 000 / 2 500 frames, us per build, k_gram2 vs k_gram1v|w): OPENCV5 47.1 / 25.6 vs 51.2 / 27.3, EUCM 35.8 /
+// 21.1 vs 36.9 / 22.2 (from 2 000 frames: two wavefronts per SIMD, no LDS accumulators; 625 frames 15.9 vs 14.2 with k_gram1v),
+// KB4 49.3 vs 49.7 two-focal but 48.2 vs 46.5 one-focal: KB4 stays on k_gram1v.  CCAL_GRAM2=0|1 forces.
+static bool use_gram2(int model, int n_obs) {
+    static const int force = [] { const char* e = std::getenv("CCAL_GRAM2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    if (force >= 0) return force == 1;
+    if (model == kOCV5) return true;
+    return (model == kUCM || model == kEUCM) && n_obs >= 2000;
+}
+hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
+    if (use_gram2(model, a.n_obs)) return launch_gram2(model, one_focal, a, s);
+    return launch_gram1v_m<false>(model, one_focal, a, s);
+}
 // one camera's blocks of a multi-camera problem: a.list / a.rec_off / a.n_obs = that camera's observation frames
-hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a0, hipStream_t s) { FusedArgs a = a0; a.fuse_elim = 0; return launch_gram1v_m<true>(model, one_focal, a, s); }
+hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a0, hipStream_t s) {
+    if (use_gram2(model, a0.n_obs)) return launch_gram2_general(model, one_focal, a0, s);
+    FusedArgs a = a0; a.fuse_elim = 0; return launch_gram1v_m<true>(model, one_focal, a, s);
+}
 template <int MODEL, bool OF>
 static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
     constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * 34;

@@ -1,0 +1,589 @@
+// k_gram2: the register Gram kernel with the block's two rows accumulated on two lanes (u rows in lanes 0-31 of the
+// wavefront, v rows in lanes 32-63), rows exchanged with v_permlane32_swap.
+//
+// What k_gram1v / k_gram1w (ccal_kernels_fused.hip) keep per lane is the upper triangle of [J | r]^T W [J | r] of a whole
+// 2-row block: 91 (EUCM) ... 136 (OPENCV5) f64 accumulators next to two scaled rows of 13 ... 16 doubles - more than the
+// 256 registers the VALU can address, hence 18 LDS accumulators (UCM / EUCM) or 105-136 accumulators spilled to AGPRs
+// behind v_accvgpr copies (KB4 / OPENCV5: 176-224 of the 600-625 instructions of a corner pass, one wavefront per SIMD).
+//
+// The block's u row does not touch fy, cy and its v row does not touch fx, cx (one focal: f is shared).  In ROW-LOCAL
+// column order
+//       [ f_row | c_row | distortion (ND) | phi (3) | t (3) | r_row ]                    NCR = ND + 9 columns
+// both rows have the SAME dense structure.  Every lane still evaluates ONE corner completely (transform, projection, both
+// Jacobian rows: nothing is computed twice), then lane l < 32 and lane l + 32 - two corners of the same frame - trade
+// rows: ONE v_permlane32_swap per register swaps the upper half of the u-row register with the lower half of the v-row
+// register, in place, after which lanes 0-31 hold the u rows of both corners and lanes 32-63 both v rows.  A lane adds the
+// two rows it holds into NCR (NCR + 1) / 2 accumulators (UCM 55, EUCM 66, KB4 91, OPENCV5 105) - the same number of FMAs per
+// corner as before, half the accumulators (and no structural zeros left to skip).  The per-frame reduction adds the two
+// rows' Grams where they meet (distortion, pose and residual columns; f with one focal) and lands in the same per-frame
+// record as before, so the pose update in front of the loop and the fused elimination behind it (ccal_gram_common.hpp)
+// are those of k_gram1w.
+//   KB4: 91 accumulators + two rows of 13 = 234 registers' worth: no AGPR copies, two wavefronts per SIMD.
+#include <algorithm>
+#include <cstdlib>
+
+#include "ccal_gram_common.hpp"
+
+namespace ccal {
+
+// ---- compile-time maps -------------------------------------------------------------------------------------------
+// full column (order of the block Jacobian: camera P_eff | pose 6 | r) of row-local column a of row `row` (0 = u, 1 = v)
+template <int MODEL, bool OF>
+__host__ __device__ constexpr int g2_fullcol(int row, int a) {
+    if (OF) return a == 0 ? 0 : (a == 1 ? (row ? 2 : 1) : a + 1);
+    return a == 0 ? (row ? 1 : 0) : (a == 1 ? (row ? 3 : 2) : a + 2);
+}
+// where entry (i <= j) of the full triangle goes in the per-frame record: dst | mirror << 16 (0xffff = none); the maps of
+// RecMap (ccal_kernels_fused.hip) with W = 0
+template <int K, bool GEN>
+__host__ __device__ constexpr uint32_t g2_rec_dst(int i, int j) {
+    constexpr int D = K + 6, K1 = K + 1;
+    const bool ip = i >= K && i < D, jp = j >= K && j < D;
+    const int ci = i < K ? i : K, cj = j < K ? j : K;
+    uint32_t a = 0, b = 0xffff;
+    if (!GEN) {
+        if (ip && jp) a = (j - K) * (j - K + 1) / 2 + (i - K);
+        else if (!ip && jp) a = 21 + (j - K) * K1 + ci;
+        else if (ip && !jp) a = 21 + (i - K) * K1 + K;
+        else { a = 21 + 6 * K1 + ci * K1 + cj; b = 21 + 6 * K1 + cj * K1 + ci; }
+    } else {
+        if (ip && jp) { a = (i - K) * 6 + (j - K); if (i != j) b = (j - K) * 6 + (i - K); }
+        else if (!ip && jp) a = 36 + ci * 6 + (j - K);
+        else if (ip && !jp) a = 36 + K * 6 + (i - K);
+        else { a = gen_a_off(K) + ci * K1 + cj; b = gen_a_off(K) + cj * K1 + ci; }
+    }
+    return a | (b << 16);
+}
+// One ITEM per entry of the full triangle, in the order of the row-local entry t it is summed from:
+//   src = t | mask << 12   (mask bit 0: the u lanes contribute, bit 1: the v lanes; 0: a structural zero of the block)
+//   rec = where it goes in the record
+// NS = number of slices the row-local triangle is reduced in (LDS per wavefront = 64 x slice); first[s] = first item of slice s.
+template <int MODEL, bool OF, bool GEN, int NS>
+struct RowMap {
+    static constexpr int P = model_np(MODEL), ND = P - 4, K = P - (OF ? 1 : 0), D = K + 6, NCF = D + 1, NEF = NCF * (NCF + 1) / 2;
+    static constexpr int NCR = ND + 9, NER = NCR * (NCR + 1) / 2, CH = (NER + NS - 1) / NS;
+    uint32_t rec[NEF];
+    uint16_t src[NEF];
+    int first[NS + 1];
+    constexpr RowMap() : rec{}, src{}, first{} {
+        bool seen[NCF][NCF] = {};
+        int n = 0, t = 0;
+        for (int s = 0; s <= NS; ++s) first[s] = -1;
+        for (int a = 0; a < NCR; ++a)
+            for (int b = a; b < NCR; ++b, ++t) {
+                const int sl = t / CH;
+                if (first[sl] < 0) first[sl] = n;
+                const int iu = g2_fullcol<MODEL, OF>(0, a), ju = g2_fullcol<MODEL, OF>(0, b);
+                const int iv = g2_fullcol<MODEL, OF>(1, a), jv = g2_fullcol<MODEL, OF>(1, b);
+                if (iu == iv && ju == jv) {
+                    rec[n] = g2_rec_dst<K, GEN>(iu, ju); src[n] = (uint16_t)(t | (3 << 12)); ++n; seen[iu][ju] = true;
+                } else {
+                    rec[n] = g2_rec_dst<K, GEN>(iu, ju); src[n] = (uint16_t)(t | (1 << 12)); ++n; seen[iu][ju] = true;
+                    rec[n] = g2_rec_dst<K, GEN>(iv, jv); src[n] = (uint16_t)(t | (2 << 12)); ++n; seen[iv][jv] = true;
+                }
+            }
+        // the block's structural zeros (fx x fy, fx x cy, fy x cx, cx x cy; one focal: cx x cy): written as zeros, last slice
+        for (int i = 0; i < NCF; ++i)
+            for (int j = i; j < NCF; ++j)
+                if (!seen[i][j]) { rec[n] = g2_rec_dst<K, GEN>(i, j); src[n] = (uint16_t)((NS - 1) * CH); ++n; }
+        for (int s = 0; s <= NS; ++s) if (first[s] < 0) first[s] = n;
+        first[NS] = n;
+    }
+    static constexpr int max_items() {              // most items any slice holds
+        RowMap m;
+        int mx = 0;
+        for (int s = 0; s < NS; ++s) mx = m.first[s + 1] - m.first[s] > mx ? m.first[s + 1] - m.first[s] : mx;
+        return mx;
+    }
+};
+template <int MODEL, bool OF, bool GEN, int NS> __device__ const RowMap<MODEL, OF, GEN, NS> g_rowmap = RowMap<MODEL, OF, GEN, NS>();
+
+// slices of the reduction: the LDS a wavefront needs is 64 lanes x (slice | 1) doubles; two wavefronts per SIMD = 8 per CU
+// have to share 160 KB with the frames' constants
+template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MODEL == kKB4 || MODEL == kOCV5) ? 3 : 2; }
+
+// diagnostic build (-DCCAL_STAMPS, tools/stamps_g2.py): the 100 MHz clock at the phase boundaries of every wavefront, parked
+// in the per-frame scratch (8 stamps per wavefront)
+#ifdef CCAL_STAMPS       // kept in (scalar) registers, stored once at the end: a store per stamp would sit in front of the next fence
+#define G2_STAMP(i) do { g2_stamps[i] = wall_clock64(); } while (0)
+#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }
+#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[8 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; } } while (0)
+#else
+#define G2_STAMP(i) do { } while (0)
+#define G2_STAMPS_DECL do { } while (0)
+#define G2_STAMPS_FLUSH do { } while (0)
+#endif
+// wavefronts per SIMD the kernel is compiled for: two where 2 NER accumulators + two rows fit 256 registers (UCM, EUCM);
+// KB4 / OPENCV5 (182 / 210 + 52 / 56) do not without scratch or LDS accumulators, both of which cost more than they buy
+// (measured, 10 000 frames, build: scratch 99 / 98 us, 16 / 32 LDS accumulators 68 / 60 us, one wavefront per SIMD 52 / 50 us)
+#ifndef CCAL_G2_MINW
+#define CCAL_G2_MINW(MODEL) (((MODEL) == kKB4 || (MODEL) == kOCV5) ? 1 : 2)
+#endif
+// R and t of the lane's frame in registers (24 of them) instead of twelve LDS reads per corner: only where they fit
+#ifndef CCAL_G2_HOIST
+#define CCAL_G2_HOIST(MODEL) ((MODEL) == kUCM)
+#endif
+// software pipeline of the corner loop (products of corner i beside the projection of corner i + 1 in one basic block).
+// Measured and left off: the scheduler does interleave them, but the longer live ranges cost 139 / 205 v_accvgpr copies per
+// pass instead of 41 / 81 (KB4 / OPENCV5, 10 000 frames: build 54.1 / 53.8 us against 49.3 / 47.1)
+#ifndef CCAL_G2_PIPE
+#define CCAL_G2_PIPE(MODEL) 0
+#endif
+// accumulators kept in LDS ([entry][lane], stride 65: lane-private ds_add_f64, fire and forget) instead of registers: the
+// first NLA entries of the row-local triangle, as many as keeps the kernel inside 256 registers without scratch
+#ifndef CCAL_G2_NLA
+#define CCAL_G2_NLA(MODEL) 0
+#endif
+
+// LPF = lanes per frame, EVEN: LPF / 2 corners of a frame per pass.  The frame's lanes are contiguous (grp = lane / LPF), so
+// the prologue and the fused tail are those of k_gram1w.
+template <int MODEL, bool OF, int LPF, bool GEN>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2(const FusedArgs a) {
+    static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 in each half of the wavefront");
+    constexpr int NS = g2_slices<MODEL>();
+    using Map = RowMap<MODEL, OF, GEN, NS>;
+    constexpr int L2 = LPF / 2;                     // lanes of a frame in each half of the wavefront
+    constexpr int G = 32 / L2;                      // frames per wavefront
+    constexpr int P = model_np(MODEL), ND = P - 4;
+    constexpr int D = block_dim(MODEL, OF, false);
+    constexpr int K = D - 6, K1 = K + 1;
+    constexpr int NCR = Map::NCR, NER = Map::NER, CH = Map::CH, NEF = Map::NEF;
+    constexpr int LS = CH | 1;                      // odd row stride (doubles): conflict-free column sums
+    constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
+    constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
+    constexpr int WSL = G * FC_N0P + RED + NEF;     // per wave: G frames' constants | reduction buffer / records | item table
+    extern __shared__ double smem[];
+    const DevState* st = a.st;
+    const bool fuse = !GEN && a.fuse_elim != 0;
+    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
+    if (st->done || (st->redo && !fuse)) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // frame g: lanes [g L2, (g + 1) L2) of BOTH halves; gl = the lane's index within its frame (u half first)
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool lane_ok = l31 < G * L2;
+    const int grp = lane_ok ? l31 / L2 : G - 1, gl = l31 % L2 + half * L2;
+    G2_STAMPS_DECL;
+    G2_STAMP(0);
+    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
+    const bool active = lane_ok && f < a.n_obs;
+    const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);
+    double* fcw = smem + wave * WSL;
+    double* fc = fcw + grp * FC_N0P;
+    double* red = fcw + G * FC_N0P;
+    // the per-item tables of the reduction (src | rec << 32), requested NOW and parked in LDS before the corner loop: the
+    // reduction and the scatter then look them up at LDS latency instead of waiting for global memory twice per slice
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(red + RED);
+    constexpr int NTQ = (NEF + 63) / 64;
+    unsigned long long tabv[NTQ];
+    {
+        const Map& gmap = g_rowmap<MODEL, OF, GEN, NS>;
+#pragma unroll
+        for (int q = 0; q < NTQ; ++q) {
+            const int it = lane + 64 * q;
+            tabv[q] = it < NEF ? ((unsigned long long)gmap.src[it] | ((unsigned long long)gmap.rec[it] << 32)) : 0ull;
+        }
+    }
+    const int cur = st->cur, first = st->first;
+    const int es = first ? cur : (cur ^ 1);
+    if constexpr (!GEN) {
+        if (st->redo) {
+            // re-elimination group (LM: rejected step or missed speculation): the accepted set's stored records, new damping
+            double* R = red + grp * GS_;
+            double mcv = 0.0;
+            int slot_r = 0;
+            if (active) {
+                const double* rec = a.praw[cur] + (int64_t)f * a.PRAW;
+                slot_r = a.obs_slot[f];
+                for (int e = gl; e < REC_; e += LPF) R[e] = rec[e];
+                if (gl == 0) mcv = a.mc_f[f];
+            }
+            wsync();
+            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_r, cur, mcv);
+            return;
+        }
+    }
+    const int cl = gl;                              // every lane has its own corner: LPF corners of a frame per pass
+    const double* th_g = a.intr[es];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    const int64_t start = a.obs_off[fa_];
+    const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
+    float pX, pY, pZ, pU, pV;
+    {
+        const int64_t g0 = start + (cl < n ? cl : 0);
+        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+    }
+    {
+        // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants; the lanes of
+        // a group compute the same values, the G groups work on G frames at once
+        const int slot = a.obs_slot[fa_];
+        double pose[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[GEN ? es : cur][(int64_t)slot * 6 + i];     // GEN: k_backsub has formed the candidate
+        double mc = 0.0;
+        if (!GEN && !first) {
+            const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+            if (pf[0] != 0.0) {
+                double dp[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double* yr = pf + 21 + i * K1;
+                    double t = yr[K];
+#pragma unroll
+                    for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                    dp[i] = -t;
+                }
+#pragma unroll
+                for (int i = 5; i >= 0; --i) {
+                    double t = dp[i];
+#pragma unroll
+                    for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+                    dp[i] = t * pf[i * (i + 1) / 2 + i];
+                }
+                const double lam = st->lambda_solve;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
+                    const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
+                    mc += dp[i] * (Dii * dp[i] - gp);
+                    pose[i] += dp[i];
+                }
+            }
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+            }
+        }
+        if (!GEN && active && gl == 0) a.mc_f[f] = mc;
+        if constexpr (GEN) {
+            const bool other = a.cam > 0;
+            double ex[6], fcr[12], ept[GEN_EPT];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
+            frame_setup_composed(pose, ex, fcr, ept);
+            if (gl == 0 && lane_ok) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
+            }
+            if (gl == 0 && active) {
+                double2* rec = reinterpret_cast<double2*>(a.praw[es] + a.rec_off[fa_] + gen_e_off(K));
+#pragma unroll
+                for (int i = 0; i < GEN_EPT / 2; ++i) rec[i] = make_double2(ept[2 * i], ept[2 * i + 1]);
+            }
+        } else {
+            double fcr[FC_N0];
+            frame_setup<false>(pose, nullptr, fcr);
+            if (gl == 0 && lane_ok) {
+#pragma unroll
+                for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
+            }
+        }
+    }
+    wsync();
+    G2_STAMP(1);
+
+    double acc[NER];
+#pragma unroll
+    for (int e = 0; e < NER; ++e) acc[e] = 0.0;
+    // same trip count for the whole wave: the largest frame of the group
+    int nmax = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) nmax = max(nmax, __shfl_xor(nmax, off, 64));
+#pragma unroll
+    for (int q = 0; q < NTQ; ++q) if (lane + 64 * q < NEF) tab[lane + 64 * q] = tabv[q];
+    constexpr bool HOIST = CCAL_G2_HOIST(MODEL);
+    constexpr int NLA = CCAL_G2_NLA(MODEL);
+    constexpr int LSA = 65;
+    static_assert(NLA * LSA <= RED, "the LDS accumulators fit the reduction buffer");
+    if constexpr (NLA > 0) {
+#pragma unroll
+        for (int t = 0; t < NLA; ++t) red[t * LSA + lane] = 0.0;
+    }
+    // a corner needs R and t only (phi basis): in registers where they fit, else re-read from LDS per corner
+    double fcl[12];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) fcl[i] = fc[i];
+    }
+    const double* fcp = HOIST ? fcl : fc;
+    // One corner in two steps.  A: transform, projection and its partials, residual - a long dependent chain (square root,
+    // reciprocal, atan / polynomials) that touches neither the accumulators nor the rows.  B: weight, the two scaled rows in
+    // row-local column order [f | c | distortion | phi | t | r] (the weight rides on the focal length, so every Jacobian entry
+    // but d / d f and the residual comes out scaled at no cost), and the trade with the lane 32 away: lanes 0-31 end up with
+    // (own u, partner's u), lanes 32-63 with (partner's v, own v).
+    struct Proj { double mx, my, dmx[3], dmy[3], ddx[ND > 0 ? ND : 1], ddy[ND > 0 ? ND : 1], rx, ry, rz, ru, rv; };
+    auto step_a = [&](double X, double Y, double Z, double uo, double vo, Proj& p) {
+        if constexpr (!HOIST) asm volatile("" ::: "memory");       // the frame constants stay in LDS
+        p.rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z;               // rotated board point: the phi columns need it without the translation
+        p.ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z;
+        p.rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
+        project_partials<MODEL>(th, p.rx + fcp[9], p.ry + fcp[10], p.rz + fcp[11], p.mx, p.my, p.dmx, p.dmy, p.ddx, p.ddy);
+        p.ru = th[0] * p.mx + th[2] - uo; p.rv = th[1] * p.my + th[3] - vo;
+    };
+    auto step_b = [&](const Proj& p, bool valid, double* su, double* sv) {
+        const double sw = valid ? huber_sqrt_weight(p.ru * p.ru + p.rv * p.rv, a.huber_delta) : 0.0;
+        const double fxs = sw * th[0], fys = sw * th[1];
+        su[0] = sw * p.mx;              sv[0] = sw * p.my;
+        su[1] = sw;                     sv[1] = sw;                              // d u / d cx = d v / d cy = 1
+#pragma unroll
+        for (int i = 0; i < ND; ++i) { su[2 + i] = fxs * p.ddx[i]; sv[2 + i] = fys * p.ddy[i]; }
+        const double u0 = fxs * p.dmx[0], u1 = fxs * p.dmx[1], u2 = fxs * p.dmx[2];
+        const double v0 = fys * p.dmy[0], v1 = fys * p.dmy[1], v2 = fys * p.dmy[2];
+        su[2 + ND + 0] = p.ry * u2 - p.rz * u1; su[2 + ND + 1] = p.rz * u0 - p.rx * u2; su[2 + ND + 2] = p.rx * u1 - p.ry * u0;   // (R X) x j
+        sv[2 + ND + 0] = p.ry * v2 - p.rz * v1; sv[2 + ND + 1] = p.rz * v0 - p.rx * v2; sv[2 + ND + 2] = p.rx * v1 - p.ry * v0;
+        su[2 + ND + 3] = u0; su[2 + ND + 4] = u1; su[2 + ND + 5] = u2;
+        sv[2 + ND + 3] = v0; sv[2 + ND + 4] = v1; sv[2 + ND + 5] = v2;
+        su[NCR - 1] = sw * p.ru;        sv[NCR - 1] = sw * p.rv;
+#pragma unroll
+        for (int i = 0; i < NCR; ++i) {
+            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+            const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(su[i]), (unsigned)__double2loint(sv[i]), false, false);
+            const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(su[i]), (unsigned)__double2hiint(sv[i]), false, false);
+            su[i] = __hiloint2double((int)hi[0], (int)lo[0]); sv[i] = __hiloint2double((int)hi[1], (int)lo[1]);
+        }
+    };
+    auto gram = [&](const double* su, const double* sv) {
+        int e = 0;
+#pragma unroll
+        for (int i = 0; i < NCR; ++i) {
+#pragma unroll
+            for (int j = i; j < NCR; ++j) {
+                if (e < NLA) {
+                    __hip_atomic_fetch_add(red + e * LSA + lane, __builtin_fma(sv[i], sv[j], su[i] * su[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    acc[e] = __builtin_fma(su[i], su[j], acc[e]);
+                    acc[e] = __builtin_fma(sv[i], sv[j], acc[e]);
+                }
+                ++e;
+            }
+        }
+    };
+    constexpr bool PIPE = CCAL_G2_PIPE(MODEL);
+    if constexpr (!PIPE) {
+        for (int base = 0; base < nmax; base += LPF) {
+            const bool valid = base + cl < n;
+            const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
+            if (base + LPF < nmax) {
+                const int cn = base + LPF + cl;
+                const int64_t gn = start + (cn < n ? cn : 0);
+                pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+            }
+            Proj p;
+            double su[NCR], sv[NCR];
+            step_a(X, Y, Z, uo, vo, p);
+            step_b(p, valid, su, sv);
+            gram(su, sv);
+        }
+    } else {
+        // Software pipeline (one wavefront per SIMD: nothing else hides the projection's dependent chain): the products of
+        // corner i and step A of corner i + 1 are independent and sit in ONE basic block, so the scheduler interleaves them.
+        double su[NCR], sv[NCR];
+        {
+            Proj p;
+            step_a(pX, pY, pZ, pU, pV, p);
+            step_b(p, cl < n, su, sv);
+            const int cn = LPF + cl;
+            const int64_t gn = start + (cn < n ? cn : 0);
+            pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+        }
+        for (int base = 0; base < nmax; base += LPF) {
+            const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;          // corner base + LPF (clamped past the frame's end: weight 0)
+            if (base + 2 * LPF < nmax) {
+                const int cn = base + 2 * LPF + cl;
+                const int64_t gn = start + (cn < n ? cn : 0);
+                pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+            }
+            Proj p;
+            step_a(X, Y, Z, uo, vo, p);
+            gram(su, sv);
+            step_b(p, base + LPF + cl < n, su, sv);
+        }
+    }
+
+    G2_STAMP(2);
+    if constexpr (NLA > 0) {              // the LDS accumulators join the others (the rows are dead: registers to spare)
+        wsync();
+#pragma unroll
+        for (int t = 0; t < NLA; ++t) acc[t] = red[t * LSA + lane];
+    }
+    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
+    // fused elimination: what its tail needs from memory is requested now, behind the reductions
+    int slot_t = 0;
+    double mc_t = 0.0;
+    if constexpr (!GEN) {
+        if (fuse && active) { slot_t = a.obs_slot[f]; if (gl == 0) mc_t = a.mc_f[f]; }
+    }
+    // the frame's LPF partial row Grams -> one Gram of the block, through LDS, slice by slice: an item = one entry of the
+    // full triangle = the sum over the frame's u lanes and / or v lanes of one row-local entry
+    constexpr Map cm = Map();                                  // slice boundaries: compile-time
+    constexpr int NQM = (G * Map::max_items() + 63) / 64;      // items per lane and slice
+    double res[NS][NQM];
+    uint32_t recm[NS][NQM];
+    static_assert(cm.first[NS] == NEF, "one item per entry of the full triangle");
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        wsync();
+#pragma unroll
+        for (int t = 0; t < CH; ++t) { const int e = s * CH + t; if (e < NER) red[lane * LS + t] = acc[e < NER ? e : 0]; }
+        wsync();
+        const int i0 = cm.first[s], ni = cm.first[s + 1] - i0;
+#pragma unroll
+        for (int q = 0; q < NQM; ++q) {
+            const int idx = lane + 64 * q;
+            double sum = 0.0;
+            if (idx < G * ni) {
+                const int g = idx / ni, it = i0 + (idx - g * ni);
+                const unsigned long long tv = tab[it];
+                const uint32_t sc = (uint32_t)tv;
+                recm[s][q] = (uint32_t)(tv >> 32);
+                const int t = (int)(sc & 0xfff) - s * CH;
+                const double* src = red + (g * L2) * LS + t;          // the frame's u lanes; its v lanes are 32 lanes on
+                double s_u = 0.0, s_v = 0.0;
+#pragma unroll
+                for (int l = 0; l < L2; ++l) { s_u += src[l * LS]; s_v += src[(32 + l) * LS]; }
+                sum = ((sc >> 12) & 1 ? s_u : 0.0) + ((sc >> 13) & 1 ? s_v : 0.0);
+            }
+            res[s][q] = sum;
+        }
+    }
+    wsync();
+    G2_STAMP(3);
+    // The records are ASSEMBLED IN LDS - C (21) | [B|g] (6 x K1) | A (K1 x K1) | J_l (9), or the general loop's record
+    // C (36) | [B|g]^T | A - with one or two ds_write per item (every sum is in registers: the reduction buffer is free), and
+    // go out to HBM as whole records with coalesced stores (they were 8-byte stores scattered by a table: ~180 per lane)
+    constexpr int RLEN = GEN ? gen_e_off(K) : REC_;              // doubles of a record that this kernel forms (GEN: E^T went out in the prologue)
+    constexpr int RSTR = GEN ? ((RLEN + 1) & ~1) : GS_;           // stride of a frame's record in LDS
+    static_assert(G * RSTR <= RED, "the frames' records fit the reduction buffer");
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int i0 = cm.first[s], ni = cm.first[s + 1] - i0;
+#pragma unroll
+        for (int q = 0; q < NQM; ++q) {
+            const int idx = lane + 64 * q;
+            if (idx < G * ni) {
+                const int g = idx / ni;
+                const uint32_t m = recm[s][q];
+                const double v = res[s][q];
+                red[g * RSTR + (m & 0xffff)] = v;
+                if ((m >> 16) != 0xffff) red[g * RSTR + (m >> 16)] = v;
+            }
+        }
+    }
+    // the frame's left Jacobian (phi -> rvec map of the elimination)
+    if constexpr (!GEN) { if (lane_ok) for (int e = gl; e < 9; e += LPF) red[grp * GS_ + praw_jl_off(K) + e] = fc[FC_A + e]; }
+    wsync();
+    if (keep_rec) {
+        double* const praw_es = a.praw[es];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int ff = fbase + g;
+            if (ff >= a.n_obs) break;                                  // wave-uniform
+            double* rec = praw_es + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
+            for (int e = lane; e < RLEN; e += 64) rec[e] = red[g * RSTR + e];
+            if (!GEN && lane == 0) a.cost_f[ff] = red[g * RSTR + 21 + 6 * K1 + K * K1 + K];      // r x r
+        }
+    }
+    if constexpr (!GEN) {
+        if (fuse) {
+            if (keep_rec) wsync();                                     // the tail reuses the records' rows
+            G2_STAMP(4);
+            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_t, es, mc_t);
+        }
+    }
+    G2_STAMP(5);
+    G2_STAMPS_FLUSH;
+}
+
+#ifdef CCAL_G2_PROBE      // register-allocation probes (developer): a few instantiations, no launchers
+template __global__ void k_gram2<kEUCM, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2<kKB4, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2<kOCV5, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2<kOCV5, true, 12, true>(const FusedArgs);
+}  // namespace ccal
+#else
+template <int MODEL, bool OF, int LPF, bool GEN>
+static hipError_t launch_gram2_l(const FusedArgs& a, hipStream_t s) {
+    constexpr int NS = g2_slices<MODEL>();
+    using Map = RowMap<MODEL, OF, GEN, NS>;
+    constexpr int G = 32 / (LPF / 2), K = block_dim(MODEL, OF, false) - 6, K1 = K + 1;
+    constexpr int LS = Map::CH | 1;
+    constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+    constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
+    constexpr int WSL = G * FC_N0P + RED + Map::NEF;
+    const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
+    void (*kern)(const FusedArgs) = k_gram2<MODEL, OF, LPF, GEN>;
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
+    const int fpb = G * CCAL_GRAMV_WPB;
+    if (a.n_obs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
+    return hipGetLastError();
+}
+
+// Lanes per frame (even: 64, 32, 16, 12, 8, 6): the cost model of gram_lanes_per_frame (ccal_kernels_fused.hip).
+// CCAL_GRAM2_LPF overrides.
+static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd) {
+    static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
+    static const int lpf_env = [] {
+        const char* e = std::getenv("CCAL_GRAM2_LPF");
+        const int v = e ? std::atoi(e) : 0;
+        for (int c : cand) if (v == c) return v;
+        return 0;
+    }();
+    if (lpf_env) return lpf_env;
+    int best = 64;
+    double best_cost = 1e300;
+    for (int i = 0; i < 6; ++i) {
+        const int lpf = cand[i], g = 64 / lpf;
+        const int64_t waves = ((int64_t)n_obs + g - 1) / g;
+        const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
+        const double c0 = lpf == 6 ? 8.0 : 6.0;  // prologue + reductions + elimination, in passes
+        double occ;
+        const double nw = (double)waves / 1024.0;
+        if (two_per_simd) occ = nw <= 1.0 ? 1.0 : (nw <= 2.0 ? 1.0 + 0.3 * (nw - 1.0) : 0.65 + 0.43 * nw);
+        else occ = (double)((waves + 1023) / 1024);
+        const double cost = occ * (c0 + passes);
+        if (cost < best_cost) { best_cost = cost; best = lpf; }
+    }
+    return best;
+}
+
+template <int MODEL, bool OF, bool GEN>
+static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
+    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL) >= 2);
+    const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
+    static const int fuse_min = [] { const char* e = std::getenv("CCAL_FUSE_MIN"); return e ? std::atoi(e) : 1; }();
+    const bool fuse = !GEN && a.n_obs >= fuse_min && a.fuse_elim != 0 && waves <= a.part_cap;
+    a.fuse_elim = fuse ? 1 : 0;
+    a.elim_fused = fuse ? 1 : 0;
+    if (fuse) a.n_part = waves;
+    switch (lpf) {
+        case 6: return launch_gram2_l<MODEL, OF, 6, GEN>(a, s);
+        case 8: return launch_gram2_l<MODEL, OF, 8, GEN>(a, s);
+        case 12: return launch_gram2_l<MODEL, OF, 12, GEN>(a, s);
+        case 16: return launch_gram2_l<MODEL, OF, 16, GEN>(a, s);
+        case 32: return launch_gram2_l<MODEL, OF, 32, GEN>(a, s);
+        default: return launch_gram2_l<MODEL, OF, 64, GEN>(a, s);
+    }
+}
+template <bool GEN>
+static hipError_t launch_gram2_m(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
+    switch (model * 2 + (one_focal ? 1 : 0)) {
+        case 0: return launch_gram2_t<kUCM, false, GEN>(a, s);
+        case 1: return launch_gram2_t<kUCM, true, GEN>(a, s);
+        case 2: return launch_gram2_t<kEUCM, false, GEN>(a, s);
+        case 3: return launch_gram2_t<kEUCM, true, GEN>(a, s);
+        case 4: return launch_gram2_t<kKB4, false, GEN>(a, s);
+        case 5: return launch_gram2_t<kKB4, true, GEN>(a, s);
+        case 6: return launch_gram2_t<kOCV5, false, GEN>(a, s);
+        case 7: return launch_gram2_t<kOCV5, true, GEN>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+// single-camera loop; a.fuse_elim in: fusion allowed, out: fusion done (then a.n_part = rows of partial sums, a.elim_fused = 1)
+hipError_t launch_gram2(int model, bool one_focal, FusedArgs& a, hipStream_t s) { return launch_gram2_m<false>(model, one_focal, a, s); }
+// one camera's blocks of a multi-camera problem
+hipError_t launch_gram2_general(int model, bool one_focal, const FusedArgs& a0, hipStream_t s) { FusedArgs a = a0; a.fuse_elim = 0; return launch_gram2_m<true>(model, one_focal, a, s); }
+
+}  // namespace ccal
+#endif

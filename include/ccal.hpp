@@ -12,6 +12,7 @@
 //   util::calib_camera                  src/util.rs:384-490         calib_camera            -> std::optional
 //   util::calib_all_camera_with_extrinsics   src/util.rs:567-715    calib_all_camera_with_extrinsics
 //   util::init_camera_extrinsic         src/util.rs:511-561         init_camera_extrinsic
+//   util::init_ucm                      src/util.rs:287-378         init_ucm                -> std::optional
 //   util::validation                    src/util.rs:721-795         validation
 //   util::convert_model                 src/util.rs:224-282         convert_model
 //   io::object_to_json / write_report   src/io.rs, src/types.rs     model_to_json / poses_to_json / extrinsics_to_json / report_text (+ *_from_json)
@@ -259,6 +260,40 @@ inline std::vector<RvecTvec> init_camera_extrinsic(const std::vector<std::map<si
         out.push_back(RvecTvec::from6(x));
     }
     return out;
+}
+
+// util::init_ucm (src/util.rs:287-378).  UCMInitFocalAlphaFactor (src/optimization/factors.rs:82-120) is the reprojection
+// factor of a UCM whose only free intrinsics are f = fx = fy and alpha, the principal point pinned at the image centre:
+// the engine's UCM + xy_same_focal problem with cx, cy fixed, f in [f0 / 3, 3 f0], alpha in [1e-6, 1] (:345-346) on the two
+// frames; then calib_camera on those two frames with xy_same_focal = true (:365-371).  `None` of the first solve ==
+// std::nullopt; a failing calib_camera is the reference's `.expect(...)`: it throws.
+inline std::optional<GenericModel>
+init_ucm(const FrameFeature& frame_feature0, const FrameFeature& frame_feature1, const RvecTvec& rtvec0, const RvecTvec& rtvec1,
+         double init_f, double init_alpha, bool fixed_focal, int device = 0) {
+    const double w = frame_feature0.img_w_h.first, h = frame_feature0.img_w_h.second;
+    const GenericModel ucm0(CCAL_MODEL_UCM, {init_f, init_f, w / 2.0, h / 2.0, init_alpha}, w, h);
+    const std::vector<std::optional<FrameFeature>> frames = {frame_feature0, frame_feature1};
+    std::vector<double> intr;
+    {
+        detail::Ctx ctx(device); detail::Prob p;
+        const auto f = detail::flatten({&frames}, {{0, 1}});
+        if (detail::make_problem(ctx, f, {ucm0}, true, p) != CCAL_OK) return std::nullopt;
+        ccal_fix_param(p.h, 0, 1); ccal_fix_param(p.h, 0, 2);                      // cx, cy (eff indices: fy removed)
+        if (fixed_focal) ccal_fix_param(p.h, 0, 0);
+        ccal_set_bounds(p.h, 0, 0, init_f / 3.0, init_f * 3.0);
+        ccal_set_bounds(p.h, 0, 3, 1e-6, 1.0);
+        intr = detail::intr_matrix({ucm0});
+        std::vector<double> poses;
+        for (const RvecTvec* rt : {&rtvec0, &rtvec1}) { const auto v = rt->as6(); poses.insert(poses.end(), v.begin(), v.end()); }
+        ccal_solver_opts o; ccal_set_defaults(&o);
+        ccal_report rep{};
+        const int rc = ccal_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);
+        if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;
+    }
+    const GenericModel ucm1(CCAL_MODEL_UCM, {intr[0], intr[0], w / 2.0, h / 2.0, intr[4]}, w, h);
+    const auto res = calib_camera(frames, ucm1, true, 0, fixed_focal, nullptr, device);
+    if (!res) throw std::runtime_error("The initial UCM model fitting failed. Might be wrong board configuration.");
+    return res->first;
 }
 
 // util::convert_model (src/util.rs:224-282): fits `target_model` in place, like the reference's &mut argument

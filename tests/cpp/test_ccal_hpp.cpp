@@ -92,12 +92,28 @@ static int run_rig(std::ifstream& f) {
     return 0;
 }
 
+// util::init_ucm (src/util.rs:287-378) on the fixture's first two frames: "UCM0", frames, then init_f, init_alpha,
+// fixed_focal and the two starting poses.
+static int run_init_ucm(std::ifstream& f) {
+    const auto frames = read_frames(f);
+    const double init_f = rd<double>(f), init_alpha = rd<double>(f);
+    const int fixed_focal = rd<int32_t>(f);
+    double p[12]; for (auto& v : p) v = rd<double>(f);
+    const auto m = init_ucm(*frames[0], *frames[1], RvecTvec::from6(p), RvecTvec::from6(p + 6), init_f, init_alpha, fixed_focal != 0);
+    if (!m) { std::printf("{\"result\": null}\n"); return 0; }
+    std::printf("{\"model\": %d, \"params\": [", m->model_id());
+    for (size_t i = 0; i < m->params().size(); ++i) std::printf("%s%.17g", i ? ", " : "", m->params()[i]);
+    std::printf("]}\n");
+    return 0;
+}
+
 int main(int argc, char** argv) {
     test_reprojection_factor();
     test_rvec_tvec_conversion();
     if (argc < 2) { std::printf("{\"unit_tests\": \"ok\"}\n"); return 0; }
     std::ifstream f(argv[1], std::ios::binary);
     if (argc > 2 && std::strcmp(argv[2], "rig") == 0) return run_rig(f);
+    if (argc > 2 && std::strcmp(argv[2], "init_ucm") == 0) return run_init_ucm(f);
     const auto frames = read_frames(f);
     const int model_id = rd<int32_t>(f), P = rd<int32_t>(f);
     std::vector<double> params(P); for (auto& v : params) v = rd<double>(f);

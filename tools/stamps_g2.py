@@ -1,0 +1,33 @@
+"""Developer tool: where a wavefront of k_gram2 spends its life (100 MHz clock at the phase boundaries; library built with
+-DCCAL_STAMPS: tools/build_tu_variants.sh ccal_kernels_gram2 "stamps:-DCCAL_STAMPS"; CCAL_LIB selects it, CCAL_GRAM2=1 for
+the models that do not take k_gram2 by default).   python tools/stamps_g2.py [frames] [model] [lm]"""
+import os, sys, ctypes as C, numpy as np
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import torch
+from camera_intrinsic_calibration_rs_amd import synth, _ffi
+from camera_intrinsic_calibration_rs_amd.engine import Context, Problem
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+model = sys.argv[2] if len(sys.argv) > 2 else "eucm"
+sp = synth.make_problem(F, model)
+ctx = Context(0); p = Problem.from_synth(ctx, sp)
+p.upload_params(sp.intr0, sp.poses0, sp.extr0)
+for _ in range(30): p.build_normal_dev(0.0)
+torch.cuda.synchronize()
+lib = _ffi.load()
+n = min(F * 40, 8 * 16384)
+buf = np.zeros(n, dtype=np.float64)
+lib.ccal_debug_fcbuf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+lib.ccal_debug_fcbuf(p.handle, buf.ctypes.data_as(C.c_void_p), n)
+st = buf.reshape(-1, 8)
+ok = st[:, 0] > 0
+st = st[ok]
+t0 = st[:, 0].min()
+nw = len(st)
+names = ["state+ids", "prologue", "corner loop", "reduction", "scatter", "fused tail"]
+print(f"{model} {F} frames: {nw} wavefronts, start spread {(st[:, 0].max() - t0) / 100:.2f} us, last end {(st[:, 5].max() - t0) / 100:.2f} us")
+half = nw // 2
+for label, sel in (("first half of the dispatch (older on their SIMD)", slice(0, half)), ("second half (younger)", slice(half, nw))):
+    s = st[sel]
+    d = np.diff(s[:, :6], axis=1) / 100.0
+    print(f"  {label}: start {np.median(s[:, 0] - t0) / 100:.2f}  " + "  ".join(f"{nm} {np.median(d[:, i]):.2f}" for i, nm in enumerate(names[1:])) +
+          f"  total {np.median(s[:, 5] - s[:, 0]) / 100:.2f}  end {np.median(s[:, 5] - t0) / 100:.2f} us")
