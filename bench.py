@@ -314,6 +314,14 @@ def main():
                     "gn": solve_stats(sprob, sub, 0, False), "lm": solve_stats(sprob, sub, 1, False),
                     "gn_device_resident": solve_stats(sprob, sub, 0, True), "lm_device_resident": solve_stats(sprob, sub, 1, True)}
                 sprob.close()
+            # The session-size regime, side by side: N independent 625-frame problems through ONE ccal_solve_batch call
+            # (a context + stream + host thread each), aggregate Gauss-Newton iterations/s against one problem at a time
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import concurrent_sessions
+                extra["concurrent_sessions"] = concurrent_sessions.measure(625, args.model, 0, reps=100, counts=(1, 2, 4, 8), device=dev_index)
+            except Exception as e:  # noqa: BLE001
+                extra["concurrent_sessions"] = {"error": repr(e)}
             # BASELINE configs[4] shape: a two-camera rig with extrinsics (calib_all_camera_with_extrinsics, src/util.rs:567),
             # both cameras seeing every frame slot - the general loop: 13-column Gram per camera at the composed pose,
             # per-slot expansion + elimination, K = 2 P_eff + 6

@@ -97,6 +97,8 @@ SYMBOLS = [
     ("ccal_build_normal_dev", C.c_int, [_vp, C.c_double]),
     ("ccal_solve", C.c_int, [_vp, C.POINTER(SolverOpts), _dp, _dp, _dp, C.POINTER(Report)]),
     ("ccal_solve_dev", C.c_int, [_vp, C.POINTER(SolverOpts), C.POINTER(Report)]),
+    ("ccal_solve_batch", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(SolverOpts), C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp),
+                                   C.POINTER(Report)]),
     ("ccal_init_poses", C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
     ("ccal_init_camera_extrinsic", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(Report)]),
     ("ccal_convert_model", C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,

@@ -89,6 +89,7 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
     return CCAL_OK;
 }
 static void ctx_free(ccal_ctx* ctx) {
+    ctx_worker_destroy(ctx);
     if (ctx->own_stream && ctx->stream) { (void)hipSetDevice(ctx->device); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
 }

@@ -58,7 +58,11 @@ struct ccal_ctx {
     // ccal_problem_destroy frees it (bindings with a garbage collector destroy in any order)
     int n_problems = 0;
     bool destroy_requested = false;
+    // ccal_solve_batch: the host thread that drives this context's stream while the caller's thread drives another one
+    // (created on first use, joined when the context is freed; ccal_solver.hip)
+    struct ccal_ctx_worker* worker = nullptr;
 };
+namespace ccal { void ctx_worker_destroy(ccal_ctx* ctx); }
 
 struct ccal_problem {
     ccal_ctx* ctx = nullptr;

@@ -277,6 +277,33 @@ class Problem:
             raise CcalError(rc, "ccal_solve_dev", self.ctx.last_error())
         return rep
 
+    @staticmethod
+    def solve_batch(problems, opts: _ffi.SolverOpts | None = None, starts=None):
+        """ccal_solve_batch: independent problems (ideally one context each) solved side by side from this thread.
+        starts = None: device-resident (every problem starts from what upload_params / a previous solve left on the device,
+        download_params fetches the results); else a list of (intr, poses, extr) per problem, returned updated.
+        Returns (reports, results-or-None); a problem's own verdict is in its report."""
+        n = len(problems)
+        lib = problems[0].lib if n else _ffi.load()
+        opts = opts or default_opts()
+        hs = (C.c_void_p * max(n, 1))(*[p.handle for p in problems])
+        reps = (_ffi.Report * max(n, 1))()
+        results = None
+        dpp = C.POINTER(C.c_double)
+        if starts is None:
+            rc = lib.ccal_solve_batch(hs, n, C.byref(opts), None, None, None, reps)
+        else:
+            results = []
+            for p, (intr, poses, extr) in zip(problems, starts):
+                i_, p_, e_ = p._params(intr, poses, extr)
+                results.append((i_.copy(), p_.copy(), e_.copy()))
+            ia = (dpp * max(n, 1))(*[_dp(r[0]) for r in results]); pa = (dpp * max(n, 1))(*[_dp(r[1]) for r in results])
+            ea = (dpp * max(n, 1))(*[_dp(r[2]) for r in results])
+            rc = lib.ccal_solve_batch(hs, n, C.byref(opts), ia, pa, ea, reps)
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_solve_batch", problems[0].ctx.last_error() if n else "")
+        return [reps[i] for i in range(n)], results
+
     # -- pose initialisation (src/util.rs:418-436) ---------------------------------------------------
     def init_poses(self, intr, min_points: int = 10):
         """T_cam_board per observation frame [n_obs, 6] and the number of corners used (0 = no pose)."""

@@ -232,6 +232,16 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda);   /* uses uploaded pa
 int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
                double* intr_io, double* poses_io, double* extr_io, ccal_report* report);
 int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* opts, ccal_report* report);
+/* n INDEPENDENT problems solved side by side in ONE call (the per-camera calib_camera calls of a rig, the retries of
+ * src/bin/camera_calibration.rs:205-246, many sessions of a service): a session-sized problem (a few hundred frames) leaves
+ * the GPU almost idle - its iteration is three dependent, latency-bound launches - so every context's problems are driven by
+ * a host thread of their own (the caller's thread takes the first context) and the contexts' streams overlap on the device.
+ * Create the problems on contexts of their own (ccal_ctx_create with stream NULL) to make them overlap; problems that share a
+ * context are solved one after the other.  Results are bit-identical to n ccal_solve calls.  intr_io == NULL: device-resident like ccal_solve_dev (poses_io / extr_io ignored);
+ * else intr_io[i] / poses_io[i] / extr_io[i] as in ccal_solve.  Every problem's verdict goes to reports[i].status; the return
+ * value is CCAL_OK unless a call failed for another reason (then the first such code).  Sharded problems are refused. */
+int ccal_solve_batch(ccal_problem** problems, int n, const ccal_solver_opts* opts,
+                     double** intr_io, double** poses_io, double** extr_io, ccal_report* reports);
 
 /* ---- per-frame pose initialisation (src/util.rs:418-436) ---------------------------------
  * What calib_camera does before it builds the problem: unproject the detections with the current model,

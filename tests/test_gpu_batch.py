@@ -1,0 +1,72 @@
+"""ccal_solve_batch: independent problems solved side by side from one host thread (the per-camera calib_camera calls of a
+rig, the retries of src/bin/camera_calibration.rs:205-246) - bit-identical to solving them one after the other."""
+import numpy as np
+import pytest
+
+from camera_intrinsic_calibration_rs_amd import _ffi, synth
+from camera_intrinsic_calibration_rs_amd.engine import CcalError, Context, Problem, default_opts
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    return [synth.make_problem(300, "eucm", seed=11, outlier_frac=0.02), synth.make_problem(200, "kb4", seed=12, xy_same_focal=True),
+            synth.make_problem(40, "eucm", n_cams=2, seed=13), synth.make_problem(150, "ucm", seed=14, ragged=True),
+            synth.make_problem(120, "opencv5", seed=15)]
+
+
+@pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
+@pytest.mark.parametrize("own_context", [True, False])
+def test_batch_equals_sequential(method, own_context):
+    sps = _cases()
+    shared = Context(0)
+    ctxs = [Context(0) if own_context else shared for _ in sps]
+    probs = [Problem.from_synth(c, s) for c, s in zip(ctxs, sps)]
+    for p in probs:
+        p.apply_reference_bounds()
+    opts = default_opts(method)
+    seq = [p.solve(s.intr0, s.poses0, s.extr0, opts=opts) for p, s in zip(probs, sps)]
+    reps, res = Problem.solve_batch(probs, opts, starts=[(s.intr0, s.poses0, s.extr0) for s in sps])
+    for (i0, p0, e0, r0), rep, (i1, p1, e1) in zip(seq, reps, res):
+        assert (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected) == (r0.status, r0.iterations, r0.lm_accepted, r0.lm_rejected)
+        assert rep.final_cost == r0.final_cost and rep.initial_cost == r0.initial_cost
+        np.testing.assert_array_equal(i1, i0); np.testing.assert_array_equal(p1, p0); np.testing.assert_array_equal(e1, e0)
+    # device-resident form: starting points uploaded, results left on the device
+    for p, s in zip(probs, sps):
+        p.upload_params(s.intr0, s.poses0, s.extr0)
+    reps2, none = Problem.solve_batch(probs, opts)
+    assert none is None
+    for p, (i0, p0, e0, r0), rep in zip(probs, seq, reps2):
+        i1, p1, e1 = p.download_params()
+        assert rep.iterations == r0.iterations and rep.final_cost == r0.final_cost
+        np.testing.assert_array_equal(i1, i0); np.testing.assert_array_equal(p1, p0)
+    for p in probs:
+        p.close()
+
+
+def test_batch_reports_each_problems_own_verdict():
+    """One problem of the batch has no step (a frame with a rank-deficient pose block: tiny-solver's None): its report says
+    NOT_PD, the others solve; the call itself succeeds."""
+    good = synth.make_problem(50, "eucm", seed=3)
+    bad = synth.make_problem(6, "eucm", seed=4)
+    bad.p3d[: bad.obs_offsets[1]] = bad.p3d[0]            # every corner of frame 0 the same board point: its 6 x 6 block is singular
+    ctxs = [Context(0), Context(0)]
+    probs = [Problem.from_synth(ctxs[0], good), Problem.from_synth(ctxs[1], bad)]
+    reps, res = Problem.solve_batch(probs, default_opts(_ffi.METHOD_GN), starts=[(good.intr0, good.poses0, None), (bad.intr0, bad.poses0, None)])
+    assert reps[0].status == _ffi.OK and reps[0].iterations >= 2
+    assert reps[1].status in (_ffi.ERR_NOT_PD, _ffi.ERR_NONFINITE)
+    _, _, _, r0 = probs[0].solve(good.intr0, good.poses0)
+    assert r0.final_cost == reps[0].final_cost
+    for p in probs:
+        p.close()
+
+
+def test_batch_argument_checks():
+    sp = synth.make_problem(10, "eucm")
+    ctx = Context(0)
+    p = Problem.from_synth(ctx, sp)
+    with pytest.raises(CcalError):
+        Problem.solve_batch([p, p], default_opts(0))                 # the same problem twice
+    reps, _ = Problem.solve_batch([], default_opts(0))
+    assert reps == []
+    p.close()

@@ -11,7 +11,7 @@ for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -ffp-contract=fast $flags -c $tu.hip -o build/var/${name}_$tu.o
     objs=$(ls build/ccal_*.o | grep -v "/$tu.o")
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libccal_$name.so $objs build/var/${name}_$tu.o -ldl
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libccal_$name.so $objs build/var/${name}_$tu.o -ldl -lpthread
     echo built $name ) &
 done
 wait
