@@ -176,3 +176,154 @@ def test_two_ranks_on_the_device_path(model, n_cams, method):
     np.testing.assert_allclose(e0, extr1, rtol=0, atol=1e-10)
     np.testing.assert_allclose(p0, poses1, rtol=0, atol=1e-9)
     assert abs(c0 - rep1.final_cost) <= 1e-10 * rep1.final_cost
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Groups enqueued AHEAD of the host in a sharded solve (what the native RCCL path does by default): the group count must
+# be a function of the decisions only, early-exit groups must still issue their collective, and that on every rank alike -
+# with LM rejections, with a pose block that fails on ONE rank only, with a rank whose shard is empty.  One GPU: both ranks
+# on cuda:0, callback transport (gloo), CCAL_FUSED_DEPTH_HOOK = 2 makes the callback path enqueue ahead like the native one.
+# A child that hangs is killed by the parent (the watchdog is the parent's queue timeout; nothing re-execs).
+# ---------------------------------------------------------------------------------------------------------------------
+def _ahead_worker(rank, world, port, scenario, method, n_cams, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ["CCAL_FUSED_DEPTH_HOOK"] = "2"              # read once per process by the library: set before it loads
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
+    from camera_intrinsic_calibration_rs_amd.engine import make_desc
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = Context(0, stream=stream.cuda_stream)
+    if scenario == "lm_rejections":                      # poor starting points on which the (CPU oracle's) LM rejects 7 / 3 steps
+        sp = synth.make_problem(12, "eucm", n_cams=n_cams, outlier_frac=0.05, ragged=True, init_perturb=0.8, seed=1 if n_cams == 1 else 0xBEEF)
+    else:
+        sp = synth.make_problem(36, "eucm", n_cams=n_cams, outlier_frac=0.03, ragged=True, seed=0xBEEF)
+    if scenario == "empty_rank1":
+        if rank == 0:
+            shard = sp
+            gp = Problem.from_synth(ctx, shard)
+        else:                                            # three pose slots, no observation frame at all
+            d, keep = make_desc(1, [1], [512.0], [512.0], False, 3, [], [], [0], [], [], [], [], [], 1.0)
+            gp = Problem(ctx, d, keep)
+            shard = synth.make_problem(3, "eucm")
+            shard = synth.dataclasses.replace(shard, intr0=sp.intr0)
+    else:
+        shard = sp.shard(rank, world)
+        if scenario == "notpd_rank1" and rank == 1:      # every corner of rank 1's first slot (all cameras) the same board point: its 6 x 6 block is singular
+            shard.p3d[: shard.obs_offsets[n_cams]] = shard.p3d[0]
+        gp = Problem.from_synth(ctx, shard)
+    gp.apply_reference_bounds()
+    calls = []
+    hook = make_allreduce_hook(device=dev)
+
+    def counting(ptr, count, st):
+        calls.append(count)
+        return hook(ptr, count, st)
+
+    gp.set_allreduce(counting)
+    intr, poses, extr, rep = gp.solve(shard.intr0, shard.poses0, shard.extr0, opts=default_opts(method), raise_on_error=False)
+    gp.set_allreduce(None)                               # drains the early-exit groups (their collectives included)
+    q.put((rank, intr, extr, rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected, rep.lm_spec_misses, rep.final_cost, list(calls)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scenario,method,n_cams", [("lm_rejections", 1, 1), ("lm_rejections", 1, 2), ("notpd_rank1", 0, 1), ("notpd_rank1", 1, 1),
+                                                    ("notpd_rank1", 0, 2), ("empty_rank1", 0, 1), ("empty_rank1", 1, 1)])
+def test_two_ranks_groups_enqueued_ahead(scenario, method, n_cams):
+    import torch.multiprocessing as mp
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    port = _free_port()
+    procs = [mpc.Process(target=_ahead_worker, args=(r, 2, port, scenario, method, n_cams, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=180) for _ in range(2)], key=lambda t: t[0])
+    except Exception:
+        for p in procs:                                  # a hung collective: kill exactly the children started here, fail
+            if p.is_alive():
+                p.kill()
+        raise AssertionError(f"sharded solve with groups enqueued ahead hung ({scenario})")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, i0, e0, s0, it0, a0, r0, m0, c0, calls0), (_, i1, e1, s1, it1, a1, r1, m1, c1, calls1) = res
+    # every decision is a function of all-reduced sums: status, iteration count, accept / reject sequence, cost and the
+    # camera block are identical on both ranks, and so is the SEQUENCE of collectives (early-exit groups included)
+    assert (s0, it0, a0, r0, m0) == (s1, it1, a1, r1, m1)
+    assert calls0 == calls1 and len(calls0) >= 2
+    np.testing.assert_array_equal(i0, i1); np.testing.assert_array_equal(e0, e1)
+    assert c0 == c1 or (np.isnan(c0) and np.isnan(c1))
+    # groups = first evaluation + one per decision + one re-elimination group per rejection / missed speculation, + the
+    # group that was in flight ahead of the deciding one (depth 2), which exits early on the device but still sums
+    groups = 1 + it0 + (r0 + m0 if method == 1 else 0)
+    assert len(calls0) in (groups, groups + 1)
+    if scenario == "lm_rejections":
+        assert s0 == _ffi.OK and r0 + m0 >= 1
+    if scenario == "notpd_rank1":
+        # Gauss-Newton: a failed pose block anywhere is tiny-solver's None on EVERY rank; LM freezes it and goes on
+        assert s0 == (_ffi.ERR_NOT_PD if method == 0 else s1)
+    if scenario == "empty_rank1":
+        assert s0 == _ffi.OK
+
+
+def _native_worker(rank, world, uid, model, n_cams, method, n_frames, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    ctx = Context(rank)
+    comm = ctx.rccl_comm_create(world, rank, uid)
+    sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+    shard = sp.shard(rank, world)
+    gp = Problem.from_synth(ctx, shard)
+    gp.apply_reference_bounds()
+    gp.set_rccl_comm(comm)
+    intr, poses, extr, rep = gp.solve(shard.intr0, shard.poses0, shard.extr0, opts=default_opts(method))
+    gp.set_rccl_comm(None)
+    q.put((rank, intr, extr, poses, rep.iterations, rep.final_cost, rep.status))
+    gp.close()
+    engine.rccl_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("model,n_cams,method", [("eucm", 1, 0), ("eucm", 1, 1), ("eucm", 2, 0), ("kb4", 2, 1)])
+def test_native_rccl_two_ranks(model, n_cams, method):
+    """ncclAllReduce issued by the library on a 2-rank communicator, one process per GPU, groups enqueued two ahead: needs
+    two GPUs (skipped on the 1-GPU box; the driver's multi-GPU node runs it)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("native multi-rank RCCL needs two GPUs")
+    import torch.multiprocessing as mp
+    n_frames = 41
+    sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+    ctx0 = Context(0)
+    full = Problem.from_synth(ctx0, sp)
+    full.apply_reference_bounds()
+    intr1, poses1, extr1, rep1 = full.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+    uid = engine.rccl_unique_id()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_native_worker, args=(r, 2, uid, model, n_cams, method, n_frames, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    except Exception:
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        raise AssertionError("native 2-rank RCCL solve hung")
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, i0, e0, p0, it0, c0, s0), (_, i1, e1, p1, it1, c1, s1) = res
+    np.testing.assert_array_equal(i0, i1); np.testing.assert_array_equal(e0, e1)
+    assert it0 == it1 == rep1.iterations and s0 == s1 == rep1.status == 0 and c0 == c1
+    np.testing.assert_allclose(i0, intr1, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([p0, p1]), poses1, rtol=0, atol=1e-9)
+    assert abs(c0 - rep1.final_cost) <= 1e-10 * rep1.final_cost
