@@ -45,13 +45,13 @@ def _latest_profile_file(name):
 
 
 def _gram_kernel_key(model, one_focal, frames):
-    """Which Gram kernel launch_gram1v_t (ccal_kernels_fused.hip) picks for a single camera, as a key of profiles/*/flops.json:
-    the register Gram for every model; its two-wavefronts-per-SIMD form (k_gram1w) from 2 000 frames up when the triangle
-    of [J | r]^T [J | r] has at most 91 entries (UCM, EUCM)."""
+    """Which Gram kernel the launchers (use_gram2 / launch_gram1v_t, ccal_kernels_fused.hip) pick for a single camera, as a key of
+    profiles/*/flops.json: k_gram2 (rows traded between the lane halves) for OPENCV5 and, from 2 000 frames, UCM / EUCM;
+    k_gram1v (all accumulators in registers / AGPRs) for KB4 and for small UCM / EUCM problems."""
     of = "one-focal" if one_focal else "two-focal"
-    ncols = {"ucm": 5, "eucm": 6, "kb4": 8, "opencv5": 9}[model] - (1 if one_focal else 0) + 7
-    w = frames >= 2000 and ncols * (ncols + 1) // 2 <= 91
-    return f"{'k_gram1w' if w else 'k_gram1v'}<{model.upper()},{of}>"
+    if model == "opencv5" or (model in ("ucm", "eucm") and frames >= 2000):
+        return f"k_gram2<{model.upper()},{of}>"
+    return f"k_gram1v<{model.upper()},{of}>"
 
 
 _REAL_STDOUT = None
@@ -260,8 +260,8 @@ def main():
             extra["mode_N_build_ms"] = ms
             extra["mode_N_evals_per_s"] = n_corners / (ms * 1e-3)
             extra["mode_N_note"] = ("ccal_build_normal_dev: reduced normal equations [S | b | cost] from resident parameters "
-                                   "(single camera, >= 2 000 frames: k_gram1w with the per-frame elimination fused into its tail "
-                                   "+ k_reduce1; below: Gram kernel + k_schur1m + k_reduce1)")
+                                   "(single camera: the register Gram kernel - k_gram2 or k_gram1v, see mode_N_roofline.kernels - "
+                                   "with the per-frame elimination fused into its tail + k_reduce1)")
             # mode-N roofline (both rooflines; the FP64 one binds): exact FP64 operation counts read off the
             # kernels' ISA (tools/count_flops.py -> profiles/<round>/flops.json), time = the three launches together
             try:

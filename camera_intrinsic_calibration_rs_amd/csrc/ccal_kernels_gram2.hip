@@ -126,6 +126,9 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 // software pipeline of the corner loop (products of corner i beside the projection of corner i + 1 in one basic block).
 // Measured and left off: the scheduler does interleave them, but the longer live ranges cost 139 / 205 v_accvgpr copies per
 // pass instead of 41 / 81 (KB4 / OPENCV5, 10 000 frames: build 54.1 / 53.8 us against 49.3 / 47.1)
+#ifndef CCAL_G2_PRIO
+#define CCAL_G2_PRIO 0
+#endif
 #ifndef CCAL_G2_PIPE
 #define CCAL_G2_PIPE(MODEL) 0
 #endif
@@ -359,6 +362,13 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         }
     };
     constexpr bool PIPE = CCAL_G2_PIPE(MODEL);
+#if CCAL_G2_PRIO > 0
+    // Two wavefronts share a SIMD; instruction arbitration is oldest-first, so the wavefront dispatched second (the second
+    // 1 024 of the launch) runs its loop at ~0.57 of the first one's speed and finishes its epilogue alone on an idle SIMD.
+    // Raising its priority for the loop evens the two out: both reach their (latency-bound) epilogues together.
+    const bool younger = (blockIdx.x * CCAL_GRAMV_WPB + wave) >= 1024;
+    if (younger) __builtin_amdgcn_s_setprio(CCAL_G2_PRIO);
+#endif
     if constexpr (!PIPE) {
         for (int base = 0; base < nmax; base += LPF) {
             const bool valid = base + cl < n;
@@ -400,6 +410,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         }
     }
 
+#if CCAL_G2_PRIO > 0
+    if (younger) __builtin_amdgcn_s_setprio(0);
+#endif
     G2_STAMP(2);
     if constexpr (NLA > 0) {              // the LDS accumulators join the others (the rows are dead: registers to spare)
         wsync();

@@ -409,6 +409,41 @@ def test_two_camera_rig_at_scale(gpu_ctx):
     assert 0.015 < r_gn.final_cost / gp.n_corners < 0.025
 
 
+def test_two_camera_rig_at_headline_size_vs_oracle(gpu_ctx, oracle):
+    """BASELINE configs[4] shape against the oracle AT SCALE: two EUCM cameras x 10 000 frames (2.88 M blocks) - the reduced
+    normal equations S / b / cost of the general loop's size-dependent choices (lanes per frame of the Gram kernels, the
+    persistent wavefronts of k_schur, the wide reduction) - and GN + LM to convergence at 2 x 1 000 frames, same iteration
+    counts and accept / reject sequences as the oracle (src/util.rs:567-715)."""
+    sp = synth.make_problem(10000, "eucm", n_cams=2)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    for lam in (0.0, 1e-3):
+        S, b, cost = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        assert S.shape == (18, 18)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max()
+        assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+        dc, dco = np.linalg.solve(S, -b), np.linalg.solve(So, -bo)
+        assert np.abs(dc - dco).max() <= 1e-6 * np.abs(dco).max()
+    gp.close()
+    sp = synth.make_problem(1000, "eucm", n_cams=2, outlier_frac=0.01)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    gp.apply_reference_bounds(); op.apply_reference_bounds()
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        assert rep.status == rep_o.status == 0
+        assert (rep.iterations, rep.lm_accepted, rep.lm_rejected) == (rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected)
+        assert abs(rep.initial_cost - rep_o.initial_cost) <= 1e-12 * rep_o.initial_cost
+        assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+        assert (np.abs(intr[:, :6] - intr_o[:, :6]) / np.abs(intr_o[:, :6])).max() <= 1e-6
+        np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-8)
+        np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+    gp.close()
+
+
 RIG_EXTR = {3: [[0.0] * 6, [0.3, -0.25, 0.2, -0.1, 0.02, 0.01], [-0.2, 0.35, -0.15, 0.1, -0.03, 0.02]],
             2: [[0.0] * 6, [0.12, -0.1, 0.3, -0.1, 0.02, 0.01]]}
 

@@ -67,17 +67,35 @@ def summarize(c):
             "lds_add_f64": c.get("ds_add_f64", 0),
             "f64_valu_instructions": sum(v for k, v in f64.items() if k.startswith("v_")),
             "all_instructions": sum(c.values()),
-            "lds_instructions": sum(v for k, v in c.items() if k.startswith("ds_"))}
+            "lds_instructions": sum(v for k, v in c.items() if k.startswith("ds_")),
+            # register-file traffic that is not arithmetic: AGPR <-> VGPR copies (accumulators that do not fit the 256 registers
+            # the VALU addresses), the row trade of k_gram2, scratch
+            "v_accvgpr_copies": sum(v for k, v in c.items() if "accvgpr" in k),
+            "v_permlane32_swap": sum(v for k, v in c.items() if "permlane32_swap" in k),
+            "scratch_instructions": sum(v for k, v in c.items() if k.startswith("scratch_"))}
+
+
+def registers(asm):
+    """kernel symbol -> (vgpr_count incl. AGPRs, agpr_count, scratch bytes) from the code object metadata"""
+    out = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.vgpr_count:\s+(\d+)", asm, re.S):
+        blk = m.group(2)
+        ag = re.search(r"\.agpr_count:\s+(\d+)", blk); sc = re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk)
+        out[m.group(1)] = {"vgpr_plus_agpr": int(m.group(3)), "agpr": int(ag.group(1)) if ag else 0, "scratch_bytes": int(sc.group(1)) if sc else 0}
+    return out
 
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    bodies, regs = {}, {}
     with tempfile.TemporaryDirectory() as td:
-        s = os.path.join(td, "fused.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-S",
-                               "--cuda-device-only", "-o", s, os.path.join(SRC, "ccal_kernels_fused.hip")], stderr=subprocess.DEVNULL)
-        bodies = kernel_bodies(open(s).read())
-    out = {"source": "gfx950 ISA of ccal_kernels_fused.hip (hipcc -O3 -ffp-contract=fast), counted by tools/count_flops.py",
+        for tu in ("ccal_kernels_fused", "ccal_kernels_gram2"):
+            s = os.path.join(td, tu + ".s")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-S",
+                                   "--cuda-device-only", "-o", s, os.path.join(SRC, tu + ".hip")], stderr=subprocess.DEVNULL)
+            asm = open(s).read()
+            bodies.update(kernel_bodies(asm)); regs.update(registers(asm))
+    out = {"source": "gfx950 ISA of ccal_kernels_fused.hip and ccal_kernels_gram2.hip (hipcc -O3 -ffp-contract=fast), counted by tools/count_flops.py",
            "fp64_vector_peak_tflops": 78.6, "kernels": {}}
     # model ids: 0 UCM 1 EUCM 2 KB4 3 OPENCV5; k_gram1w<MODEL, OF, LPF>, k_gram1v<...>, k_gram1<MODEL, OF>, k_schur1m<K>
     names = {0: "UCM", 1: "EUCM", 2: "KB4", 3: "OPENCV5"}
@@ -89,6 +107,10 @@ def main():
             want[f"k_gram1w<{nm},{focal}>"] = f"k_gram1wILi{m}ELb{of}ELi12ELb0EE"
             want[f"k_gram1v<{nm},{focal}>"] = f"k_gram1vILi{m}ELb{of}ELi12ELb0EE"
             want[f"k_gram1<{nm},{focal}>"] = f"k_gram1ILi{m}ELb{of}EE"
+            want[f"k_gram2<{nm},{focal}>"] = f"k_gram2ILi{m}ELb{of}ELi12ELb0EE"
+            # KB4 / OPENCV5 run 10 frames per wavefront at 10 000 frames (6 lanes per frame): the instantiation the bench times
+            want[f"k_gram1v<{nm},{focal},6 lanes>"] = f"k_gram1vILi{m}ELb{of}ELi6ELb0EE"
+            want[f"k_gram2<{nm},{focal},6 lanes>"] = f"k_gram2ILi{m}ELb{of}ELi6ELb0EE"
     for name, key in want.items():
         hits = [k for k in bodies if key in k]
         if not hits:
@@ -104,7 +126,7 @@ def main():
         whole = summarize(ops(body))
         mf = ops(body[a:b + 1]).get("v_mfma_f64_16x16x4_f64", 0)
         out["kernels"][name] = {"per_corner": loop, "outside_corner_loop_per_wavefront": {k: whole[k] - loop[k] for k in whole},
-                                "mfma_f64_16x16x4_in_loop": mf}
+                                "mfma_f64_16x16x4_in_loop": mf, "registers": regs.get(hits[0])}
     for K in (5, 6, 7, 8, 9):
         hits = [k for k in bodies if f"k_schur1mILi{K}EE" in k]
         if hits:
