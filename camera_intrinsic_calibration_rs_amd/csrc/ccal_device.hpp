@@ -76,6 +76,9 @@ __device__ __forceinline__ void fast_sincos(double x, double& s, double& c) {
 //   Newton + one residual correction), and the octant folded back as  theta = k pi/4 -+ atan(x)  with pi/4 in two parts.
 // A third of the instructions of the general-purpose library atan2 (no special cases: r > 0 excludes them, no branches).
 __device__ __forceinline__ double fast_atan2_pos(double r, double z) {
+#ifdef CCAL_LIB_ATAN2          // A/B builds (tools/ab_eval.py): the general-purpose library function
+    return atan2(r, z);
+#endif
     const double az = __builtin_fabs(z);
     const bool big = r > az, neg = z < 0.0;
     const double a = big ? az : r, b = big ? r : az;                   // 0 <= a <= b, b > 0

@@ -300,8 +300,11 @@ struct SchurArgs {
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+#ifndef CCAL_SCHUR_MINW
+#define CCAL_SCHUR_MINW 4
+#endif
 template <bool REC>
-__global__ __launch_bounds__(256, 4) void k_schur(const SchurArgs a) {      // four wavefronts per SIMD: <= 128 VGPRs
+__global__ __launch_bounds__(256, CCAL_SCHUR_MINW) void k_schur(const SchurArgs a) {      // four wavefronts per SIMD: <= 128 VGPRs
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int K = a.K, K1 = a.K + 1, RB = a.RB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave-uniform values in SGPRs
