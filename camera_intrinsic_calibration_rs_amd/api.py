@@ -270,6 +270,62 @@ def calib_camera(frame_feature_list: Sequence[Optional[FrameFeature]], generic_c
         prob.close()
 
 
+def calib_cameras(cams_frame_feature_lists: Sequence[Sequence[Optional[FrameFeature]]], generic_cameras: Sequence[GenericModel],
+                  xy_same_focal: bool, disabled_distortions: int, fixed_focal: bool, device: int = 0,
+                  opts: Optional[_ffi.SolverOpts] = None
+                  ) -> List[Optional[Tuple[GenericModel, Dict[int, RvecTvec]]]]:
+    """The per-camera loop of the tool - `for cam in 0..cam_num { calib_camera(...) }` (src/bin/camera_calibration.rs:255-265) -
+    as ONE ccal_solve_batch: every camera's single-camera problem on a context of its own, solved side by side (a session-
+    sized problem leaves the GPU almost idle).  Entry i equals calib_camera(cams_frame_feature_lists[i], generic_cameras[i], ...)
+    bit for bit."""
+    n = len(generic_cameras)
+    ctxs = [Context(device) for _ in range(n)]
+    out: List[Optional[Tuple[GenericModel, Dict[int, RvecTvec]]]] = [None] * n
+    jobs = []                                       # (camera, problem, slots, intr, poses)
+    try:
+        for c in range(n):
+            frames, cam = cams_frame_feature_lists[c], generic_cameras[c]
+            init = init_frame_poses(frames, cam, ctx=ctxs[c])
+            valid = [i for i, f in enumerate(frames) if f is not None and i in init]
+            if not valid:
+                continue
+            slots, obs_cam, obs_slot, offs, X, U = _flatten([frames], [valid])
+            d, keep = make_desc(1, [cam.model_id], [cam.width()], [cam.height()], xy_same_focal, len(slots), obs_cam, obs_slot, offs,
+                                X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
+            prob = Problem(ctxs[c], d, keep)
+            intr = _intr_matrix([cam])
+            prob.apply_reference_bounds()
+            prob.disable_distortions(disabled_distortions, intr)
+            jobs.append([c, prob, slots, intr, np.stack([init[i].as6() for i in slots])])
+        o = opts or default_opts()
+        reps, res = Problem.solve_batch([j[1] for j in jobs], o, starts=[(j[3], j[4], None) for j in jobs])
+        alive = []
+        for j, rep, r in zip(jobs, reps, res):
+            if rep.status not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE):
+                continue                                                # result_option.as_ref()?  -> None
+            j[3], j[4] = r[0], r[1]
+            alive.append(j)
+        if fixed_focal and alive:                                       # src/util.rs:459-464 "set focal and opt again."
+            for j in alive:
+                j[1].fix_param(0, 0)
+                j[3][0, 0] = generic_cameras[j[0]].params()[0]
+                if xy_same_focal:
+                    j[3][0, 1] = j[3][0, 0]
+            reps, res = Problem.solve_batch([j[1] for j in alive], o, starts=[(j[3], j[4], None) for j in alive])
+            for j, r in zip(alive, res):
+                j[3], j[4] = r[0], r[1]
+        for c, prob, slots, intr, poses in alive:
+            m = generic_cameras[c].copy()
+            m.set_params(intr[0, :len(m._params)])
+            out[c] = (m, {fi: RvecTvec.from6(poses[s]) for s, fi in enumerate(slots)})
+        return out
+    finally:
+        for j in jobs:
+            j[1].close()
+        for cx in ctxs:
+            cx.close()
+
+
 def _joint_problem_inputs(cameras, t_cam_i_0, cam_rtvecs, cams_detected_feature_frames, xy_same_focal):
     """Problem description and starting point of the joint problem exactly as src/util.rs:576-651 lays it out (the tests
     hand the same arrays to the oracle): slots = sorted union of the frame indices with a pose, T_0_b per slot = cam0's

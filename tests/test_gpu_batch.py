@@ -70,3 +70,21 @@ def test_batch_argument_checks():
     reps, _ = Problem.solve_batch([], default_opts(0))
     assert reps == []
     p.close()
+
+
+def test_calib_cameras_equals_per_camera_calib_camera(gpu_ctx):
+    """api.calib_cameras = the tool's per-camera loop (src/bin/camera_calibration.rs:255-265) through one ccal_solve_batch."""
+    from camera_intrinsic_calibration_rs_amd import api
+    sp = synth.make_problem(24, "eucm", n_cams=3, seed=21)
+    frames = [api.frames_from_synth(sp, c) for c in range(3)]
+    frames[1][5] = None
+    cams0 = [api.GenericModel("eucm", sp.intr0[c, :6], 512, 512) for c in range(3)]
+    for fixed_focal in (False, True):
+        batch = api.calib_cameras(frames, cams0, True, 0, fixed_focal)
+        for c in range(3):
+            one = api.calib_camera(frames[c], cams0[c], True, 0, fixed_focal, None, ctx=gpu_ctx)
+            assert (one is None) == (batch[c] is None)
+            np.testing.assert_array_equal(batch[c][0].params(), one[0].params())
+            assert sorted(batch[c][1]) == sorted(one[1])
+            for k in one[1]:
+                np.testing.assert_array_equal(batch[c][1][k].as6(), one[1][k].as6())
