@@ -93,9 +93,12 @@ def test_config2_solve(gpu_ctx, oracle, cfg2_problems, model, one_focal, method)
     gp.close()
 
 
-@pytest.mark.parametrize("model,one_focal", [("kb4", False), ("opencv5", False), ("kb4", True)])
+@pytest.mark.parametrize("model,one_focal", [("kb4", False), ("opencv5", False), ("kb4", True), ("eucm", False), ("eucm", True), ("ucm", False),
+                                             ("opencv5", True)])
 def test_config2_models_at_headline_size_sampled(gpu_ctx, oracle, model, one_focal):
-    """10 000 frames x 144 corners, KB4 / OPENCV5: sampled frames of the GPU pass equal the oracle on those frames."""
+    """10 000 frames x 144 corners, every model: sampled frames of the GPU pass equal the oracle on those frames, and the reduced
+    normal equations equal the oracle's on all 10 000 frames - the size at which UCM / EUCM / OPENCV5 take k_gram2 (rows traded
+    between the halves of the wavefront, 12 lanes per frame) and KB4 k_gram1v with 6 lanes per frame."""
     sp = synth.make_problem(10000, model, xy_same_focal=one_focal)
     gp = Problem.from_synth(gpu_ctx, sp)
     D = gp.block_dim(0)
