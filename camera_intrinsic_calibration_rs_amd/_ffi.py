@@ -50,7 +50,8 @@ class Report(C.Structure):
 
 
 class ModelConventions(C.Structure):
-    _fields_ = [("kb4_small_radius", C.c_double), ("dist_lo", (C.c_double * 5) * 4), ("dist_hi", (C.c_double * 5) * 4)]
+    _fields_ = [("kb4_small_radius", C.c_double), ("dist_lo", (C.c_double * 5) * 4), ("dist_hi", (C.c_double * 5) * 4),
+                ("unproject_small_radius", C.c_double), ("ocv5_order", C.c_int32 * 5), ("reserved_", C.c_int32)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

@@ -45,6 +45,9 @@ static int upload(ccal_ctx* ctx, T** dst, const T* src, size_t n) {
 
 static void default_conventions(ccal_model_conventions* cv) {
     cv->kb4_small_radius = kDefaultKb4SmallRadius;
+    cv->unproject_small_radius = kDefaultUnprojectSmallRadius;
+    for (int i = 0; i < 5; ++i) cv->ocv5_order[i] = i;
+    cv->reserved_ = 0;
     for (int m = 0; m < kNumModels; ++m)
         for (int i = 0; i < kMaxDist; ++i) { cv->dist_lo[m][i] = kDefaultDistLo[m][i]; cv->dist_hi[m][i] = kDefaultDistHi[m][i]; }
 }
@@ -60,7 +63,12 @@ int ccal_get_model_conventions(const ccal_ctx* ctx, ccal_model_conventions* out)
 int ccal_set_model_conventions(ccal_ctx* ctx, const ccal_model_conventions* in) {
     if (!ctx) return CCAL_ERR_INVALID_ARG;
     if (!in) { default_conventions(&ctx->conv); return CCAL_OK; }
-    if (!(in->kb4_small_radius >= 0.0)) return CCAL_ERR_INVALID_ARG;
+    if (!(in->kb4_small_radius >= 0.0) || !(in->unproject_small_radius >= 0.0)) return CCAL_ERR_INVALID_ARG;
+    {   // ocv5_order: a permutation of 0..4
+        int seen = 0;
+        for (int i = 0; i < 5; ++i) { if (in->ocv5_order[i] < 0 || in->ocv5_order[i] > 4) return CCAL_ERR_INVALID_ARG; seen |= 1 << in->ocv5_order[i]; }
+        if (seen != 31) return CCAL_ERR_INVALID_ARG;
+    }
     for (int m = 0; m < kNumModels; ++m)
         for (int i = 0; i < model_np(m) - 4; ++i) if (!(in->dist_lo[m][i] <= in->dist_hi[m][i])) return CCAL_ERR_INVALID_ARG;
     ctx->conv = *in;
@@ -257,7 +265,11 @@ int ccal_apply_reference_bounds(ccal_problem* p) {
         ccal_set_bounds(p, c, 1 - shift, 0.0, 10000.0);
         ccal_set_bounds(p, c, 2 - shift, 0.0, cl.width);
         ccal_set_bounds(p, c, 3 - shift, 0.0, cl.height);
-        for (int i = 4; i < cl.P; ++i) ccal_set_bounds(p, c, i - shift, cv.dist_lo[cl.model][i - 4], cv.dist_hi[cl.model][i - 4]);
+        // the table is indexed by coefficient (OPENCV5: k1, k2, p1, p2, k3), the bound goes to where the caller's vector keeps it
+        for (int i = 4; i < cl.P; ++i) {
+            const int at = cl.model == kOCV5 ? 4 + cv.ocv5_order[i - 4] : i;
+            ccal_set_bounds(p, c, at - shift, cv.dist_lo[cl.model][i - 4], cv.dist_hi[cl.model][i - 4]);
+        }
     }
     return CCAL_OK;
 }
@@ -312,7 +324,7 @@ static KArgs make_args(const ccal_problem* p, int cam) {
     a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
-    a.huber_delta = p->huber_delta; a.kb4_eps = p->ctx->conv.kb4_small_radius;
+    a.huber_delta = p->huber_delta; a.rt = model_rt(p->ctx);
     return a;
 }
 

@@ -33,7 +33,7 @@ namespace ccal {
 // Model inverse as published (UCM/EUCM: Usenko et al. 2018; KB4: Newton on theta; OPENCV5: fixed-point
 // undistortion); rays may point backwards (z <= 0) for fisheye models.  false = `unproject` gives None.
 template <int MODEL>
-__device__ bool unproject_ray(const double* th, double u, double v, double& x, double& y, double& z) {
+__device__ bool unproject_ray(const double* th, double small_radius, double u, double v, double& x, double& y, double& z) {
     const double mx = (u - th[2]) / th[0], my = (v - th[3]) / th[1];
     const double r2 = mx * mx + my * my;
     if constexpr (MODEL == kUCM || MODEL == kEUCM) {
@@ -47,7 +47,7 @@ __device__ bool unproject_ray(const double* th, double u, double v, double& x, d
         return true;
     } else if constexpr (MODEL == kKB4) {
         const double r = sqrt(r2);
-        if (r < kUnprojectSmallRadius) { x = mx; y = my; z = 1.0; return true; }
+        if (r < small_radius) { x = mx; y = my; z = 1.0; return true; }
         double t = r;
         for (int it = 0; it < 20; ++it) {
             const double t2 = t * t;
@@ -103,18 +103,19 @@ struct ConvArgs {
     double* rays;                               // [n_grid][CONV_REC]
     int32_t n_rows, n_cols, edge, steps;
     double* out;                                // [P (P+1)/2 | P | s | n_points]
-    double kb4_eps;                             // ccal_model_conventions.kb4_small_radius
+    ModelRt rt;                                 // the context's conventions; the OPENCV5 order is the canonical one here: the
+                                                // parameter vectors are permuted at the API boundary (ccal_convert_model)
 };
 
 template <int SRC>
 __global__ __launch_bounds__(256) void k_convert_rays(const ConvArgs a) {
     const int n = a.n_rows * a.n_cols;
     double th[th_len<SRC>()];
-    load_theta<SRC, false>(a.src, a.kb4_eps, th);
+    load_theta<SRC, false>(a.src, a.rt, th);
     for (int k = blockIdx.x * 256 + threadIdx.x; k < n; k += gridDim.x * 256) {
         const int r = a.edge + (k / a.n_cols) * a.steps, c = a.edge + (k % a.n_cols) * a.steps;
         double x = 0.0, y = 0.0, z = 0.0, u0 = 0.0, v0 = 0.0, state = 0.0;
-        if (unproject_ray<SRC>(th, (double)c, (double)r, x, y, z)) {
+        if (unproject_ray<SRC>(th, a.rt.unproject_eps, (double)c, (double)r, x, y, z)) {
             if (project_valid<SRC>(th, x, y, z)) { project_uv<SRC>(th, x, y, z, u0, v0); state = 1.0; }
             else state = 2.0;
         }
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256) void k_convert_gram(const ConvArgs a) {
     constexpr int P = model_np(TGT), ND = P - 4, NT = P * (P + 1) / 2, NA = NT + P + 2;
     __shared__ double part[4][NA];
     double th[th_len<TGT>()];
-    load_theta<TGT, false>(a.tgt, a.kb4_eps, th);
+    load_theta<TGT, false>(a.tgt, a.rt, th);
     double acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.0;
@@ -244,16 +245,25 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
     double* d_buf = nullptr;                    // [src 10 | tgt 10 | out 64 | rays]
     HIP_TRY(ctx, hipMalloc((void**)&d_buf, sizeof(double) * (size_t)(20 + 64 + (size_t)n_grid * CONV_REC)));
     struct Free { double* p; ~Free() { (void)hipFree(p); } } guard{ d_buf };
-    ConvArgs a{ d_buf, d_buf + 10, d_buf + 84, n_rows, n_cols, (int32_t)edge, steps, d_buf + 20, ctx->conv.kb4_small_radius };
+    // The fit runs in the kernels' canonical OPENCV5 order (k1, k2, p1, p2, k3): both parameter vectors are permuted HERE, at the
+    // boundary (ccal_model_conventions.ocv5_order), the kernels get the identity
+    ModelRt rt = model_rt(ctx);
+    rt.ocv5_perm = kOcv5IdentityPerm;
+    const int32_t* ord = ctx->conv.ocv5_order;
+    auto canon = [&](int model, int i) { return (model == kOCV5 && i >= 4) ? 4 + ord[i - 4] : i; };     // canonical index -> caller's index
+    ConvArgs a{ d_buf, d_buf + 10, d_buf + 84, n_rows, n_cols, (int32_t)edge, steps, d_buf + 20, rt };
 
-    double th[CCAL_PMAX] = { 0 }, lo[CCAL_PMAX], hi[CCAL_PMAX];
-    for (int i = 0; i < P; ++i) th[i] = tgt_params_io[i];
+    double th[CCAL_PMAX] = { 0 }, lo[CCAL_PMAX], hi[CCAL_PMAX], src_c[CCAL_PMAX] = { 0 };
+    for (int i = 0; i < PS; ++i) src_c[i] = src_params[canon(src_model, i)];
+    for (int i = 0; i < P; ++i) th[i] = tgt_params_io[canon(tgt_model, i)];
     for (int i = 0; i < 4; ++i) th[i] = src_params[i];                      // util.rs:256-258
     bool fx[CCAL_PMAX] = { false };
-    for (int i = 0; i < disabled_distortions; ++i) { fx[P - 1 - i] = true; th[P - 1 - i] = 0.0; }
+    for (int i = 0; i < disabled_distortions; ++i) {                        // the LAST k of the caller's vector (src/util.rs:58-70)
+        for (int c = 0; c < P; ++c) if (canon(tgt_model, c) == P - 1 - i) { fx[c] = true; th[c] = 0.0; }
+    }
     reference_bounds(ctx->conv, tgt_model, width, height, lo, hi);
 
-    HIP_TRY(ctx, hipMemcpyAsync(d_buf, src_params, sizeof(double) * PS, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(d_buf, src_c, sizeof(double) * PS, hipMemcpyHostToDevice, st));
     switch (src_model) {
         case kUCM: hipLaunchKernelGGL(k_convert_rays<kUCM>, dim3((n_grid + 255) / 256), dim3(256), 0, st, a); break;
         case kEUCM: hipLaunchKernelGGL(k_convert_rays<kEUCM>, dim3((n_grid + 255) / 256), dim3(256), 0, st, a); break;
@@ -307,7 +317,7 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
     }
     R.final_cost = cur; R.status = status;
     if (rep) *rep = R;
-    if (status == CCAL_OK || status == CCAL_ERR_NO_CONVERGENCE) for (int i = 0; i < P; ++i) tgt_params_io[i] = th[i];
+    if (status == CCAL_OK || status == CCAL_ERR_NO_CONVERGENCE) for (int i = 0; i < P; ++i) tgt_params_io[canon(tgt_model, i)] = th[i];
     if (status != CCAL_OK && ctx->err.empty()) ctx->err = "ccal_convert_model: solve failed";
     return status;
     CCAL_API_CATCH(ctx)

@@ -231,12 +231,21 @@ __device__ inline void frame_setup_composed(const double* pose, const double* ex
 // Intrinsics of one camera as the kernels hold them: th[0 .. P) = FULL model parameters (fy := fx with ONE_FOCAL)
 // and th[P] = the run-time convention slot (KB4: the small-radius threshold of project_one, dead for the others).
 template <int MODEL> __host__ __device__ constexpr int th_len() { return model_np(MODEL) + 1; }
+// OPENCV5: th[4 ..] = k1, k2, p1, p2, k3 (the kernels' canonical order) gathered from wherever the caller's params() vector
+// keeps them (rt.ocv5_perm: ccal_model_conventions.ocv5_order; wave-uniform, the identity by default).
 template <int MODEL, bool ONE_FOCAL>
-__device__ __forceinline__ void load_theta(const double* th_g, double kb4_small_radius, double* th) {
+__device__ __forceinline__ void load_theta(const double* th_g, const ModelRt& rt, double* th) {
+    if constexpr (MODEL == kOCV5) {
 #pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+        for (int i = 0; i < 4; ++i) th[i] = th_g[i];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) th[4 + i] = th_g[4 + ocv5_pos(rt.ocv5_perm, i)];
+    } else {
+#pragma unroll
+        for (int i = 0; i < model_np(MODEL); ++i) th[i] = th_g[i];
+    }
     if constexpr (ONE_FOCAL) th[1] = th[0];
-    th[model_np(MODEL)] = kb4_small_radius;
+    th[model_np(MODEL)] = rt.kb4_eps;
 }
 
 // Normalised projection m = (mx, my) with partials w.r.t. the camera-frame point (dmx[3], dmy[3])

@@ -188,7 +188,7 @@ struct FusedArgs {
     int32_t n_obs, K, PF, PRAW, n_pw;
     int32_t n_part;                // workgroups of the elimination kernel = partial sums per entry (set by the launcher)
     double huber_delta, min_diag, max_diag;
-    double kb4_eps;                // ccal_model_conventions.kb4_small_radius of the context
+    ModelRt rt;                    // the context's run-time conventions (KB4 threshold, OPENCV5 coefficient order)
     double* intr[2]; double* poses[2]; double* pf[2]; double* praw[2];
     double* fcbuf; double* mc_f; double* cost_f;
     const double* dc; const DevState* st;

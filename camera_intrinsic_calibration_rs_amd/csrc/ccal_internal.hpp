@@ -29,7 +29,7 @@ struct KArgs {
     const double* poses;           // [n_slots][6]
     const double* extr;            // [n_cams][6]
     double huber_delta;
-    double kb4_eps;                // ccal_model_conventions.kb4_small_radius of the context
+    ModelRt rt;                    // the context's run-time conventions (KB4 threshold, OPENCV5 coefficient order)
     int32_t apply_loss;
     double* r_out;                 // mode E
     double* J_out;
@@ -62,7 +62,18 @@ struct ccal_ctx {
     // (created on first use, joined when the context is freed; ccal_solver.hip)
     struct ccal_ctx_worker* worker = nullptr;
 };
-namespace ccal { void ctx_worker_destroy(ccal_ctx* ctx); }
+namespace ccal {
+void ctx_worker_destroy(ccal_ctx* ctx);
+// the context's conventions as the kernels take them
+inline ModelRt model_rt(const ccal_ctx* ctx) {
+    ModelRt rt = {};
+    rt.kb4_eps = ctx->conv.kb4_small_radius; rt.unproject_eps = ctx->conv.unproject_small_radius;
+    rt.ocv5_perm = 0;
+    for (int i = 0; i < 5; ++i) rt.ocv5_perm |= (uint32_t)(ctx->conv.ocv5_order[i] & 7) << (3 * i);
+    return rt;
+}
+inline bool ocv5_identity(const ccal_ctx* ctx) { return model_rt(ctx).ocv5_perm == kOcv5IdentityPerm; }
+}  // namespace ccal
 
 struct ccal_problem {
     ccal_ctx* ctx = nullptr;

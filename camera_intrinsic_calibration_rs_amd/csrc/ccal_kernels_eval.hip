@@ -69,7 +69,7 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     const int n = (int)(a.obs_off[o + 1] - start);
     const double* th_g = a.intr + a.cam * CCAL_PMAX;
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
 
     // software prefetch: the first pass's corner rows are requested before the (latency-bound) exponential map below,
     // every later pass one pass ahead - one exposed memory latency per frame instead of one per pass (it is the read
@@ -133,6 +133,18 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         double* row = tile + lane * TS;
 #pragma unroll
         for (int i = 0; i < D; ++i) *reinterpret_cast<double2*>(row + 2 * i) = make_double2(J[2 * i], J[2 * i + 1]);
+        if constexpr (MODEL == kOCV5) {
+            // the block's columns follow the CALLER's parameter order: under a non-default ccal_model_conventions.ocv5_order
+            // the five distortion columns of both rows move (wave-uniform branch, never taken with OpenCV's own order)
+            if (a.rt.ocv5_perm != kOcv5IdentityPerm) {
+                constexpr int D0 = OF ? 3 : 4;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    const int at = D0 + ocv5_pos(a.rt.ocv5_perm, i);
+                    row[at] = J[D0 + i]; row[D + at] = J[D + D0 + i];
+                }
+            }
+        }
         wave_lds_sync();
         // contiguous tile of J_out: 16 B per lane, 1 KiB per wave-instruction
         const int nv = min(64, n - base);
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
     const int n = (int)(a.obs_off[o + 1] - start);
     const double* th_g = a.intr + a.cam * CCAL_PMAX;
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
     {
         double pose[6], ex[6];
 #pragma unroll

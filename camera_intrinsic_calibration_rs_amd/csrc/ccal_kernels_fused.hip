@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     const int es = first ? cur : (cur ^ 1);
     const double* th_g = a.intr[es];
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[f];
     const int n = (int)(a.obs_off[f + 1] - start);
     // software prefetch: the first pass's corner rows are requested before the (long, latency-bound)
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     }
     const double* th_g = a.intr[es];
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
     float pX, pY, pZ, pU, pV;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     }
     const double* th_g = a.intr[es];
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
     float pX, pY, pZ, pU, pV;

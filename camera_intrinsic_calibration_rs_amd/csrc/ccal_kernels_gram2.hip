@@ -249,7 +249,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
     const int cl = gl;                              // every lane has its own corner: LPF corners of a frame per pass
     const double* th_g = a.intr[es];
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
     float pX, pY, pZ, pU, pV;

@@ -15,7 +15,7 @@ namespace ccal {
 // KB4 Newton on theta; OPENCV5 fixed-point undistortion).  Returns false where the reference's
 // `unproject` yields None (outside the model's domain) or the ray is not in front of the camera.
 template <int MODEL>
-__device__ __forceinline__ bool unproject_normalized(const double* th, double u, double v, double& xn, double& yn) {
+__device__ __forceinline__ bool unproject_normalized(const double* th, double small_radius, double u, double v, double& xn, double& yn) {
     const double mx = (u - th[2]) / th[0], my = (v - th[3]) / th[1];
     const double r2 = mx * mx + my * my;
     if constexpr (MODEL == kUCM || MODEL == kEUCM) {
@@ -29,7 +29,7 @@ __device__ __forceinline__ bool unproject_normalized(const double* th, double u,
         return true;
     } else if constexpr (MODEL == kKB4) {
         const double r = sqrt(r2);
-        if (r < kUnprojectSmallRadius) { xn = mx; yn = my; return true; }
+        if (r < small_radius) { xn = mx; yn = my; return true; }
         double t = r;
         for (int it = 0; it < 10; ++it) {
             const double t2 = t * t;
@@ -68,6 +68,7 @@ struct InitArgs {
     double* poses_obs;      // [n_obs][6]  T_cam_board
     int32_t* valid_obs;     // [n_obs]     number of corners used, 0 = no pose
     int32_t min_points;
+    ModelRt rt;             // the context's run-time conventions
 };
 
 template <int MODEL>
@@ -78,9 +79,8 @@ __global__ __launch_bounds__(256) void k_pose_init(const InitArgs a) {
     const int o = __builtin_amdgcn_readfirstlane(a.list[widx]);
     const int64_t start = a.obs_off[o];
     const int n = (int)(a.obs_off[o + 1] - start);
-    double th[model_np(MODEL)];
-#pragma unroll
-    for (int i = 0; i < model_np(MODEL); ++i) th[i] = a.intr[a.cam * CCAL_PMAX + i];
+    double th[th_len<MODEL>()];
+    load_theta<MODEL, false>(a.intr + a.cam * CCAL_PMAX, a.rt, th);
 
     double M[36], rhs[8];            // upper triangle of A^T A (row-major packed) and A^T b
 #pragma unroll
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_pose_init(const InitArgs a) {
         const double X = a.x[g], Y = a.y[g];
         if (a.z[g] != 0.0f) nonplanar = 1;
         double xn, yn;
-        if (!unproject_normalized<MODEL>(th, (double)a.u[g], (double)a.v[g], xn, yn)) continue;
+        if (!unproject_normalized<MODEL>(th, a.rt.unproject_eps, (double)a.u[g], (double)a.v[g], xn, yn)) continue;
         ++cnt;
         const double r1[8] = { X, Y, 1.0, 0.0, 0.0, 0.0, -xn * X, -xn * Y };
         const double r2[8] = { 0.0, 0.0, 0.0, X, Y, 1.0, -yn * X, -yn * Y };
@@ -183,7 +183,7 @@ hipError_t launch_pose_init(const ccal_problem* p, int cam, const double* d_intr
     InitArgs a = {};
     a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
     a.obs_off = p->d_obs_off; a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
-    a.intr = d_intr; a.poses_obs = d_poses_obs; a.valid_obs = d_valid; a.min_points = min_points;
+    a.intr = d_intr; a.poses_obs = d_poses_obs; a.valid_obs = d_valid; a.min_points = min_points; a.rt = model_rt(p->ctx);
     const int blocks = (a.n_list + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (blocks == 0) return hipSuccess;
     switch (p->cams[cam].model) {

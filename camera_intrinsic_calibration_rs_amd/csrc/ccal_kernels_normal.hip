@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_gram(const GramArgs ga) {
     const int n = (int)(a.obs_off[o + 1] - start);
     const double* th_g = p_intr + a.cam * CCAL_PMAX;
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.kb4_eps, th);
+    load_theta<MODEL, OF>(th_g, a.rt, th);
     {
         double pose[6], ex[6];
 #pragma unroll
@@ -246,7 +246,7 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
     a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = cand ? p->d_intr_c : p->d_intr; a.poses = cand ? p->d_poses_c : p->d_poses; a.extr = cand ? p->d_extr_c : p->d_extr;
-    a.huber_delta = p->huber_delta; a.kb4_eps = p->ctx->conv.kb4_small_radius;
+    a.huber_delta = p->huber_delta; a.rt = model_rt(p->ctx);
     ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf];
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
 }
@@ -261,7 +261,7 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
         fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
         fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
         fa.list = p->cams[cam].d_obs; fa.n_obs = (int32_t)p->cams[cam].obs.size(); fa.rec_off = w->d_goff;
-        fa.K = p->cams[cam].Peff; fa.huber_delta = p->huber_delta; fa.kb4_eps = p->ctx->conv.kb4_small_radius;
+        fa.K = p->cams[cam].Peff; fa.huber_delta = p->huber_delta; fa.rt = model_rt(p->ctx);
         fa.intr[0] = p->d_intr + cam * CCAL_PMAX; fa.intr[1] = p->d_intr_c + cam * CCAL_PMAX;
         fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
         fa.extr[0] = p->d_extr; fa.extr[1] = p->d_extr_c; fa.cam = cam;
@@ -277,7 +277,7 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
     a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
     ga.intr2 = p->d_intr_c; ga.poses2 = p->d_poses_c; ga.extr2 = p->d_extr_c;
-    a.huber_delta = p->huber_delta; a.kb4_eps = p->ctx->conv.kb4_small_radius;
+    a.huber_delta = p->huber_delta; a.rt = model_rt(p->ctx);
     ga.goff = w->d_goff; ga.G = w->G[w->cur]; ga.cost_o = w->cost_o[w->cur]; ga.G2 = w->G[w->cur ^ 1]; ga.cost_o2 = w->cost_o[w->cur ^ 1];
     ga.st = st;
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);

@@ -209,10 +209,14 @@ static void build_cols(const ccal_problem* p, ColInfo* cols) {
         const CamLayout& cl = p->cams[c];
         for (int i = 0; i < cl.Peff; ++i) {
             ColInfo& ci = cols[cl.col_theta + i];
-            const int q = c * CCAL_PMAX + i;
+            // column i of the camera's block is the kernels' canonical parameter `full`; an OPENCV5 coefficient lives at
+            // position 4 + ocv5_order[.] of the CALLER's vector: that is where its bounds / fixed flag were set (eff index
+            // space of the caller) and where the step goes
+            int full = p->one_focal ? (i == 0 ? 0 : i + 1) : i;          // eff -> full index (fy re-inserted)
+            if (cl.model == kOCV5 && full >= 4) full = 4 + p->ctx->conv.ocv5_order[full - 4];
+            const int q = c * CCAL_PMAX + (full - (p->one_focal && full > 0 ? 1 : 0));
             ci.lo = p->lo[q]; ci.hi = p->hi[q]; ci.has_bound = p->has_bound[q]; ci.fixed = p->fixed[q];
             ci.is_extr = 0;
-            const int full = p->one_focal ? (i == 0 ? 0 : i + 1) : i;     // eff -> full index (fy re-inserted)
             ci.dst = c * CCAL_PMAX + full;
             ci.dst2 = (p->one_focal && i == 0) ? c * CCAL_PMAX + 1 : -1;
         }
@@ -220,6 +224,18 @@ static void build_cols(const ccal_problem* p, ColInfo* cols) {
             ColInfo& ci = cols[cl.col_extr + i];
             ci.is_extr = 1; ci.dst = c * 6 + i; ci.dst2 = -1;
         }
+    }
+}
+
+// reduced-system column (the kernels' canonical parameter order) -> the same parameter's column in the CALLER's order
+// (differs only for OPENCV5 cameras under a non-default ccal_model_conventions.ocv5_order)
+static void caller_columns(const ccal_problem* p, int* ext) {
+    for (int k = 0; k < p->K; ++k) ext[k] = k;
+    for (int c = 0; c < p->n_cams; ++c) {
+        const CamLayout& cl = p->cams[c];
+        if (cl.model != kOCV5) continue;
+        const int shift = p->one_focal ? 1 : 0;
+        for (int d = 0; d < 5; ++d) ext[cl.col_theta + 4 - shift + d] = cl.col_theta + 4 - shift + p->ctx->conv.ocv5_order[d];
     }
 }
 
@@ -280,7 +296,7 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
     fa.n_obs = p->n_obs; fa.K = p->K; fa.PF = w->PF; fa.PRAW = f->PRAW; fa.n_pw = f->n_pw;
     fa.fcbuf = f->fcbuf; fa.mc_f = f->mc_f; fa.cost_f = f->cost_f;
-    fa.huber_delta = p->huber_delta; fa.min_diag = min_diag; fa.max_diag = max_diag; fa.kb4_eps = p->ctx->conv.kb4_small_radius;
+    fa.huber_delta = p->huber_delta; fa.min_diag = min_diag; fa.max_diag = max_diag; fa.rt = model_rt(p->ctx);
     fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
     fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
@@ -692,6 +708,8 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
     if ((rc = ccal_build_normal_dev(p, lambda)) != CCAL_OK) return rc;
     const int K = w->K, K1 = K + 1;
     double failed = 0.0;
+    int ec[CCAL_KMAX];
+    caller_columns(p, ec);                   // S and b leave in the caller's parameter order
     if (w->red_fused) {
         // [A_dir | Y^T Y | . | failed]: S = A_dir - Y^T Y on the camera block, b its last column, cost = the r x r corner of A_dir
         double* h = w->fws->h_stage;
@@ -701,9 +719,9 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
         if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
             double v = A[i * K1 + j] - Y[i * K1 + j];
             if (i == j && lambda > 0.0) v += lambda * std::min(std::max(A[i * K1 + i], 1e-6), 1e32);
-            S[i * K + j] = v;
+            S[ec[i] * K + ec[j]] = v;
         }
-        if (b) for (int i = 0; i < K; ++i) b[i] = A[i * K1 + K] - Y[i * K1 + K];
+        if (b) for (int i = 0; i < K; ++i) b[ec[i]] = A[i * K1 + K] - Y[i * K1 + K];
         if (cost) *cost = A[K * K1 + K];
         failed = h[2 * K1 * K1 + 1];
     } else {
@@ -715,9 +733,9 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
         if (S) for (int i = 0; i < K; ++i) for (int j = 0; j < K; ++j) {
             double v = h[i >= j ? i * K1 + j : j * K1 + i];
             if (i == j && lambda > 0.0) v += lambda * std::min(std::max(hd[i], 1e-6), 1e32);
-            S[i * K + j] = v;
+            S[ec[i] * K + ec[j]] = v;
         }
-        if (b) for (int i = 0; i < K; ++i) b[i] = h[K * K1 + i];
+        if (b) for (int i = 0; i < K; ++i) b[ec[i]] = h[K * K1 + i];
         if (cost) *cost = h[w->RB - 3];
         failed = h[w->RB - 1];
     }

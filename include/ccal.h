@@ -83,12 +83,20 @@ typedef enum {                    /* camera-intrinsic-model GenericModel variant
 
 /* What this build assumes about the crate camera-intrinsic-model 0.8 (Cargo.toml:25; its source is not part of the
  * reference tree) and can be changed at run time, per context, without rebuilding a kernel.  Defaults:
- * camera_intrinsic_calibration_rs_amd/csrc/ccal_models.hpp (which also holds the compile-time conventions: the OPENCV5
- * parameter order and the unprojection thresholds). */
+ * camera_intrinsic_calibration_rs_amd/csrc/ccal_models.hpp. */
 typedef struct {
     double kb4_small_radius;       /* KB4 project_one: sqrt(x^2+y^2) <= this -> pinhole limit.  Default 1e-8 */
-    double dist_lo[4][5];          /* [ccal_model][i]: lower / upper bound of distortion parameter 4 + i, i.e. what */
-    double dist_hi[4][5];          /* distortion_params_bound() returns (applied at src/util.rs:40-48)             */
+    double dist_lo[4][5];          /* [ccal_model][i]: lower / upper bound of distortion parameter i in the order of the     */
+    double dist_hi[4][5];          /* model rows of ccal_model above (OPENCV5: k1, k2, p1, p2, k3 whatever ocv5_order says), */
+                                   /* i.e. what distortion_params_bound() returns (applied at src/util.rs:40-48)             */
+    double unproject_small_radius; /* unprojection (pose initialisation, convert_model's rays): image-plane radius below which
+                                      the ray is the optical axis.  Default 1e-8 */
+    int32_t ocv5_order[5];         /* WHERE k1, k2, p1, p2, k3 sit among the five distortion parameters of an OPENCV5 params()
+                                      vector: parameter 4 + ocv5_order[i] is k1 (i = 0), k2, p1, p2, k3 (i = 4).  Default
+                                      {0, 1, 2, 3, 4} = OpenCV's own order.  Every array of this ABI that follows the parameter
+                                      order (intrinsics in / out, eff indices of bounds and fixed parameters, Jacobian and
+                                      normal-equation columns, "the last k distortion parameters") follows THIS order */
+    int32_t reserved_;
 } ccal_model_conventions;
 
 typedef struct ccal_ctx ccal_ctx;          /* one GPU + one HIP stream; single caller */
