@@ -287,17 +287,6 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
 // k_schur: persistent wavefronts, each walks frame slots with stride (number of waves) and keeps the
 // reduced system A[(K+1)^2] + extras in its own LDS accumulators (flushed once at the end).
 // ---------------------------------------------------------------------------------------------
-struct SchurArgs {
-    const double* G;
-    const int64_t* slot_desc;      // per (slot, observation) in slot order: goff * 8 + camera - one load instead of three
-    const int32_t* slot_off; const int32_t* caminfo; int32_t n_cams;
-    int32_t n_slots, K, RB, PF, n_pw;
-    int32_t STG;                   // per-wavefront staging (doubles) for record-format observations, 0 = none
-    double lambda, min_diag, max_diag;
-    double* partial; double* pf; const double* mc_slot;
-    const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
-};
-
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
 #ifndef CCAL_SCHUR_MINW
@@ -567,7 +556,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     const NormalWs* w = p->nws;
     SchurArgs a = {};
     a.st = st; a.G2 = w->G[gbuf ^ 1];
-    a.G = w->G[gbuf]; a.slot_desc = w->d_slot_desc; a.slot_off = w->d_slot_off;
+    a.G = w->G[gbuf]; a.slot_desc = w->schurq ? w->d_slot_rec : w->d_slot_desc; a.slot_off = w->d_slot_off;
     a.caminfo = w->d_caminfo; a.n_cams = p->n_cams;
     a.n_slots = p->n_slots; a.K = w->K; a.RB = w->RB; a.PF = w->PF; a.n_pw = w->n_pw;
     a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
@@ -583,6 +572,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     if (!w->register_gram) for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
     const size_t lds = sizeof(double) * ((size_t)WS * WAVES_PER_BLOCK + tab_entries);
     static DynLdsGuard lds_guard;
+    if (w->schurq) return launch_schurq(a, p->cams[0].Peff, w->n_rows, s);
     const int blocks = (w->n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (w->register_gram) {
         static DynLdsGuard lds_guard_rec;
@@ -618,7 +608,7 @@ __global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw,
 }
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_pw / WAVES_PER_BLOCK, w->red, st);
+    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_rows, w->red, st);
     return hipGetLastError();
 }
 

@@ -1,0 +1,472 @@
+// k_schurq: the per-slot elimination of a TWO-camera rig whose cameras have the same number of free intrinsics (same model,
+// same focal mode - the reference's stereo case, e.g. TUM-VI cam0 + cam1), with FOUR LANES per frame slot and everything
+// about the layout known at compile time.
+//
+// k_schur (ccal_kernels_normal.hip) is generic in the number of cameras and their block sizes: every phase of a slot carries
+// run-time index arithmetic, table look-ups, exec-mask regions and a wavefront hand-off, ~750 - 1 250 instructions per slot
+// however the lanes are arranged (a 16-lanes-per-slot variant of it measured 38 us against 29.6 us: the time goes with the
+// instruction count, not with the idle lanes).  Here the system is [theta_0 (PE) | theta_1 (PE) | extrinsics (6) | r], all
+// loops are unrolled, every LDS address is a per-lane base plus a constant, a wavefront works on 16 slots in straight-line
+// code and the four lanes of a slot share the work by "index = q (mod 4)".  ~2 000 instructions per wavefront = ~125 per slot.
+//
+// Sums are reproducible: a slot's contributions go to the slot's own image of the reduced system in LDS in program order,
+// the 16 images of a wavefront are added in a fixed order, one row of partial sums per wavefront goes to k_reduce.
+// Inputs / outputs as k_schur<true>: GEN records of the register Gram kernels (ccal_fused.hpp), slot records pf for
+// k_backsub.  Reference contract: the linear solve of one tiny-solver step (src/util.rs:670).
+#include <algorithm>
+#include <cstdlib>
+
+#include "ccal_gram_common.hpp"
+#include "ccal_normal.hpp"
+
+namespace ccal {
+
+constexpr int SQ_SLOTS = 16;       // frame slots per wavefront
+
+// entry e of a row-major lower triangle -> (i, j)
+__device__ __forceinline__ void sq_tri_decode(int e, int& i, int& j) {
+    i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    if ((i + 1) * (i + 2) / 2 <= e) ++i;
+    if (i * (i + 1) / 2 > e) --i;
+    j = e - i * (i + 1) / 2;
+}
+__device__ __forceinline__ void sq_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__host__ __device__ constexpr int sq_tri(int i, int j) { return i * (i + 1) / 2 + j; }
+
+// per-slot LDS area (doubles)
+template <int PE> struct SqLayout {
+    static constexpr int K1c = PE + 1, K = 2 * PE + 6, K1 = K + 1, NT = K1 * (K1 + 1) / 2;
+    static constexpr int XH = NT, XG = NT + K, XC = NT + 2 * K, XM = XC + 1, XF = XC + 2, ACCN = XC + 3;
+    static constexpr int HS = 36 + 6 * K1c;                              // record head: C | [B|g]^T
+    static constexpr int H0 = 0, E0 = HS, H1 = HS + 36, E1 = 2 * HS + 36;   // staging of the two records (E^T: 6 rows / 12 rows)
+    static constexpr int STG = 2 * HS + 108;
+    static constexpr int IMG = 0;                                        // the slot's image of the reduced system: over the (dead) staging
+    static constexpr int YL = ((STG > ACCN ? STG : ACCN) + 1) & ~1;       // [B|g] of the slot, then Y: K1 columns of 6
+    static constexpr int CX = YL + 6 * K1;                               // C of the slot (6 x 6)
+    static constexpr int DUM = CX + 36;                                  // one double per lane for sums nobody wants
+    static constexpr int SS0 = DUM + 4;
+    static constexpr int SS = SS0 + ((2 - SS0 % 4) + 4) % 4;              // = 2 (mod 4): the 16 slots' 16-byte pieces of a broadcast read fall into 16 different bank groups
+};
+
+#ifdef CCAL_STAMPS      // diagnostic build: 100 MHz clock at the phase boundaries, parked behind the partial sums (tools/stamps_sq.py)
+#define SQ_STAMP(i) do { sq_stamps[i] = wall_clock64(); } while (0)
+#else
+#define SQ_STAMP(i) do { } while (0)
+#endif
+
+template <int PE>
+__global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
+#ifdef CCAL_STAMPS
+    long long sq_stamps[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    SQ_STAMP(0);
+    using Lt = SqLayout<PE>;
+    constexpr int K1c = Lt::K1c, K = Lt::K, K1 = Lt::K1, NT = Lt::NT, HS = Lt::HS, ACCN = Lt::ACCN;
+    constexpr int CT0 = 0, CT1 = PE, CE = 2 * PE;
+    constexpr int TR = (K1c + 3) / 4;                       // rows of a record's [B|g]^T per lane
+    constexpr int TY = (K1 + 3) / 4;                        // columns / rows of the slot's Y per lane
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (a.st && a.st->done) return;
+    const double* p_G = (a.st && schur_set(a.st) == 1) ? a.G2 : a.G;
+    const double lambda = a.st ? schur_lambda(a.st) : a.lambda;
+    const int lane = threadIdx.x, sl = lane >> 2, q = lane & 3;
+    const int s = blockIdx.x * SQ_SLOTS + sl;
+    const bool has = s < a.n_slots;
+    double* sb = smem + sl * Lt::SS;
+    double* dum = sb + Lt::DUM + q;
+
+    // ---- the two records of the slot -> LDS (16 bytes per lane and load; a missing record is a record of zeros)
+    const int64_t d0 = has ? a.slot_desc[2 * (int64_t)s] : -1, d1 = has ? a.slot_desc[2 * (int64_t)s + 1] : -1;
+    const bool live = d0 >= 0 || d1 >= 0;
+    const double mc_s = (has && q == 0) ? a.mc_slot[s] : 0.0;          // model decrease of this slot's pose block for the step under decision
+    // the camera | r blocks of the records: this lane's rows i = q + 4 t of the lower triangles, straight from HBM into
+    // registers (they are direct terms of the reduced system, wanted only once the products are done)
+    double av[2][TR][K1c];
+    {
+        constexpr int NH = HS / 2;                                      // 16-byte pieces of a head
+        constexpr int TH = (NH + 3) / 4;
+        const double* r0 = p_G + (d0 >= 0 ? d0 : 0);
+        const double* r1 = p_G + (d1 >= 0 ? d1 : 0);
+        const double2* g0 = reinterpret_cast<const double2*>(r0);
+        const double2* g1 = reinterpret_cast<const double2*>(r1);
+        const double2 z2 = { 0.0, 0.0 };
+        double2* w = reinterpret_cast<double2*>(sb);
+        {
+            double2 h0[TH], e0[5];
+#pragma unroll
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h0[t] = (d0 >= 0 && c < NH) ? g0[c] : z2; }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; e0[t] = (d0 >= 0 && c < 18) ? g0[gen_e_off(PE) / 2 + c] : z2; }
+#pragma unroll
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H0 / 2 + c] = h0[t]; }
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; if (c < 18) w[Lt::E0 / 2 + c] = e0[t]; }
+        }
+        {
+            double2 h1[TH], e1[9];
+#pragma unroll
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h1[t] = (d1 >= 0 && c < NH) ? g1[c] : z2; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { const int c = q + 4 * t; e1[t] = d1 >= 0 ? g1[gen_e_off(PE) / 2 + c] : z2; }
+#pragma unroll
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H1 / 2 + c] = h1[t]; }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { const int c = q + 4 * t; w[Lt::E1 / 2 + c] = e1[t]; }
+        }
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const int i = q + 4 * t;
+#pragma unroll
+            for (int j = 0; j < K1c; ++j) {
+                if (j > 4 * t + 3) { av[0][t][j] = 0.0; av[1][t][j] = 0.0; continue; }      // compile time: j <= i impossible
+                const bool in = i < K1c && j <= i;
+                av[0][t][j] = (in && d0 >= 0) ? r0[HS + i * K1c + j] : 0.0;
+                av[1][t][j] = (in && d1 >= 0) ? r1[HS + i * K1c + j] : 0.0;
+            }
+        }
+    }
+    wsync();
+    SQ_STAMP(1);
+
+    // ---- products with E (frame_setup_composed): E_p = diag(M, N) maps the composed pose's (phi, delta) to (rvec_0_b, tvec_0_b),
+    // E_x (camera 1) to (rvec_1_0, tvec_1_0).  E^T rows b: M(m, b) = Et[6 b + m], N(m, b) = Et[21 + 6 b + m]  (b, m < 3)
+    double racc[6] = { 0, 0, 0, 0, 0, 0 };                  // [B|g] column r: both cameras' row r meet in the same lane
+    double cmb[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };          // this lane's 3 x 3 block (rh, ch) of the slot's C
+    double cross[TR][6];                                    // camera 1: rows of [B|g]^T times E_x -> theta_1 (| r) x extrinsics
+    double xx[2][6];                                        // E_x^T (C E_x) columns j = q, q + 4
+    const int rh = q >> 1, ch = q & 1;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double* H = sb + (c == 0 ? Lt::H0 : Lt::H1);
+        const double* Et = sb + (c == 0 ? Lt::E0 : Lt::E1);
+        // E_p^T rows 0..5 in registers
+        double ep[6][6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double2* r = reinterpret_cast<const double2*>(Et + 6 * b);
+            const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+            ep[b][0] = r0.x; ep[b][1] = r0.y; ep[b][2] = r1.x; ep[b][3] = r1.y; ep[b][4] = r2.x; ep[b][5] = r2.y;
+        }
+        {   // block (rh, ch) of E_p^T C E_p = P_rh^T C_(rh,ch) P_ch,  P_0 = M, P_1 = N
+            double cb[3][3], pr[3][3], pc[3][3], tm[3][3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    cb[m][n] = H[(3 * rh + m) * 6 + 3 * ch + n];
+                    pr[m][n] = Et[21 * rh + 6 * n + m];       // P_rh(m, n)
+                    pc[m][n] = Et[21 * ch + 6 * n + m];
+                }
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) tm[m][n] = cb[m][0] * pc[0][n] + cb[m][1] * pc[1][n] + cb[m][2] * pc[2][n];
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int n = 0; n < 3; ++n) cmb[3 * m + n] += pr[0][m] * tm[0][n] + pr[1][m] * tm[1][n] + pr[2][m] * tm[2][n];
+        }
+        double ex[6][6];                                    // camera 1: E_x^T rows j (E^T rows 6 + j)
+        if (c == 1) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const double2* r = reinterpret_cast<const double2*>(Et + 36 + 6 * j);
+                const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+                ex[j][0] = r0.x; ex[j][1] = r0.y; ex[j][2] = r1.x; ex[j][3] = r1.y; ex[j][4] = r2.x; ex[j][5] = r2.y;
+            }
+        }
+        // rows i = q + 4 t of [B|g]^T: E_p^T b_i -> column theta_c,i of the slot's [B|g] (i = PE: the r column)
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const int i = q + 4 * t, ic = i < K1c ? i : 0;
+            const double2* r = reinterpret_cast<const double2*>(H + 36 + 6 * ic);
+            const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+            const double bi[6] = { r0.x, r0.y, r1.x, r1.y, r2.x, r2.y };
+            double y[6];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                y[b] = ep[b][0] * bi[0] + ep[b][1] * bi[1] + ep[b][2] * bi[2];
+                y[3 + b] = ep[3 + b][3] * bi[3] + ep[3 + b][4] * bi[4] + ep[3 + b][5] * bi[5];
+            }
+            const bool is_r = i == PE;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) racc[k] += is_r ? y[k] : 0.0;
+            if (i < PE) {
+                double2* yo = reinterpret_cast<double2*>(sb + Lt::YL + 6 * ((c == 0 ? CT0 : CT1) + i));
+                yo[0] = double2{ y[0], y[1] }; yo[1] = double2{ y[2], y[3] }; yo[2] = double2{ y[4], y[5] };
+            }
+            if (c == 1) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    cross[t][j] = ((ex[j][0] * bi[0] + ex[j][1] * bi[1]) + (ex[j][2] * bi[2] + ex[j][3] * bi[3])) + (ex[j][4] * bi[4] + ex[j][5] * bi[5]);
+            }
+        }
+        if (c == 1) {
+            // columns j = q, q + 4 of E_x: z = C E_x[:, j];  E_p^T z -> extrinsics column of [B|g];  E_x^T z -> extrinsics block
+            double z[2][6];
+            double exj[2][6];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = q + 4 * t, jc = j < 6 ? j : 0;
+                const double2* r = reinterpret_cast<const double2*>(Et + 36 + 6 * jc);
+                const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+                exj[t][0] = r0.x; exj[t][1] = r0.y; exj[t][2] = r1.x; exj[t][3] = r1.y; exj[t][4] = r2.x; exj[t][5] = r2.y;
+            }
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                const double2* r = reinterpret_cast<const double2*>(H + 6 * m);
+                const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    z[t][m] = ((r0.x * exj[t][0] + r0.y * exj[t][1]) + (r1.x * exj[t][2] + r1.y * exj[t][3])) + (r2.x * exj[t][4] + r2.y * exj[t][5]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int j = q + 4 * t;
+                double y[6];
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    y[b] = ep[b][0] * z[t][0] + ep[b][1] * z[t][1] + ep[b][2] * z[t][2];
+                    y[3 + b] = ep[3 + b][3] * z[t][3] + ep[3 + b][4] * z[t][4] + ep[3 + b][5] * z[t][5];
+                }
+                if (j < 6) {
+                    double2* yo = reinterpret_cast<double2*>(sb + Lt::YL + 6 * (CE + j));
+                    yo[0] = double2{ y[0], y[1] }; yo[1] = double2{ y[2], y[3] }; yo[2] = double2{ y[4], y[5] };
+                }
+#pragma unroll
+                for (int jp = 0; jp < 6; ++jp)
+                    xx[t][jp] = ((ex[jp][0] * z[t][0] + ex[jp][1] * z[t][1]) + (ex[jp][2] * z[t][2] + ex[jp][3] * z[t][3])) + (ex[jp][4] * z[t][4] + ex[jp][5] * z[t][5]);
+            }
+        }
+    }
+    if (q == (PE & 3)) {                                    // the lane that had row r of both records
+        double2* yo = reinterpret_cast<double2*>(sb + Lt::YL + 6 * K);
+        yo[0] = double2{ racc[0], racc[1] }; yo[1] = double2{ racc[2], racc[3] }; yo[2] = double2{ racc[4], racc[5] };
+    }
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) sb[Lt::CX + (3 * rh + m) * 6 + 3 * ch + n] = cmb[3 * m + n];
+    wsync();
+    SQ_STAMP(2);
+
+    // ---- C + lambda clamp(diag C) = L L^T: the four lanes of a slot run the same 6 x 6 factorisation
+    double L[21], dC[6];
+    bool ok = true;
+    {
+        double cm[21];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) cm[i * (i + 1) / 2 + j] = sb[Lt::CX + i * 6 + j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            dC[i] = cm[i * (i + 1) / 2 + i];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double t = cm[i * (i + 1) / 2 + j];
+                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
+#pragma unroll
+                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+                if (i == j) {
+                    ok = ok && (t > 0.0) && (t < 1.7e308);
+                    double sq, rsq;
+                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
+                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;                  // diagonal stored inverted
+                } else {
+                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
+                }
+            }
+        }
+    }
+    const bool go = live && ok;
+    SQ_STAMP(3);
+    double* pf = a.pf + (int64_t)(has ? s : 0) * a.PF;
+    double* img = sb + Lt::IMG;
+    // ---- the slot's image of the reduced system (over the staging, dead now): zero, then the direct terms
+    {
+        double2* w = reinterpret_cast<double2*>(img);
+#pragma unroll
+        for (int t = 0; t < (ACCN / 2 + 4) / 4; ++t) { const int c = q + 4 * t; if (c < (ACCN + 1) / 2) w[c] = double2{ 0.0, 0.0 }; }
+    }
+    wsync();
+    if (q == 0) {
+        if (has) img[Lt::XM] = mc_s;
+        if (live && !ok) img[Lt::XF] = 1.0;                  // failed pose block (all-reduced with the sums: every rank sees it)
+    }
+    // Direct terms: every entry has ONE writer (plain stores over the zeros), except (r, r) = cost, where the two records'
+    // entries meet in the same lane.  camera | r blocks of the records (rows i = q + 4 t): + hdiag, g_c, cost
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+        const int i = q + 4 * t;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int ct = c == 0 ? CT0 : CT1;
+            const int ii = i < PE ? ct + i : K, rowb = ii * (ii + 1) / 2;
+#pragma unroll
+            for (int j = 0; j < PE; ++j) {
+                if (j > 4 * t + 3) continue;                 // compile time: j <= i impossible
+                const double v = av[c][t][j];
+                const bool in = i < K1c && j <= i;
+                *(in ? img + rowb + ct + j : dum) = v;
+                *((in && i == PE) ? img + Lt::XG + ct + j : ((in && i == j) ? img + Lt::XH + ii : dum)) = v;
+            }
+        }
+        if (PE / 4 == t) {                                   // compile time: the row of r is among this t's rows
+            const double v = av[0][t][PE] + av[1][t][PE];
+            *(i == PE ? img + sq_tri(K, K) : dum) = v;
+            *(i == PE ? img + Lt::XC : dum) = v;
+        }
+    }
+    // camera 1: theta_1 (| r) x extrinsics, extrinsics x extrinsics
+#pragma unroll
+    for (int t = 0; t < TR; ++t) {
+        const int i = q + 4 * t;
+        const int col = i < PE ? CT1 + i : K;                // i == PE: row r of the system (g_c of the extrinsic columns)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int hi = i < PE ? CE + j : K, lo = i < PE ? col : CE + j;
+            *(i < K1c ? img + hi * (hi + 1) / 2 + lo : dum) = cross[t][j];
+            if (PE / 4 == t) *(i == PE ? img + Lt::XG + CE + j : dum) = cross[t][j];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int j = q + 4 * t;
+#pragma unroll
+        for (int jp = 0; jp < 6; ++jp) {
+            if (jp < 4 * t) continue;                        // compile time: jp >= j impossible
+            const bool in = j < 6 && jp >= j;
+            *(in ? img + sq_tri(CE + jp, 0) + CE + j : dum) = xx[t][jp];
+            if (jp <= 4 * t + 3) *((in && jp == j) ? img + Lt::XH + CE + j : dum) = xx[t][jp];
+        }
+    }
+    SQ_STAMP(4);
+    // ---- Y = L^-1 [B | g_p], columns c = q + 4 t, in place; the slot's record for k_backsub
+    if (has && !go) for (int e = q; e < a.PF; e += 4) pf[e] = 0.0;          // no observations or a failed block
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+        const int c = q + 4 * t, cc = c < K1 ? c : 0;
+        double2* yp = reinterpret_cast<double2*>(sb + Lt::YL + 6 * cc);
+        const double2 b0 = yp[0], b1 = yp[1], b2 = yp[2];
+        const double bc[6] = { b0.x, b0.y, b1.x, b1.y, b2.x, b2.y };
+        double y[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double v = bc[i];
+#pragma unroll
+            for (int k = 0; k < i; ++k) v -= L[i * (i + 1) / 2 + k] * y[k];
+            y[i] = go ? v * L[i * (i + 1) / 2 + i] : 0.0;
+        }
+        if (c < K1) {
+            yp[0] = double2{ y[0], y[1] }; yp[1] = double2{ y[2], y[3] }; yp[2] = double2{ y[4], y[5] };
+            if (go) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) pf[21 + i * K1 + c] = y[i];
+                if (c == K) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
+                }
+            }
+        }
+    }
+    if (go) {
+        // L (21) and diag C (6): every lane holds them; lane q stores entries q, q + 4, ...
+#pragma unroll
+        for (int e = 0; e < 21; ++e) if ((e & 3) == q) pf[e] = L[e];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) if ((e & 3) == q) pf[21 + 6 * K1 + 6 + e] = dC[e];
+    }
+    wsync();
+    SQ_STAMP(5);
+    // ---- image -= Y^T Y: rows i = q + 4 t of the lower triangle, the columns j stream through (one read serves all of a lane's rows)
+    {
+        double yi[TY][6];
+        int rowb[TY];
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+            const int i = q + 4 * t, ic = i < K1 ? i : 0;
+            const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * ic);
+            const double2 r0 = r[0], r1 = r[1], r2 = r[2];
+            yi[t][0] = r0.x; yi[t][1] = r0.y; yi[t][2] = r1.x; yi[t][3] = r1.y; yi[t][4] = r2.x; yi[t][5] = r2.y;
+            rowb[t] = i * (i + 1) / 2;
+        }
+        // software pipeline by hand: column j + 1 (Y_j and the direct terms under it) is read before column j is worked on -
+        // one writer per entry, plain read - modify - write (a ds_add_f64 per entry cost 32 cycles of the LDS pipe each)
+        double2 c0[2], c1[2], c2[2];
+        double dv[2][TY];
+        auto fetch = [&](const int j, const int b) {
+            const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * j);
+            c0[b] = r[0]; c1[b] = r[1]; c2[b] = r[2];
+#pragma unroll
+            for (int t = 0; t < TY; ++t) {
+                if (4 * t + 3 < j) continue;                 // compile time: every row of this t lies above column j
+                const int i = q + 4 * t;
+                dv[b][t] = *((i < K1 && j <= i) ? img + rowb[t] + j : dum);
+            }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int j = 0; j < K1; ++j) {
+            const int b = j & 1;
+            if (j + 1 < K1) fetch(j + 1, b ^ 1);
+#pragma unroll
+            for (int t = 0; t < TY; ++t) {
+                if (4 * t + 3 < j) continue;
+                const int i = q + 4 * t;
+                const double v = ((yi[t][0] * c0[b].x + yi[t][1] * c0[b].y) + (yi[t][2] * c1[b].x + yi[t][3] * c1[b].y)) + (yi[t][4] * c2[b].x + yi[t][5] * c2[b].y);
+                *((i < K1 && j <= i) ? img + rowb[t] + j : dum) = dv[b][t] - v;
+            }
+        }
+    }
+    wsync();
+    SQ_STAMP(6);
+    // ---- the wavefront's 16 images in a fixed order -> one row of partial sums (k_reduce's layout: the full (K+1)^2 image,
+    // lower triangle filled, then the extras)
+    for (int e = lane; e < K1 * K1 + 2 * K + 3; e += 64) {
+        int src;
+        if (e < K1 * K1) { const int i = e / K1, j = e - i * K1; src = j <= i ? i * (i + 1) / 2 + j : -1; }
+        else src = NT + (e - K1 * K1);
+        double t = 0.0;
+        if (src >= 0) {
+#pragma unroll
+            for (int g = 0; g < SQ_SLOTS; g += 4)
+                t += (smem[g * Lt::SS + Lt::IMG + src] + smem[(g + 1) * Lt::SS + Lt::IMG + src]) + (smem[(g + 2) * Lt::SS + Lt::IMG + src] + smem[(g + 3) * Lt::SS + Lt::IMG + src]);
+        }
+        a.partial[(int64_t)e * gridDim.x + blockIdx.x] = t;
+    }
+#ifdef CCAL_STAMPS
+    sq_stamps[7] = wall_clock64();
+    if (lane == 0) for (int i = 0; i < 8; ++i) a.partial[(int64_t)a.RB * gridDim.x + 8 * blockIdx.x + i] = (double)sq_stamps[i];
+#endif
+}
+
+// two cameras, the same number of free intrinsics, the standard column layout [theta_0 | theta_1 | extrinsics_1]
+bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* col_extr) {
+    if (n_cams != 2 || peff[0] != peff[1] || peff[0] < 4 || peff[0] > 9) return false;
+    return col_theta[0] == 0 && col_theta[1] == peff[0] && col_extr[1] == 2 * peff[0];
+}
+int schurq_rows(int n_slots) { return (std::max(n_slots, 1) + SQ_SLOTS - 1) / SQ_SLOTS; }
+
+template <int PE>
+static hipError_t launch_schurq_t(const SchurArgs& a, int rows, hipStream_t s) {
+    const size_t lds = sizeof(double) * (size_t)SQ_SLOTS * SqLayout<PE>::SS;
+    static DynLdsGuard guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schurq<PE>), lds, guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_schurq<PE>, dim3(rows), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, hipStream_t s) {
+    switch (peff) {
+        case 4: return launch_schurq_t<4>(a, rows, s);
+        case 5: return launch_schurq_t<5>(a, rows, s);
+        case 6: return launch_schurq_t<6>(a, rows, s);
+        case 7: return launch_schurq_t<7>(a, rows, s);
+        case 8: return launch_schurq_t<8>(a, rows, s);
+        case 9: return launch_schurq_t<9>(a, rows, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace ccal

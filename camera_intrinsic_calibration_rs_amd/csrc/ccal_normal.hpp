@@ -37,11 +37,14 @@ struct ColInfo {          // one column of the reduced camera system
 
 struct NormalWs {
     int K = 0, RB = 0, PF = 0, n_pw = 0;
+    bool schurq = false;                       // two cameras with equal blocks: elimination with four lanes per slot (k_schurq) instead of k_schur<true>
+    int n_rows = 0;                            // rows of partial sums the elimination kernel in use writes = what k_reduce adds up
     double* G[2] = { nullptr, nullptr };       // per-observation-frame Gram blocks (current / candidate)
     double* cost_o[2] = { nullptr, nullptr };  // per-observation-frame cost
     int64_t* d_goff = nullptr;                 // [n_obs] offset of G_o
     int32_t* d_slot_off = nullptr;             // [n_slots+1] CSR slot -> observation frames
     int32_t* d_slot_obs = nullptr;
+    int64_t* d_slot_rec = nullptr;             // k_schurq: [n_slots][2] record offset of camera 0 / 1 in that slot, -1 = none
     int64_t* d_slot_desc = nullptr;            // [n_obs] in slot order: goff * 8 + camera
     int32_t* d_obs_cam = nullptr;
     int32_t* d_caminfo = nullptr;              // [n_cams][4]: Peff, col_theta, col_extr, NCP
@@ -86,6 +89,24 @@ struct FusedWs {
     bool tail_pending = false;                 // early-exit groups of the previous solve may still be in flight
 };
 
+struct DevState;
+// argument block of the per-slot elimination kernels (k_schur: ccal_kernels_normal.hip, k_schurq: ccal_kernels_schurq.hip)
+struct SchurArgs {
+    const double* G;
+    const int64_t* slot_desc;      // k_schur: per (slot, observation) in slot order: goff * 8 + camera - one load instead of three;
+                                   // k_schurq: [n_slots][2] record offset (doubles) of camera 0 / 1 in the slot, -1 = none
+    const int32_t* slot_off; const int32_t* caminfo; int32_t n_cams;
+    int32_t n_slots, K, RB, PF, n_pw;
+    int32_t STG;                   // per-wavefront staging (doubles) for record-format observations, 0 = none
+    double lambda, min_diag, max_diag;
+    double* partial; double* pf; const double* mc_slot;
+    const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
+};
+// Kept at the 128 bytes it had before k_schurq: with a ninth pointer (136 bytes) the member at offset 128 reached the
+// kernels wrong on this stack (ROCm 7.2, gfx950) whichever member it was - observed, not explained.  k_schurq takes its
+// own per-slot table through `slot_desc`.
+static_assert(sizeof(SchurArgs) == 128, "see above");
+
 void normal_ws_destroy(ccal_problem* p);
 int normal_ws_ensure(ccal_problem* p);          // allocate on first use
 int normal_upload_cols(ccal_problem* p);        // bounds / fixed flags -> device
@@ -99,6 +120,9 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool use_candidate_params
 hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s);
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
                         const DevState* st = nullptr);
+bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* col_extr);      // ccal_kernels_schurq.hip
+int schurq_rows(int n_slots);
+hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, hipStream_t s);
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st = nullptr);
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st = nullptr,
                         HostStatus* hs = nullptr, int seq = 0, bool publish_all = false);

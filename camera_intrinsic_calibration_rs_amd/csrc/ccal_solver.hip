@@ -56,7 +56,7 @@ void normal_ws_destroy(ccal_problem* p) {
         (void)hipDeviceSynchronize();
     }
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
-                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc };
+                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc, w->d_slot_rec };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
     if (w->d_gstate) (void)hipFree(w->d_gstate);
@@ -151,6 +151,14 @@ int normal_ws_ensure(ccal_problem* p) {
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
     { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm'); }
+    // two cameras with equal blocks: k_schurq;  CCAL_SCHURQ=0 (and every other rig): the generic k_schur<true>
+    {
+        int pe[CCAL_MAX_CAMS], ct[CCAL_MAX_CAMS], ce[CCAL_MAX_CAMS];
+        for (int c = 0; c < p->n_cams; ++c) { pe[c] = p->cams[c].Peff; ct[c] = p->cams[c].col_theta; ce[c] = p->cams[c].col_extr; }
+        const char* e = std::getenv("CCAL_SCHURQ");
+        w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && !(e && e[0] == '0');
+    }
+    w->n_rows = w->schurq ? schurq_rows(p->n_slots) : n_pw / WAVES_PER_BLOCK;
     std::vector<int> ncp_of(p->n_cams);
     for (int c = 0; c < p->n_cams; ++c) {
         ncp_of[c] = (p->cams[c].D + 1) <= 16 ? 16 : 32;
@@ -172,6 +180,11 @@ int normal_ws_ensure(ccal_problem* p) {
     for (int i = 0; i < p->n_obs; ++i) slot_desc[i] = goff[slot_obs[i]] * 8 + p->h_obs_cam[slot_obs[i]];
     int rc;
     if ((rc = dev_upload(ctx, &w->d_slot_desc, slot_desc))) return rc;
+    if (w->schurq) {
+        std::vector<int64_t> slot_rec((size_t)std::max(p->n_slots, 1) * 2, -1);
+        for (int o = 0; o < p->n_obs; ++o) slot_rec[(size_t)p->h_obs_slot[o] * 2 + p->h_obs_cam[o]] = goff[o];
+        if ((rc = dev_upload(ctx, &w->d_slot_rec, slot_rec))) return rc;
+    }
     if ((rc = dev_upload(ctx, &w->d_goff, goff)) || (rc = dev_upload(ctx, &w->d_slot_off, slot_off)) ||
         (rc = dev_upload(ctx, &w->d_slot_obs, slot_obs)) || (rc = dev_upload(ctx, &w->d_obs_cam, p->h_obs_cam)) ||
         (rc = dev_upload(ctx, &w->d_caminfo, caminfo)))
@@ -183,7 +196,7 @@ int normal_ws_ensure(ccal_problem* p) {
         HIP_TRY(ctx, hipMalloc((void**)&w->cost_o[i], std::max(p->n_obs, 1) * sizeof(double)));
         HIP_TRY(ctx, hipMemset(w->cost_o[i], 0, std::max(p->n_obs, 1) * sizeof(double)));
     }
-    HIP_TRY(ctx, hipMalloc((void**)&w->partial, (size_t)w->RB * n_pw * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->partial, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->red, (size_t)(w->RB + 8) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
@@ -656,7 +669,13 @@ extern "C" {
 // developer hook (not part of include/ccal.h): copy the per-frame scratch of the fast path to the host;
 // diagnostic builds (tools/) park in-kernel timestamps there
 int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
-    if (!p || !p->nws || !p->nws->fws || !out) return CCAL_ERR_INVALID_ARG;
+    if (!p || !p->nws || !out) return CCAL_ERR_INVALID_ARG;
+    if (!p->nws->fws) {          // general loop: what a -DCCAL_STAMPS build of k_schur4 leaves behind the partial sums
+        const NormalWs* w = p->nws;
+        const int64_t room = (int64_t)w->RB * (std::max(w->n_pw, w->n_rows) - w->n_rows), m = std::min(n, room);
+        if (m > 0 && hipMemcpy(out, w->partial + (int64_t)w->RB * w->n_rows, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return CCAL_ERR_HIP;
+        return CCAL_OK;
+    }
     const int64_t m = std::min<int64_t>(n, (int64_t)std::max(p->n_obs, 1) * 40);
     if (hipMemcpy(out, p->nws->fws->fcbuf, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return CCAL_ERR_HIP;
     return CCAL_OK;

@@ -1,16 +1,13 @@
 #!/bin/bash
-# Developer tool: rocprofv3 --kernel-trace --stats of one time_kernels.py run, printed as a short table.
-#   tools/kstats.sh <tag> <time_kernels.py arguments...>
-R=${GRAFT_REPO_ROOT:-/root/repo}
-tag=$1; shift
-mkdir -p $R/gpurun_out/r03
+# Developer tool: rocprofv3 kernel table (name, calls, average ns) of one run of tools/time_kernels.py with the given arguments.
+#   tools/kstats.sh --what normal --cams 2 --reps 50
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03/ks_$tag -o stats -- python3 $R/tools/time_kernels.py "$@" > $R/gpurun_out/r03/ks_$tag.json 2> $R/gpurun_out/r03/ks_$tag.err
+rm -rf /tmp/kstats_out
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kstats_out -o ks -- python3 $REPO/tools/time_kernels.py "$@" > /tmp/kstats_run.json 2>/tmp/kstats_err.txt
 python3 - <<PY
-import csv
-f="$R/gpurun_out/r03/ks_$tag/stats_kernel_stats.csv"
-for r in csv.DictReader(open(f)):
-    n=r["Name"].replace("void ccal::","")
-    print(n[:64].ljust(64), r["Calls"].rjust(6), "%9.1f us avg" % (float(r["AverageNs"])/1e3), "%5.1f %%" % float(r["Percentage"]))
+import csv, glob
+f = glob.glob("/tmp/kstats_out/**/*kernel_stats.csv", recursive=True)[0]
+for r in list(csv.DictReader(open(f)))[:10]: print(f'{r["Name"][:90]:90s} {r["Calls"]:>6s} {float(r["AverageNs"]):10.0f}')
 PY
-tail -1 $R/gpurun_out/r03/ks_$tag.json
+tail -1 /tmp/kstats_run.json
