@@ -202,6 +202,9 @@ struct FusedArgs {
     // one row of partial sums per wavefront.  Set by launch_gram1v when the kernel it picks supports it (elim_fused = 1)
     int32_t fuse_elim, elim_fused;
     int32_t part_cap;              // rows the partial-sum buffer holds
+    // GEN, all cameras of a rig in ONE launch (same model and focal mode): the camera of every observation frame; `list` then
+    // holds every camera's frames, `intr` / `extr` point at camera 0.  NULL: one camera per launch (`cam`)
+    const int32_t* obs_cam;
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:

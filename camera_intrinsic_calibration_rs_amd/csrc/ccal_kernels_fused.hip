@@ -283,6 +283,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
     const bool active = lane_ok && f < a.n_obs;
     const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
+    const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
     double* red = fcw + G * FC_N0P;
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             return;
         }
     }
-    const double* th_g = a.intr[es];
+    const double* th_g = a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0);
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[fa_];
@@ -362,10 +363,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         if constexpr (GEN) {
             // composed pose T_c0 o T_0b and the 6 x 12 expansion matrix E (frame_setup_composed); E^T goes straight into
             // the frame's record, where k_schur finds it
-            const bool other = a.cam > 0;
+            const bool other = camf > 0;
             double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
+            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][camf * 6 + i] : 0.0;
             frame_setup_composed(pose, ex, fcr, ept);
             if (gl == 0 && lane_ok) {
 #pragma unroll
@@ -535,6 +536,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
     const bool active = lane_ok && f < a.n_obs;
     const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
+    const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
     double* red = fcw + G * FC_N0P;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             return;
         }
     }
-    const double* th_g = a.intr[es];
+    const double* th_g = a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0);
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[fa_];
@@ -614,10 +616,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
         if constexpr (GEN) {
             // composed pose T_c0 o T_0b and the 6 x 12 expansion matrix E (frame_setup_composed); E^T goes straight into
             // the frame's record, where k_schur finds it
-            const bool other = a.cam > 0;
+            const bool other = camf > 0;
             double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
+            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][camf * 6 + i] : 0.0;
             frame_setup_composed(pose, ex, fcr, ept);
             if (gl == 0 && lane_ok) {
 #pragma unroll

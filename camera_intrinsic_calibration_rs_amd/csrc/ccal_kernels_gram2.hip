@@ -211,6 +211,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
     const bool active = lane_ok && f < a.n_obs;
     const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);
+    const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
     double* red = fcw + G * FC_N0P;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
         }
     }
     const int cl = gl;                              // every lane has its own corner: LPF corners of a frame per pass
-    const double* th_g = a.intr[es];
+    const double* th_g = a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0);
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.rt, th);
     const int64_t start = a.obs_off[fa_];
@@ -300,10 +301,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
         }
         if (!GEN && active && gl == 0) a.mc_f[f] = mc;
         if constexpr (GEN) {
-            const bool other = a.cam > 0;
+            const bool other = camf > 0;
             double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][a.cam * 6 + i] : 0.0;
+            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][camf * 6 + i] : 0.0;
             frame_setup_composed(pose, ex, fcr, ept);
             if (gl == 0 && lane_ok) {
 #pragma unroll

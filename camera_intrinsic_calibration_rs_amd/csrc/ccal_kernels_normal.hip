@@ -251,8 +251,33 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
 }
 // device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1])
+hipError_t launch_gram_dev_all(const ccal_problem* p, const DevState* st, hipStream_t s) {
+    const NormalWs* w = p->nws;
+    if (w->merged_gram) return launch_gram_dev(p, -1, st, s);
+    for (int c = 0; c < p->n_cams; ++c)
+        if (hipError_t e = launch_gram_dev(p, c, st, s); e != hipSuccess) return e;
+    return hipSuccess;
+}
+
+// cam < 0: the merged launch (w->merged_gram)
 hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s) {
     const NormalWs* w = p->nws;
+    if (w->register_gram && cam < 0) {
+        // Two launches of 2 000 wavefronts each leave the FP64 pipes half empty twice (the second wavefront of every SIMD
+        // runs alone for its last ~9 us); one launch refills the slot of a finished wavefront at once
+        FusedArgs fa = {};
+        fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
+        fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
+        fa.list = w->d_all_obs; fa.n_obs = p->n_obs; fa.rec_off = w->d_goff; fa.obs_cam = w->d_obs_cam;
+        fa.K = p->cams[0].Peff; fa.huber_delta = p->huber_delta; fa.rt = model_rt(p->ctx);
+        fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c;
+        fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
+        fa.extr[0] = p->d_extr; fa.extr[1] = p->d_extr_c; fa.cam = 0;
+        fa.praw[0] = w->G[w->cur]; fa.praw[1] = w->G[w->cur ^ 1];
+        fa.st = st;
+        fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
+        return launch_gram1v_general(p->cams[0].model, p->one_focal, fa, s);
+    }
     if (w->register_gram) {
         // every camera's blocks (6 + P_eff + 1 columns at the composed pose: a triangle of <= 136 entries) through the
         // register Gram kernels of the single-camera loop, record format; k_schur expands the records (caminfo NCP = 0).

@@ -44,6 +44,8 @@ struct NormalWs {
     int64_t* d_goff = nullptr;                 // [n_obs] offset of G_o
     int32_t* d_slot_off = nullptr;             // [n_slots+1] CSR slot -> observation frames
     int32_t* d_slot_obs = nullptr;
+    int32_t* d_all_obs = nullptr;              // merged Gram launch: every camera's observation frames, camera-major
+    bool merged_gram = false;                  // all cameras share model and focal mode: their blocks in ONE launch of the register Gram kernel
     int64_t* d_slot_rec = nullptr;             // k_schurq: [n_slots][2] record offset of camera 0 / 1 in that slot, -1 = none
     int64_t* d_slot_desc = nullptr;            // [n_obs] in slot order: goff * 8 + camera
     int32_t* d_obs_cam = nullptr;
@@ -118,6 +120,7 @@ struct DevState;
 struct HostStatus;
 hipError_t launch_gram(const ccal_problem* p, int cam, bool use_candidate_params, int gbuf, hipStream_t s);
 hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s);
+hipError_t launch_gram_dev_all(const ccal_problem* p, const DevState* st, hipStream_t s);     // every camera: one launch if w->merged_gram, else one per camera
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
                         const DevState* st = nullptr);
 bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* col_extr);      // ccal_kernels_schurq.hip

@@ -56,7 +56,7 @@ void normal_ws_destroy(ccal_problem* p) {
         (void)hipDeviceSynchronize();
     }
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
-                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc, w->d_slot_rec };
+                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc, w->d_slot_rec, w->d_all_obs };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
     if (w->d_gstate) (void)hipFree(w->d_gstate);
@@ -151,14 +151,23 @@ int normal_ws_ensure(ccal_problem* p) {
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
     { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm'); }
-    // two cameras with equal blocks: k_schurq;  CCAL_SCHURQ=0 (and every other rig): the generic k_schur<true>
+    // two cameras with equal blocks and enough slots to fill the chip with 16 per wavefront: k_schurq (10 000 slots: 21 against
+    // 29.6 us; 5 000: equal; 1 000: 7 us slower - 63 wavefronts, each a 19 us critical path);  CCAL_SCHURQ=1 / 0 forces it /
+    // the generic k_schur<true>, which every other rig takes
     {
         int pe[CCAL_MAX_CAMS], ct[CCAL_MAX_CAMS], ce[CCAL_MAX_CAMS];
         for (int c = 0; c < p->n_cams; ++c) { pe[c] = p->cams[c].Peff; ct[c] = p->cams[c].col_theta; ce[c] = p->cams[c].col_extr; }
         const char* e = std::getenv("CCAL_SCHURQ");
-        w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && !(e && e[0] == '0');
+        w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && (e ? e[0] != '0' : p->n_slots >= 6000);
     }
     w->n_rows = w->schurq ? schurq_rows(p->n_slots) : n_pw / WAVES_PER_BLOCK;
+    // cameras of one model (and the problem's one focal mode): their blocks go through ONE launch (CCAL_MERGE_GRAM=0: one per camera)
+    {
+        bool same = p->n_cams > 1;
+        for (int c = 1; c < p->n_cams; ++c) same = same && p->cams[c].model == p->cams[0].model && p->cams[c].Peff == p->cams[0].Peff;
+        const char* e = std::getenv("CCAL_MERGE_GRAM");
+        w->merged_gram = w->register_gram && same && !(e && e[0] == '0');
+    }
     std::vector<int> ncp_of(p->n_cams);
     for (int c = 0; c < p->n_cams; ++c) {
         ncp_of[c] = (p->cams[c].D + 1) <= 16 ? 16 : 32;
@@ -180,6 +189,12 @@ int normal_ws_ensure(ccal_problem* p) {
     for (int i = 0; i < p->n_obs; ++i) slot_desc[i] = goff[slot_obs[i]] * 8 + p->h_obs_cam[slot_obs[i]];
     int rc;
     if ((rc = dev_upload(ctx, &w->d_slot_desc, slot_desc))) return rc;
+    if (w->merged_gram) {
+        std::vector<int32_t> all;
+        all.reserve(p->n_obs);
+        for (int c = 0; c < p->n_cams; ++c) all.insert(all.end(), p->cams[c].obs.begin(), p->cams[c].obs.end());
+        if ((rc = dev_upload(ctx, &w->d_all_obs, all))) return rc;
+    }
     if (w->schurq) {
         std::vector<int64_t> slot_rec((size_t)std::max(p->n_slots, 1) * 2, -1);
         for (int o = 0; o < p->n_obs; ++o) slot_rec[(size_t)p->h_obs_slot[o] * 2 + p->h_obs_cam[o]] = goff[o];
@@ -274,7 +289,7 @@ static int enqueue_gram(ccal_problem* p, bool cand, int gbuf) {
             HIP_TRY(ctx, launch_state_eval(w->d_gstate, 0.0, ctx->stream));
             w->gstate_is_eval = true;
         }
-        for (int c = 0; c < p->n_cams; ++c) HIP_TRY(ctx, launch_gram_dev(p, c, w->d_gstate, ctx->stream));
+        HIP_TRY(ctx, launch_gram_dev_all(p, w->d_gstate, ctx->stream));
         return CCAL_OK;
     }
     if (w->register_gram) { ctx->err = "enqueue_gram: candidate sets go through the device loop"; return CCAL_ERR_UNSUPPORTED; }
@@ -622,7 +637,7 @@ struct GeneralJob : SolveJob {
     int enqueue() override {          // returns the sequence number that marks the group's end, < 0 on error
         const double min_d = o->lm_min_diagonal, max_d = o->lm_max_diagonal;
         DevState* ds = w->d_gstate;
-        for (int c = 0; c < p->n_cams; ++c) HIP_TRYN(ctx, launch_gram_dev(p, c, ds, st));
+        HIP_TRYN(ctx, launch_gram_dev_all(p, ds, st));
         HIP_TRYN(ctx, launch_schur(p, w->cur, 0.0, min_d, max_d, st, ds));
         HIP_TRYN(ctx, launch_reduce(p, st, ds));
         if (int e = allreduce(p, w->red, (size_t)w->RB); e != CCAL_OK) return -e;

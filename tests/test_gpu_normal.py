@@ -494,6 +494,52 @@ def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatc
     gm.close()
 
 
+@pytest.mark.parametrize("model", ["ucm", "eucm", "kb4", "opencv5"])
+@pytest.mark.parametrize("one_focal", [False, True])
+def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal, monkeypatch):
+    """A rig of two cameras of one model takes, above 6 000 slots, the compile-time structured elimination k_schurq (four lanes
+    per slot, P_eff = 4 .. 9) and ONE launch of the register Gram kernel for both cameras.  Forced here on a small rig - 0.4 rad
+    extrinsic rotation, slots seen by one camera only, ragged corner sets - against the oracle and against
+    the generic pair (k_schur, one Gram launch per camera): normal equations, GN, LM."""
+    sp = synth.make_rig(37, (model, model), RIG_EXTR[2], xy_same_focal=one_focal, seed=0xC0DE)
+    seen = np.zeros((sp.n_slots, sp.n_cams), bool)
+    seen[sp.obs_slot, sp.obs_cam] = True
+    assert (seen.sum(1) == 1).any() and (~seen[:, 0]).any() and (~seen[:, 1]).any()
+    op = oracle.OracleProblem.from_synth(sp)
+    probs = {}
+    for name, env in (("fast", {"CCAL_SCHURQ": "1", "CCAL_MERGE_GRAM": "1"}), ("generic", {"CCAL_SCHURQ": "0", "CCAL_MERGE_GRAM": "0"}),
+                      ("merged_only", {"CCAL_SCHURQ": "0", "CCAL_MERGE_GRAM": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        g = Problem.from_synth(gpu_ctx, sp)
+        g.build_normal(sp.intr0, sp.poses0, sp.extr0)                   # the workspace (and the choice of kernels) is made here
+        probs[name] = g
+    monkeypatch.delenv("CCAL_SCHURQ"); monkeypatch.delenv("CCAL_MERGE_GRAM")
+    for lam in (0.0, 1e-3):
+        So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        for g in probs.values():
+            S, b, cost = g.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+            assert abs(cost - costo) <= 1e-12 * costo
+            assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max()
+            assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+        # the merged launch forms the same records as one launch per camera: bit-identical systems
+        np.testing.assert_array_equal(probs["merged_only"].build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)[0],
+                                      probs["generic"].build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)[0])
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        op.apply_reference_bounds()
+        intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        for g in probs.values():
+            g.apply_reference_bounds()
+            intr, poses, extr, rep = g.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+            assert rep.status == rep_o.status == 0 and rep.iterations == rep_o.iterations
+            assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+            assert (np.abs(intr - intr_o) / np.maximum(np.abs(intr_o), 1e-3)).max() <= 1e-6
+            np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+            np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-7)
+    for g in probs.values():
+        g.close()
+
+
 @pytest.mark.parametrize("model,frames", [("eucm", 2600), ("kb4", 2100), ("eucm", 300)])
 def test_fused_elimination_equals_separate_launch(gpu_ctx, oracle, model, frames, monkeypatch):
     """The Gram kernels eliminate their frames' pose blocks in their own tail (k_gram1w from 2 000 frames up for UCM / EUCM,
