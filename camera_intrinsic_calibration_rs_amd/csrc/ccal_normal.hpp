@@ -105,8 +105,9 @@ struct SchurArgs {
     const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
 };
 // Kept at the 128 bytes it had before k_schurq: with a ninth pointer (136 bytes) the member at offset 128 reached the
-// kernels wrong on this stack (ROCm 7.2, gfx950) whichever member it was - observed, not explained.  k_schurq takes its
-// own per-slot table through `slot_desc`.
+// kernels wrong on this stack (ROCm 7.2, gfx950) whichever member it was - observed through the parity tests, not explained
+// (tools/ubench/kernarg136.hip: the same block in a stand-alone kernel arrives intact).  k_schurq takes its own per-slot
+// table through `slot_desc`.
 static_assert(sizeof(SchurArgs) == 128, "see above");
 
 void normal_ws_destroy(ccal_problem* p);
