@@ -423,17 +423,16 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     SQ_STAMP(6);
     // ---- the wavefront's 16 images in a fixed order -> one row of partial sums (k_reduce's layout: the full (K+1)^2 image,
     // lower triangle filled, then the extras)
-    for (int e = lane; e < K1 * K1 + 2 * K + 3; e += 64) {
-        int src;
-        if (e < K1 * K1) { const int i = e / K1, j = e - i * K1; src = j <= i ? i * (i + 1) / 2 + j : -1; }
-        else src = NT + (e - K1 * K1);
+    // (rows of the upper triangle are never written: the buffer is cleared once when the workspace is made)
+    for (int e = lane; e < ACCN; e += 64) {
+        int dst;
+        if (e < NT) { int i, j; sq_tri_decode(e, i, j); dst = i * K1 + j; }
+        else dst = K1 * K1 + (e - NT);
         double t = 0.0;
-        if (src >= 0) {
 #pragma unroll
-            for (int g = 0; g < SQ_SLOTS; g += 4)
-                t += (smem[g * Lt::SS + Lt::IMG + src] + smem[(g + 1) * Lt::SS + Lt::IMG + src]) + (smem[(g + 2) * Lt::SS + Lt::IMG + src] + smem[(g + 3) * Lt::SS + Lt::IMG + src]);
-        }
-        a.partial[(int64_t)e * gridDim.x + blockIdx.x] = t;
+        for (int g = 0; g < SQ_SLOTS; g += 4)
+            t += (smem[g * Lt::SS + Lt::IMG + e] + smem[(g + 1) * Lt::SS + Lt::IMG + e]) + (smem[(g + 2) * Lt::SS + Lt::IMG + e] + smem[(g + 3) * Lt::SS + Lt::IMG + e]);
+        a.partial[(int64_t)dst * gridDim.x + blockIdx.x] = t;
     }
 #ifdef CCAL_STAMPS
     sq_stamps[7] = wall_clock64();

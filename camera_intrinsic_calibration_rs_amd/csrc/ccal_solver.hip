@@ -212,6 +212,10 @@ int normal_ws_ensure(ccal_problem* p) {
         HIP_TRY(ctx, hipMemset(w->cost_o[i], 0, std::max(p->n_obs, 1) * sizeof(double)));
     }
     HIP_TRY(ctx, hipMalloc((void**)&w->partial, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double)));
+    // k_schurq writes the lower triangle and the extras only: the rows of the upper triangle stay zero.  On the context's
+    // stream: it does not synchronise with the null stream, a plain hipMemset could still be running when the first
+    // elimination writes the buffer
+    HIP_TRY(ctx, hipMemsetAsync(w->partial, 0, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMalloc((void**)&w->red, (size_t)(w->RB + 8) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
