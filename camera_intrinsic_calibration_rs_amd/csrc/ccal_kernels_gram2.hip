@@ -637,7 +637,7 @@ static hipError_t launch_gram2_l(const FusedArgs& a, hipStream_t s) {
 
 // Lanes per frame (even: 64, 32, 16, 12, 8, 6): the cost model of gram_lanes_per_frame (ccal_kernels_fused.hip).
 // CCAL_GRAM2_LPF overrides.
-static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, bool quad) {
+static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, bool quad, bool gen) {
     static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
     static const int lpf_env = [] {
         const char* e = std::getenv("CCAL_GRAM2_LPF");
@@ -652,7 +652,11 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
         const int lpf = cand[i], g = 64 / lpf;
         const int64_t waves = ((int64_t)n_obs + g - 1) / g;
         const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
-        const double c0 = lpf == 6 ? 8.0 : 6.0;  // prologue + reductions + elimination, in passes
+        // prologue + reductions + elimination, in passes; the general loop's launches (GEN) have no elimination in their tail
+        // (two EUCM cameras x 10 000 frames in one launch, whole build: 6 lanes 77.0 us, 8: 81.5, 12: 83.1, 16: 85.0)
+        // - but what they measure at 20 000 frames is a larger fixed cost per wavefront (the record goes to HBM, the
+        // occupancy term below is optimistic beyond four wavefronts per SIMD)
+        const double c0 = gen ? (lpf == 6 ? 8.0 : 7.0) : (lpf == 6 ? 8.0 : 6.0);
         double occ;
         const double nw = (double)waves / 1024.0;
         if (two_per_simd) occ = nw <= 1.0 ? 1.0 : (nw <= 2.0 ? 1.0 + 0.3 * (nw - 1.0) : 0.65 + 0.43 * nw);
@@ -666,7 +670,7 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
 template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
     constexpr bool QUAD = CCAL_G2_QUAD(MODEL);
-    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL, QUAD) >= 2, QUAD);
+    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL, QUAD) >= 2, QUAD, GEN);
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
     static const int fuse_min = [] { const char* e = std::getenv("CCAL_FUSE_MIN"); return e ? std::atoi(e) : 1; }();
     const bool fuse = !GEN && a.n_obs >= fuse_min && a.fuse_elim != 0 && waves <= a.part_cap;
