@@ -9,7 +9,7 @@ import os
 
 PMAX = 10
 MAX_CAMS = 8
-KMAX = 64
+KMAX = 128
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_NONFINITE, ERR_NOT_PD, ERR_NO_CONVERGENCE, ERR_UNSUPPORTED, ERR_NO_MEMORY = range(8)
 STATUS_NAMES = ["CCAL_OK", "CCAL_ERR_INVALID_ARG", "CCAL_ERR_HIP", "CCAL_ERR_NONFINITE", "CCAL_ERR_NOT_PD",

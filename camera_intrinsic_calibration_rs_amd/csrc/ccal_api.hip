@@ -149,7 +149,7 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
         if (c > 0) { cl.col_extr = K; K += 6; }
         cl.width = d->width ? d->width[c] : 0.0; cl.height = d->height ? d->height[c] : 0.0;
     }
-    if (K >= CCAL_KMAX) return fail(ctx, CCAL_ERR_INVALID_ARG, "reduced system too large");      // k_solve: rows 0..K of a 64-lane wavefront (row K = right-hand side)
+    if (K >= CCAL_KMAX) return fail(ctx, CCAL_ERR_INVALID_ARG, "reduced system too large");      // k_solve: thread i owns row i of K + 1 <= 128 (row K = right-hand side)
     p->K = K;
     if (d->n_obs > 0) {
         p->h_obs_off.assign(d->obs_offsets, d->obs_offsets + d->n_obs + 1);

@@ -317,12 +317,14 @@ __device__ __forceinline__ double clampd(double v, double lo, double hi) { retur
 #ifndef CCAL_SCHUR_MINW
 #define CCAL_SCHUR_MINW 4
 #endif
-template <bool REC>
-__global__ __launch_bounds__(256, CCAL_SCHUR_MINW) void k_schur(const SchurArgs a) {      // four wavefronts per SIMD: <= 128 VGPRs
+// WPB wavefronts per workgroup: 4 (four wavefronts per SIMD: <= 128 VGPRs), or 1 for reduced systems of 64 .. 127 columns,
+// whose (K + 1)^2 accumulators (up to 131 KB) leave room for one wavefront per CU only
+template <bool REC, int WPB>
+__global__ __launch_bounds__(64 * WPB, WPB == 4 ? CCAL_SCHUR_MINW : 1) void k_schur(const SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int K = a.K, K1 = a.K + 1, RB = a.RB;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;     // wave-uniform values in SGPRs
-    const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
+    const int gw = blockIdx.x * WPB + wave;
     // per-wave LDS: acc[RB] | Baug[6][K1] | C[36] | Y[6][K1] | record staging [STG]
     const int WS = ((RB + 12 * K1 + 36 + 1) & ~1) + a.STG;
     double* acc = smem + wave * WS;
@@ -337,10 +339,11 @@ __global__ __launch_bounds__(256, CCAL_SCHUR_MINW) void k_schur(const SchurArgs 
     // instructions before (SQ_INSTS_SALU = SQ_INSTS_VALU = 5 k per wavefront).
     __shared__ int32_t cbase[CCAL_MAX_CAMS + 1], cnc2[CCAL_MAX_CAMS], cinfo[CCAL_MAX_CAMS][4];
     if (threadIdx.x < a.n_cams * 4) cinfo[threadIdx.x >> 2][threadIdx.x & 3] = a.caminfo[threadIdx.x];
-    int64_t* tab = reinterpret_cast<int64_t*>(smem + WAVES_PER_BLOCK * WS);
-    __shared__ uint16_t tri[REC ? (CCAL_KMAX + 1) * (CCAL_KMAX + 2) / 2 : 1];      // lower-triangle entry -> i | j << 8
-    if constexpr (REC) {
-        for (int e = threadIdx.x; e < K1 * K1; e += 256) {
+    int64_t* tab = reinterpret_cast<int64_t*>(smem + WPB * WS);
+    constexpr bool TRI = REC && WPB == 4;              // K + 1 <= 64: (i, j) of a lower-triangle entry from a table
+    __shared__ uint16_t tri[TRI ? 65 * 66 / 2 : 1];     // lower-triangle entry -> i | j << 8
+    if constexpr (TRI) {
+        for (int e = threadIdx.x; e < K1 * K1; e += 64 * WPB) {
             const int i = e / K1, j = e - i * K1;
             if (j <= i) tri[i * (i + 1) / 2 + j] = (uint16_t)(i | (j << 8));
         }
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(256, CCAL_SCHUR_MINW) void k_schur(const SchurArgs 
             const int D = Pe + (c > 0 ? 12 : 6), NC = D + 1;
             if (NCP == 0) continue;                 // record format: expanded in the slot loop, no table
             if (threadIdx.x == 0) { cbase[c] = base; cnc2[c] = NC * NC; }
-            for (int e = threadIdx.x; e < NC * NC; e += 256) {
+            for (int e = threadIdx.x; e < NC * NC; e += 64 * WPB) {
                 const int i = e / NC, j = e - i * NC;
                 // local column -> (kind, index): kind 0 = camera-system column (r maps to K), 1 = pose
                 int ki, ii, kj, jj;
@@ -550,7 +553,14 @@ __global__ __launch_bounds__(256, CCAL_SCHUR_MINW) void k_schur(const SchurArgs 
         if constexpr (REC) {
             const int NT = K1 * (K1 + 1) / 2;
             for (int e = lane; e < NT; e += 64) {
-                const int ij = tri[e], i = ij & 255, j = ij >> 8;
+                int i, j;
+                if constexpr (TRI) { const int ij = tri[e]; i = ij & 255; j = ij >> 8; }
+                else {           // large systems: decoded (no room for the table beside the accumulators)
+                    i = (int)((__builtin_sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                    if ((i + 1) * (i + 2) / 2 <= e) ++i;
+                    if (i * (i + 1) / 2 > e) --i;
+                    j = e - i * (i + 1) / 2;
+                }
                 double t = 0.0;
 #pragma unroll
                 for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
@@ -571,9 +581,11 @@ __global__ __launch_bounds__(256, CCAL_SCHUR_MINW) void k_schur(const SchurArgs 
     // the four wavefronts of the workgroup combine in LDS (fixed order): a quarter of the partial sums to write and for
     // k_reduce to read (4 096 wavefronts x 367 doubles were 12 MB per group for two EUCM cameras)
     __syncthreads();
-    const int nblk = a.n_pw / WAVES_PER_BLOCK;
-    for (int e = threadIdx.x; e < RB; e += 256)
-        a.partial[(int64_t)e * nblk + blockIdx.x] = (smem[e] + smem[WS + e]) + (smem[2 * WS + e] + smem[3 * WS + e]);
+    const int nblk = a.n_pw / WPB;
+    for (int e = threadIdx.x; e < RB; e += 64 * WPB) {
+        if constexpr (WPB == 4) a.partial[(int64_t)e * nblk + blockIdx.x] = (smem[e] + smem[WS + e]) + (smem[2 * WS + e] + smem[3 * WS + e]);
+        else a.partial[(int64_t)e * nblk + blockIdx.x] = smem[e];
+    }
 }
 
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
@@ -596,17 +608,24 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     int tab_entries = 0;
     if (!w->register_gram) for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
     const size_t lds = sizeof(double) * ((size_t)WS * WAVES_PER_BLOCK + tab_entries);
-    static DynLdsGuard lds_guard;
     if (w->schurq) return launch_schurq(a, p->cams[0].Peff, w->n_rows, s);
+    if (w->schur_wpb == 1) {           // 64 .. 127 columns: one wavefront per workgroup (record format only: normal_ws_ensure)
+        const size_t lds1 = sizeof(double) * (size_t)WS;
+        static DynLdsGuard lds_guard_big;
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<true, 1>), lds1, lds_guard_big); e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_schur<true, 1>), dim3(w->n_pw), dim3(64), lds1, s, a);
+        return hipGetLastError();
+    }
+    static DynLdsGuard lds_guard;
     const int blocks = (w->n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     if (w->register_gram) {
         static DynLdsGuard lds_guard_rec;
-        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<true>), lds, lds_guard_rec); e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_schur<true>, dim3(blocks), dim3(256), lds, s, a);
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<true, 4>), lds, lds_guard_rec); e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_schur<true, 4>), dim3(blocks), dim3(256), lds, s, a);
         return hipGetLastError();
     }
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<false>), lds, lds_guard); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_schur<false>, dim3(blocks), dim3(256), lds, s, a);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<false, 4>), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_schur<false, 4>), dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
@@ -651,7 +670,11 @@ struct SolveArgs {
     DevState* st;                  // device-resident loop: current set = st->cur (0: intr/extr, 1: intr_c/extr_c), lambda from the state
     HostStatus* hs; int32_t seq, publish_all;
 };
-__global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
+// BIG: reduced systems of 64 .. 127 columns - two wavefronts (thread i still owns row i), the matrix in dynamic LDS with a
+// run-time row stride, pivots and finished components travel through LDS instead of wavefront shuffles
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
+    constexpr int NTH = BIG ? 128 : 64;
     SolveArgs a = a0;
     __shared__ int go;
     __shared__ DevState S0;            // the optimizer state is staged in LDS: the decision touches ~20 fields one after the
@@ -664,7 +687,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         {
             const double* src = reinterpret_cast<const double*>(gst);
             double* dst = reinterpret_cast<double*>(&S0);
-            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += NTH) dst[e] = src[e];
         }
         __syncthreads();
         a.st = &S0;
@@ -674,7 +697,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         if (!go) {
             const double* src = reinterpret_cast<const double*>(&S0);
             double* dst = reinterpret_cast<double*>(gst);
-            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += NTH) dst[e] = src[e];
             __syncthreads();
             if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0);
             return;
@@ -682,18 +705,24 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         a.lambda = S0.lambda;
         if (S0.cur) { a.intr = a0.intr_c; a.extr = a0.extr_c; a.intr_c = const_cast<double*>(a0.intr); a.extr_c = const_cast<double*>(a0.extr); }
     }
-    __shared__ double S[(CCAL_KMAX + 1) * (CCAL_KMAX + 1)];       // rows 0..K-1: the system, row K: the right-hand side
+    constexpr int KS = 64;                                          // the one-wavefront form: K + 1 <= 64 rows
+    __shared__ double S_small[BIG ? 1 : (KS + 1) * (KS + 1)];       // rows 0..K-1: the system, row K: the right-hand side
+    extern __shared__ __attribute__((aligned(16))) double S_big[];
     __shared__ double x[CCAL_KMAX];
+    __shared__ double pivs;
+    __shared__ double mcs[2];
     __shared__ int bad;
     const int K = a.K, K1 = K + 1;
+    double* const S = BIG ? S_big : S_small;
+    const int LD = BIG ? (K1 | 1) : KS + 1;                          // odd row stride: a column walk touches every bank
     const double* hdiag = a.red + K1 * K1;
     const double* gc = hdiag + K;
     __shared__ int fxs[CCAL_KMAX];
     ColInfo ci = {};
     if (lane < K) { ci = a.cols[lane]; fxs[lane] = ci.fixed; }
     if (lane == 0) bad = 0;
-    for (int e = lane; e < a.n_intr; e += 64) a.intr_c[e] = a.intr[e];
-    for (int e = lane; e < a.n_extr; e += 64) a.extr_c[e] = a.extr[e];
+    for (int e = lane; e < a.n_intr; e += NTH) a.intr_c[e] = a.intr[e];
+    for (int e = lane; e < a.n_extr; e += NTH) a.extr_c[e] = a.extr[e];
     const double rhs = lane < K ? a.red[K * K1 + lane] : 0.0;          // the system is kept as its lower triangle (row K = b^T)
     const double hd = lane < K ? hdiag[lane] : 0.0, gcl = lane < K ? gc[lane] : 0.0;
     const double xsrc = lane < K ? (ci.is_extr ? a.extr : a.intr)[ci.dst] : 0.0;
@@ -701,23 +730,22 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     {
         const float rk = 1.0f / (float)K;
 #pragma unroll 4
-        for (int e = lane; e < K * K; e += 64) {
+        for (int e = lane; e < K * K; e += NTH) {
             const int i = (int)(((float)e + 0.5f) * rk), j = e - i * K;
             double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
             if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
-            S[i * (CCAL_KMAX + 1) + j] = v;
+            S[i * LD + j] = v;
         }
     }
     __syncthreads();
-    if (lane < K && !ci.fixed && a.lambda > 0.0) S[lane * (CCAL_KMAX + 1) + lane] += a.lambda * clampd(hd, a.min_diag, a.max_diag);
+    if (lane < K && !ci.fixed && a.lambda > 0.0) S[lane * LD + lane] += a.lambda * clampd(hd, a.min_diag, a.max_diag);
     // the right-hand side rides along as row K of the matrix: the factorisation's own recurrence turns it into L^-1 rhs
     // (the forward substitution costs nothing extra: lane K is one more row)
-    if (lane < K) S[K * (CCAL_KMAX + 1) + lane] = ci.fixed ? 0.0 : -rhs;
+    if (lane < K) S[K * LD + lane] = ci.fixed ? 0.0 : -rhs;
     __syncthreads();
     // left-looking Cholesky, lane i owns row i: t = S[i][j] - sum_{k<j} L[i][k] L[j][k] (no stores inside the sum,
     // so the LDS reads pipeline), the pivot travels by shuffle; one barrier per column.  Same operation order as
     // the right-looking form.
-    constexpr int LD = CCAL_KMAX + 1;
     for (int j = 0; j < K; ++j) {
         double t = 0.0;
         if (lane >= j && lane <= K) {
@@ -725,7 +753,9 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
 #pragma unroll 4
             for (int k = 0; k < j; ++k) t -= S[lane * LD + k] * S[j * LD + k];
         }
-        const double piv = __shfl(t, j, 64);
+        double piv;
+        if constexpr (BIG) { if (lane == j) pivs = t; __syncthreads(); piv = pivs; }
+        else piv = __shfl(t, j, 64);
         if (!(piv > 0.0) || !(piv < 1.7e308)) { if (lane == 0) bad = 1; break; }      // uniform
         double sq, inv;
         fast_sqrt_rsqrt(piv, sq, inv);                    // hardware seed + Newton steps (<= 2 ulp), not the IEEE sqrt + division expansions
@@ -749,7 +779,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         if (a.st) {
             const double* src = reinterpret_cast<const double*>(&S0);
             double* dst = reinterpret_cast<double*>(gst);
-            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+            for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += NTH) dst[e] = src[e];
             __syncthreads();
             if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0);
         }
@@ -759,7 +789,9 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
         double xi = lane < K ? S[K * LD + lane] : 0.0;
         for (int j = K - 1; j >= 0; --j) {
             if (lane == j) xi = xi * S[j * LD + j];
-            const double xj = __shfl(xi, j, 64);
+            double xj;
+            if constexpr (BIG) { if (lane == j) pivs = xi; __syncthreads(); xj = pivs; __syncthreads(); }
+            else xj = __shfl(xi, j, 64);
             if (lane < j) xi -= S[j * LD + lane] * xj;
         }
         if (lane < K) x[lane] = xi;
@@ -781,6 +813,11 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
+    if constexpr (BIG) {
+        if ((lane & 63) == 0) mcs[lane >> 6] = mc;
+        __syncthreads();
+        mc = mcs[0] + mcs[1];
+    }
     if (lane == 0) {
         a.scal[2] = mc;
         if (a.st) { a.st->mc_cam = mc; a.st->lambda_solve = a.lambda; }
@@ -789,7 +826,7 @@ __global__ __launch_bounds__(64) void k_solve(const SolveArgs a0) {
     if (a.st) {
         const double* src = reinterpret_cast<const double*>(&S0);
         double* dst = reinterpret_cast<double*>(gst);
-        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += NTH) dst[e] = src[e];
         __syncthreads();
         if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0);
     }
@@ -803,7 +840,15 @@ hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, d
     a.intr = p->d_intr; a.extr = p->d_extr; a.intr_c = p->d_intr_c; a.extr_c = p->d_extr_c;
     a.n_intr = p->n_cams * CCAL_PMAX; a.n_extr = p->n_cams * 6;
     a.dc = w->dc; a.scal = w->scal; a.flags = w->flags;
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, a);
+    if (w->K >= 64) {
+        const int K1 = w->K + 1;
+        const size_t lds = sizeof(double) * (size_t)(K1 | 1) * K1;
+        static DynLdsGuard guard;
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_solve<true>), lds, guard); e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_solve<true>, dim3(1), dim3(128), lds, s, a);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_solve<false>, dim3(1), dim3(64), 0, s, a);
     return hipGetLastError();
 }
 

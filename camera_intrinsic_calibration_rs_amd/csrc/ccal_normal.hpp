@@ -37,6 +37,7 @@ struct ColInfo {          // one column of the reduced camera system
 
 struct NormalWs {
     int K = 0, RB = 0, PF = 0, n_pw = 0;
+    int schur_wpb = 4;                         // wavefronts per workgroup of k_schur: 1 for reduced systems of 64 .. 127 columns
     bool schurq = false;                       // two cameras with equal blocks: elimination with four lanes per slot (k_schurq) instead of k_schur<true>
     int n_rows = 0;                            // rows of partial sums the elimination kernel in use writes = what k_reduce adds up
     double* G[2] = { nullptr, nullptr };       // per-observation-frame Gram blocks (current / candidate)

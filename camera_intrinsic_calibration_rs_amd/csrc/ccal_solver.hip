@@ -143,6 +143,9 @@ int normal_ws_ensure(ccal_problem* p) {
     // persistent wavefronts of k_schur: 4 per SIMD (measured at 10 000 slots x 2 cameras: 2048 -> 165.7, 4096 -> 158.5, 8192 -> 173 us per build)
     int n_pw = std::min(std::max(p->n_slots, 1), env_sw ? std::max(4, std::atoi(env_sw)) : 4096);
     n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+    // 64 .. 127 columns (five and more cameras): the (K + 1)^2 accumulators of a wavefront take up to 131 KB of LDS - one
+    // wavefront per workgroup and CU, 512 of them (each writes its own row of partial sums: 512 x RB doubles)
+    if (p->K >= 64) { w->schur_wpb = 1; n_pw = std::min(std::max(p->n_slots, 1), 512); }
     w->n_pw = n_pw;
     std::vector<int64_t> goff(p->n_obs);
     std::vector<int32_t> caminfo(p->n_cams * 4);
@@ -150,7 +153,7 @@ int normal_ws_ensure(ccal_problem* p) {
     // Register Gram kernels + record format for every camera (k_gram1v / k_gram1w, GEN; k_schur expands the records).
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
-    { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm'); }
+    { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || p->K >= 64; }      // the matrix-core pair stops at 63 columns
     // two cameras with equal blocks and enough slots to fill the chip with 16 per wavefront: k_schurq (10 000 slots: 21 against
     // 29.6 us; 5 000: equal; 1 000: 7 us slower - 63 wavefronts, each a 19 us critical path);  CCAL_SCHURQ=1 / 0 forces it /
     // the generic k_schur<true>, which every other rig takes
@@ -160,7 +163,7 @@ int normal_ws_ensure(ccal_problem* p) {
         const char* e = std::getenv("CCAL_SCHURQ");
         w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && (e ? e[0] != '0' : p->n_slots >= 6000);
     }
-    w->n_rows = w->schurq ? schurq_rows(p->n_slots) : n_pw / WAVES_PER_BLOCK;
+    w->n_rows = w->schurq ? schurq_rows(p->n_slots) : n_pw / w->schur_wpb;
     // cameras of one model (and the problem's one focal mode): their blocks go through ONE launch (CCAL_MERGE_GRAM=0: one per camera)
     {
         bool same = p->n_cams > 1;

@@ -58,7 +58,7 @@ extern "C" {
 
 #define CCAL_PMAX 10          /* row stride of intr / bounds arrays (max model has 9 params) */
 #define CCAL_MAX_CAMS 8
-#define CCAL_KMAX 64          /* max size of the reduced camera system */
+#define CCAL_KMAX 128         /* the reduced camera system has fewer columns than this: eight cameras of any model fit (8 x 9 + 7 x 6 = 114) */
 
 typedef enum {
     CCAL_OK = 0,

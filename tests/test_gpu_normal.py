@@ -259,8 +259,8 @@ def test_one_degenerate_frame_gn_not_pd_lm_recovers(gpu_ctx, fused, monkeypatch)
 
 
 def test_six_cameras_matches_oracle(gpu_ctx, oracle):
-    """Six one-focal UCM cameras: reduced system K = 6 * 4 + 5 * 6 = 54 (CCAL_KMAX is 64); eight would be 74 and must be
-    refused at problem creation, not crash later."""
+    """Six one-focal UCM cameras: reduced system K = 6 * 4 + 5 * 6 = 54, the largest that the one-wavefront camera solve and
+    the four-wavefront elimination serve (K + 1 <= 64)."""
     sp = synth.make_problem(12, "ucm", n_cams=6, xy_same_focal=True)
     gp, op = _pair(gpu_ctx, oracle, sp)
     intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0)
@@ -268,10 +268,37 @@ def test_six_cameras_matches_oracle(gpu_ctx, oracle):
     assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations) and rep.status == 0
     assert (np.abs(intr[:, :5] / intr_o[:, :5] - 1)).max() <= 1e-9
     np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-9)
-    sp8 = synth.make_problem(4, "ucm", n_cams=8, xy_same_focal=True)
-    with pytest.raises(CcalError) as ei:
-        Problem.from_synth(gpu_ctx, sp8)
-    assert ei.value.code == _ffi.ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("model,one_focal,K", [("ucm", True, 74), ("eucm", False, 90), ("opencv5", False, 114)])
+def test_eight_cameras_matches_oracle(gpu_ctx, oracle, model, one_focal, K):
+    """The reference has no cap on --cam-num (src/bin/camera_calibration.rs:25-68); this ABI stops at CCAL_MAX_CAMS = 8
+    cameras, whose reduced system has up to 8 * 9 + 7 * 6 = 114 columns.  Systems of 64 .. 127 columns take the large forms of
+    the elimination (one wavefront per workgroup, (K + 1)^2 accumulators in LDS) and of the camera solve (two wavefronts, the
+    matrix in dynamic LDS): normal equations, GN and LM against the oracle."""
+    if model == "opencv5":          # narrow field of view: a rig whose cameras see different subsets of the slots
+        rng = np.random.default_rng(8)
+        extr = [[0.0] * 6] + [list(np.concatenate([rng.uniform(-0.04, 0.04, 3), rng.uniform(-0.03, 0.03, 3)])) for _ in range(7)]
+        sp = synth.make_rig(16, (model,) * 8, extr, xy_same_focal=one_focal, seed=0xE16)
+    else:
+        sp = synth.make_problem(10, model, n_cams=8, xy_same_focal=one_focal, ragged=True)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    assert gp.K == K
+    for lam in (0.0, 1e-3):
+        S, b, cost = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max()
+        assert np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        gp.apply_reference_bounds(); op.apply_reference_bounds()
+        intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations) and rep.status == 0
+        assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+        assert (np.abs(intr - intr_o) / np.maximum(np.abs(intr_o), 1e-3)).max() <= 1e-6
+        np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+        np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-7)
 
 
 @pytest.mark.parametrize("n_corners,n_frames", [(400, 6), (700, 3), (24, 30), (6, 40)])
