@@ -316,7 +316,11 @@ def main():
                 sprob.close()
             # The session-size regime, side by side: N independent 625-frame problems through ONE ccal_solve_batch call
             # (a context + stream + host thread each), aggregate Gauss-Newton iterations/s against one problem at a time
+            # (CCAL_BENCH_NO_CONCURRENT=1: the counter passes of profiles/run_profile.sh leave it out - rocprofv3 --pmc crashed
+            # once inside a launch from a worker thread, profiles/r03)
             try:
+                if os.environ.get("CCAL_BENCH_NO_CONCURRENT"):
+                    raise RuntimeError("skipped (CCAL_BENCH_NO_CONCURRENT)")
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import concurrent_sessions
                 extra["concurrent_sessions"] = concurrent_sessions.measure(625, args.model, 0, reps=100, counts=(1, 2, 4, 8), device=dev_index)
