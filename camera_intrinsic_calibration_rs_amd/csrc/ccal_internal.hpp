@@ -144,6 +144,7 @@ inline hipError_t ensure_dyn_lds(const void* fn, size_t lds, DynLdsGuard& g) {
     if (lds <= have) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) have = lds;
+    else (void)hipGetLastError();      // reported here: the runtime's sticky copy must not surface in an unrelated launcher's hipGetLastError()
     return e;
 }
 }  // namespace ccal

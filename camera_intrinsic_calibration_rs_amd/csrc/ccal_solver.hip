@@ -145,7 +145,14 @@ int normal_ws_ensure(ccal_problem* p) {
     n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     // 64 .. 127 columns (five and more cameras): the (K + 1)^2 accumulators of a wavefront take up to 131 KB of LDS - one
     // wavefront per workgroup and CU, 512 of them (each writes its own row of partial sums: 512 x RB doubles)
-    if (p->K >= 64) { w->schur_wpb = 1; n_pw = std::min(std::max(p->n_slots, 1), 512); }
+    // (also below 64 columns when four wavefronts' images do not fit the CU's 160 KB: K + 1 = 62 .. 64 with OPENCV5-sized records)
+    {
+        int stg = 0;
+        for (int c = 0; c < p->n_cams; ++c) stg = std::max(stg, gen_rec_size(p->cams[c].Peff) + 72);
+        const int K1 = p->K + 1;
+        const size_t ws4 = sizeof(double) * WAVES_PER_BLOCK * (size_t)((((w->RB + 12 * K1 + 36 + 1) & ~1)) + stg);
+        if (p->K >= 64 || ws4 + 6 * 1024 > 160 * 1024) { w->schur_wpb = 1; n_pw = std::min(std::max(p->n_slots, 1), 512); }
+    }
     w->n_pw = n_pw;
     std::vector<int64_t> goff(p->n_obs);
     std::vector<int32_t> caminfo(p->n_cams * 4);
@@ -153,7 +160,7 @@ int normal_ws_ensure(ccal_problem* p) {
     // Register Gram kernels + record format for every camera (k_gram1v / k_gram1w, GEN; k_schur expands the records).
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
-    { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || p->K >= 64; }      // the matrix-core pair stops at 63 columns
+    { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || w->schur_wpb == 1; }      // the matrix-core pair: four-wavefront elimination only
     // two cameras with equal blocks and enough slots to fill the chip with 16 per wavefront: k_schurq (10 000 slots: 21 against
     // 29.6 us; 5 000: equal; 1 000: 7 us slower - 63 wavefronts, each a 19 us critical path);  CCAL_SCHURQ=1 / 0 forces it /
     // the generic k_schur<true>, which every other rig takes

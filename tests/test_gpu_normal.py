@@ -301,6 +301,31 @@ def test_eight_cameras_matches_oracle(gpu_ctx, oracle, model, one_focal, K):
         np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-7)
 
 
+@pytest.mark.parametrize("models,one_focal,K", [(("opencv5",) * 4 + ("kb4",), True, 63), (("opencv5", "kb4", "ucm", "kb4", "kb4"), False, 62),
+                                                 (("opencv5", "ucm", "eucm", "opencv5", "kb4"), False, 61)])
+def test_five_camera_rigs_at_the_lds_boundary(gpu_ctx, oracle, models, one_focal, K):
+    """61 .. 63 columns: four wavefronts' (K + 1)^2 accumulators plus OPENCV5-sized record staging exceed a CU's 160 KB of LDS -
+    the elimination has to take its one-wavefront form below 64 columns too (found by tools/fuzz_parity.py: the launch was
+    refused with 'invalid argument', and the runtime's sticky error then surfaced in the next problem's first launch)."""
+    rng = np.random.default_rng(5)
+    extr = [[0.0] * 6] + [list(np.concatenate([rng.uniform(-0.04, 0.04, 3), rng.uniform(-0.05, 0.05, 3)])) for _ in range(4)]
+    sp = synth.make_rig(24, models, extr, xy_same_focal=one_focal, seed=0x5CA)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    assert gp.K == K
+    S, b, cost = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=1e-3)
+    So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=1e-3)
+    assert abs(cost - costo) <= 1e-12 * costo and np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+    gp.apply_reference_bounds(); op.apply_reference_bounds()
+    intr, poses, extr_s, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(_ffi.METHOD_LM))
+    intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(_ffi.METHOD_LM))
+    assert (rep.status, rep.iterations) == (rep_o.status, rep_o.iterations) and rep.status == 0
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+    np.testing.assert_allclose(extr_s, extr_o, rtol=0, atol=1e-7)
+    # and a failed launch does not leak into the next problem
+    r, J = Problem.from_synth(gpu_ctx, synth.make_problem(5, "kb4")).eval(synth.make_problem(5, "kb4").intr0, synth.make_problem(5, "kb4").poses0)
+    assert np.isfinite(r).all()
+
+
 @pytest.mark.parametrize("n_corners,n_frames", [(400, 6), (700, 3), (24, 30), (6, 40)])
 def test_frames_of_any_size(gpu_ctx, oracle, n_corners, n_frames):
     """Frames far larger than the 144-corner board (several 64-corner tiles per wavefront, lanes per frame that do not
