@@ -75,9 +75,12 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     double* sb = smem + sl * Lt::SS;
     double* dum = sb + Lt::DUM + q;
 
-    // ---- the two records of the slot -> LDS (16 bytes per lane and load; a missing record is a record of zeros)
-    const int64_t d0 = has ? a.slot_desc[2 * (int64_t)s] : -1, d1 = has ? a.slot_desc[2 * (int64_t)s + 1] : -1;
-    const bool live = d0 >= 0 || d1 >= 0;
+    // ---- the two records of the slot -> LDS (16 bytes per lane and load).  They sit side by side at (2 s + camera) x record size
+    // (normal_ws_ensure): requested at once, no look-up first; a missing record is a hole of zeros.  The table only says
+    // whether the slot has an observation at all (wanted much later)
+    const int64_t d0 = has ? 2 * (int64_t)s * gen_rec_size(PE) : 0, d1 = d0 + (has ? gen_rec_size(PE) : 0);
+    const int64_t p0 = has ? a.slot_desc[2 * (int64_t)s] : -1, p1 = has ? a.slot_desc[2 * (int64_t)s + 1] : -1;
+    const bool live = p0 >= 0 || p1 >= 0;
     const double mc_s = (has && q == 0) ? a.mc_slot[s] : 0.0;          // model decrease of this slot's pose block for the step under decision
     // the camera | r blocks of the records: this lane's rows i = q + 4 t of the lower triangles, straight from HBM into
     // registers (they are direct terms of the reduced system, wanted only once the products are done)
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     {
         constexpr int NH = HS / 2;                                      // 16-byte pieces of a head
         constexpr int TH = (NH + 3) / 4;
-        const double* r0 = p_G + (d0 >= 0 ? d0 : 0);
-        const double* r1 = p_G + (d1 >= 0 ? d1 : 0);
+        const double* r0 = p_G + d0;
+        const double* r1 = p_G + d1;
         const double2* g0 = reinterpret_cast<const double2*>(r0);
         const double2* g1 = reinterpret_cast<const double2*>(r1);
         const double2 z2 = { 0.0, 0.0 };
@@ -94,9 +97,9 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         {
             double2 h0[TH], e0[5];
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h0[t] = (d0 >= 0 && c < NH) ? g0[c] : z2; }
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h0[t] = (has && c < NH) ? g0[c] : z2; }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; e0[t] = (d0 >= 0 && c < 18) ? g0[gen_e_off(PE) / 2 + c] : z2; }
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; e0[t] = (has && c < 18) ? g0[gen_e_off(PE) / 2 + c] : z2; }
 #pragma unroll
             for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H0 / 2 + c] = h0[t]; }
 #pragma unroll
@@ -105,9 +108,9 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         {
             double2 h1[TH], e1[9];
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h1[t] = (d1 >= 0 && c < NH) ? g1[c] : z2; }
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h1[t] = (has && c < NH) ? g1[c] : z2; }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { const int c = q + 4 * t; e1[t] = d1 >= 0 ? g1[gen_e_off(PE) / 2 + c] : z2; }
+            for (int t = 0; t < 9; ++t) { const int c = q + 4 * t; e1[t] = has ? g1[gen_e_off(PE) / 2 + c] : z2; }
 #pragma unroll
             for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H1 / 2 + c] = h1[t]; }
 #pragma unroll
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             for (int j = 0; j < K1c; ++j) {
                 if (j > 4 * t + 3) { av[0][t][j] = 0.0; av[1][t][j] = 0.0; continue; }      // compile time: j <= i impossible
                 const bool in = i < K1c && j <= i;
-                av[0][t][j] = (in && d0 >= 0) ? r0[HS + i * K1c + j] : 0.0;
-                av[1][t][j] = (in && d1 >= 0) ? r1[HS + i * K1c + j] : 0.0;
+                av[0][t][j] = (in && has) ? r0[HS + i * K1c + j] : 0.0;
+                av[1][t][j] = (in && has) ? r1[HS + i * K1c + j] : 0.0;
             }
         }
     }

@@ -184,10 +184,19 @@ int normal_ws_ensure(ccal_problem* p) {
         caminfo[c * 4 + 0] = p->cams[c].Peff; caminfo[c * 4 + 1] = p->cams[c].col_theta;
         caminfo[c * 4 + 2] = p->cams[c].col_extr; caminfo[c * 4 + 3] = w->register_gram ? 0 : ncp_of[c];
     }
-    for (int o = 0; o < p->n_obs; ++o) {
-        goff[o] = gl;
-        const int c = p->h_obs_cam[o];
-        gl += w->register_gram ? (int64_t)gen_rec_size(p->cams[c].Peff) : (int64_t)ncp_of[c] * ncp_of[c];
+    if (w->schurq) {
+        // k_schurq: a slot's two records side by side at (2 slot + camera) x record size - the kernel computes the addresses and
+        // requests the records with its first instructions instead of after a look-up; a missing record is a hole that stays
+        // zero (the buffers are cleared below and nothing ever writes there)
+        const int64_t rs = gen_rec_size(p->cams[0].Peff);
+        for (int o = 0; o < p->n_obs; ++o) goff[o] = (2 * (int64_t)p->h_obs_slot[o] + p->h_obs_cam[o]) * rs;
+        gl = 2 * (int64_t)std::max(p->n_slots, 1) * rs;
+    } else {
+        for (int o = 0; o < p->n_obs; ++o) {
+            goff[o] = gl;
+            const int c = p->h_obs_cam[o];
+            gl += w->register_gram ? (int64_t)gen_rec_size(p->cams[c].Peff) : (int64_t)ncp_of[c] * ncp_of[c];
+        }
     }
     w->g_len = gl;
     std::vector<int32_t> slot_off(p->n_slots + 1, 0), slot_obs(p->n_obs);
@@ -217,11 +226,13 @@ int normal_ws_ensure(ccal_problem* p) {
     const size_t gbytes = std::max<int64_t>(gl, 1) * sizeof(double);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(ctx, hipMalloc((void**)&w->G[i], gbytes));
-        HIP_TRY(ctx, hipMemset(w->G[i], 0, gbytes));     // tile (1,0) of two-tile blocks is never written
+        HIP_TRY(ctx, hipMemsetAsync(w->G[i], 0, gbytes, ctx->stream));     // tile (1,0) of two-tile blocks is never written
         HIP_TRY(ctx, hipMalloc((void**)&w->cost_o[i], std::max(p->n_obs, 1) * sizeof(double)));
-        HIP_TRY(ctx, hipMemset(w->cost_o[i], 0, std::max(p->n_obs, 1) * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(w->cost_o[i], 0, std::max(p->n_obs, 1) * sizeof(double), ctx->stream));
     }
     HIP_TRY(ctx, hipMalloc((void**)&w->partial, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double)));
+    // (every clear of this function is ordered on the context's stream: it does not synchronise with the null stream, and the
+    // kernels rely on what is never written staying zero - holes in the record buffers, upper-triangle rows of `partial`)
     // k_schurq writes the lower triangle and the extras only: the rows of the upper triangle stay zero.  On the context's
     // stream: it does not synchronise with the null stream, a plain hipMemset could still be running when the first
     // elimination writes the buffer
@@ -230,16 +241,16 @@ int normal_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->mc_slot, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
-    HIP_TRY(ctx, hipMemset(w->mc_slot, 0, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
+    HIP_TRY(ctx, hipMemsetAsync(w->mc_slot, 0, (size_t)std::max(p->n_slots, 1) * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMalloc((void**)&w->scal, 8 * sizeof(double)));
-    HIP_TRY(ctx, hipMemset(w->scal, 0, 8 * sizeof(double)));
+    HIP_TRY(ctx, hipMemsetAsync(w->scal, 0, 8 * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMalloc((void**)&w->flags, 4 * sizeof(int32_t)));
     HIP_TRY(ctx, hipMalloc((void**)&w->d_gstate, sizeof(DevState)));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstatus, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstate, sizeof(DevState), hipHostMallocDefault));
     std::memset((void*)w->h_gstatus, 0, sizeof(HostStatus));
-    HIP_TRY(ctx, hipMemset(w->flags, 0, 4 * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), ctx->stream));
     HIP_TRY(ctx, hipMalloc((void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_pinned, (size_t)(w->RB + 16) * sizeof(double), hipHostMallocDefault));
     return normal_upload_cols(p);
