@@ -656,7 +656,8 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
         // (two EUCM cameras x 10 000 frames in one launch, whole build: 6 lanes 77.0 us, 8: 81.5, 12: 83.1, 16: 85.0)
         // - but what they measure at 20 000 frames is a larger fixed cost per wavefront (the record goes to HBM, the
         // occupancy term below is optimistic beyond four wavefronts per SIMD)
-        const double c0 = gen ? (lpf == 6 ? 8.0 : 7.0) : (lpf == 6 ? 8.0 : 6.0);
+        // (single camera, 20 000 frames, whole build: 6 lanes 55.1 us, 8: 59.1, 12: 63.8; 50 000 frames: 133.8, 123.5, 136.8)
+        const double c0 = gen ? (lpf == 6 ? 8.0 : 7.0) : (lpf == 6 ? 7.0 : 6.0);
         double occ;
         const double nw = (double)waves / 1024.0;
         if (two_per_simd) occ = nw <= 1.0 ? 1.0 : (nw <= 2.0 ? 1.0 + 0.3 * (nw - 1.0) : 0.65 + 0.43 * nw);
