@@ -7,7 +7,7 @@
 // however the lanes are arranged (a 16-lanes-per-slot variant of it measured 38 us against 29.6 us: the time goes with the
 // instruction count, not with the idle lanes).  Here the system is [theta_0 (PE) | theta_1 (PE) | extrinsics (6) | r], all
 // loops are unrolled, every LDS address is a per-lane base plus a constant, a wavefront works on 16 slots in straight-line
-// code and the four lanes of a slot share the work by "index = q (mod 4)".  ~2 000 instructions per wavefront = ~125 per slot.
+// code and the four lanes of a slot share the work by "index = q (mod 4)".  ~3 500 instructions per wavefront = ~220 per slot.
 //
 // Sums are reproducible: a slot's contributions go to the slot's own image of the reduced system in LDS in program order,
 // the 16 images of a wavefront are added in a fixed order, one row of partial sums per wavefront goes to k_reduce.

@@ -89,7 +89,7 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     bodies, regs = {}, {}
     with tempfile.TemporaryDirectory() as td:
-        for tu in ("ccal_kernels_fused", "ccal_kernels_gram2"):
+        for tu in ("ccal_kernels_fused", "ccal_kernels_gram2", "ccal_kernels_schurq"):
             s = os.path.join(td, tu + ".s")
             subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-S",
                                    "--cuda-device-only", "-o", s, os.path.join(SRC, tu + ".hip")], stderr=subprocess.DEVNULL)
@@ -133,6 +133,13 @@ def main():
             w = summarize(ops(bodies[hits[0]]))
             w["per_frame_flops_16_lanes"] = 16 * w["flops"]
             out["kernels"][f"k_schur1m<K={K}>"] = {"per_lane_whole_kernel": w}
+    # k_schurq<PE>: straight-line code, one wavefront = 16 frame slots of a two-camera rig (4 lanes per slot)
+    for PE in (4, 5, 6, 7, 8, 9):
+        hits = [k for k in bodies if f"k_schurqILi{PE}EE" in k]
+        if hits:
+            w = summarize(ops(bodies[hits[0]]))
+            w["per_slot_flops_4_lanes"] = 4 * w["flops"]
+            out["kernels"][f"k_schurq<PE={PE}>"] = {"per_lane_whole_kernel": w, "registers": regs.get(hits[0])}
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
     with open(os.path.join(dst, "flops.json"), "w") as f:
