@@ -443,9 +443,12 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
 #endif
 }
 
-// two cameras, the same number of free intrinsics, the standard column layout [theta_0 | theta_1 | extrinsics_1]
+// two cameras, the same number of free intrinsics - at most 6 (UCM, EUCM) -, the standard column layout [theta_0 | theta_1 |
+// extrinsics_1].  KB4 / OPENCV5 blocks (7 .. 9): a slot's area grows to 3.5 - 4.7 KB, two wavefronts of 16 slots per CU instead
+// of three, i.e. two rounds of wavefronts - two KB4 cameras x 10 000 frames: 147.7 us per build against 137.5 with k_schur
+// (136.9 / 117.6 one-focal), also with half-full wavefronts of 8 slots that are all resident; they stay with k_schur
 bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* col_extr) {
-    if (n_cams != 2 || peff[0] != peff[1] || peff[0] < 4 || peff[0] > 9) return false;
+    if (n_cams != 2 || peff[0] != peff[1] || peff[0] < 4 || peff[0] > 6) return false;
     return col_theta[0] == 0 && col_theta[1] == peff[0] && col_extr[1] == 2 * peff[0];
 }
 int schurq_rows(int n_slots) { return (std::max(n_slots, 1) + SQ_SLOTS - 1) / SQ_SLOTS; }
@@ -464,9 +467,6 @@ hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, hipStream_t s) 
         case 4: return launch_schurq_t<4>(a, rows, s);
         case 5: return launch_schurq_t<5>(a, rows, s);
         case 6: return launch_schurq_t<6>(a, rows, s);
-        case 7: return launch_schurq_t<7>(a, rows, s);
-        case 8: return launch_schurq_t<8>(a, rows, s);
-        case 9: return launch_schurq_t<9>(a, rows, s);
     }
     return hipErrorInvalidValue;
 }

@@ -134,7 +134,7 @@ def main():
             w["per_frame_flops_16_lanes"] = 16 * w["flops"]
             out["kernels"][f"k_schur1m<K={K}>"] = {"per_lane_whole_kernel": w}
     # k_schurq<PE>: straight-line code, one wavefront = 16 frame slots of a two-camera rig (4 lanes per slot)
-    for PE in (4, 5, 6, 7, 8, 9):
+    for PE in (4, 5, 6):
         hits = [k for k in bodies if f"k_schurqILi{PE}EE" in k]
         if hits:
             w = summarize(ops(bodies[hits[0]]))
