@@ -8,13 +8,14 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-# the counter passes run without the worker threads of ccal_solve_batch (bench.py: extra.concurrent_sessions)
 BENCH="python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 python3 $REPO/bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
+# every rocprofv3 pass runs without the worker threads of ccal_solve_batch (bench.py: extra.concurrent_sessions): the profiler
+# crashed twice inside a kernel launch issued from a worker thread (SIGSEGV in its interception layer; never without it)
+export CCAL_BENCH_NO_CONCURRENT=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH --no-extra > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH --no-extra > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err
-export CCAL_BENCH_NO_CONCURRENT=1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -o pmc -- $BENCH > $OUT/pmc_sq_bench.json 2> $OUT/pmc_sq.err
 # mode N: issue / wait breakdown of the Gram and elimination kernels (second SQ pass: 8 SQ slots per pass)
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU_FMA_F64 --output-format csv -d $OUT/pmc_sq2 -o pmc -- $BENCH > $OUT/pmc_sq2_bench.json 2> $OUT/pmc_sq2.err
