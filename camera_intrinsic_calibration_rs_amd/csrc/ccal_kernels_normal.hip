@@ -383,7 +383,8 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? CCAL_SCHUR_MINW : 1) void k_sc
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
     __syncthreads();
     if (gw >= a.n_pw || (a.st && a.st->done)) return;
-    const double* p_G = (a.st && schur_set(a.st) == 1) ? a.G2 : a.G;
+    const int g_set = a.st ? schur_set(a.st) : 0;
+    const double* p_G = a.Gs[g_set];
     const double lambda = a.st ? schur_lambda(a.st) : a.lambda;
 
     int o0n = gw < a.n_slots ? a.slot_off[gw] : 0, o1n = gw < a.n_slots ? a.slot_off[gw + 1] : 0;
@@ -592,8 +593,8 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
                         const DevState* st) {
     const NormalWs* w = p->nws;
     SchurArgs a = {};
-    a.st = st; a.G2 = w->G[gbuf ^ 1];
-    a.G = w->G[gbuf]; a.slot_desc = w->schurq ? w->d_slot_rec : w->d_slot_desc; a.slot_off = w->d_slot_off;
+    a.st = st; a.Gs[1] = w->G[gbuf ^ 1];
+    a.Gs[0] = w->G[gbuf]; a.slot_desc = w->schurq ? w->d_slot_rec : w->d_slot_desc; a.slot_off = w->d_slot_off;
     a.caminfo = w->d_caminfo; a.n_cams = p->n_cams;
     a.n_slots = p->n_slots; a.K = w->K; a.RB = w->RB; a.PF = w->PF; a.n_pw = w->n_pw;
     a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;

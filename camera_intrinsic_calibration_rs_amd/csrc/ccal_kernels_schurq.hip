@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     constexpr int TY = (K1 + 3) / 4;                        // columns / rows of the slot's Y per lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (a.st && a.st->done) return;
-    const double* p_G = (a.st && schur_set(a.st) == 1) ? a.G2 : a.G;
+    const int g_set = a.st ? schur_set(a.st) : 0;
+    const double* p_G = a.Gs[g_set];
     const double lambda = a.st ? schur_lambda(a.st) : a.lambda;
     const int lane = threadIdx.x, sl = lane >> 2, q = lane & 3;
     const int s = blockIdx.x * SQ_SLOTS + sl;

@@ -95,7 +95,12 @@ struct FusedWs {
 struct DevState;
 // argument block of the per-slot elimination kernels (k_schur: ccal_kernels_normal.hip, k_schurq: ccal_kernels_schurq.hip)
 struct SchurArgs {
-    const double* G;
+    // the record buffers of parameter set 0 / 1 of the device-resident loop (host-driven form: [0] only).  An ARRAY indexed with
+    // the set - one scalar load at a computed offset - and not `set == 1 ? G2 : G`: hipcc -O1 (ROCm 7.2) compiled that select
+    // of two kernel-argument pointers behind `st != NULL && ...` into a branch that skips the load of G (every general solve
+    // ended NOT_PD on records of zeros); at -O3 the same source happened to come out right - and stopped doing so when the
+    // block grew by a pointer (the "136-byte" failures of this round).  Found with a -O1 host-sanitizer build
+    const double* Gs[2];
     const int64_t* slot_desc;      // k_schur: per (slot, observation) in slot order: goff * 8 + camera - one load instead of three;
                                    // k_schurq: [n_slots][2] record offset (doubles) of camera 0 / 1 in the slot, -1 = none
     const int32_t* slot_off; const int32_t* caminfo; int32_t n_cams;
@@ -103,13 +108,9 @@ struct SchurArgs {
     int32_t STG;                   // per-wavefront staging (doubles) for record-format observations, 0 = none
     double lambda, min_diag, max_diag;
     double* partial; double* pf; const double* mc_slot;
-    const DevState* st; const double* G2;      // device-resident loop: Gram set and lambda come from the state
+    const DevState* st;                        // device-resident loop: Gram set and lambda come from the state
 };
-// Kept at the 128 bytes it had before k_schurq: with a ninth pointer (136 bytes) the member at offset 128 reached the
-// kernels wrong on this stack (ROCm 7.2, gfx950) whichever member it was - observed through the parity tests, not explained
-// (tools/ubench/kernarg136.hip: the same block in a stand-alone kernel arrives intact).  k_schurq takes its own per-slot
-// table through `slot_desc`.
-static_assert(sizeof(SchurArgs) == 128, "see above");
+
 
 void normal_ws_destroy(ccal_problem* p);
 int normal_ws_ensure(ccal_problem* p);          // allocate on first use

@@ -1,5 +1,6 @@
-// Developer check: does a kernel argument struct of 136 bytes arrive intact (member at offset 128)?  Same member types and
-// order as the SchurArgs variant that misbehaved (tools/ubench, not part of the library).
+// Developer check: does a kernel argument struct of 136 bytes arrive intact (member at offset 128), also through one
+// s_load_dwordx16 at offset 0x48?  It does - this ruled the argument block out when the elimination kernels misbehaved with a
+// 136-byte SchurArgs; the cause was a miscompiled select of two kernel-argument pointers.
 //   hipcc --offload-arch=gfx950 -O3 -o kernarg136.bin kernarg136.hip && ./kernarg136.bin
 #include <hip/hip_runtime.h>
 #include <cstdint>
