@@ -860,7 +860,8 @@ hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, d
 // back-substitutes - the same operation order as before.
 // ---------------------------------------------------------------------------------------------
 struct BacksubArgs {
-    const double* pf; const double* dc; const double* poses; double* poses_c; double* mc_slot;
+    const double* pf; const double* dc; double* mc_slot;
+    double* poses_s[2];            // parameter set 0 / 1; read [cur], write [cur ^ 1] - indexed, never selected (see SchurArgs::Gs)
     int32_t n_slots, K, PF; double lambda, min_diag, max_diag;
     const DevState* st;
 };
@@ -871,8 +872,10 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     if (a.st) {
         if (a.st->done || a.st->redo) return;      // finished, or this group's decision asked for a re-elimination (nothing was solved)
         a.lambda = a.st->lambda;
-        if (a.st->cur) { a.poses = a0.poses_c; a.poses_c = const_cast<double*>(a0.poses); }
     }
+    const int cur_set = a.st ? a.st->cur : 0;
+    const double* const poses = a0.poses_s[cur_set];          // the kernel argument itself: one scalar load at a computed offset
+    double* const poses_c = a0.poses_s[cur_set ^ 1];
     if (threadIdx.x < a.K) dcs[threadIdx.x] = a.dc[threadIdx.x];
     const int g = threadIdx.x >> 4, gl = threadIdx.x & 15;
     const int s = blockIdx.x * 16 + g;
@@ -894,7 +897,7 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     if (!active || gl != 0) return;
     if (R[0] == 0.0) {          // no observations / failed factorisation: pose unchanged
 #pragma unroll
-        for (int i = 0; i < 6; ++i) a.poses_c[(int64_t)s * 6 + i] = a.poses[(int64_t)s * 6 + i];
+        for (int i = 0; i < 6; ++i) poses_c[(int64_t)s * 6 + i] = poses[(int64_t)s * 6 + i];
         a.mc_slot[s] = 0.0;
         return;
     }
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
         const double gp = R[21 + 6 * K1 + i], dC = R[21 + 6 * K1 + 6 + i];
         const double Dii = a.lambda > 0.0 ? a.lambda * clampd(dC, a.min_diag, a.max_diag) : 0.0;
         mc += dp[i] * (Dii * dp[i] - gp);
-        a.poses_c[(int64_t)s * 6 + i] = a.poses[(int64_t)s * 6 + i] + dp[i];
+        poses_c[(int64_t)s * 6 + i] = poses[(int64_t)s * 6 + i] + dp[i];
     }
     a.mc_slot[s] = mc;
 }
@@ -925,7 +928,7 @@ hipError_t launch_backsub(const ccal_problem* p, double lambda, double min_diag,
     if (p->n_slots == 0) return hipSuccess;
     BacksubArgs a = {};
     a.st = st;
-    a.pf = w->pf; a.dc = w->dc; a.poses = p->d_poses; a.poses_c = p->d_poses_c; a.mc_slot = w->mc_slot;
+    a.pf = w->pf; a.dc = w->dc; a.poses_s[0] = p->d_poses; a.poses_s[1] = p->d_poses_c; a.mc_slot = w->mc_slot;
     a.n_slots = p->n_slots; a.K = w->K; a.PF = w->PF; a.lambda = lambda;
     a.min_diag = min_diag; a.max_diag = max_diag;
     const size_t lds = sizeof(double) * 16 * (size_t)(w->PF + 6);
