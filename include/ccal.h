@@ -45,6 +45,13 @@
  * (src/util.rs:411, 621-627).
  * Reduced ("camera") system column order (ccal_build_normal): for c = 0..n_cams-1:
  * theta_c (P_eff(c)), then for c>0 rvec_c_0, tvec_c_0.  K = sum P_eff + 6 (n_cams-1).
+ *
+ * Environment.  The behaviour contract of this ABI does not depend on the environment: the library reads a number of
+ * CCAL_* variables ("Developer switches"), every one of them a developer switch that selects between
+ * implementations of the SAME result - which kernel forms a Gram block or eliminates a pose block, lanes per frame, groups
+ * enqueued ahead - for A/B measurements and for the tests that hold the implementations against each other.  Results agree to
+ * rounding (summation order), statuses and iteration counts are the same; with none of them set the library takes the
+ * measured winners.  Some are read once per process or per problem workspace; a binding should set none.
  */
 #ifndef CCAL_H
 #define CCAL_H
