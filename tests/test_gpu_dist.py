@@ -146,11 +146,16 @@ def _gpu_worker(rank, world, port, model, n_cams, method, n_frames, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("model,n_cams,method", [("eucm", 1, 0), ("eucm", 1, 1), ("eucm", 2, 0), ("kb4", 2, 1)])
-def test_two_ranks_on_the_device_path(model, n_cams, method):
+@pytest.mark.parametrize("model,n_cams,method,fast", [("eucm", 1, 0, False), ("eucm", 1, 1, False), ("eucm", 2, 0, False), ("kb4", 2, 1, False),
+                                                      ("eucm", 2, 1, True), ("ucm", 2, 0, True)])
+def test_two_ranks_on_the_device_path(model, n_cams, method, fast, monkeypatch):
     """Frame-sharded solve, two ranks, HIP kernels on both: identical camera block on both ranks (bit for bit), the same
-    collective sequence on both ranks, and the single-process solve of the whole problem up to summation order."""
+    collective sequence on both ranks, and the single-process solve of the whole problem up to summation order.
+    fast: the two-camera rig's shards through k_schurq (forced: the shards are far below its 6 000-slot threshold) and the
+    merged Gram launch - their partial sums feed the same all-reduce."""
     import torch.multiprocessing as mp
+    if fast:
+        monkeypatch.setenv("CCAL_SCHURQ", "1")           # inherited by the spawned ranks
     n_frames = 41                                      # odd: shards of 20 and 21 slots
     sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
     ctx0 = Context(0)
