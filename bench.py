@@ -77,6 +77,15 @@ def _emit(out):
         os.write(1, line)
 
 
+def _under_rocprofiler() -> bool:
+    """rocprofv3 preloads its tool library into the process it profiles."""
+    try:
+        with open("/proc/self/maps") as f:
+            return any("rocprofiler-sdk-tool" in line or "rocprofv3" in line for line in f)      # (librocprofiler-register.so is always there)
+    except OSError:
+        return False
+
+
 def main():
     _stdout_for_the_line_only()
     ap = argparse.ArgumentParser()
@@ -321,6 +330,9 @@ def main():
             try:
                 if os.environ.get("CCAL_BENCH_NO_CONCURRENT"):
                     raise RuntimeError("skipped (CCAL_BENCH_NO_CONCURRENT)")
+                if _under_rocprofiler():
+                    raise RuntimeError("skipped: rocprofiler is loaded in this process (it crashed twice inside kernel launches issued "
+                                       "from ccal_solve_batch's worker threads, profiles/r03; never without it)")
                 sys.path.insert(0, os.path.join(ROOT, "tools"))
                 import concurrent_sessions
                 extra["concurrent_sessions"] = concurrent_sessions.measure(625, args.model, 0, reps=100, counts=(1, 2, 4, 8), device=dev_index)
