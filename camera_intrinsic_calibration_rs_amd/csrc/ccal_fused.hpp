@@ -214,9 +214,37 @@ __host__ __device__ constexpr int praw_size(int K) { return (praw_jl_off(K) + 9 
 // GEN record of one observation frame (general loop), laid out for k_schur's expansion: every row it multiplies with E is
 // six contiguous doubles:  C (6 x 6, full symmetric) | [B|g]^T (K1 x 6: row = camera column, r last) | A (K1 x K1) |
 // E^T dense (12 x 6, frame_setup_composed);  K = the camera's P_eff
+// (round 3: A as its packed lower triangle - row i, column j <= i at i (i + 1) / 2 + j - and E as its 36 structural non-zeros
+//  E_c = [M | N | J1 | SJ], each 3 x 3 with X(m, b) at 3 b + m:  E^T row b = [M(.,b) 0], row 3+b = [0 N(.,b)], row 6+b = [J1(.,b) SJ(.,b)],
+//  row 9+b = [0 e_b]  (frame_setup_composed); 142 doubles for EUCM where the dense form had 230: the records are written once
+//  and read once per group, 37 -> 23 MB each way for two cameras x 10 000 frames)
 __host__ __device__ constexpr int gen_a_off(int K) { return 36 + 6 * (K + 1); }
-__host__ __device__ constexpr int gen_e_off(int K) { return (36 + 6 * (K + 1) + (K + 1) * (K + 1) + 1) & ~1; }    // 16-byte aligned rows
-__host__ __device__ constexpr int gen_rec_size(int K) { return gen_e_off(K) + 72; }
+__host__ __device__ constexpr int gen_e_off(int K) { return (36 + 6 * (K + 1) + (K + 1) * (K + 2) / 2 + 1) & ~1; }    // 16-byte aligned
+constexpr int GEN_EC = 36;
+__host__ __device__ constexpr int gen_rec_size(int K) { return gen_e_off(K) + GEN_EC; }
+// entry e (row-major 12 x 6) of the dense E^T from the compact form
+__device__ __forceinline__ double gen_et_dense(const double* ec, int e) {
+    const int row = e / 6, k = e - 6 * row, blk = row / 3, b = row - 3 * blk;
+    if (blk == 0) return k < 3 ? ec[3 * b + k] : 0.0;
+    if (blk == 1) return k >= 3 ? ec[9 + 3 * b + (k - 3)] : 0.0;
+    if (blk == 2) return k < 3 ? ec[18 + 3 * b + k] : ec[27 + 3 * b + (k - 3)];
+    return (k - 3) == b ? 1.0 : 0.0;
+}
+// where stored value v (0 .. 35) sits in the dense (row-major 12 x 6) E^T
+__host__ __device__ constexpr int gen_et_pos(int v) {
+    const int blk = v / 9, r = v - 9 * blk, b = r / 3, m = r - 3 * b;
+    return blk == 0 ? 6 * b + m : (blk == 1 ? 6 * (3 + b) + 3 + m : (blk == 2 ? 6 * (6 + b) + m : 6 * (6 + b) + 3 + m));
+}
+// the compact form from frame_setup_composed's dense E^T
+__device__ __forceinline__ void gen_et_compact(const double* ept, double* ec) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            ec[3 * b + m] = ept[6 * b + m]; ec[9 + 3 * b + m] = ept[6 * (3 + b) + 3 + m];
+            ec[18 + 3 * b + m] = ept[6 * (6 + b) + m]; ec[27 + 3 * b + m] = ept[6 * (6 + b) + 3 + m];
+        }
+}
 // rows of partial sums up to which k_head adds them up itself (session-sized problems: <= 1 280 frames); see solve_fused
 constexpr int kHeadReduceRows = 40;
 // red / partial rows of the single-camera path: [A_dir (K1 x K1) | Y^T Y (K1 x K1) | mc_pose | failed pose blocks]

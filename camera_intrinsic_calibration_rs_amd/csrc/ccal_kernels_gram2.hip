@@ -50,7 +50,7 @@ __host__ __device__ constexpr uint32_t g2_rec_dst(int i, int j) {
         if (ip && jp) { a = (i - K) * 6 + (j - K); if (i != j) b = (j - K) * 6 + (i - K); }
         else if (!ip && jp) a = 36 + ci * 6 + (j - K);
         else if (ip && !jp) a = 36 + K * 6 + (i - K);
-        else { a = gen_a_off(K) + ci * K1 + cj; b = gen_a_off(K) + cj * K1 + ci; }
+        else a = gen_a_off(K) + cj * (cj + 1) / 2 + ci;                    // packed lower triangle (ci <= cj)
     }
     return a | (b << 16);
 }
@@ -311,9 +311,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
                 for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
             }
             if (gl == 0 && active) {
+                double ec[GEN_EC];
+                gen_et_compact(ept, ec);
                 double2* rec = reinterpret_cast<double2*>(a.praw[es] + a.rec_off[fa_] + gen_e_off(K));
 #pragma unroll
-                for (int i = 0; i < GEN_EPT / 2; ++i) rec[i] = make_double2(ept[2 * i], ept[2 * i + 1]);
+                for (int i = 0; i < GEN_EC / 2; ++i) rec[i] = make_double2(ec[2 * i], ec[2 * i + 1]);
             }
         } else {
             double fcr[FC_N0];

@@ -381,6 +381,13 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? CCAL_SCHUR_MINW : 1) void k_sc
         }
     }
     for (int e = lane; e < RB; e += 64) acc[e] = 0.0;
+    // record format: the dense 12 x 6 image of E^T sits behind the largest record; its zeros and the three ones of the
+    // tvec_c_0 rows are the same for every record - set once; a record's 36 stored values go to their places (et_pos)
+    const int EOD = a.STG - 144;
+    const int et_pos = gen_et_pos(lane < GEN_EC ? lane : 0);
+    if constexpr (REC) {
+        for (int e = lane; e < 72; e += 64) { const int row = e / 6, k = e - 6 * row; stg[EOD + e] = (row >= 9 && k - 3 == row - 9) ? 1.0 : 0.0; }
+    }
     __syncthreads();
     if (gw >= a.n_pw || (a.st && a.st->done)) return;
     const int g_set = a.st ? schur_set(a.st) : 0;
@@ -413,15 +420,19 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? CCAL_SCHUR_MINW : 1) void k_sc
                 // without a division; each accumulator receives one addend per observation frame (ordered sums).
                 const int Pe = cinfo[cam][0], ct = cinfo[cam][1], ce = cinfo[cam][2];
                 const int K1c = Pe + 1, EO = gen_e_off(Pe), NEc = cam > 0 ? 12 : 6;
-                const double* ept = stg + EO;             // E^T, 12 x 6
-                double* wvt = stg + EO + 72;              // (C E)^T, 12 x 6
-                {   // all loads first (one memory latency per record), then the LDS image
-                    constexpr int RV = (gen_rec_size(9) + 63) / 64;        // P_eff <= 9 (OPENCV5)
-                    double rv[RV];
+                const double* ept = stg + EOD;            // E^T, 12 x 6 (dense image)
+                double* wvt = stg + EOD + 72;             // (C E)^T, 12 x 6
+                {   // all loads first (one memory latency per record), then the LDS image: C | [B|g]^T | A (packed lower triangle)
+                    // as stored, E^T expanded from its 36 stored non-zeros to the dense 12 x 6 the products read
+                    constexpr int RV = (gen_e_off(9) + 63) / 64;           // P_eff <= 9 (OPENCV5)
+                    double rv[RV], ecv = 0.0;
 #pragma unroll
-                    for (int t = 0; t < RV; ++t) rv[t] = (lane + 64 * t) < EO + 72 ? Go[lane + 64 * t] : 0.0;
+                    for (int t = 0; t < RV; ++t) rv[t] = (lane + 64 * t) < EO ? Go[lane + 64 * t] : 0.0;
+                    if (lane < GEN_EC) ecv = Go[EO + lane];
 #pragma unroll
-                    for (int t = 0; t < RV; ++t) if ((lane + 64 * t) < EO + 72) stg[lane + 64 * t] = rv[t];
+                    for (int t = 0; t < RV; ++t) if ((lane + 64 * t) < EO) stg[lane + 64 * t] = rv[t];
+                    // the dense image's zeros and the three ones of the tvec_c_0 rows are the same for every record (set once, below)
+                    if (lane < GEN_EC) stg[EOD + et_pos] = ecv;
                 }
                 wave_sync_lds();
                 // (row group, column b) of the two products: 4 x 16 lanes for twelve columns, 8 x 8 for camera 0's six
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(64 * WPB, WPB == 4 ? CCAL_SCHUR_MINW : 1) void k_sc
                     for (int i = lane >> 4; i < K1c; i += 4) {
                         if (j > i) continue;
                         const int ii = i < Pe ? ct + i : K, jj = j < Pe ? ct + j : K;
-                        const double v = stg[gen_a_off(Pe) + i * K1c + j];
+                        const double v = stg[gen_a_off(Pe) + i * (i + 1) / 2 + j];
                         __hip_atomic_fetch_add(acc + ii * K1 + jj, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         const int x = i == j ? (i < Pe ? K1 * K1 + ii : K1 * K1 + 2 * K) : ((i == Pe) ? K1 * K1 + K + jj : -1);
                         if (x >= 0) __hip_atomic_fetch_add(acc + x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -603,7 +614,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     // record-format cameras: staging for the largest record (with E^T) + (C E)^T (72)
     int stg = 0;
     if (w->register_gram)
-        for (int c = 0; c < p->n_cams; ++c) stg = std::max(stg, gen_rec_size(p->cams[c].Peff) + 72);
+        for (int c = 0; c < p->n_cams; ++c) stg = std::max(stg, gen_e_off(p->cams[c].Peff) + 144);       // record + dense E^T + (C E)^T
     a.STG = stg;
     const int WS = ((w->RB + 12 * K1 + 36 + 1) & ~1) + stg;
     int tab_entries = 0;

@@ -38,8 +38,8 @@ template <int PE> struct SqLayout {
     static constexpr int K1c = PE + 1, K = 2 * PE + 6, K1 = K + 1, NT = K1 * (K1 + 1) / 2;
     static constexpr int XH = NT, XG = NT + K, XC = NT + 2 * K, XM = XC + 1, XF = XC + 2, ACCN = XC + 3;
     static constexpr int HS = 36 + 6 * K1c;                              // record head: C | [B|g]^T
-    static constexpr int H0 = 0, E0 = HS, H1 = HS + 36, E1 = 2 * HS + 36;   // staging of the two records (E^T: 6 rows / 12 rows)
-    static constexpr int STG = 2 * HS + 108;
+    static constexpr int H0 = 0, E0 = HS, H1 = HS + 36, E1 = 2 * HS + 36;   // staging of the two records (E as stored: [M | N | J1 | SJ], ccal_fused.hpp)
+    static constexpr int STG = 2 * HS + 72;
     static constexpr int IMG = 0;                                        // the slot's image of the reduced system: over the (dead) staging
     static constexpr int YL = ((STG > ACCN ? STG : ACCN) + 1) & ~1;       // [B|g] of the slot, then Y: K1 columns of 6
     static constexpr int CX = YL + 6 * K1;                               // C of the slot (6 x 6)
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     const int64_t p0 = has ? a.slot_desc[2 * (int64_t)s] : -1, p1 = has ? a.slot_desc[2 * (int64_t)s + 1] : -1;
     const bool live = p0 >= 0 || p1 >= 0;
     const double mc_s = (has && q == 0) ? a.mc_slot[s] : 0.0;          // model decrease of this slot's pose block for the step under decision
-    // the camera | r blocks of the records: this lane's rows i = q + 4 t of the lower triangles, straight from HBM into
-    // registers (they are direct terms of the reduced system, wanted only once the products are done)
+    // the camera | r blocks of the records (direct terms of the reduced system, wanted only once the products are done): this
+    // lane's rows i = q + 4 t of the lower triangles, held in registers from the staging on
     double av[2][TR][K1c];
     {
         constexpr int NH = HS / 2;                                      // 16-byte pieces of a head
@@ -107,16 +107,18 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; if (c < 18) w[Lt::E0 / 2 + c] = e0[t]; }
         }
         {
-            double2 h1[TH], e1[9];
+            double2 h1[TH], e1[5];
 #pragma unroll
             for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h1[t] = (has && c < NH) ? g1[c] : z2; }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { const int c = q + 4 * t; e1[t] = has ? g1[gen_e_off(PE) / 2 + c] : z2; }
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; e1[t] = (has && c < 18) ? g1[gen_e_off(PE) / 2 + c] : z2; }
 #pragma unroll
             for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H1 / 2 + c] = h1[t]; }
 #pragma unroll
-            for (int t = 0; t < 9; ++t) { const int c = q + 4 * t; w[Lt::E1 / 2 + c] = e1[t]; }
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; if (c < 18) w[Lt::E1 / 2 + c] = e1[t]; }
         }
+        // (the A blocks through 16-byte pieces into LDS - 8 wide loads instead of 2 x 28 narrow ones - put them on the critical path
+        // of the staging: 11.4 us against 8.4; as 8-byte loads straight into registers they arrive while the products run)
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
             const int i = q + 4 * t;
@@ -124,8 +126,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             for (int j = 0; j < K1c; ++j) {
                 if (j > 4 * t + 3) { av[0][t][j] = 0.0; av[1][t][j] = 0.0; continue; }      // compile time: j <= i impossible
                 const bool in = i < K1c && j <= i;
-                av[0][t][j] = (in && has) ? r0[HS + i * K1c + j] : 0.0;
-                av[1][t][j] = (in && has) ? r1[HS + i * K1c + j] : 0.0;
+                av[0][t][j] = (in && has) ? r0[HS + i * (i + 1) / 2 + j] : 0.0;      // packed lower triangle
+                av[1][t][j] = (in && has) ? r1[HS + i * (i + 1) / 2 + j] : 0.0;
             }
         }
     }
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     SQ_STAMP(1);
 
     // ---- products with E (frame_setup_composed): E_p = diag(M, N) maps the composed pose's (phi, delta) to (rvec_0_b, tvec_0_b),
-    // E_x (camera 1) to (rvec_1_0, tvec_1_0).  E^T rows b: M(m, b) = Et[6 b + m], N(m, b) = Et[21 + 6 b + m]  (b, m < 3)
+    // E_x (camera 1) to (rvec_1_0, tvec_1_0).  Stored as [M | N | J1 | SJ], X(m, b) at 3 b + m (ccal_fused.hpp)
     double racc[6] = { 0, 0, 0, 0, 0, 0 };                  // [B|g] column r: both cameras' row r meet in the same lane
     double cmb[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };          // this lane's 3 x 3 block (rh, ch) of the slot's C
     double cross[TR][6];                                    // camera 1: rows of [B|g]^T times E_x -> theta_1 (| r) x extrinsics
@@ -142,15 +144,16 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const double* H = sb + (c == 0 ? Lt::H0 : Lt::H1);
-        const double* Et = sb + (c == 0 ? Lt::E0 : Lt::E1);
-        // E_p^T rows 0..5 in registers
+        const double* Ec = sb + (c == 0 ? Lt::E0 : Lt::E1);        // [M | N | J1 | SJ], X(m, b) at 3 b + m
+        // E_p^T rows 0..5 in registers: row b = [M(., b) | 0], row 3 + b = [0 | N(., b)] - only the non-zero halves are used
         double ep[6][6];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) {
-            const double2* r = reinterpret_cast<const double2*>(Et + 6 * b);
-            const double2 r0 = r[0], r1 = r[1], r2 = r[2];
-            ep[b][0] = r0.x; ep[b][1] = r0.y; ep[b][2] = r1.x; ep[b][3] = r1.y; ep[b][4] = r2.x; ep[b][5] = r2.y;
-        }
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                ep[b][m] = Ec[3 * b + m]; ep[b][3 + m] = 0.0;
+                ep[3 + b][m] = 0.0; ep[3 + b][3 + m] = Ec[9 + 3 * b + m];
+            }
         {   // block (rh, ch) of E_p^T C E_p = P_rh^T C_(rh,ch) P_ch,  P_0 = M, P_1 = N
             double cb[3][3], pr[3][3], pc[3][3], tm[3][3];
 #pragma unroll
@@ -158,8 +161,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
 #pragma unroll
                 for (int n = 0; n < 3; ++n) {
                     cb[m][n] = H[(3 * rh + m) * 6 + 3 * ch + n];
-                    pr[m][n] = Et[21 * rh + 6 * n + m];       // P_rh(m, n)
-                    pc[m][n] = Et[21 * ch + 6 * n + m];
+                    pr[m][n] = Ec[9 * rh + 3 * n + m];        // P_rh(m, n)
+                    pc[m][n] = Ec[9 * ch + 3 * n + m];
                 }
 #pragma unroll
             for (int m = 0; m < 3; ++m)
@@ -173,11 +176,12 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         double ex[6][6];                                    // camera 1: E_x^T rows j (E^T rows 6 + j)
         if (c == 1) {
 #pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const double2* r = reinterpret_cast<const double2*>(Et + 36 + 6 * j);
-                const double2 r0 = r[0], r1 = r[1], r2 = r[2];
-                ex[j][0] = r0.x; ex[j][1] = r0.y; ex[j][2] = r1.x; ex[j][3] = r1.y; ex[j][4] = r2.x; ex[j][5] = r2.y;
-            }
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    ex[j][k] = Ec[18 + 3 * j + k]; ex[j][3 + k] = Ec[27 + 3 * j + k];         // rvec_1_0: [J1(., j) | SJ(., j)]
+                    ex[3 + j][k] = 0.0; ex[3 + j][3 + k] = k == j ? 1.0 : 0.0;                // tvec_1_0: unit vectors (folded by the compiler)
+                }
         }
         // rows i = q + 4 t of [B|g]^T: E_p^T b_i -> column theta_c,i of the slot's [B|g] (i = PE: the r column)
 #pragma unroll
@@ -211,10 +215,12 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             double exj[2][6];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const int j = q + 4 * t, jc = j < 6 ? j : 0;
-                const double2* r = reinterpret_cast<const double2*>(Et + 36 + 6 * jc);
-                const double2 r0 = r[0], r1 = r[1], r2 = r[2];
-                exj[t][0] = r0.x; exj[t][1] = r0.y; exj[t][2] = r1.x; exj[t][3] = r1.y; exj[t][4] = r2.x; exj[t][5] = r2.y;
+                const int j = q + 4 * t, jr = j < 3 ? j : 0;             // column j of E_x: rotation columns stored, translation columns unit
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    exj[t][k] = j < 3 ? Ec[18 + 3 * jr + k] : 0.0;
+                    exj[t][3 + k] = j < 3 ? Ec[27 + 3 * jr + k] : (j - 3 == k ? 1.0 : 0.0);
+                }
             }
 #pragma unroll
             for (int m = 0; m < 6; ++m) {

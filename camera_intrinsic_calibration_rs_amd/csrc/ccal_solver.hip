@@ -148,7 +148,7 @@ int normal_ws_ensure(ccal_problem* p) {
     // (also below 64 columns when four wavefronts' images do not fit the CU's 160 KB: K + 1 = 62 .. 64 with OPENCV5-sized records)
     {
         int stg = 0;
-        for (int c = 0; c < p->n_cams; ++c) stg = std::max(stg, gen_rec_size(p->cams[c].Peff) + 72);
+        for (int c = 0; c < p->n_cams; ++c) stg = std::max(stg, gen_e_off(p->cams[c].Peff) + 144);       // as launch_schur
         const int K1 = p->K + 1;
         const size_t ws4 = sizeof(double) * WAVES_PER_BLOCK * (size_t)((((w->RB + 12 * K1 + 36 + 1) & ~1)) + stg);
         if (p->K >= 64 || ws4 + 6 * 1024 > 160 * 1024) { w->schur_wpb = 1; n_pw = std::min(std::max(p->n_slots, 1), 512); }
