@@ -30,7 +30,6 @@ __device__ __forceinline__ void sq_tri_decode(int e, int& i, int& j) {
     if (i * (i + 1) / 2 > e) --i;
     j = e - i * (i + 1) / 2;
 }
-__device__ __forceinline__ void sq_add(double* p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __host__ __device__ constexpr int sq_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // per-slot LDS area (doubles)
