@@ -15,6 +15,8 @@ OK, ERR_INVALID_ARG, ERR_HIP, ERR_NONFINITE, ERR_NOT_PD, ERR_NO_CONVERGENCE, ERR
 STATUS_NAMES = ["CCAL_OK", "CCAL_ERR_INVALID_ARG", "CCAL_ERR_HIP", "CCAL_ERR_NONFINITE", "CCAL_ERR_NOT_PD",
                 "CCAL_ERR_NO_CONVERGENCE", "CCAL_ERR_UNSUPPORTED", "CCAL_ERR_NO_MEMORY"]
 METHOD_GN, METHOD_LM = 0, 1
+TRANSPORT_NONE, TRANSPORT_RCCL, TRANSPORT_INPROC = 0, 1, 2
+MULTI_MAX_DEVICES = 16
 
 _dp = C.POINTER(C.c_double)
 _fp = C.POINTER(C.c_float)
@@ -102,6 +104,32 @@ SYMBOLS = [
                                    C.POINTER(Report)]),
     ("ccal_init_poses", C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
     ("ccal_init_camera_extrinsic", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(Report)]),
+    ("ccal_se3_factor", C.c_int, [_dp, _dp, _dp, _dp, _dp]),
+    # one process, several GPUs
+    ("ccal_solve_sharded", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(SolverOpts), _dp, C.POINTER(_dp), _dp, C.POINTER(Report)]),
+    ("ccal_multi_create", C.c_int, [_ip, C.c_int, C.POINTER(_vp)]),
+    ("ccal_multi_destroy", None, [_vp]),
+    ("ccal_multi_num_devices", C.c_int, [_vp]),
+    ("ccal_multi_transport", C.c_int, [_vp]),
+    ("ccal_multi_ctx", _vp, [_vp, C.c_int]),
+    ("ccal_multi_last_error", C.c_char_p, [_vp]),
+    ("ccal_multi_set_model_conventions", C.c_int, [_vp, C.POINTER(ModelConventions)]),
+    ("ccal_multi_sync", C.c_int, [_vp]),
+    ("ccal_multi_problem_create", C.c_int, [_vp, C.POINTER(ProblemDesc), C.POINTER(_vp)]),
+    ("ccal_multi_problem_destroy", None, [_vp]),
+    ("ccal_multi_problem_num_shards", C.c_int, [_vp]),
+    ("ccal_multi_problem_shard", _vp, [_vp, C.c_int]),
+    ("ccal_multi_problem_slot_range", C.c_int, [_vp, C.c_int, _ip, _ip]),
+    ("ccal_multi_set_bounds", C.c_int, [_vp, C.c_int, C.c_int, C.c_double, C.c_double]),
+    ("ccal_multi_clear_bounds", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("ccal_multi_fix_param", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("ccal_multi_unfix_param", C.c_int, [_vp, C.c_int, C.c_int]),
+    ("ccal_multi_apply_reference_bounds", C.c_int, [_vp]),
+    ("ccal_multi_disable_distortions", C.c_int, [_vp, C.c_int, _dp]),
+    ("ccal_multi_init_poses", C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
+    ("ccal_multi_upload_params", C.c_int, [_vp, _dp, _dp, _dp]),
+    ("ccal_multi_eval_dev", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
+    ("ccal_multi_solve", C.c_int, [_vp, C.POINTER(SolverOpts), _dp, _dp, _dp, C.POINTER(Report)]),
     ("ccal_convert_model", C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,
                                      C.POINTER(SolverOpts), C.POINTER(Report)]),
     ("ccal_reprojection_errors", C.c_int, [_vp, _dp, _dp, _dp, _dp]),

@@ -31,7 +31,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _ffi
-from .engine import CcalError, Context, Problem, default_opts, make_desc
+from .engine import CcalError, Context, MultiContext, MultiProblem, Problem, default_opts, make_desc
 from .synth import MODEL_NAMES, MODEL_NPARAMS, PMAX, rodrigues, rotmat_to_rvec
 
 _MODEL_KEYS = {
@@ -188,6 +188,32 @@ def _ctx(ctx: Optional[Context]) -> Context:
     return _default_ctx
 
 
+class _Opened:
+    """A problem on one context, or - `devices` given - sharded by the library over a device set of this process
+    (ccal_multi_*: one call, every listed GPU; a device listed twice = two shards on it)."""
+
+    def __init__(self, ctx: Optional[Context], devices: Optional[Sequence[int]], d, keep):
+        self.mctx = None
+        if devices is not None:
+            self.mctx = MultiContext(list(devices))
+            try:
+                self.prob = MultiProblem(self.mctx, d, keep)
+            except Exception:
+                self.mctx.close()
+                raise
+        else:
+            self.prob = Problem(_ctx(ctx), d, keep)
+
+    def __enter__(self):
+        return self.prob
+
+    def __exit__(self, *exc):
+        self.prob.close()
+        if self.mctx is not None:
+            self.mctx.close()
+        return False
+
+
 def _flatten(cams_frames: Sequence[Sequence[Optional[FrameFeature]]], use: Sequence[Sequence[int]]):
     """(cam, frame index) observation frames -> CSR + SoA arrays; slots = sorted union of frame indices."""
     slots = sorted({i for idxs in use for i in idxs})
@@ -214,7 +240,7 @@ def _intr_matrix(cameras: Sequence[GenericModel]) -> np.ndarray:
 
 
 def init_frame_poses(frame_feature_list: Sequence[Optional[FrameFeature]], generic_camera: GenericModel,
-                     min_points: int = 10, ctx: Optional[Context] = None) -> Dict[int, RvecTvec]:
+                     min_points: int = 10, ctx: Optional[Context] = None, devices: Optional[Sequence[int]] = None) -> Dict[int, RvecTvec]:
     """The pose initialisation inside calib_camera (src/util.rs:418-436): `unproject` the detections with
     the current model, keep the valid ones, normalise by z, planar PnP -- one wavefront per frame."""
     valid = [i for i, f in enumerate(frame_feature_list) if f is not None]
@@ -223,32 +249,30 @@ def init_frame_poses(frame_feature_list: Sequence[Optional[FrameFeature]], gener
     slots, obs_cam, obs_slot, offs, X, U = _flatten([frame_feature_list], [valid])
     d, keep = make_desc(1, [generic_camera.model_id], [generic_camera.width()], [generic_camera.height()], False,
                         len(slots), obs_cam, obs_slot, offs, X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
-    prob = Problem(_ctx(ctx), d, keep)
-    try:
+    with _Opened(ctx, devices, d, keep) as prob:
         poses, used = prob.init_poses(_intr_matrix([generic_camera]), min_points)
-    finally:
-        prob.close()
     return {fi: RvecTvec.from6(poses[s]) for s, fi in enumerate(slots) if used[s] > 0}
 
 
 def calib_camera(frame_feature_list: Sequence[Optional[FrameFeature]], generic_camera: GenericModel,
                  xy_same_focal: bool, disabled_distortions: int, fixed_focal: bool,
                  initial_poses: Optional[Dict[int, RvecTvec]] = None, ctx: Optional[Context] = None,
-                 opts: Optional[_ffi.SolverOpts] = None
+                 opts: Optional[_ffi.SolverOpts] = None, devices: Optional[Sequence[int]] = None
                  ) -> Optional[Tuple[GenericModel, Dict[int, RvecTvec]]]:
     """util::calib_camera (src/util.rs:384-490): single-camera bundle adjustment, Gauss-Newton.
     `initial_poses=None` reproduces the reference's in-function initialisation (unproject + planar PnP
-    per frame on the GPU, frames with fewer than 10 valid points are skipped, src/util.rs:418-436)."""
+    per frame on the GPU, frames with fewer than 10 valid points are skipped, src/util.rs:418-436).
+    `devices`: still ONE call of ONE process, like the reference's - the library shards the frames over the listed GPUs
+    (ccal_multi_*), one all-reduce per Gauss-Newton step."""
     if initial_poses is None:
-        initial_poses = init_frame_poses(frame_feature_list, generic_camera, ctx=ctx)
+        initial_poses = init_frame_poses(frame_feature_list, generic_camera, ctx=ctx, devices=devices)
     valid = [i for i, f in enumerate(frame_feature_list) if f is not None and i in initial_poses]
     if not valid:
         return None
     slots, obs_cam, obs_slot, offs, X, U = _flatten([frame_feature_list], [valid])
     d, keep = make_desc(1, [generic_camera.model_id], [generic_camera.width()], [generic_camera.height()],
                         xy_same_focal, len(slots), obs_cam, obs_slot, offs, X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
-    prob = Problem(_ctx(ctx), d, keep)
-    try:
+    with _Opened(ctx, devices, d, keep) as prob:
         intr = _intr_matrix([generic_camera])
         poses = np.stack([initial_poses[i].as6() for i in slots])
         prob.apply_reference_bounds()                                  # src/util.rs:446
@@ -266,8 +290,6 @@ def calib_camera(frame_feature_list: Sequence[Optional[FrameFeature]], generic_c
         out = generic_camera.copy()
         out.set_params(intr[0, :len(generic_camera._params)])          # fy = f re-inserted by the engine (:467-470)
         return out, {fi: RvecTvec.from6(poses[s]) for s, fi in enumerate(slots)}
-    finally:
-        prob.close()
 
 
 def calib_cameras(cams_frame_feature_lists: Sequence[Sequence[Optional[FrameFeature]]], generic_cameras: Sequence[GenericModel],
@@ -312,7 +334,9 @@ def calib_cameras(cams_frame_feature_lists: Sequence[Sequence[Optional[FrameFeat
                 if xy_same_focal:
                     j[3][0, 1] = j[3][0, 0]
             reps, res = Problem.solve_batch([j[1] for j in alive], o, starts=[(j[3], j[4], None) for j in alive])
-            for j, r in zip(alive, res):
+            for j, rep, r in zip(alive, reps, res):
+                if rep.status not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE):     # calib_camera's second solve is `.unwrap()`ed (src/util.rs:463)
+                    raise CcalError(rep.status, "ccal_solve_batch", f"camera {j[0]}: the fixed-focal re-optimisation failed")
                 j[3], j[4] = r[0], r[1]
         for c, prob, slots, intr, poses in alive:
             m = generic_cameras[c].copy()
@@ -356,16 +380,17 @@ def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0:
                                      cam_rtvecs: Sequence[Dict[int, RvecTvec]],
                                      cams_detected_feature_frames: Sequence[Sequence[Optional[FrameFeature]]],
                                      xy_same_focal: bool, disabled_distortions: int, cam0_fixed_focal: bool,
-                                     ctx: Optional[Context] = None, opts: Optional[_ffi.SolverOpts] = None
+                                     ctx: Optional[Context] = None, opts: Optional[_ffi.SolverOpts] = None,
+                                     devices: Optional[Sequence[int]] = None
                                      ) -> Optional[Tuple[List[GenericModel], List[RvecTvec], Dict[int, RvecTvec]]]:
-    """util::calib_all_camera_with_extrinsics (src/util.rs:567-715): joint intrinsics + extrinsics."""
+    """util::calib_all_camera_with_extrinsics (src/util.rs:567-715): joint intrinsics + extrinsics.
+    `devices`: one call, the frame slots sharded over the listed GPUs (ccal_multi_*)."""
     n_cams = len(cameras)
     built = _joint_problem_inputs(cameras, t_cam_i_0, cam_rtvecs, cams_detected_feature_frames, xy_same_focal)
     if built is None:
         return None
     d, keep, slots, intr, poses, extr = built
-    prob = Problem(_ctx(ctx), d, keep)
-    try:
+    with _Opened(ctx, devices, d, keep) as prob:
         prob.apply_reference_bounds()
         prob.disable_distortions(disabled_distortions, intr)
         if cam0_fixed_focal:
@@ -379,8 +404,6 @@ def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0:
             mm = m.copy(); mm.set_params(intr[c, :len(m._params)]); out_models.append(mm)
         t_i_0 = [RvecTvec((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))] + [RvecTvec.from6(extr[c]) for c in range(1, n_cams)]
         return out_models, t_i_0, {fi: RvecTvec.from6(poses[s]) for s, fi in enumerate(slots)}
-    finally:
-        prob.close()
 
 
 def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]]) -> List[RvecTvec]:

@@ -117,8 +117,10 @@ double cost(const std::vector<Iso>& a, const std::vector<Iso>& binv, const doubl
 
 }  // namespace
 
-// developer / test hook (not in include/ccal.h): one SE3Factor block, residual r[6] and Jacobian J[6][6] row-major
-extern "C" int ccal_debug_se3_factor(const double* pose_0_b, const double* pose_i_b, const double* x, double* r, double* J) {
+// SE3Factor::residual_func (src/optimization/factors.rs:248-271) for one frame: residual r[6] and the 6 x 6 block Jacobian
+// (row-major) the reference's dual numbers evaluate to
+extern "C" int ccal_se3_factor(const double* pose_0_b, const double* pose_i_b, const double* x, double* r, double* J) {
+    if (!pose_0_b || !pose_i_b || !x || !r || !J) return CCAL_ERR_INVALID_ARG;
     double Jm[6][6];
     se3_residual_jac(iso_from6(pose_0_b), iso_inv(iso_from6(pose_i_b)), x, r, Jm);
     std::memcpy(J, Jm, sizeof Jm);

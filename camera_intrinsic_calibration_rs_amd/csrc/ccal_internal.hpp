@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -101,6 +103,8 @@ struct ccal_problem {
     ccal_allreduce_fn allreduce = nullptr;     // callback form of the step's collective (tests over gloo)
     void* allreduce_user = nullptr;
     void* rccl_comm = nullptr;                 // ncclComm_t: the library issues ncclAllReduce itself (ccal_set_rccl_comm)
+    bool allreduce_stream_ordered = false;     // the callback only enqueues on the stream (the library's in-process transport,
+                                               // ccal_multi.hip): groups are enqueued ahead of the host like with RCCL
     bool counted = false;                      // registered in ctx->n_problems (creation succeeded)
     bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
 };
@@ -133,18 +137,43 @@ hipError_t validation_stats_device(const ccal_problem* p, int cam, const double*
 hipError_t launch_pose_init(const ccal_problem* p, int cam, const double* d_intr, double* d_poses_obs, int32_t* d_valid,
                             int min_points, hipStream_t s);
 // Dynamic LDS above 48 KiB has to be enabled per kernel AND per device: remember the largest size enabled on each
-// device of this process (contexts on several GPUs may share the process).
-struct DynLdsGuard { size_t enabled[16] = {}; };
+// device of this process (contexts on several GPUs may share the process).  Launchers run on any host thread
+// (ccal_solve_batch / ccal_solve_sharded drive one thread per context): the fast path is one atomic load, the
+// check-and-set runs under one process-wide mutex, so the attribute only ever grows and `enabled` never claims more
+// than what was last set.
+struct DynLdsGuard { std::atomic<size_t> enabled[16] = {}; };
+inline std::mutex& dyn_lds_mutex() { static std::mutex m; return m; }
 inline hipError_t ensure_dyn_lds(const void* fn, size_t lds, DynLdsGuard& g) {
     if (lds <= 48 * 1024) return hipSuccess;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    size_t& have = g.enabled[dev & 15];
-    if (lds <= have) return hipSuccess;
+    std::atomic<size_t>& have = g.enabled[dev & 15];
+    if (lds <= have.load(std::memory_order_acquire)) return hipSuccess;
+    std::lock_guard<std::mutex> lk(dyn_lds_mutex());
+    if (lds <= have.load(std::memory_order_relaxed)) return hipSuccess;
     e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) have = lds;
+    if (e == hipSuccess) have.store(lds, std::memory_order_release);
     else (void)hipGetLastError();      // reported here: the runtime's sticky copy must not surface in an unrelated launcher's hipGetLastError()
     return e;
 }
+
+// ccal_multi.hip: the in-process transport of single-process sharded solves (shards on one GPU, or on GPUs with peer
+// access when RCCL is not there) - events order the ranks' streams, a kernel adds the ranks' buffers in rank order.
+struct InprocComm;
+InprocComm* inproc_create(int n, const int* devices, std::string* err);
+void inproc_destroy(InprocComm* c);
+void inproc_abort(InprocComm* c);                       // a rank failed: release the ranks waiting in the host barrier
+bool inproc_aborted(const InprocComm* c);
+int inproc_recover(InprocComm* c);                      // after an abort, no rank inside: drain the devices, reset the barrier
+void inproc_set_timeout(InprocComm* c, double seconds); // host barrier: how long a rank waits for its peers (<= 0: 600 s)
+void* inproc_rank_handle(InprocComm* c, int rank);      // `user` of inproc_allreduce for that rank
+int inproc_allreduce(void* user, double* device_buf, size_t count, void* hip_stream);      // a ccal_allreduce_fn
+// ccal_rccl.hip: communicators of one process, one per device (ncclCommInitAll); abort = ncclCommAbort
+int rccl_comm_init_all(const int* devices, int n, void** comms_out, std::string* err);
+void rccl_comm_abort(void* comm);
+// ccal_solver.hip: n shards of ONE problem (distinct contexts, a transport set on every shard), each driven by a host
+// thread of its own; `inproc` (may be NULL) is aborted when a rank fails
+int solve_sharded_run(ccal_problem** shards, int n, const ccal_solver_opts* o, double* intr_io, double* const* poses_io,
+                      double* extr_io, ccal_report* rep, InprocComm* inproc);
 }  // namespace ccal

@@ -1,0 +1,464 @@
+// Single-process multi-GPU (include/ccal.h, "one process, several GPUs"): the reference is ONE process whose
+// calib_camera is one blocking call (src/util.rs:384-390, src/bin/camera_calibration.rs:70), so the drop-in for it must
+// reach all GPUs of a node from one call too.  A ccal_multi is a set of contexts - one per listed device, each with its
+// own stream and, inside ccal_solve_sharded, its own host thread - plus the transport of the step's one all-reduce:
+//   * devices all different and RCCL there:  one communicator per device from ncclCommInitAll, the library issues
+//     ncclAllReduce on every context's stream (ccal_rccl.hip) - the production path over xGMI;
+//   * otherwise (a device listed more than once - how the 1-GPU test box runs the sharded path - or no RCCL but peer
+//     access): the IN-PROCESS transport below.  Stream-ordered like RCCL: nothing waits on the host for the device.
+// A ccal_multi_problem is one problem description sharded by contiguous frame-slot ranges, balanced by corner count, all
+// cameras' observations of a slot on one shard; its entry points mirror the single-GPU ones.
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+#include "ccal_fused.hpp"
+
+using namespace ccal;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// In-process transport.  Per collective and rank r (the rank's host thread, its stream):
+//     record ready[r]            | host barrier A (every rank has recorded, every buffer address is published)
+//     wait ready[q], q != r      | k_sum_ranks: sum[r] = buf[0] + buf[1] + ... + buf[n-1]  (rank order: the same bits on every rank)
+//     record summed[r]           | host barrier B
+//     wait summed[q], q != r     | buf[r] = sum[r]          (in place only once every peer has read buf[r])
+// The host barriers order the event records against the waits (a wait captures the record made before it); they never wait
+// for the device.  A rank that fails sets `abort`, which releases the peers spinning in a barrier with an error.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace ccal {
+
+constexpr int kInprocMaxRanks = CCAL_MULTI_MAX_DEVICES;
+struct SumArgs { const double* src[kInprocMaxRanks]; int32_t n; };
+
+__global__ void __launch_bounds__(256) k_sum_ranks(const SumArgs a, const size_t count, double* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = a.src[0][i];
+    for (int r = 1; r < a.n; ++r) s += a.src[r][i];
+    out[i] = s;
+}
+__global__ void __launch_bounds__(256) k_copy_sum(const double* __restrict__ src, const size_t count, double* __restrict__ dst) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < count) dst[i] = src[i];
+}
+
+struct InprocRank { InprocComm* c; int rank; };
+struct InprocComm {
+    int n = 0;
+    size_t cap = 0;
+    std::vector<int> device;
+    std::vector<double*> sum;
+    std::vector<hipEvent_t> ready, summed;           // [parity][rank]
+    std::vector<const double*> src;
+    std::vector<size_t> cnt;
+    std::vector<uint64_t> calls;
+    std::vector<InprocRank> handles;
+    std::atomic<int> arrived{0}, gen{0}, abort{0};
+    double timeout_s = 600.0;
+};
+
+static inline void relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+}
+// false: aborted (by a peer, or by this rank after `timeout_s` without the peers arriving)
+static bool inproc_barrier(InprocComm* c) {
+    if (c->abort.load(std::memory_order_acquire)) return false;
+    const int g = c->gen.load(std::memory_order_acquire);
+    if (c->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->n) {
+        c->arrived.store(0, std::memory_order_relaxed);
+        c->gen.fetch_add(1, std::memory_order_release);
+        return !c->abort.load(std::memory_order_acquire);
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (long spins = 1;; ++spins) {
+        if (c->gen.load(std::memory_order_acquire) != g) return !c->abort.load(std::memory_order_acquire);
+        if (c->abort.load(std::memory_order_acquire)) return false;
+        if ((spins & 0x3FF) == 0) std::this_thread::yield(); else relax();
+        if ((spins & 0xFFFF) == 0 && c->timeout_s > 0 &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
+            c->abort.store(1, std::memory_order_release);
+            return false;
+        }
+    }
+}
+
+InprocComm* inproc_create(int n, const int* devices, std::string* err) {
+    auto fail = [&](const std::string& m) -> InprocComm* { if (err) *err = m; return nullptr; };
+    if (n < 1 || n > kInprocMaxRanks) return fail("in-process transport: 1 .. 16 ranks");
+    // peer access between every pair of different devices (same device: nothing to enable)
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < n; ++k) {
+            if (devices[i] == devices[k]) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[i], devices[k]) != hipSuccess || !can)
+                return fail("in-process transport: no peer access between device " + std::to_string(devices[i]) + " and " + std::to_string(devices[k]) + " (and no RCCL)");
+            if (hipSetDevice(devices[i]) != hipSuccess) return fail("hipSetDevice failed");
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+            (void)hipGetLastError();
+        }
+    std::unique_ptr<InprocComm> c(new InprocComm());
+    c->n = n;
+    c->cap = (size_t)fused_red_size(CCAL_KMAX);              // the largest all-reduce buffer of any problem (~266 KB)
+    c->device.assign(devices, devices + n);
+    c->sum.assign((size_t)n, nullptr);
+    c->ready.assign((size_t)2 * n, nullptr); c->summed.assign((size_t)2 * n, nullptr);
+    c->src.assign((size_t)n, nullptr); c->cnt.assign((size_t)n, 0); c->calls.assign((size_t)n, 0);
+    c->handles.resize((size_t)n);
+    for (int r = 0; r < n; ++r) {
+        c->handles[r] = InprocRank{ c.get(), r };
+        bool ok = hipSetDevice(devices[r]) == hipSuccess && hipMalloc((void**)&c->sum[r], c->cap * sizeof(double)) == hipSuccess;
+        for (int par = 0; par < 2 && ok; ++par)
+            ok = hipEventCreateWithFlags(&c->ready[par * n + r], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&c->summed[par * n + r], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { InprocComm* raw = c.release(); inproc_destroy(raw); return fail("in-process transport: device allocation failed"); }
+    }
+    return c.release();
+}
+void inproc_destroy(InprocComm* c) {
+    if (!c) return;
+    for (int r = 0; r < c->n; ++r) {
+        (void)hipSetDevice(c->device[r]);
+        if (c->sum[r]) (void)hipFree(c->sum[r]);
+        for (int par = 0; par < 2; ++par) {
+            if (c->ready[par * c->n + r]) (void)hipEventDestroy(c->ready[par * c->n + r]);
+            if (c->summed[par * c->n + r]) (void)hipEventDestroy(c->summed[par * c->n + r]);
+        }
+    }
+    delete c;
+}
+void inproc_abort(InprocComm* c) { if (c) c->abort.store(1, std::memory_order_release); }
+bool inproc_aborted(const InprocComm* c) { return c && c->abort.load(std::memory_order_acquire) != 0; }
+void inproc_set_timeout(InprocComm* c, double seconds) { if (c) c->timeout_s = seconds > 0 ? seconds : 600.0; }
+void* inproc_rank_handle(InprocComm* c, int rank) { return &c->handles[(size_t)rank]; }
+int inproc_recover(InprocComm* c) {
+    if (!c) return CCAL_OK;
+    // no rank is inside a collective any more (their threads have returned): whatever they enqueued runs to its end - a
+    // wait on an event that was never recorded is no wait - then the barrier and the call counters start over
+    for (int r = 0; r < c->n; ++r)
+        if (hipSetDevice(c->device[r]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return CCAL_ERR_HIP;
+    c->arrived.store(0); c->gen.store(0); c->abort.store(0);
+    std::fill(c->calls.begin(), c->calls.end(), 0);
+    return CCAL_OK;
+}
+
+int inproc_allreduce(void* user, double* buf, size_t count, void* hip_stream) {
+    InprocRank* h = static_cast<InprocRank*>(user);
+    InprocComm* c = h->c;
+    const int r = h->rank, n = c->n;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (count > c->cap) { inproc_abort(c); return 1; }
+    const int par = (int)(c->calls[r]++ & 1);
+    c->src[r] = buf; c->cnt[r] = count;
+    bool ok = hipEventRecord(c->ready[par * n + r], st) == hipSuccess;
+    if (!ok) inproc_abort(c);
+    if (!inproc_barrier(c)) return 1;
+    SumArgs a = {};
+    a.n = n;
+    for (int q = 0; q < n; ++q) {
+        a.src[q] = c->src[q];
+        ok = ok && c->cnt[q] == count;                     // every rank sums the same buffer of the same step
+        if (q != r) ok = ok && hipStreamWaitEvent(st, c->ready[par * n + q], 0) == hipSuccess;
+    }
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    if (ok && count) { hipLaunchKernelGGL(k_sum_ranks, dim3(blocks), dim3(256), 0, st, a, count, c->sum[r]); ok = hipGetLastError() == hipSuccess; }
+    ok = ok && hipEventRecord(c->summed[par * n + r], st) == hipSuccess;
+    if (!ok) inproc_abort(c);
+    if (!inproc_barrier(c)) return 1;
+    for (int q = 0; q < n; ++q) if (q != r) ok = ok && hipStreamWaitEvent(st, c->summed[par * n + q], 0) == hipSuccess;
+    if (ok && count) { hipLaunchKernelGGL(k_copy_sum, dim3(blocks), dim3(256), 0, st, c->sum[r], count, buf); ok = hipGetLastError() == hipSuccess; }
+    if (!ok) { inproc_abort(c); return 1; }
+    return 0;
+}
+
+}  // namespace ccal
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct ccal_multi {
+    int n = 0;
+    std::vector<int> device;
+    std::vector<ccal_ctx*> ctx;
+    int transport = CCAL_TRANSPORT_NONE;
+    std::vector<void*> comms;                  // RCCL: one ncclComm_t per device
+    InprocComm* inproc = nullptr;
+    bool broken = false;                       // a sharded solve failed with the RCCL communicators in an unknown state
+    std::string err;
+    int n_problems = 0;
+    bool destroy_requested = false;
+};
+struct ccal_multi_problem {
+    ccal_multi* m = nullptr;
+    int n_slots = 0, n_obs = 0, n_cams = 0;
+    int64_t n_corners = 0;
+    std::vector<ccal_problem*> shard;
+    std::vector<int32_t> first;                // [n + 1] slot range of every shard
+    std::vector<std::vector<int32_t>> obs_of;  // shard -> its observation frames (indices into the caller's description)
+};
+
+static void multi_free(ccal_multi* m) {
+    if (m->inproc) inproc_destroy(m->inproc);
+    for (void* c : m->comms) if (c) { if (m->broken) rccl_comm_abort(c); else (void)ccal_rccl_comm_destroy(c); }
+    for (ccal_ctx* c : m->ctx) if (c) ccal_ctx_destroy(c);
+    delete m;
+}
+static int mfail(ccal_multi* m, int code, const std::string& msg) { if (m) { try { m->err = msg; } catch (...) { } } return code; }
+// run fn(i) for every shard: shard 0 on the caller's thread, the others on short-lived threads (one-shot entry points: pose
+// initialisation, uploads; the solver's own threads are the contexts' persistent helpers, ccal_solver.hip)
+template <class F>
+static void for_each_shard(int n, F&& fn) {
+    std::vector<std::thread> th;
+    th.reserve((size_t)n);
+    try { for (int i = 1; i < n; ++i) th.emplace_back([&fn, i] { fn(i); }); }
+    catch (...) { for (auto& t : th) t.join(); throw; }
+    fn(0);
+    for (auto& t : th) t.join();
+}
+
+extern "C" {
+
+int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out) {
+    if (!out) return CCAL_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!device_ids || n_dev < 1 || n_dev > CCAL_MULTI_MAX_DEVICES) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    std::unique_ptr<ccal_multi> m(new ccal_multi());
+    m->n = n_dev;
+    m->device.assign(device_ids, device_ids + n_dev);
+    m->ctx.assign((size_t)n_dev, nullptr);
+    auto bail = [&](int rc) { ccal_multi* raw = m.release(); multi_free(raw); return rc; };
+    for (int i = 0; i < n_dev; ++i) {
+        const int rc = ccal_ctx_create(device_ids[i], nullptr, &m->ctx[i]);
+        if (rc != CCAL_OK) return bail(rc);
+    }
+    if (n_dev > 1) {
+        bool distinct = true;
+        for (int i = 0; i < n_dev; ++i) for (int k = 0; k < i; ++k) distinct = distinct && device_ids[i] != device_ids[k];
+        const char* force = std::getenv("CCAL_MULTI_TRANSPORT");          // developer switch: "inproc" keeps RCCL out of it
+        const bool want_rccl = distinct && ccal_rccl_available() && !(force && force[0] == 'i');
+        if (want_rccl) {
+            m->comms.assign((size_t)n_dev, nullptr);
+            std::string err;
+            const int rc = rccl_comm_init_all(device_ids, n_dev, m->comms.data(), &err);
+            if (rc != CCAL_OK) { m->comms.clear(); return bail(rc); }
+            m->transport = CCAL_TRANSPORT_RCCL;
+        } else {
+            std::string err;
+            m->inproc = inproc_create(n_dev, device_ids, &err);
+            if (!m->inproc) return bail(CCAL_ERR_UNSUPPORTED);
+            m->transport = CCAL_TRANSPORT_INPROC;
+        }
+    }
+    *out = m.release();
+    return CCAL_OK;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+void ccal_multi_destroy(ccal_multi* m) {
+    if (!m) return;
+    if (m->n_problems > 0) { m->destroy_requested = true; return; }       // freed by its last problem
+    multi_free(m);
+}
+int ccal_multi_num_devices(const ccal_multi* m) { return m ? m->n : -1; }
+int ccal_multi_transport(const ccal_multi* m) { return m ? m->transport : -1; }
+ccal_ctx* ccal_multi_ctx(ccal_multi* m, int i) { return (m && i >= 0 && i < m->n) ? m->ctx[i] : nullptr; }
+const char* ccal_multi_last_error(const ccal_multi* m) { return m ? m->err.c_str() : "null device set"; }
+int ccal_multi_set_model_conventions(ccal_multi* m, const ccal_model_conventions* in) {
+    if (!m) return CCAL_ERR_INVALID_ARG;
+    for (ccal_ctx* c : m->ctx) { const int rc = ccal_set_model_conventions(c, in); if (rc != CCAL_OK) return rc; }
+    return CCAL_OK;
+}
+int ccal_multi_sync(ccal_multi* m) {
+    if (!m) return CCAL_ERR_INVALID_ARG;
+    for (ccal_ctx* c : m->ctx) { const int rc = ccal_sync(c); if (rc != CCAL_OK) return mfail(m, rc, ccal_last_error(c)); }
+    return CCAL_OK;
+}
+
+void ccal_multi_problem_destroy(ccal_multi_problem* mp) {
+    if (!mp) return;
+    for (ccal_problem* p : mp->shard) if (p) {
+        // the transport outlives its users: early-exit groups still queued hold its events / communicator
+        (void)drain_pending_groups(p);
+        ccal_problem_destroy(p);
+    }
+    ccal_multi* m = mp->m;
+    delete mp;
+    if (m && --m->n_problems == 0 && m->destroy_requested) multi_free(m);
+}
+
+int ccal_multi_problem_create(ccal_multi* m, const ccal_problem_desc* d, ccal_multi_problem** out) {
+    if (!m || !d || !out) return CCAL_ERR_INVALID_ARG;
+    *out = nullptr;
+    CCAL_API_TRY
+    if (d->n_cams < 1 || d->n_cams > CCAL_MAX_CAMS || d->n_slots < 0 || d->n_obs < 0 || !d->model ||
+        (d->n_obs > 0 && (!d->obs_cam || !d->obs_slot || !d->obs_offsets)))
+        return mfail(m, CCAL_ERR_INVALID_ARG, "bad problem description");
+    const int n = m->n;
+    // contiguous slot ranges, balanced by corner count: boundary r = the first slot at which the corners of the slots
+    // before it reach r / n of all corners ("balanced by corner count (CSR offsets)")
+    std::vector<int64_t> before((size_t)d->n_slots + 1, 0);
+    for (int o = 0; o < d->n_obs; ++o) {
+        const int s = d->obs_slot[o];
+        const int64_t c = d->obs_offsets[o + 1] - d->obs_offsets[o];
+        if (s < 0 || s >= d->n_slots || c < 0) return mfail(m, CCAL_ERR_INVALID_ARG, "bad observation frame table");
+        before[(size_t)s + 1] += c;
+    }
+    for (int s = 0; s < d->n_slots; ++s) before[(size_t)s + 1] += before[(size_t)s];
+    const int64_t total = before[(size_t)d->n_slots];
+    std::unique_ptr<ccal_multi_problem> mp(new ccal_multi_problem());
+    mp->m = m; mp->n_slots = d->n_slots; mp->n_obs = d->n_obs; mp->n_cams = d->n_cams; mp->n_corners = total;
+    mp->first.assign((size_t)n + 1, 0);
+    mp->first[(size_t)n] = d->n_slots;
+    for (int r = 1; r < n; ++r) {
+        int s;
+        if (total > 0) {
+            const int64_t target = (int64_t)(((__int128)total * r) / n);
+            s = (int)(std::lower_bound(before.begin(), before.end(), target) - before.begin());
+        } else s = (int)((int64_t)d->n_slots * r / n);
+        mp->first[(size_t)r] = std::min(std::max(s, mp->first[(size_t)r - 1]), d->n_slots);
+    }
+    mp->obs_of.assign((size_t)n, {});
+    std::vector<int> shard_of_slot((size_t)std::max(d->n_slots, 1), 0);
+    for (int r = 0; r < n; ++r) for (int s = mp->first[(size_t)r]; s < mp->first[(size_t)r + 1]; ++s) shard_of_slot[(size_t)s] = r;
+    for (int o = 0; o < d->n_obs; ++o) mp->obs_of[(size_t)shard_of_slot[(size_t)d->obs_slot[o]]].push_back(o);
+    mp->shard.assign((size_t)n, nullptr);
+    m->n_problems += 1;                                       // from here on ccal_multi_problem_destroy undoes everything
+    auto bail = [&](int rc, const std::string& msg) { ccal_multi_problem* raw = mp.release(); m->err = msg; ccal_multi_problem_destroy(raw); return rc; };
+    for (int r = 0; r < n; ++r) {
+        const std::vector<int32_t>& obs = mp->obs_of[(size_t)r];
+        std::vector<int32_t> cam(obs.size()), slot(obs.size());
+        std::vector<int64_t> off(obs.size() + 1, 0);
+        for (size_t i = 0; i < obs.size(); ++i) {
+            const int o = obs[i];
+            cam[i] = d->obs_cam[o]; slot[i] = d->obs_slot[o] - mp->first[(size_t)r];
+            off[i + 1] = off[i] + (d->obs_offsets[o + 1] - d->obs_offsets[o]);
+        }
+        const size_t nc = (size_t)off.back();
+        std::vector<float> x(nc), y(nc), z(nc), u(nc), v(nc);
+        if (nc && (!d->p3d_x || !d->p3d_y || !d->p3d_z || !d->p2d_u || !d->p2d_v)) return bail(CCAL_ERR_INVALID_ARG, "null corner arrays");
+        for (size_t i = 0; i < obs.size(); ++i) {
+            const int64_t s0 = d->obs_offsets[obs[i]], cnt = off[i + 1] - off[i];
+            if (!cnt) continue;
+            std::memcpy(&x[(size_t)off[i]], d->p3d_x + s0, (size_t)cnt * sizeof(float)); std::memcpy(&y[(size_t)off[i]], d->p3d_y + s0, (size_t)cnt * sizeof(float));
+            std::memcpy(&z[(size_t)off[i]], d->p3d_z + s0, (size_t)cnt * sizeof(float)); std::memcpy(&u[(size_t)off[i]], d->p2d_u + s0, (size_t)cnt * sizeof(float));
+            std::memcpy(&v[(size_t)off[i]], d->p2d_v + s0, (size_t)cnt * sizeof(float));
+        }
+        ccal_problem_desc sd = *d;
+        sd.n_slots = mp->first[(size_t)r + 1] - mp->first[(size_t)r];
+        sd.n_obs = (int32_t)obs.size();
+        sd.obs_cam = cam.data(); sd.obs_slot = slot.data(); sd.obs_offsets = off.data();
+        sd.p3d_x = x.data(); sd.p3d_y = y.data(); sd.p3d_z = z.data(); sd.p2d_u = u.data(); sd.p2d_v = v.data();
+        const int rc = ccal_problem_create(m->ctx[(size_t)r], &sd, &mp->shard[(size_t)r]);
+        if (rc != CCAL_OK) return bail(rc, std::string("shard ") + std::to_string(r) + ": " + ccal_last_error(m->ctx[(size_t)r]));
+        ccal_problem* p = mp->shard[(size_t)r];
+        if (m->transport == CCAL_TRANSPORT_RCCL) p->rccl_comm = m->comms[(size_t)r];
+        else if (m->transport == CCAL_TRANSPORT_INPROC) {
+            p->allreduce = inproc_allreduce; p->allreduce_user = inproc_rank_handle(m->inproc, r); p->allreduce_stream_ordered = true;
+        }
+    }
+    *out = mp.release();
+    return CCAL_OK;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+
+int ccal_multi_problem_num_shards(const ccal_multi_problem* mp) { return mp ? (int)mp->shard.size() : -1; }
+ccal_problem* ccal_multi_problem_shard(ccal_multi_problem* mp, int i) { return (mp && i >= 0 && i < (int)mp->shard.size()) ? mp->shard[(size_t)i] : nullptr; }
+int ccal_multi_problem_slot_range(const ccal_multi_problem* mp, int i, int32_t* first_slot, int32_t* n_slots) {
+    if (!mp || i < 0 || i >= (int)mp->shard.size()) return CCAL_ERR_INVALID_ARG;
+    if (first_slot) *first_slot = mp->first[(size_t)i];
+    if (n_slots) *n_slots = mp->first[(size_t)i + 1] - mp->first[(size_t)i];
+    return CCAL_OK;
+}
+
+// constraints: the same on every shard (ccal_solve_sharded checks it)
+#define CCAL_MULTI_FORALL(call)                                                                   \
+    if (!mp) return CCAL_ERR_INVALID_ARG;                                                          \
+    for (ccal_problem* p : mp->shard) { const int rc = (call); if (rc != CCAL_OK) return rc; }     \
+    return CCAL_OK;
+int ccal_multi_set_bounds(ccal_multi_problem* mp, int cam, int eff_idx, double lo, double hi) { CCAL_MULTI_FORALL(ccal_set_bounds(p, cam, eff_idx, lo, hi)) }
+int ccal_multi_clear_bounds(ccal_multi_problem* mp, int cam, int eff_idx) { CCAL_MULTI_FORALL(ccal_clear_bounds(p, cam, eff_idx)) }
+int ccal_multi_fix_param(ccal_multi_problem* mp, int cam, int eff_idx) { CCAL_MULTI_FORALL(ccal_fix_param(p, cam, eff_idx)) }
+int ccal_multi_unfix_param(ccal_multi_problem* mp, int cam, int eff_idx) { CCAL_MULTI_FORALL(ccal_unfix_param(p, cam, eff_idx)) }
+int ccal_multi_apply_reference_bounds(ccal_multi_problem* mp) { CCAL_MULTI_FORALL(ccal_apply_reference_bounds(p)) }
+int ccal_multi_disable_distortions(ccal_multi_problem* mp, int n_disabled, double* intr_io) { CCAL_MULTI_FORALL(ccal_disable_distortions(p, n_disabled, intr_io)) }
+#undef CCAL_MULTI_FORALL
+
+int ccal_multi_upload_params(ccal_multi_problem* mp, const double* intr, const double* poses, const double* extr) {
+    if (!mp) return CCAL_ERR_INVALID_ARG;
+    for (size_t r = 0; r < mp->shard.size(); ++r) {
+        const int rc = ccal_upload_params(mp->shard[r], intr, poses ? poses + 6 * (size_t)mp->first[r] : nullptr, extr);
+        if (rc != CCAL_OK) return mfail(mp->m, rc, ccal_last_error(mp->m->ctx[r]));
+    }
+    return CCAL_OK;
+}
+// Mode E needs no collective: every shard's launches are enqueued on its context's stream and run side by side.
+// r_dev[i] / J_dev[i]: device buffers on shard i's GPU, sized for ITS corners (ccal_num_corners / ccal_jacobian_len of the shard).
+int ccal_multi_eval_dev(ccal_multi_problem* mp, int apply_loss, double* const* r_dev, double* const* J_dev) {
+    if (!mp || !r_dev || !J_dev) return CCAL_ERR_INVALID_ARG;
+    for (size_t r = 0; r < mp->shard.size(); ++r) {
+        const int rc = ccal_eval_dev(mp->shard[r], apply_loss, r_dev[r], J_dev[r]);
+        if (rc != CCAL_OK) return mfail(mp->m, rc, ccal_last_error(mp->m->ctx[r]));
+    }
+    return CCAL_OK;
+}
+
+int ccal_multi_init_poses(ccal_multi_problem* mp, const double* intr, int min_points, double* poses_obs, int32_t* n_used) {
+    if (!mp || !intr || !poses_obs || !n_used) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    const int n = (int)mp->shard.size();
+    std::vector<int> rc((size_t)n, CCAL_OK);
+    std::vector<std::vector<double>> po((size_t)n);
+    std::vector<std::vector<int32_t>> nu((size_t)n);
+    for (int r = 0; r < n; ++r) { po[(size_t)r].assign(std::max<size_t>(mp->obs_of[(size_t)r].size(), 1) * 6, 0.0); nu[(size_t)r].assign(std::max<size_t>(mp->obs_of[(size_t)r].size(), 1), 0); }
+    for_each_shard(n, [&](int r) { rc[(size_t)r] = ccal_init_poses(mp->shard[(size_t)r], intr, min_points, po[(size_t)r].data(), nu[(size_t)r].data()); });
+    for (int r = 0; r < n; ++r) {
+        if (rc[(size_t)r] != CCAL_OK) return mfail(mp->m, rc[(size_t)r], ccal_last_error(mp->m->ctx[(size_t)r]));
+        const std::vector<int32_t>& obs = mp->obs_of[(size_t)r];
+        for (size_t i = 0; i < obs.size(); ++i) {
+            std::memcpy(poses_obs + 6 * (size_t)obs[i], &po[(size_t)r][6 * i], 6 * sizeof(double));
+            n_used[obs[i]] = nu[(size_t)r][i];
+        }
+    }
+    return CCAL_OK;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+
+int ccal_multi_solve(ccal_multi_problem* mp, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
+    if (!mp || !o || !intr_io || (!poses_io && mp->n_slots) || (!extr_io && mp->n_cams > 1)) return CCAL_ERR_INVALID_ARG;
+    ccal_multi* m = mp->m;
+    CCAL_API_TRY
+    const int n = (int)mp->shard.size();
+    if (n == 1) {
+        const int rc = ccal_solve(mp->shard[0], o, intr_io, poses_io, extr_io, rep);
+        if (rc != CCAL_OK) m->err = ccal_last_error(m->ctx[0]);
+        return rc;
+    }
+    if (m->broken) return mfail(m, CCAL_ERR_HIP, "an earlier sharded solve failed inside a collective: the RCCL communicators of this ccal_multi were aborted - destroy it and create a new one");
+    std::vector<double*> pp((size_t)n);
+    for (int r = 0; r < n; ++r) pp[(size_t)r] = poses_io ? poses_io + 6 * (size_t)mp->first[(size_t)r] : nullptr;
+    if (m->inproc) inproc_set_timeout(m->inproc, o->timeout_s > 0 ? (double)o->timeout_s : 600.0);
+    const int rc = solve_sharded_run(mp->shard.data(), n, o, intr_io, pp.data(), extr_io, rep, m->inproc);
+    const bool verdict = rc == CCAL_OK || rc == CCAL_ERR_NONFINITE || rc == CCAL_ERR_NOT_PD || rc == CCAL_ERR_NO_CONVERGENCE;
+    if (rc != CCAL_OK) m->err = ccal_last_error(m->ctx[0]);
+    if (!verdict) {
+        // a rank left the shared sequence of collectives.  In-process transport: drain the devices, start over.  RCCL: peers
+        // may sit inside ncclAllReduce with no partner - abort the communicators, this device set is finished
+        if (m->inproc) {
+            if (inproc_recover(m->inproc) != CCAL_OK) m->broken = true;
+            else for (ccal_problem* p : mp->shard) if (p->nws) { p->nws->tail_pending = false; if (p->nws->fws) p->nws->fws->tail_pending = false; }
+        }
+        else if (m->transport == CCAL_TRANSPORT_RCCL) {
+            for (size_t r = 0; r < m->comms.size(); ++r) { rccl_comm_abort(m->comms[r]); m->comms[r] = nullptr; mp->shard[r]->rccl_comm = nullptr; }
+            m->broken = true;
+        }
+    }
+    return rc;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+
+}  // extern "C"

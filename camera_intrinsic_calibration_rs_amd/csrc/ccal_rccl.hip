@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -30,6 +32,8 @@ struct RcclApi {
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     bool ok = false;
 };
 RcclApi g_rccl;
@@ -48,7 +52,7 @@ void load_rccl() {
 #define SYM(field, name) g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name))
     SYM(AllReduce, "ncclAllReduce"); SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank");
     SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount"); SYM(GetErrorString, "ncclGetErrorString");
-    SYM(GetVersion, "ncclGetVersion");
+    SYM(GetVersion, "ncclGetVersion"); SYM(CommInitAll, "ncclCommInitAll"); SYM(CommAbort, "ncclCommAbort");
 #undef SYM
     g_rccl.ok = g_rccl.AllReduce && g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.GetErrorString;
 }
@@ -68,6 +72,24 @@ int rccl_allreduce_sum(ccal_ctx* ctx, void* comm, double* buf, size_t count, hip
         return CCAL_ERR_HIP;
     }
     return CCAL_OK;
+}
+
+// One communicator per listed device, all in THIS process (single-process sharded solves, ccal_multi.hip): the n
+// communicators are then driven by n host threads, one ncclAllReduce per thread and step.
+int rccl_comm_init_all(const int* devices, int n, void** comms_out, std::string* err) {
+    const RcclApi* r = rccl();
+    if (!r || !r->CommInitAll) { if (err) *err = "RCCL is not available (librccl.so.1 / ncclCommInitAll not found)"; return CCAL_ERR_UNSUPPORTED; }
+    std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    const ncclResult_t e = r->CommInitAll(comms.data(), n, devices);
+    if (e != ncclSuccess) { if (err) *err = std::string("ncclCommInitAll: ") + r->GetErrorString(e); return CCAL_ERR_HIP; }
+    for (int i = 0; i < n; ++i) comms_out[i] = comms[i];
+    return CCAL_OK;
+}
+void rccl_comm_abort(void* comm) {
+    const RcclApi* r = rccl();
+    if (!r || !comm) return;
+    if (r->CommAbort) (void)r->CommAbort(static_cast<ncclComm_t>(comm));
+    else (void)r->CommDestroy(static_cast<ncclComm_t>(comm));
 }
 
 }  // namespace ccal

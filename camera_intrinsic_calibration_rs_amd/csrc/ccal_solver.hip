@@ -422,9 +422,12 @@ static int check_status(ccal_ctx* ctx, hipStream_t st, HostStatus* hst, const De
     return CCAL_OK;
 }
 
+// Seconds WITHOUT A STEP COMPLETING before the host gives up.  Single GPU: 30.  Sharded: 600 - a peer that is still
+// uploading or setting up its RCCL channels is waited for (a rank that gave up after 30 s left its peers inside a
+// collective with no partner), but a peer that died must not hang the survivors for ever.
 static double wait_timeout(const ccal_problem* p, const ccal_solver_opts* o) {
     if (o->timeout_s > 0) return (double)o->timeout_s;
-    return p->sharded() ? 0.0 : 30.0;
+    return p->sharded() ? 600.0 : 30.0;
 }
 static void init_state(DevState* s, const ccal_solver_opts* o) {
     std::memset(s, 0, sizeof *s);
@@ -444,7 +447,7 @@ static int max_groups_for(const ccal_solver_opts* o) {
 // another stream operation, so sharded solves run ahead like single-GPU ones; a callback is host code - the loop waits
 // for every group before the next one (no collective is ever issued for a solve that has finished).
 static int groups_in_flight(const ccal_problem* p, const char* env_name) {
-    if (p->allreduce && !p->rccl_comm) {
+    if (p->allreduce && !p->rccl_comm && !p->allreduce_stream_ordered) {
         static const int hook_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH_HOOK"); return e ? std::max(1, std::atoi(e)) : 1; }();
         return hook_depth;
     }
@@ -706,8 +709,9 @@ static bool use_fused_path(const ccal_problem* p) { return p->n_cams == 1 && !st
 
 extern "C" {
 
-// developer hook (not part of include/ccal.h): copy the per-frame scratch of the fast path to the host;
-// diagnostic builds (tools/) park in-kernel timestamps there
+// developer hook of -DCCAL_STAMPS builds only (not part of include/ccal.h, not exported by the product build): copy the
+// per-frame scratch of the fast path to the host; the diagnostic builds (tools/stamps_*.py) park in-kernel timestamps there
+#ifdef CCAL_STAMPS
 int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
     if (!p || !p->nws || !out) return CCAL_ERR_INVALID_ARG;
     if (!p->nws->fws) {          // general loop: what a -DCCAL_STAMPS build of k_schur4 leaves behind the partial sums
@@ -720,6 +724,7 @@ int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
     if (hipMemcpy(out, p->nws->fws->fcbuf, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return CCAL_ERR_HIP;
     return CCAL_OK;
 }
+#endif
 
 int ccal_build_normal_dev(ccal_problem* p, double lambda) {
     if (!p) return CCAL_ERR_INVALID_ARG;
@@ -825,31 +830,46 @@ static int solve_entry(ccal_problem* p, const ccal_solver_opts* o, bool host_io,
 // A context's helper thread for ccal_solve_batch.  Persistent: a session-sized solve is ~0.15 ms, creating a thread per call
 // costs a third of that (measured: four problems per call 1.35x over one at a time with threads made per call).  It spins for
 // a short while after a task (the next batch usually follows at once), then sleeps on a condition variable.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 struct ccal_ctx_worker {
     std::thread th;
     std::mutex m;
-    std::condition_variable cv;
+    std::condition_variable cv, cv_done;
     std::function<void()> task;
     std::atomic<int> has_task{0}, done{0}, stop{0};
     void loop() {
         for (;;) {
             int spins = 0;
             while (!has_task.load(std::memory_order_acquire) && !stop.load(std::memory_order_acquire)) {
-                if (++spins < 200000) { __builtin_ia32_pause(); continue; }
+                if (++spins < 200000) { cpu_relax(); continue; }
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return has_task.load() || stop.load(); });
             }
             if (stop.load()) return;
             task();
             has_task.store(0, std::memory_order_release);
-            done.store(1, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(m); done.store(1, std::memory_order_release); }
+            cv_done.notify_all();
         }
     }
     void submit(std::function<void()> fn) {
         { std::lock_guard<std::mutex> lk(m); task = std::move(fn); done.store(0); has_task.store(1, std::memory_order_release); }
         cv.notify_one();
     }
-    void wait() { while (!done.load(std::memory_order_acquire)) __builtin_ia32_pause(); }
+    // spin briefly (a session-sized solve is ~0.1 ms), then sleep on the condition variable
+    void wait() {
+        for (int spins = 0; spins < 400000; ++spins) { if (done.load(std::memory_order_acquire)) return; cpu_relax(); }
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return done.load(std::memory_order_acquire) != 0; });
+    }
 };
 namespace ccal {
 void ctx_worker_destroy(ccal_ctx* ctx) {
@@ -862,10 +882,15 @@ void ctx_worker_destroy(ccal_ctx* ctx) {
     ctx->worker = nullptr;
 }
 }  // namespace ccal
+// The helper is published to the context only once its thread runs: if std::thread throws (EAGAIN) the context keeps no
+// worker and the exception becomes the call's CCAL_ERR_HIP - a later call tries again instead of waiting on a thread
+// that never existed.
 static ccal_ctx_worker* ctx_worker(ccal_ctx* ctx) {
     if (!ctx->worker) {
-        ctx->worker = new ccal_ctx_worker();
-        ctx->worker->th = std::thread([w = ctx->worker] { w->loop(); });
+        std::unique_ptr<ccal_ctx_worker> w(new ccal_ctx_worker());
+        ccal_ctx_worker* raw = w.get();
+        w->th = std::thread([raw] { raw->loop(); });
+        ctx->worker = w.release();
     }
     return ctx->worker;
 }
@@ -922,6 +947,118 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
     for (int i = 0; i < n; ++i)
         if (rc[i] == CCAL_ERR_HIP || rc[i] == CCAL_ERR_INVALID_ARG || rc[i] == CCAL_ERR_NO_MEMORY || rc[i] == CCAL_ERR_UNSUPPORTED) return rc[i];
     return CCAL_OK;
+    CCAL_API_CATCH(c0)
+}
+
+// ---- ONE problem whose frame slots are sharded over n contexts of THIS process (include/ccal.h) --------------------
+// Every shard is driven by a host thread of its own - the caller's thread takes shard 0, the contexts' persistent helper
+// threads the others - exactly like the ranks of a multi-process run: each thread runs the ordinary device-resident loop
+// on its shard and issues the step's collective on its context's stream (native RCCL: one communicator per device made
+// by ncclCommInitAll; or a stream-ordered callback transport).  The decisions are functions of all-reduced sums only, so
+// every shard ends with the same status, iteration count and - bit for bit - the same camera block.
+static bool verdict(int rc) { return rc == CCAL_OK || rc == CCAL_ERR_NONFINITE || rc == CCAL_ERR_NOT_PD || rc == CCAL_ERR_NO_CONVERGENCE; }
+}  // extern "C"
+namespace ccal {
+int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, double* intr_io, double* const* poses_io, double* extr_io,
+                      ccal_report* rep, InprocComm* inproc) {
+    const int n_cams = ps[0]->n_cams;
+    const size_t ni = (size_t)n_cams * CCAL_PMAX, ne = (size_t)n_cams * 6;
+    std::vector<double> intr((size_t)n * ni), extr((size_t)n * ne, 0.0);
+    for (int i = 0; i < n; ++i) {
+        std::memcpy(&intr[i * ni], intr_io, ni * sizeof(double));
+        if (extr_io) std::memcpy(&extr[i * ne], extr_io, ne * sizeof(double));
+    }
+    std::vector<int> rc((size_t)n, CCAL_ERR_HIP);
+    std::vector<ccal_report> reps((size_t)n);
+    auto run = [&](int i) noexcept {
+        try {
+            rc[i] = solve_entry(ps[i], o, true, &intr[i * ni], poses_io ? poses_io[i] : nullptr, &extr[i * ne], &reps[i]);
+        } catch (const std::bad_alloc&) { rc[i] = CCAL_ERR_NO_MEMORY; note_error(ps[i]->ctx, "out of host memory");
+        } catch (...) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "C++ exception in ccal_solve_sharded"); }
+        if (!verdict(rc[i]) && inproc) inproc_abort(inproc);      // the peers wait for this rank in the host barrier
+    };
+    std::vector<ccal_ctx_worker*> busy;
+    busy.reserve((size_t)n);
+    try {
+        for (int i = 1; i < n; ++i) {
+            ccal_ctx_worker* wk = ctx_worker(ps[i]->ctx);
+            wk->submit([&run, i] { run(i); });
+            busy.push_back(wk);
+        }
+    } catch (...) {          // a helper thread could not be made: the ranks already started wait for the missing one
+        if (inproc) inproc_abort(inproc);
+        for (ccal_ctx_worker* wk : busy) wk->wait();
+        throw;
+    }
+    run(0);
+    for (ccal_ctx_worker* wk : busy) wk->wait();
+    int first_bad = -1;
+    for (int i = 0; i < n && first_bad < 0; ++i) if (!verdict(rc[i])) first_bad = i;
+    if (first_bad >= 0) {
+        if (first_bad != 0) note_error(ps[0]->ctx, (std::string("shard ") + std::to_string(first_bad) + ": " + ps[first_bad]->ctx->err).c_str());
+        if (rep) { *rep = ccal_report{}; rep->status = rc[first_bad]; }
+        return rc[first_bad];
+    }
+    // one decision sequence, one camera block: anything else is a defect of the transport (sums that differ between ranks)
+    for (int i = 1; i < n; ++i) {
+        if (rc[i] != rc[0] || reps[i].iterations != reps[0].iterations ||
+            std::memcmp(&intr[i * ni], &intr[0], ni * sizeof(double)) != 0 || std::memcmp(&extr[i * ne], &extr[0], ne * sizeof(double)) != 0) {
+            note_error(ps[0]->ctx, "ccal_solve_sharded: the shards disagree on the result (transport defect)");
+            if (rep) { *rep = ccal_report{}; rep->status = CCAL_ERR_HIP; }
+            return CCAL_ERR_HIP;
+        }
+    }
+    std::memcpy(intr_io, &intr[0], ni * sizeof(double));
+    if (extr_io) std::memcpy(extr_io, &extr[0], ne * sizeof(double));
+    if (rep) {
+        *rep = reps[0];
+        for (int i = 1; i < n; ++i) rep->solve_ms = std::max(rep->solve_ms, reps[i].solve_ms);
+    }
+    return rc[0];
+}
+}  // namespace ccal
+extern "C" {
+
+int ccal_solve_sharded(ccal_problem** ps, int n, const ccal_solver_opts* o, double* intr_io, double** poses_io, double* extr_io,
+                       ccal_report* rep) {
+    if (!ps || n < 1 || !o || !intr_io) return CCAL_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i) if (!ps[i]) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* c0 = ps[0]->ctx;
+    CCAL_API_TRY
+    int n_native = 0, n_cb = 0;
+    for (int i = 0; i < n; ++i) {
+        const ccal_problem* p = ps[i];
+        if ((p->n_slots && !(poses_io && poses_io[i])) || (p->n_cams > 1 && !extr_io)) { c0->err = "ccal_solve_sharded: null parameter array"; return CCAL_ERR_INVALID_ARG; }
+        for (int k = 0; k < i; ++k) if (ps[k]->ctx == p->ctx) { c0->err = "ccal_solve_sharded: every shard needs a context of its own (one host thread and one stream per shard)"; return CCAL_ERR_INVALID_ARG; }
+        if (p->n_cams != ps[0]->n_cams || p->K != ps[0]->K || p->one_focal != ps[0]->one_focal || p->huber_delta != ps[0]->huber_delta) { c0->err = "ccal_solve_sharded: the shards describe different problems"; return CCAL_ERR_INVALID_ARG; }
+        for (int c = 0; c < p->n_cams; ++c) if (p->cams[c].model != ps[0]->cams[c].model) { c0->err = "ccal_solve_sharded: the shards describe different cameras"; return CCAL_ERR_INVALID_ARG; }
+        if (std::memcmp(p->lo.data(), ps[0]->lo.data(), p->lo.size() * sizeof(double)) || std::memcmp(p->hi.data(), ps[0]->hi.data(), p->hi.size() * sizeof(double)) ||
+            p->has_bound != ps[0]->has_bound || p->fixed != ps[0]->fixed) { c0->err = "ccal_solve_sharded: the shards carry different bounds / fixed parameters"; return CCAL_ERR_INVALID_ARG; }
+        n_native += p->rccl_comm ? 1 : 0; n_cb += (!p->rccl_comm && p->allreduce) ? 1 : 0;
+    }
+    if (n == 1 && !ps[0]->sharded()) return solve_entry(ps[0], o, true, intr_io, poses_io ? poses_io[0] : nullptr, extr_io, rep);
+    if ((n_native && n_native != n) || (n_cb && n_cb != n) || (n_native && n_cb)) { c0->err = "ccal_solve_sharded: a transport on some shards only"; return CCAL_ERR_INVALID_ARG; }
+    if (n_native || n_cb) return solve_sharded_run(ps, n, o, intr_io, poses_io, extr_io, rep, nullptr);
+    // no transport set: the library's own in-process one for the duration of the call (shards on one GPU, or on GPUs with
+    // peer access); ccal_multi_* keeps a transport - RCCL when the devices differ - for the lifetime of the device set
+    std::vector<int> devs((size_t)n);
+    for (int i = 0; i < n; ++i) devs[i] = ps[i]->ctx->device;
+    std::string err;
+    InprocComm* ic = inproc_create(n, devs.data(), &err);
+    if (!ic) { c0->err = "ccal_solve_sharded: " + err; return CCAL_ERR_UNSUPPORTED; }
+    for (int i = 0; i < n; ++i) { ps[i]->allreduce = inproc_allreduce; ps[i]->allreduce_user = inproc_rank_handle(ic, i); ps[i]->allreduce_stream_ordered = true; }
+    inproc_set_timeout(ic, wait_timeout(ps[0], o));
+    int rc = CCAL_ERR_HIP;
+    try { rc = solve_sharded_run(ps, n, o, intr_io, poses_io, extr_io, rep, ic); } catch (...) { rc = CCAL_ERR_NO_MEMORY; }
+    // the early-exit groups enqueued ahead reference the transport's events and buffers: drain them before it goes
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(ps[i]->ctx->device);
+        (void)hipStreamSynchronize(ps[i]->ctx->stream);
+        if (ps[i]->nws) { ps[i]->nws->tail_pending = false; if (ps[i]->nws->fws) ps[i]->nws->fws->tail_pending = false; }
+        ps[i]->allreduce = nullptr; ps[i]->allreduce_user = nullptr; ps[i]->allreduce_stream_ordered = false;
+    }
+    inproc_destroy(ic);
+    return rc;
     CCAL_API_CATCH(c0)
 }
 

@@ -148,6 +148,157 @@ def default_opts(method: int = _ffi.METHOD_GN, **kw) -> _ffi.SolverOpts:
     return o
 
 
+class MultiContext:
+    """A set of GPUs driven from THIS process (ccal_multi): one context per listed device plus the transport of the step's
+    all-reduce - RCCL when the devices differ, the library's in-process transport when a device is listed more than once."""
+
+    def __init__(self, devices):
+        self.lib = _ffi.load()
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        h = C.c_void_p()
+        rc = self.lib.ccal_multi_create(devs.ctypes.data_as(C.POINTER(C.c_int32)), len(devs), C.byref(h))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_multi_create")
+        self.handle = h
+        self.devices = [int(d) for d in devs]
+        self._problems = weakref.WeakSet()
+
+    @property
+    def transport(self) -> int:
+        return int(self.lib.ccal_multi_transport(self.handle))
+
+    def last_error(self) -> str:
+        return (self.lib.ccal_multi_last_error(self.handle) or b"").decode()
+
+    def set_model_conventions(self, cv):
+        rc = self.lib.ccal_multi_set_model_conventions(self.handle, C.byref(cv) if cv is not None else None)
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_multi_set_model_conventions")
+
+    def sync(self):
+        rc = self.lib.ccal_multi_sync(self.handle)
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_multi_sync", self.last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            for p in list(getattr(self, "_problems", ())):
+                p.close()
+            self.lib.ccal_multi_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MultiProblem:
+    """One problem whose frame slots the library shards over the GPUs of a MultiContext (ccal_multi_problem)."""
+
+    def __init__(self, mctx: MultiContext, desc: _ffi.ProblemDesc, keep=None):
+        self.mctx = mctx
+        self.lib = mctx.lib
+        self._keep = keep
+        h = C.c_void_p()
+        rc = self.lib.ccal_multi_problem_create(mctx.handle, C.byref(desc), C.byref(h))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_multi_problem_create", mctx.last_error())
+        self.handle = h
+        mctx._problems.add(self)
+        self.n_cams = desc.n_cams
+        self.n_slots = desc.n_slots
+        self.n_obs = int(desc.n_obs)
+        self.n_shards = int(self.lib.ccal_multi_problem_num_shards(h))
+
+    @classmethod
+    def from_synth(cls, mctx: MultiContext, sp) -> "MultiProblem":
+        d, keep = desc_from_synth(sp)
+        return cls(mctx, d, keep)
+
+    def _check(self, rc: int, where: str):
+        if rc != _ffi.OK:
+            raise CcalError(rc, where, self.mctx.last_error())
+
+    def slot_range(self, i: int):
+        a = C.c_int32(); b = C.c_int32()
+        self._check(self.lib.ccal_multi_problem_slot_range(self.handle, i, C.byref(a), C.byref(b)), "ccal_multi_problem_slot_range")
+        return a.value, b.value
+
+    def shard_handle(self, i: int):
+        return C.c_void_p(self.lib.ccal_multi_problem_shard(self.handle, i))
+
+    def set_bounds(self, cam, idx, lo, hi):
+        self._check(self.lib.ccal_multi_set_bounds(self.handle, cam, idx, lo, hi), "ccal_multi_set_bounds")
+
+    def fix_param(self, cam, idx):
+        self._check(self.lib.ccal_multi_fix_param(self.handle, cam, idx), "ccal_multi_fix_param")
+
+    def unfix_param(self, cam, idx):
+        self._check(self.lib.ccal_multi_unfix_param(self.handle, cam, idx), "ccal_multi_unfix_param")
+
+    def apply_reference_bounds(self):
+        self._check(self.lib.ccal_multi_apply_reference_bounds(self.handle), "ccal_multi_apply_reference_bounds")
+
+    def disable_distortions(self, n: int, intr: np.ndarray):
+        self._check(self.lib.ccal_multi_disable_distortions(self.handle, n, _dp(intr)), "ccal_multi_disable_distortions")
+
+    def _params(self, intr, poses, extr):
+        intr = _f64(intr, (self.n_cams, PMAX))
+        poses = _f64(poses, (self.n_slots, 6))
+        extr = _f64(np.zeros((self.n_cams, 6)) if extr is None else extr, (self.n_cams, 6))
+        return intr, poses, extr
+
+    def init_poses(self, intr, min_points: int = 10):
+        intr = _f64(intr, (self.n_cams, PMAX))
+        poses = np.zeros((max(self.n_obs, 1), 6)); used = np.zeros(max(self.n_obs, 1), dtype=np.int32)
+        self._check(self.lib.ccal_multi_init_poses(self.handle, _dp(intr), int(min_points), _dp(poses),
+                                                   used.ctypes.data_as(C.POINTER(C.c_int32))), "ccal_multi_init_poses")
+        return poses[:self.n_obs], used[:self.n_obs]
+
+    def solve(self, intr, poses, extr=None, opts: _ffi.SolverOpts | None = None, raise_on_error=True):
+        """ccal_multi_solve: ONE call, every GPU of the set; poses in the caller's slot order."""
+        intr, poses, extr = self._params(intr, poses, extr)
+        intr, poses, extr = intr.copy(), poses.copy(), extr.copy()
+        opts = opts or default_opts()
+        rep = _ffi.Report()
+        rc = self.lib.ccal_multi_solve(self.handle, C.byref(opts), _dp(intr), _dp(poses), _dp(extr), C.byref(rep))
+        if rc not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE) and raise_on_error:
+            raise CcalError(rc, "ccal_multi_solve", self.mctx.last_error())
+        return intr, poses, extr, rep
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ccal_multi_problem_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def solve_sharded(problems, intr, poses_list, extr=None, opts: _ffi.SolverOpts | None = None, raise_on_error=True):
+    """ccal_solve_sharded: shards built by the caller (one Problem per context), solved as ONE problem from this thread."""
+    n = len(problems)
+    lib = problems[0].lib
+    n_cams = problems[0].n_cams
+    intr = _f64(intr, (n_cams, PMAX)).copy()
+    extr = _f64(np.zeros((n_cams, 6)) if extr is None else extr, (n_cams, 6)).copy()
+    poses = [_f64(p, (q.n_slots, 6)).copy() for p, q in zip(poses_list, problems)]
+    opts = opts or default_opts()
+    hs = (C.c_void_p * n)(*[p.handle for p in problems])
+    dpp = C.POINTER(C.c_double)
+    pa = (dpp * n)(*[_dp(p) for p in poses])
+    rep = _ffi.Report()
+    rc = lib.ccal_solve_sharded(hs, n, C.byref(opts), _dp(intr), pa, _dp(extr), C.byref(rep))
+    if rc not in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE) and raise_on_error:
+        raise CcalError(rc, "ccal_solve_sharded", problems[0].ctx.last_error())
+    return intr, poses, extr, rep
+
+
 class Problem:
     """Calib-frame inputs resident in HBM (ccal_problem)."""
 

@@ -145,11 +145,13 @@ typedef struct {
     double lm_max_diagonal;        /* 1e32 */
     int32_t verbose;
     int32_t timeout_s;             /* host-side watchdog of the device-resident loop, seconds without a step completing.
-                                      0 = default: 30 s on a single GPU; NONE in a sharded solve (a communicator or an
+                                      0 = default: 30 s on a single GPU, 600 s in a sharded solve (a communicator or an
                                       all-reduce callback is set): a step that waits for a peer - still uploading, still
-                                      setting up RCCL channels - is waited for, the wait ends when the stream does.  Give
-                                      every rank the same value: a rank that gives up (CCAL_ERR_HIP, "timed out") leaves
-                                      the shared sequence of collectives while its peers are inside ncclAllReduce */
+                                      setting up RCCL channels - is waited for, a peer that died does not hang the
+                                      survivors for ever.  Give every rank the same value: a rank that gives up
+                                      (CCAL_ERR_HIP, "timed out") leaves the shared sequence of collectives while its peers
+                                      are inside ncclAllReduce - see "Errors" below: exit or abort the communicator, never
+                                      re-exec a process that has touched the GPU */
 } ccal_solver_opts;
 
 typedef struct {
@@ -258,6 +260,61 @@ int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* opts, ccal_report* r
 int ccal_solve_batch(ccal_problem** problems, int n, const ccal_solver_opts* opts,
                      double** intr_io, double** poses_io, double** extr_io, ccal_report* reports);
 
+/* ---- one process, several GPUs ------------------------------------------------------------------
+ * The reference is ONE process: calib_camera is one blocking call of the tool's main (src/util.rs:384-390,
+ * src/bin/camera_calibration.rs:70).  These entry points keep it that way on a multi-GPU node: the library shards the
+ * frame slots, drives every GPU from a host thread of its own and owns the transport of the step's one all-reduce.
+ *
+ * ccal_solve_sharded: n shards of ONE problem - problems created by the caller on n DIFFERENT contexts (one per GPU;
+ *   contexts on the same GPU work too), each holding a contiguous range of the frame slots with every camera's
+ *   observations of those slots, the same cameras, bounds and fixed parameters.  intr_io / extr_io: the shared camera
+ *   block (in: starting point, out: result - bit-identical on every shard, checked); poses_io[i]: shard i's poses
+ *   [n_slots_i][6].  Transport: whatever is set on ALL shards (ccal_set_rccl_comm / ccal_set_allreduce); none set = the
+ *   library's in-process transport for the duration of the call (HIP events order the shards' streams, a kernel adds the
+ *   shards' buffers in shard order; needs the shards on one GPU or peer access between their GPUs).  The report is the
+ *   solve's (every shard reaches the same verdict and iteration count; solve_ms = the slowest shard).
+ * ccal_multi_*: the same with the sharding done by the library.  ccal_multi_create makes one context per listed device
+ *   and the transport between them - RCCL (ncclCommInitAll, one communicator per device) when the devices are all
+ *   different and RCCL can be resolved, the in-process transport otherwise (a device listed twice: two shards on one GPU).
+ *   ccal_multi_problem_create takes the SAME description as ccal_problem_create and cuts it into contiguous slot ranges
+ *   balanced by corner count; poses / poses_obs / n_used keep the caller's slot and observation-frame order.
+ * Errors: as for sharded solves above.  After an error other than the solver's verdicts a ccal_multi with the in-process
+ * transport recovers by itself; with RCCL its communicators are aborted and every later ccal_multi_solve on it fails
+ * (CCAL_ERR_HIP): destroy it and create a new one. */
+#define CCAL_MULTI_MAX_DEVICES 16
+typedef enum { CCAL_TRANSPORT_NONE = 0 /* one device */, CCAL_TRANSPORT_RCCL = 1, CCAL_TRANSPORT_INPROC = 2 } ccal_transport;
+typedef struct ccal_multi ccal_multi;                  /* a set of contexts (one per listed device) + their transport */
+typedef struct ccal_multi_problem ccal_multi_problem;  /* one problem, frame slots sharded over the contexts of a ccal_multi */
+
+int ccal_solve_sharded(ccal_problem** shards, int n, const ccal_solver_opts* opts,
+                       double* intr_io, double** poses_io, double* extr_io, ccal_report* report);
+
+int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out);
+void ccal_multi_destroy(ccal_multi* m);                /* deferred to the last ccal_multi_problem_destroy if problems are alive */
+int ccal_multi_num_devices(const ccal_multi* m);
+int ccal_multi_transport(const ccal_multi* m);         /* ccal_transport */
+ccal_ctx* ccal_multi_ctx(ccal_multi* m, int i);        /* context of device i (ccal_last_error, conventions) */
+const char* ccal_multi_last_error(const ccal_multi* m);
+int ccal_multi_set_model_conventions(ccal_multi* m, const ccal_model_conventions* in);   /* on every context */
+int ccal_multi_sync(ccal_multi* m);
+
+int ccal_multi_problem_create(ccal_multi* m, const ccal_problem_desc* desc, ccal_multi_problem** out);
+void ccal_multi_problem_destroy(ccal_multi_problem* mp);
+int ccal_multi_problem_num_shards(const ccal_multi_problem* mp);
+ccal_problem* ccal_multi_problem_shard(ccal_multi_problem* mp, int i);   /* borrowed: sizes, mode E buffers; do not destroy */
+int ccal_multi_problem_slot_range(const ccal_multi_problem* mp, int i, int32_t* first_slot, int32_t* n_slots);
+int ccal_multi_set_bounds(ccal_multi_problem* mp, int cam, int eff_idx, double lo, double hi);
+int ccal_multi_clear_bounds(ccal_multi_problem* mp, int cam, int eff_idx);
+int ccal_multi_fix_param(ccal_multi_problem* mp, int cam, int eff_idx);
+int ccal_multi_unfix_param(ccal_multi_problem* mp, int cam, int eff_idx);
+int ccal_multi_apply_reference_bounds(ccal_multi_problem* mp);
+int ccal_multi_disable_distortions(ccal_multi_problem* mp, int n_disabled, double* intr_io);
+int ccal_multi_init_poses(ccal_multi_problem* mp, const double* intr, int min_points, double* poses_obs, int32_t* n_used);
+int ccal_multi_upload_params(ccal_multi_problem* mp, const double* intr, const double* poses /* [n_slots][6], all slots */, const double* extr);
+int ccal_multi_eval_dev(ccal_multi_problem* mp, int apply_loss, double* const* r_dev, double* const* J_dev);   /* per shard device buffers; no collective */
+int ccal_multi_solve(ccal_multi_problem* mp, const ccal_solver_opts* opts,
+                     double* intr_io, double* poses_io /* [n_slots][6], all slots */, double* extr_io, ccal_report* report);
+
 /* ---- per-frame pose initialisation (src/util.rs:418-436) ---------------------------------
  * What calib_camera does before it builds the problem: unproject the detections with the current model,
  * keep the valid ones, divide by z, planar PnP (the reference calls sqpnp_simple; here a plane-induced
@@ -273,6 +330,9 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
  * library, needs no context.  poses_* are [n_common][6] rvec,tvec. */
 int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common,
                                double* t_i_0_io, int use_initial, ccal_report* report);
+/* One SE3Factor block (src/optimization/factors.rs:248-271): r[6] = the rvec,tvec of T_i_b^-1 * (T_i_0 * T_0_b) and its
+ * 6 x 6 Jacobian (row-major) with respect to x = rvec,tvec of T_i_0 - what tiny-solver's dual numbers evaluate to. */
+int ccal_se3_factor(const double* pose_0_b, const double* pose_i_b, const double* x, double* r_out, double* J_out);
 
 /* ---- convert_model (src/util.rs:224-282) -----------------------------------------------------
  * Fit the target model to the source model over the reference's pixel grid: ModelConvertFactor

@@ -28,6 +28,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"missing export {name}"
 
 
+def test_library_exports_nothing_beyond_the_header():
+    """Every ccal_* symbol the product build exports is declared in include/ccal.h (developer hooks live behind build
+    macros such as -DCCAL_STAMPS and are not in the shipped library)."""
+    import subprocess
+    nm = "/opt/rocm/lib/llvm/bin/llvm-nm"
+    if not os.path.exists(nm):
+        nm = "nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and re.fullmatch(r"ccal_[a-z0-9_]+", ln.split()[-1])})
+    assert exported, "no ccal_* exports found"
+    extra = sorted(set(exported) - set(_declared()))
+    assert not extra, f"exported but not declared in include/ccal.h: {extra}"
+
+
 def test_host_only_entry_points():
     lib = _ffi.load()
     assert lib.ccal_version().startswith(b"ccal-mi355x")

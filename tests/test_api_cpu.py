@@ -57,7 +57,7 @@ def test_se3_factor_analytic_jacobian_matches_dual_numbers(oracle):
     import ctypes as C
     from camera_intrinsic_calibration_rs_amd import _ffi
     lib = _ffi.load()
-    fn = lib.ccal_debug_se3_factor
+    fn = lib.ccal_se3_factor
     dp = C.POINTER(C.c_double)
     fn.restype = C.c_int; fn.argtypes = [dp, dp, dp, dp, dp]
     rng = np.random.default_rng(11)

@@ -1,0 +1,223 @@
+"""GPU: ONE process, several shards - ccal_multi_* and ccal_solve_sharded (include/ccal.h, "one process, several GPUs").
+The reference's calib_camera is one blocking call of one process (src/util.rs:384-390): this is the entry a Rust
+calib_camera body uses to reach every GPU of a node.
+  * on the 1-GPU box the device set is [0, 0, ...]: several contexts on device 0 and the library's in-process transport
+    (HIP events + a device-side add in shard order) - LM rejections, a pose block that fails on ONE shard, an empty shard;
+  * with two or more GPUs visible the same tests also run on range(device_count) with native RCCL (ncclCommInitAll).
+Every solve runs in a fresh child process that the parent kills when it hangs (never a re-exec of a process that has
+touched the GPU); the library itself verifies that the camera block is bit-identical on all shards."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _device_sets():
+    """[0, 0] style sets for the in-process transport; the real devices when there are at least two."""
+    sets = [("inproc2", [0, 0]), ("inproc3", [0, 0, 0])]
+    try:
+        import torch
+        n = torch.cuda.device_count()               # counting devices does not initialise the GPU in this process
+    except Exception:
+        n = 1
+    if n >= 2:
+        sets.append((f"rccl{min(n, 8)}", list(range(min(n, 8)))))
+    return sets
+
+
+def _problem(scenario, model, n_cams):
+    from camera_intrinsic_calibration_rs_amd import synth
+    if scenario == "lm_rejections":          # poor starting points on which LM rejects several steps (tests/test_gpu_dist.py)
+        return synth.make_problem(12, "eucm", n_cams=n_cams, outlier_frac=0.05, ragged=True, init_perturb=0.8, seed=1 if n_cams == 1 else 0xBEEF)
+    if scenario == "notpd_last":             # every corner of the LAST slot the same board point: singular 6 x 6 block on the last shard only
+        sp = synth.make_problem(36, "eucm", n_cams=n_cams, outlier_frac=0.03, ragged=True, seed=0xBEEF)
+        last = np.nonzero(sp.obs_slot == sp.n_slots - 1)[0]
+        for o in last:
+            sp.p3d[sp.obs_offsets[o]: sp.obs_offsets[o + 1]] = sp.p3d[sp.obs_offsets[o]]
+        return sp
+    if scenario == "few_slots":              # fewer slots than shards: some shards hold no slot at all
+        return synth.make_problem(2, model, n_cams=n_cams, seed=5)
+    return synth.make_problem(41, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
+
+
+def _child_multi(q, devices, scenario, model, n_cams, method, one_focal):
+    sys.path.insert(0, ROOT)
+    from camera_intrinsic_calibration_rs_amd.engine import Context, MultiContext, MultiProblem, Problem, default_opts
+    sp = _problem(scenario, model, n_cams)
+    if one_focal:
+        import dataclasses
+        sp = dataclasses.replace(sp, xy_same_focal=True)
+    ctx = Context(0)
+    full = Problem.from_synth(ctx, sp)
+    full.apply_reference_bounds()
+    i1, p1, e1, r1 = full.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method), raise_on_error=False)
+    po1, nu1 = full.init_poses(sp.intr0)
+    mc = MultiContext(devices)
+    mpb = MultiProblem.from_synth(mc, sp)
+    mpb.apply_reference_bounds()
+    ranges = [mpb.slot_range(i) for i in range(mpb.n_shards)]
+    out = []
+    for rep_i in range(2):                   # twice: the second solve starts behind the first one's early-exit groups
+        i2, p2, e2, r2 = mpb.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method), raise_on_error=False)
+        out.append((i2, p2, e2, (r2.status, r2.iterations, r2.lm_accepted, r2.lm_rejected, r2.lm_spec_misses, r2.final_cost, r2.initial_cost)))
+    po2, nu2 = mpb.init_poses(sp.intr0)
+    q.put(dict(transport=mc.transport, ranges=ranges, single=(i1, p1, e1, (r1.status, r1.iterations, r1.lm_accepted, r1.lm_rejected, r1.lm_spec_misses, r1.final_cost, r1.initial_cost)),
+               multi=out, init=(po1, nu1, po2, nu2)))
+    mpb.close(); mc.close(); full.close()
+
+
+def _run_child(target, args, timeout=240):
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=target, args=(q,) + tuple(args))
+    p.start()
+    try:
+        res = q.get(timeout=timeout)
+    except Exception:
+        if p.is_alive():
+            p.kill()                          # exactly the child started here
+        p.join(10)
+        raise AssertionError(f"single-process sharded solve hung or crashed (exit code {p.exitcode})")
+    p.join(60)
+    assert p.exitcode == 0
+    return res
+
+
+def _check_against_single(res, n_slots, expect_transport, method):
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    assert res["transport"] == expect_transport
+    ranges = res["ranges"]
+    assert ranges[0][0] == 0 and sum(c for _, c in ranges) == n_slots
+    for (a, c), (b, _) in zip(ranges[:-1], ranges[1:]):
+        assert a + c == b                                   # contiguous, in order
+    i1, p1, e1, r1 = res["single"]
+    for i2, p2, e2, r2 in res["multi"]:
+        assert r2[0] == r1[0] and r2[1] == r1[1], (r1, r2)       # status, iterations
+        if method == 1:
+            assert r2[2:5] == r1[2:5]                            # accept / reject / missed speculations
+        if r1[0] in (_ffi.OK, _ffi.ERR_NO_CONVERGENCE):
+            np.testing.assert_allclose(i2, i1, rtol=1e-9, atol=1e-12)
+            np.testing.assert_allclose(e2, e1, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(p2, p1, rtol=0, atol=1e-9)
+            assert abs(r2[5] - r1[5]) <= 1e-10 * abs(r1[5])
+            assert abs(r2[6] - r1[6]) <= 1e-12 * abs(r1[6])
+    # two solves of the same sharded problem: bit-identical (fixed summation order everywhere)
+    (ia, pa, ea, ra), (ib, pb, eb, rb) = res["multi"]
+    assert ra == rb or (np.isnan(ra[5]) and np.isnan(rb[5]))
+    np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(pa, pb); np.testing.assert_array_equal(ea, eb)
+    po1, nu1, po2, nu2 = res["init"]
+    np.testing.assert_array_equal(nu1, nu2)                 # pose initialisation is per frame: the same bits, caller's order
+    np.testing.assert_array_equal(po1, po2)
+
+
+@pytest.mark.parametrize("devset", _device_sets(), ids=lambda d: d[0])
+@pytest.mark.parametrize("model,n_cams,method,one_focal", [("eucm", 1, 0, False), ("eucm", 1, 1, False), ("kb4", 1, 0, True), ("eucm", 2, 0, False),
+                                                           ("kb4", 2, 1, False), ("opencv5", 3, 0, False)])
+def test_multi_solve_equals_the_unsharded_solve(devset, model, n_cams, method, one_focal):
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    name, devices = devset
+    res = _run_child(_child_multi, (devices, "plain", model, n_cams, method, one_focal))
+    _check_against_single(res, 41, _ffi.TRANSPORT_RCCL if name.startswith("rccl") else _ffi.TRANSPORT_INPROC, method)
+    assert res["single"][3][0] == _ffi.OK
+
+
+@pytest.mark.parametrize("devset", _device_sets(), ids=lambda d: d[0])
+@pytest.mark.parametrize("scenario,n_cams,method", [("lm_rejections", 1, 1), ("lm_rejections", 2, 1), ("notpd_last", 1, 0), ("notpd_last", 1, 1),
+                                                    ("notpd_last", 2, 0), ("few_slots", 1, 0), ("few_slots", 1, 1), ("few_slots", 2, 0)])
+def test_multi_solve_hard_cases(devset, scenario, n_cams, method):
+    """LM with rejected steps; a pose block that is singular on ONE shard (Gauss-Newton: NOT_PD for the whole solve, LM freezes
+    it); shards without a single slot - same verdict, iteration count and accept / reject sequence as the unsharded solve."""
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    name, devices = devset
+    res = _run_child(_child_multi, (devices, scenario, "eucm", n_cams, method, False))
+    n_slots = {"lm_rejections": 12, "notpd_last": 36, "few_slots": 2}[scenario]
+    _check_against_single(res, n_slots, _ffi.TRANSPORT_RCCL if name.startswith("rccl") else _ffi.TRANSPORT_INPROC, method)
+    st = res["single"][3]
+    if scenario == "lm_rejections":
+        assert st[0] == _ffi.OK and st[3] + st[4] >= 1
+    if scenario == "notpd_last" and method == 0:
+        assert st[0] == _ffi.ERR_NOT_PD
+    if scenario == "few_slots":
+        assert any(c == 0 for _, c in res["ranges"]) or len(res["ranges"]) <= 2
+
+
+def _child_sharded(q, n_shards, model, n_cams, method):
+    """Caller-built shards (one Problem per context) through ccal_solve_sharded."""
+    sys.path.insert(0, ROOT)
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.engine import CcalError, Context, Problem, default_opts, solve_sharded
+    sp = synth.make_problem(37, model, n_cams=n_cams, outlier_frac=0.01, ragged=True, seed=77)
+    full = Problem.from_synth(Context(0), sp)
+    full.apply_reference_bounds()
+    i1, p1, e1, r1 = full.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+    ctxs = [Context(0) for _ in range(n_shards)]
+    shards = [sp.shard(r, n_shards) for r in range(n_shards)]
+    probs = [Problem.from_synth(c, s) for c, s in zip(ctxs, shards)]
+    for p in probs:
+        p.apply_reference_bounds()
+    i2, ps2, e2, r2 = solve_sharded(probs, sp.intr0, [s.poses0 for s in shards], sp.extr0, opts=default_opts(method))
+    errors = {}
+    try:                                       # the same context twice
+        solve_sharded([probs[0], Problem.from_synth(ctxs[0], shards[1])], sp.intr0, [shards[0].poses0, shards[1].poses0], sp.extr0)
+    except CcalError as e:
+        errors["same_ctx"] = e.code
+    probs[1].fix_param(0, 0)
+    try:                                       # different constraints on the shards
+        solve_sharded(probs, sp.intr0, [s.poses0 for s in shards], sp.extr0)
+    except CcalError as e:
+        errors["constraints"] = e.code
+    probs[1].unfix_param(0, 0)
+    # and the shards still work one more time afterwards (the temporary transport left nothing behind)
+    i3, ps3, e3, r3 = solve_sharded(probs, sp.intr0, [s.poses0 for s in shards], sp.extr0, opts=default_opts(method))
+    q.put(dict(single=(i1, p1, e1, r1.status, r1.iterations, r1.final_cost), sharded=(i2, np.concatenate(ps2), e2, r2.status, r2.iterations, r2.final_cost),
+               again=(i3, np.concatenate(ps3), e3, r3.status, r3.iterations, r3.final_cost), errors=errors))
+
+
+@pytest.mark.parametrize("n_shards,model,n_cams,method", [(2, "eucm", 1, 0), (4, "ucm", 1, 1), (3, "eucm", 2, 0)])
+def test_solve_sharded_with_caller_built_shards(n_shards, model, n_cams, method):
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    res = _run_child(_child_sharded, (n_shards, model, n_cams, method))
+    i1, p1, e1, s1, it1, c1 = res["single"]
+    for key in ("sharded", "again"):
+        i2, p2, e2, s2, it2, c2 = res[key]
+        assert (s2, it2) == (s1, it1) and s1 == _ffi.OK
+        np.testing.assert_allclose(i2, i1, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(e2, e1, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(p2, p1, rtol=0, atol=1e-9)
+        assert abs(c2 - c1) <= 1e-10 * c1
+    np.testing.assert_array_equal(res["sharded"][0], res["again"][0])
+    np.testing.assert_array_equal(res["sharded"][1], res["again"][1])
+    assert res["errors"] == {"same_ctx": _ffi.ERR_INVALID_ARG, "constraints": _ffi.ERR_INVALID_ARG}
+
+
+def _child_api(q, devices):
+    """api.calib_camera(devices=[...]): the reference's one-call form over several shards."""
+    sys.path.insert(0, ROOT)
+    from camera_intrinsic_calibration_rs_amd import api, synth
+    sp = synth.make_problem(60, "eucm", seed=9, outlier_frac=0.01, ragged=True)
+    frames = api.frames_from_synth(sp, 0)
+    frames[7] = None
+    cam = api.GenericModel("eucm", sp.intr0[0, :6], 512, 512)
+    one = api.calib_camera(frames, cam, False, 0, False)
+    many = api.calib_camera(frames, cam, False, 0, False, devices=devices)
+    ff = api.calib_camera(frames, cam, True, 1, True)
+    ffm = api.calib_camera(frames, cam, True, 1, True, devices=devices)
+    q.put(dict(one=(one[0].params(), {k: v.as6() for k, v in one[1].items()}), many=(many[0].params(), {k: v.as6() for k, v in many[1].items()}),
+               ff=(ff[0].params(), {k: v.as6() for k, v in ff[1].items()}), ffm=(ffm[0].params(), {k: v.as6() for k, v in ffm[1].items()})))
+
+
+@pytest.mark.parametrize("devset", _device_sets()[:1] + _device_sets()[2:], ids=lambda d: d[0])
+def test_calib_camera_over_several_shards(devset):
+    res = _run_child(_child_api, (devset[1],))
+    for a, b in (("one", "many"), ("ff", "ffm")):
+        pa, posa = res[a]; pb, posb = res[b]
+        np.testing.assert_allclose(pb, pa, rtol=1e-9, atol=1e-12)
+        assert sorted(posa) == sorted(posb) and 7 not in posb
+        for k in posa:
+            np.testing.assert_allclose(posb[k], posa[k], rtol=0, atol=1e-9)

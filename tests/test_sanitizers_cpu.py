@@ -61,7 +61,7 @@ class Report(C.Structure):
     _fields_ = [("status", C.c_int32), ("iterations", C.c_int32), ("lm_accepted", C.c_int32), ("lm_rejected", C.c_int32),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms", C.c_double), ("h", C.c_int32), ("m", C.c_int32)]
 lib.ccal_init_camera_extrinsic.argtypes = [dp, dp, C.c_int, dp, C.c_int, C.POINTER(Report)]
-lib.ccal_debug_se3_factor.argtypes = [dp] * 5
+lib.ccal_se3_factor.argtypes = [dp] * 5
 rng = np.random.default_rng(1)
 for n in (1, 2, 40):
     p0 = np.ascontiguousarray(rng.normal(0, 1, (n, 6))); pi = np.ascontiguousarray(p0 + rng.normal(0, 1e-2, (n, 6)))
@@ -71,7 +71,7 @@ for n in (1, 2, 40):
     x2 = x.copy()
     lib.ccal_init_camera_extrinsic(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, x2.ctypes.data_as(dp), 1, None)
     r = np.empty(6); J = np.empty((6, 6))
-    lib.ccal_debug_se3_factor(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), x.ctypes.data_as(dp), r.ctypes.data_as(dp), J.ctypes.data_as(dp))
+    lib.ccal_se3_factor(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), x.ctypes.data_as(dp), r.ctypes.data_as(dp), J.ctypes.data_as(dp))
 assert lib.ccal_init_camera_extrinsic(None, None, 0, None, 0, None) == 1
 print("SAN-OK")
 """
