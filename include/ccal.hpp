@@ -92,7 +92,28 @@ private:
     int model_; std::vector<double> p_; double w_, h_;
 };
 
+// Which GPUs a call may use: one device (an int) or several ({0, 1, ..., 7}) - still ONE call of ONE process like the
+// reference's (src/util.rs:384-390); with several the library shards the frame slots and sums the reduced system once per
+// step (ccal_multi_*, include/ccal.h).  A device listed twice = two shards on that GPU.
+struct Devices {
+    std::vector<int> ids;
+    Devices(int device = 0) : ids{device} {}
+    Devices(std::vector<int> v) : ids(std::move(v)) {}
+    Devices(std::initializer_list<int> l) : ids(l) {}
+};
+
 namespace detail {
+
+struct Multi {   // RAII over ccal_multi
+    ccal_multi* h = nullptr;
+    explicit Multi(const Devices& d) { if (ccal_multi_create(d.ids.data(), (int)d.ids.size(), &h) != CCAL_OK) throw std::runtime_error("ccal_multi_create failed: no usable HIP device / library / transport"); }
+    ~Multi() { ccal_multi_destroy(h); }
+    Multi(const Multi&) = delete; Multi& operator=(const Multi&) = delete;
+};
+struct MProb {
+    ccal_multi_problem* h = nullptr;
+    ~MProb() { ccal_multi_problem_destroy(h); }
+};
 
 struct Ctx {     // RAII over ccal_ctx
     ccal_ctx* h = nullptr;
@@ -139,6 +160,17 @@ inline int make_problem(Ctx& ctx, const Flat& f, const std::vector<GenericModel>
     d.huber_delta = 1.0;                                             // HuberLoss::new(1.0), src/util.rs:413
     return ccal_problem_create(ctx.h, &d, &out.h);
 }
+inline int make_problem(Multi& m, const Flat& f, const std::vector<GenericModel>& cams, bool xy_same_focal, MProb& out) {
+    std::vector<int32_t> model; std::vector<double> w, h;
+    for (auto& c : cams) { model.push_back(c.model_id()); w.push_back(c.width()); h.push_back(c.height()); }
+    ccal_problem_desc d{};
+    d.n_cams = (int32_t)cams.size(); d.model = model.data(); d.width = w.data(); d.height = h.data();
+    d.xy_same_focal = xy_same_focal; d.n_slots = (int32_t)f.slots.size(); d.n_obs = (int32_t)f.obs_cam.size();
+    d.obs_cam = f.obs_cam.data(); d.obs_slot = f.obs_slot.data(); d.obs_offsets = f.offs.data();
+    d.p3d_x = f.x.data(); d.p3d_y = f.y.data(); d.p3d_z = f.z.data(); d.p2d_u = f.u.data(); d.p2d_v = f.v.data();
+    d.huber_delta = 1.0;                                             // HuberLoss::new(1.0), src/util.rs:413
+    return ccal_multi_problem_create(m.h, &d, &out.h);
+}
 inline std::vector<double> intr_matrix(const std::vector<GenericModel>& cams) {
     std::vector<double> intr(cams.size() * CCAL_PMAX, 0.0);
     for (size_t c = 0; c < cams.size(); ++c) for (size_t i = 0; i < cams[c].params().size(); ++i) intr[c * CCAL_PMAX + i] = cams[c].params()[i];
@@ -148,17 +180,17 @@ inline std::vector<double> intr_matrix(const std::vector<GenericModel>& cams) {
 }  // namespace detail
 
 // The pose initialisation inside calib_camera (src/util.rs:418-436): unproject, keep valid, planar PnP.
-inline std::map<size_t, RvecTvec> init_frame_poses(const std::vector<std::optional<FrameFeature>>& frames, const GenericModel& cam, int min_points = 10, int device = 0) {
+inline std::map<size_t, RvecTvec> init_frame_poses(const std::vector<std::optional<FrameFeature>>& frames, const GenericModel& cam, int min_points = 10, const Devices& device = 0) {
     std::set<size_t> valid;
     for (size_t i = 0; i < frames.size(); ++i) if (frames[i]) valid.insert(i);
     std::map<size_t, RvecTvec> out;
     if (valid.empty()) return out;
-    detail::Ctx ctx(device); detail::Prob p;
+    detail::Multi ctx(device); detail::MProb p;
     const auto f = detail::flatten({&frames}, {valid});
     if (detail::make_problem(ctx, f, {cam}, false, p) != CCAL_OK) return out;
     std::vector<double> poses(f.slots.size() * 6); std::vector<int32_t> used(f.slots.size());
     const auto intr = detail::intr_matrix({cam});
-    if (ccal_init_poses(p.h, intr.data(), min_points, poses.data(), used.data()) != CCAL_OK) return out;
+    if (ccal_multi_init_poses(p.h, intr.data(), min_points, poses.data(), used.data()) != CCAL_OK) return out;
     for (size_t s = 0; s < f.slots.size(); ++s) if (used[s] > 0) out[f.slots[s]] = RvecTvec::from6(&poses[6 * s]);
     return out;
 }
@@ -167,28 +199,28 @@ inline std::map<size_t, RvecTvec> init_frame_poses(const std::vector<std::option
 inline std::optional<std::pair<GenericModel, std::map<size_t, RvecTvec>>>
 calib_camera(const std::vector<std::optional<FrameFeature>>& frame_feature_list, const GenericModel& generic_camera,
              bool xy_same_focal, size_t disabled_distortions, bool fixed_focal,
-             const std::map<size_t, RvecTvec>* initial_poses = nullptr, int device = 0) {
+             const std::map<size_t, RvecTvec>* initial_poses = nullptr, const Devices& device = 0) {
     std::map<size_t, RvecTvec> init_local;
     if (!initial_poses) { init_local = init_frame_poses(frame_feature_list, generic_camera, 10, device); initial_poses = &init_local; }
     std::set<size_t> valid;
     for (size_t i = 0; i < frame_feature_list.size(); ++i) if (frame_feature_list[i] && initial_poses->count(i)) valid.insert(i);
     if (valid.empty()) return std::nullopt;
-    detail::Ctx ctx(device); detail::Prob p;
+    detail::Multi ctx(device); detail::MProb p;
     const auto f = detail::flatten({&frame_feature_list}, {valid});
     if (detail::make_problem(ctx, f, {generic_camera}, xy_same_focal, p) != CCAL_OK) return std::nullopt;
     auto intr = detail::intr_matrix({generic_camera});
     std::vector<double> poses;
     for (size_t fi : f.slots) { const auto v = initial_poses->at(fi).as6(); poses.insert(poses.end(), v.begin(), v.end()); }
-    ccal_apply_reference_bounds(p.h);                                               // src/util.rs:446
-    ccal_disable_distortions(p.h, (int)disabled_distortions, intr.data());          // src/util.rs:447-454
+    ccal_multi_apply_reference_bounds(p.h);                                         // src/util.rs:446
+    ccal_multi_disable_distortions(p.h, (int)disabled_distortions, intr.data());    // src/util.rs:447-454
     ccal_solver_opts o; ccal_set_defaults(&o);                                      // GaussNewtonOptimizer::default()
     ccal_report rep{};
-    int rc = ccal_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);         // :455
+    int rc = ccal_multi_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);   // :455 - one call, every listed GPU
     if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;        // result_option.as_ref()?
     if (fixed_focal) {                                                              // :459-464
-        ccal_fix_param(p.h, 0, 0);
+        ccal_multi_fix_param(p.h, 0, 0);
         intr[0] = generic_camera.params()[0]; if (xy_same_focal) intr[1] = intr[0];
-        rc = ccal_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);
+        rc = ccal_multi_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);
         if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) throw std::runtime_error("second solve failed");   // .unwrap()
     }
     GenericModel out = generic_camera;
@@ -205,14 +237,14 @@ inline std::optional<AllCameraResult>
 calib_all_camera_with_extrinsics(const std::vector<GenericModel>& cameras, const std::vector<RvecTvec>& t_cam_i_0,
                                  const std::vector<std::map<size_t, RvecTvec>>& cam_rtvecs,
                                  const std::vector<std::vector<std::optional<FrameFeature>>>& cams_detected_feature_frames,
-                                 bool xy_same_focal, size_t disabled_distortions, bool cam0_fixed_focal, int device = 0) {
+                                 bool xy_same_focal, size_t disabled_distortions, bool cam0_fixed_focal, const Devices& device = 0) {
     const size_t n = cameras.size();
     std::vector<std::set<size_t>> use(n);
     std::vector<const std::vector<std::optional<FrameFeature>>*> fr;
     for (size_t c = 0; c < n; ++c) { for (auto& kv : cam_rtvecs[c]) use[c].insert(kv.first); fr.push_back(&cams_detected_feature_frames[c]); }
     const auto f = detail::flatten(fr, use);
     if (f.slots.empty()) return std::nullopt;
-    detail::Ctx ctx(device); detail::Prob p;
+    detail::Multi ctx(device); detail::MProb p;
     if (detail::make_problem(ctx, f, cameras, xy_same_focal, p) != CCAL_OK) return std::nullopt;
     auto intr = detail::intr_matrix(cameras);
     std::vector<double> extr(n * 6, 0.0), poses(f.slots.size() * 6, 0.0);
@@ -225,12 +257,12 @@ calib_all_camera_with_extrinsics(const std::vector<GenericModel>& cameras, const
             for (int i = 0; i < 6; ++i) poses[6 * s + i] = v[i];
             break;
         }
-    ccal_apply_reference_bounds(p.h);
-    ccal_disable_distortions(p.h, (int)disabled_distortions, intr.data());
-    if (cam0_fixed_focal) ccal_fix_param(p.h, 0, 0);                                 // :664-667
+    ccal_multi_apply_reference_bounds(p.h);
+    ccal_multi_disable_distortions(p.h, (int)disabled_distortions, intr.data());
+    if (cam0_fixed_focal) ccal_multi_fix_param(p.h, 0, 0);                           // :664-667
     ccal_solver_opts o; ccal_set_defaults(&o);
     ccal_report rep{};
-    const int rc = ccal_solve(p.h, &o, intr.data(), poses.data(), extr.data(), &rep);
+    const int rc = ccal_multi_solve(p.h, &o, intr.data(), poses.data(), extr.data(), &rep);
     if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;
     AllCameraResult r;
     for (size_t c = 0; c < n; ++c) {

@@ -2,6 +2,7 @@
 // Built and run by tests/test_gpu_cpp_api.py on the GPU box; prints one JSON object.
 #include <cassert>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -120,7 +121,13 @@ int main(int argc, char** argv) {
     const double w = rd<double>(f), h = rd<double>(f);
     const int one_focal = rd<int32_t>(f), disabled = rd<int32_t>(f), fixed_focal = rd<int32_t>(f);
     const GenericModel cam(model_id, params, w, h);
-    const auto res = calib_camera(frames, cam, one_focal != 0, (size_t)disabled, fixed_focal != 0);     // poses initialised inside
+    // CCAL_TEST_DEVICES="0,0": the same ONE call over several shards (ccal::Devices -> ccal_multi_*); default: device 0
+    Devices devs(0);
+    if (const char* e = std::getenv("CCAL_TEST_DEVICES")) {
+        devs.ids.clear();
+        for (const char* q = e; *q;) { devs.ids.push_back(std::atoi(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+    }
+    const auto res = calib_camera(frames, cam, one_focal != 0, (size_t)disabled, fixed_focal != 0, nullptr, devs);     // poses initialised inside
     if (!res) { std::printf("{\"result\": null}\n"); return 0; }
     const auto val = validation(0, res->first, res->second, frames);
     std::printf("{\"params\": [");

@@ -90,6 +90,14 @@ def test_cpp_calib_camera_matches_python_binding(tmp_path, gpu_ctx):
     np.testing.assert_allclose(got["pose0"], poses[min(poses)].as6(), atol=1e-12)
     kb4 = api.convert_model(model, api.GenericModel("kb4", [0.0] * 8, 512, 512), 0, ctx=gpu_ctx)
     np.testing.assert_allclose(got["kb4"], kb4.params(), rtol=1e-12, atol=1e-14)
+    # the same ONE call over three shards of device 0 (ccal::Devices{0, 0, 0} -> ccal_multi_*: the library shards the frames,
+    # one all-reduce per step): the reference's single-process form of a multi-GPU solve
+    out3 = subprocess.check_output([exe, str(fix)], env=dict(os.environ, LD_LIBRARY_PATH=LIBDIR + ":/opt/rocm/lib", CCAL_TEST_DEVICES="0,0,0"),
+                                   timeout=300).decode()
+    got3 = json.loads(out3.strip().splitlines()[-1])
+    np.testing.assert_allclose(got3["params"], got["params"], rtol=1e-9)
+    assert got3["n_poses"] == got["n_poses"]
+    np.testing.assert_allclose(got3["pose0"], got["pose0"], atol=1e-9)
 
 
 def _write_frames(f, frames):
