@@ -76,6 +76,7 @@ def load():
         "oracle_convert_model": (C.c_int, [C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int, _dp, _dp, _u8,
                                            C.POINTER(C.c_int), C.c_void_p]),
         "oracle_hardware_threads": (C.c_int, []),
+        "oracle_set_solve_threads": (C.c_int, [C.c_int]),
         "oracle_usable_cpus": (C.c_int, []),
         "oracle_eval_timed_heap": (C.c_double, [D, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
         "oracle_eval_heap": (C.c_int, [D, _dp, _dp, _dp, C.c_int, C.c_int, _dp, _dp]),
@@ -313,6 +314,12 @@ def convert_model(src_model: int, src_params, tgt_model: int, tgt_params, width:
                                      _p(lo_a) if lo is not None else None, _p(hi_a) if lo is not None else None,
                                      hb.ctypes.data_as(_u8) if lo is not None else None, C.byref(n), None)
     return tgt, n.value, rc
+
+
+def set_solve_threads(n: int) -> int:
+    """Threads of OracleProblem.solve's passes over the blocks (1 = the serial restatement the parity tests use; bench.py's
+    all-cores Gauss-Newton baseline sets more).  Returns the previous value."""
+    return int(load().oracle_set_solve_threads(int(n)))
 
 
 def hardware_threads() -> int:

@@ -106,6 +106,20 @@ struct Normal {
 
 static inline double clampd(double v, double lo, double hi) { return std::min(std::max(v, lo), hi); }
 
+// Threads of the solver's two passes over the blocks (normal equations, cost): 1 = the serial restatement every parity test
+// uses; bench.py's all-cores Gauss-Newton baseline sets more (oracle_set_solve_threads).  A thread takes a contiguous range
+// of frame SLOTS (all cameras' observations of a slot: its pose block is complete), accumulates into its own camera block,
+// the blocks are added in thread order.
+static int g_solve_threads = 1;
+template <class F>
+static void for_slot_ranges(int n_slots, F&& fn) {
+    const int T = std::max(1, std::min(g_solve_threads, std::max(n_slots, 1)));
+    if (T == 1) { fn(0, 0, n_slots); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([&fn, t, T, n_slots] { fn(t, (int)((int64_t)n_slots * t / T), (int)((int64_t)n_slots * (t + 1) / T)); });
+    for (auto& x : th) x.join();
+}
+
 // Accumulate the full arrow-shaped normal equations from dual-number Jacobians and reduce.
 static void build_normal(const ccal_problem_desc* d, const Layout& L, const double* intr, const double* poses,
                          const double* extr, double lambda, double min_diag, double max_diag, Normal& N) {
@@ -115,10 +129,20 @@ static void build_normal(const ccal_problem_desc* d, const Layout& L, const doub
     for (auto& s : N.slots) { std::memset(s.C, 0, sizeof s.C); s.B.assign((size_t)6 * K, 0.0); std::memset(s.g, 0, sizeof s.g); }
     double eff[CCAL_MAX_CAMS][9];
     for (int c = 0; c < L.n_cams; ++c) full_to_eff(L, c, intr + (size_t)c * CCAL_PMAX, eff[c]);
+    const int T = std::max(1, std::min(g_solve_threads, std::max(d->n_slots, 1)));
+    std::vector<std::vector<double>> tH(T > 1 ? T : 0), tg(T > 1 ? T : 0);
+    std::vector<double> tcost(T, 0.0);
+    for_slot_ranges(d->n_slots, [&](int t, int s_lo, int s_hi) {
+    std::vector<double>& Hcc = T > 1 ? tH[t] : N.Hcc;
+    std::vector<double>& gcv = T > 1 ? tg[t] : N.gc;
+    if (T > 1) { Hcc.assign((size_t)K * K, 0.0); gcv.assign(K, 0.0); }
+    double cost_local = 0.0;
+    double& cost = T > 1 ? cost_local : N.cost;       // (a thread's running sum stays off the shared cache line)
     double J[2 * 21], r[2];
     int colmap[21];
     for (int o = 0; o < d->n_obs; ++o) {
         const int cam = d->obs_cam[o], slot = d->obs_slot[o];
+        if (slot < s_lo || slot >= s_hi) continue;
         const int D = L.D[cam], Pe = L.Peff[cam];
         for (int i = 0; i < Pe; ++i) colmap[i] = L.col_theta[cam] + i;
         for (int i = 0; i < 6; ++i) colmap[Pe + i] = K + i;                       // pose columns (local)
@@ -128,18 +152,18 @@ static void build_normal(const ccal_problem_desc* d, const Layout& L, const doub
             eval_block(d, L, cam, k, eff[cam], poses + (size_t)slot * 6, extr + (size_t)cam * 6, r, J);
             const double s = r[0] * r[0] + r[1] * r[1];
             const double w = d->huber_delta > 0.0 ? huber_weight(s, d->huber_delta) : 1.0;
-            N.cost += w * s;
+            cost += w * s;
             for (int row = 0; row < 2; ++row) {
                 const double* Jr = J + row * D;
                 const double wr = w * r[row];
                 for (int a = 0; a < D; ++a) {
                     const int ca = colmap[a];
                     const double wja = w * Jr[a];
-                    if (ca < K) N.gc[ca] += Jr[a] * wr; else sb.g[ca - K] += Jr[a] * wr;
+                    if (ca < K) gcv[ca] += Jr[a] * wr; else sb.g[ca - K] += Jr[a] * wr;
                     for (int bq = 0; bq < D; ++bq) {
                         const int cb = colmap[bq];
                         const double v = wja * Jr[bq];
-                        if (ca < K && cb < K) N.Hcc[(size_t)ca * K + cb] += v;
+                        if (ca < K && cb < K) Hcc[(size_t)ca * K + cb] += v;
                         else if (ca >= K && cb >= K) sb.C[(ca - K) * 6 + (cb - K)] += v;
                         else if (ca >= K && cb < K) sb.B[(size_t)(ca - K) * K + cb] += v;
                     }
@@ -147,16 +171,30 @@ static void build_normal(const ccal_problem_desc* d, const Layout& L, const doub
             }
         }
     }
+    if (T > 1) tcost[t] = cost_local;
+    });
+    if (T > 1) for (int t = 0; t < T; ++t) {
+        for (size_t i = 0; i < N.Hcc.size(); ++i) N.Hcc[i] += tH[t][i];
+        for (int i = 0; i < K; ++i) N.gc[i] += tg[t][i];
+        N.cost += tcost[t];
+    }
     // Schur complement of every pose block (Marquardt damping lambda * clamp(diag)).
     // (the camera block's own damping lambda * clamp(diag Hcc) is added at solve time, after any all-reduce)
     N.S = N.Hcc; N.b = N.gc;
+    std::vector<std::vector<double>> tS(T > 1 ? T : 0), tb(T > 1 ? T : 0);
+    std::vector<char> tbad(T, 0);
+    for_slot_ranges(d->n_slots, [&](int t, int s_lo, int s_hi) {
+    std::vector<double>& Sv = T > 1 ? tS[t] : N.S;
+    std::vector<double>& bv = T > 1 ? tb[t] : N.b;
+    if (T > 1) { Sv.assign((size_t)K * K, 0.0); bv.assign(K, 0.0); }
     std::vector<double> Y((size_t)6 * (K + 1));
-    for (auto& sb : N.slots) {
+    for (int si = s_lo; si < s_hi; ++si) {
+        SlotBlocks& sb = N.slots[si];
         double Cl[36]; std::memcpy(Cl, sb.C, sizeof Cl);
         bool any = false; for (int i = 0; i < 6; ++i) any |= Cl[i * 6 + i] != 0.0;
         if (!any) continue;                                        // slot without observations
         if (lambda > 0.0) for (int i = 0; i < 6; ++i) Cl[i * 6 + i] += lambda * clampd(sb.C[i * 6 + i], min_diag, max_diag);
-        if (!cholesky(Cl, 6)) { N.cost = NAN; return; }
+        if (!cholesky(Cl, 6)) { tbad[t] = 1; return; }
         // Y = L^-1 [B | g]
         for (int j = 0; j <= K; ++j) {
             for (int i = 0; i < 6; ++i) {
@@ -168,21 +206,31 @@ static void build_normal(const ccal_problem_desc* d, const Layout& L, const doub
         for (int a = 0; a < K; ++a) {
             for (int bq = 0; bq < K; ++bq) {
                 double t = 0.0; for (int k = 0; k < 6; ++k) t += Y[(size_t)k * (K + 1) + a] * Y[(size_t)k * (K + 1) + bq];
-                N.S[(size_t)a * K + bq] -= t;
+                Sv[(size_t)a * K + bq] -= t;
             }
             double t = 0.0; for (int k = 0; k < 6; ++k) t += Y[(size_t)k * (K + 1) + a] * Y[(size_t)k * (K + 1) + K];
-            N.b[a] -= t;
+            bv[a] -= t;
         }
+    }
+    });
+    for (int t = 0; t < T; ++t) if (tbad[t]) { N.cost = NAN; return; }
+    if (T > 1) for (int t = 0; t < T; ++t) {
+        for (size_t i = 0; i < N.S.size(); ++i) N.S[i] += tS[t][i];
+        for (int i = 0; i < K; ++i) N.b[i] += tb[t][i];
     }
 }
 
 static double total_cost(const ccal_problem_desc* d, const Layout& L, const double* intr, const double* poses, const double* extr) {
     using T = double;
-    double cost = 0.0;
     double eff[CCAL_MAX_CAMS][9];
     for (int c = 0; c < L.n_cams; ++c) full_to_eff(L, c, intr + (size_t)c * CCAL_PMAX, eff[c]);
+    const int NT = std::max(1, std::min(g_solve_threads, std::max(d->n_slots, 1)));
+    std::vector<double> tcost(NT, 0.0);
+    for_slot_ranges(d->n_slots, [&](int t, int s_lo, int s_hi) {
+    double cost = 0.0;
     for (int o = 0; o < d->n_obs; ++o) {
         const int cam = d->obs_cam[o], slot = d->obs_slot[o];
+        if (slot < s_lo || slot >= s_hi) continue;
         const double* ps = poses + (size_t)slot * 6; const double* ex = extr + (size_t)cam * 6;
         for (int64_t k = d->obs_offsets[o]; k < d->obs_offsets[o + 1]; ++k) {
             const float p3[3] = { d->p3d_x[k], d->p3d_y[k], d->p3d_z[k] };
@@ -194,6 +242,10 @@ static double total_cost(const ccal_problem_desc* d, const Layout& L, const doub
             cost += (d->huber_delta > 0.0 ? huber_weight(s, d->huber_delta) : 1.0) * s;
         }
     }
+    tcost[t] = cost;
+    });
+    double cost = 0.0;
+    for (int t = 0; t < NT; ++t) cost += tcost[t];
     return cost;
 }
 
@@ -743,6 +795,8 @@ int oracle_convert_model(int src_model, const double* src, int tgt_model, double
     return status;
 }
 
+// threads of oracle_solve's passes over the blocks (bench.py's all-cores CPU baseline of the optimizer); 1 = serial
+int oracle_set_solve_threads(int n) { const int old = g_solve_threads; g_solve_threads = n > 0 ? n : 1; return old; }
 int oracle_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 // CPUs this process may actually run on: the scheduler affinity mask (a container / cgroup cpuset shrinks it)
 int oracle_usable_cpus(void) {

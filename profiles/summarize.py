@@ -53,28 +53,69 @@ def main() -> None:
             if lines:
                 with open(os.path.join(dst, jf), "w") as o:
                     o.write(lines[-1])
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    dropped = defaultdict(int)
+    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_mem"):
         path = os.path.join(src, sub, "pmc_counter_collection.csv")
         if not os.path.exists(path):
             continue
         per_dispatch = defaultdict(float)        # a counter is reported once per XCD/instance: sum them per dispatch
-        names = {}
+        names, dur = {}, {}
         for r in csv.DictReader(open(path)):
             if not r["Kernel_Name"].startswith(("ccal::", "void ccal::")):
                 continue
             key = (r["Dispatch_Id"], r["Counter_Name"])
             per_dispatch[key] += float(r["Counter_Value"])
             names[r["Dispatch_Id"]] = short(r["Kernel_Name"])
+            dur[r["Dispatch_Id"]] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+        # The device-resident loops enqueue groups ahead: the kernels of a group that runs after the solve has finished return at
+        # their first instruction.  Such dispatches (and re-elimination groups that skip the evaluation) carry the kernel's name
+        # and almost none of its work: a dispatch shorter than HALF its kernel's median duration is left out of the means.
+        by_kernel = defaultdict(list)
+        for disp, k in names.items():
+            by_kernel[k].append(dur[disp])
+        median = {k: sorted(v)[len(v) // 2] for k, v in by_kernel.items()}
+        keep = {disp for disp, k in names.items() if dur[disp] >= 0.5 * median[k]}
+        for disp, k in names.items():
+            if disp not in keep:
+                dropped[k] += 1
         for (disp, cname), v in per_dispatch.items():
-            counters[names[disp]][cname].append(v)
+            if disp in keep:
+                counters[names[disp]][cname].append(v)
+        for disp in keep:
+            counters[names[disp]]["duration_ns__" + sub].append(dur[disp])
 
     out_c = {}
     for k, cs in counters.items():
         out_c[k] = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in sorted(cs.items())}
+        m = {c: d["mean"] for c, d in out_c[k].items()}
+        derived = {}
+        # fractions of quantities that one pass measured together (the same dispatches): the two SQ passes of run_profile.sh
+        if m.get("SQ_LDS_IDX_ACTIVE"):
+            derived["lds_bank_conflict_frac_of_lds_active_cycles"] = m.get("SQ_LDS_BANK_CONFLICT", 0.0) / m["SQ_LDS_IDX_ACTIVE"]
+        if m.get("SQ_WAVES") and "SQ_INSTS_VALU" in m:
+            derived["valu_insts_per_wavefront"] = m["SQ_INSTS_VALU"] / m["SQ_WAVES"]
+        if "SQ_ACTIVE_INST_VALU" in m and m.get("SQ_ACTIVE_INST_ANY"):
+            derived["valu_frac_of_active_inst_cycles"] = m["SQ_ACTIVE_INST_VALU"] / m["SQ_ACTIVE_INST_ANY"]
+        if "SQ_WAIT_ANY" in m and "SQ_ACTIVE_INST_ANY" in m and "SQ_WAIT_INST_ANY" in m:
+            # a wavefront's cycles ~ waiting (s_waitcnt) + issuing + stalled at issue: the pass has no SQ_WAVE_CYCLES, so the
+            # fractions are of the sum of the three it measured
+            tot = m["SQ_WAIT_ANY"] + m["SQ_ACTIVE_INST_ANY"] + m["SQ_WAIT_INST_ANY"]
+            if tot > 0:
+                derived["wait_any_frac"] = m["SQ_WAIT_ANY"] / tot
+                derived["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] / tot if "SQ_ACTIVE_INST_VALU" in m else None
+                derived["issue_stall_frac"] = m["SQ_WAIT_INST_ANY"] / tot
+        if m.get("SQ_WAVE_CYCLES") and "SQ_BUSY_CYCLES" in m and m.get("SQ_WAVES"):
+            derived["wave_cycles_per_wavefront"] = m["SQ_WAVE_CYCLES"] / m["SQ_WAVES"]
+        if derived:
+            out_c[k]["derived"] = derived
+        if dropped.get(k):
+            out_c[k]["dispatches_left_out_as_early_exits"] = dropped[k]
     ev = next((k for k in out_c if k.startswith("ccal::k_eval")), None)
     summary = {
         "note": "rocprofv3 --pmc passes of `bench.py --steps 50 --warmup 5 --no-cpu-baseline` "
-                f"({bench['config']['workload']}); per-dispatch means. FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 "
+                f"({bench['config']['workload']}); per-dispatch means over the dispatches that did the kernel's work (a dispatch shorter "
+                "than half its kernel's median duration - an early-exit group enqueued ahead of a finished solve - is left out). "
+                "FETCH_SIZE/WRITE_SIZE are KiB; on gfx950 "
                 "FETCH_SIZE under-reports streaming reads by 2x (MI355X_MICROARCH.md, HBM) so read bytes = "
                 "2 * FETCH_SIZE * 1024.",
     }

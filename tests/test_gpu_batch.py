@@ -88,3 +88,27 @@ def test_calib_cameras_equals_per_camera_calib_camera(gpu_ctx):
             assert sorted(batch[c][1]) == sorted(one[1])
             for k in one[1]:
                 np.testing.assert_array_equal(batch[c][1][k].as6(), one[1][k].as6())
+
+
+def test_calib_cameras_raises_when_the_fixed_focal_resolve_fails(monkeypatch):
+    """calib_camera `.unwrap()`s its second, fixed-focal solve (src/util.rs:463): a camera whose re-optimisation ends NOT_PD
+    must not come back as a silently copied result.  The failing verdict is injected into the second ccal_solve_batch's
+    reports (a real one is hard to provoke once the first solve has converged)."""
+    from camera_intrinsic_calibration_rs_amd import api
+    sp = synth.make_problem(12, "eucm", n_cams=2, seed=22)
+    frames = [api.frames_from_synth(sp, c) for c in range(2)]
+    cams0 = [api.GenericModel("eucm", sp.intr0[c, :6], 512, 512) for c in range(2)]
+    real = Problem.solve_batch
+    calls = []
+
+    def patched(problems, opts=None, starts=None):
+        reps, res = real(problems, opts, starts)
+        calls.append(len(problems))
+        if len(calls) == 2:
+            reps[1].status = _ffi.ERR_NOT_PD
+        return reps, res
+
+    monkeypatch.setattr(Problem, "solve_batch", staticmethod(patched))
+    with pytest.raises(CcalError) as ei:
+        api.calib_cameras(frames, cams0, True, 0, True)
+    assert ei.value.code == _ffi.ERR_NOT_PD and calls == [2, 2]

@@ -40,8 +40,10 @@ if "eval" in args.what:
     jp = J.data_ptr() + off * 8
     out["J_ptr"] = hex(jp); out["r_ptr"] = hex(r.data_ptr())
     us = min(timeit(lambda: prob.eval_dev(r.data_ptr(), jp), args.reps) for _ in range(3))
-    D = prob.block_dim(0)
-    out["eval_us"] = us; out["eval_GBps"] = (prob.n_corners * (36 + 16 * D) + sp.n_slots * 48) / us / 1e3
+    # algorithmic bytes of one pass: 5 f32 in + r[2] per corner, the block Jacobians as laid out (every camera's own width:
+    # j_len sums 2 D_cam doubles per corner of that camera), one 48-B pose per slot
+    algo = prob.n_corners * 36 + prob.j_len * 8 + sp.n_slots * 48
+    out["eval_us"] = us; out["eval_algorithmic_bytes"] = algo; out["eval_GBps"] = algo / us / 1e3
 if "normal" in args.what:
     out["normal_us"] = min(timeit(lambda: prob.build_normal_dev(0.0), args.reps) for _ in range(3))
 if "solve" in args.what:
