@@ -255,15 +255,23 @@ struct HeadArgs {
     double* intr[2]; double* dc;
     int32_t K, seq;
     double min_diag, max_diag;
+    // session-sized solves with host pointers: the group that finishes the solve writes the result - intrinsics and the
+    // accepted poses - straight into pinned host memory before it publishes `done`: ccal_solve then returns from its poll
+    // with no copy and no synchronise (result_host == NULL: the host fetches the result itself)
+    double* result_host; const double* poses[2]; int64_t np6;
     // single-GPU loop: the head reduces the elimination kernel's partial sums itself (no k_reduce1 launch);
     // partial == NULL: `red` holds the (all-)reduced sums
     const double* partial; int32_t n_part;
     int32_t publish_all;           // verbose solves: the whole report after every group
 };
 
-struct UnpackArgs {               // staging block (doubles): [intr CCAL_PMAX | DevState | ColInfo x CCAL_KMAX | poses np6]
-    const double* stage; int64_t small_doubles, np6;
-    int32_t poses_on_device;      // ccal_solve_dev: the starting point is already in intr0 / poses0, only state + columns are staged
+constexpr int kFusedMaxK = 9;     // the single-camera loop: at most 9 camera columns (OPENCV5, two focal lengths)
+struct UnpackArgs {               // the starting point of a single-camera solve
+    // the small part travels in the kernel-argument block itself (~600 bytes: no staging copy, no dependent load)
+    DevState st0; ColInfo col0[kFusedMaxK]; double intr_h[CCAL_PMAX]; int32_t n_cols;
+    const double* poses_src;      // ccal_solve: the caller's poses in pinned host memory (read by the kernel: zero-copy) or their
+    int64_t np6;                  // staged device copy (large problems); ccal_solve_dev: unused
+    int32_t poses_on_device;      // ccal_solve_dev: the starting point is already in intr0 / poses0, only state + columns arrive
     double* intr0; double* intr1; double* poses0; double* poses1;
     DevState* st; ColInfo* cols;
 };

@@ -25,23 +25,25 @@
 namespace ccal {
 
 // ---------------------------------------------------------------------------------------------
-// k_unpack1: the whole starting point arrives as ONE host-to-device copy of the staging block
-// [intr | DevState | ColInfo x KMAX | poses]; this kernel distributes it (both parameter sets start from the
-// caller's values, slots without observations never change) and clears the flags.  Seven stream operations
-// (five of them tiny copies at ~5 us each) became two.
+// k_unpack1: the starting point of a solve in ONE launch.  Optimizer state, column table and intrinsics ride in the kernel's
+// argument block (round 4; they were a staging copy the kernel then waited for), the poses are read where the caller left them:
+// pinned host memory for session-sized problems (zero-copy: no H2D operation at all), a staged device copy for large ones.
+// Both parameter sets start from the caller's values; slots without observations never change.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_unpack1(const UnpackArgs a) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x, nt = (int64_t)gridDim.x * 256;
-    const double* small = a.stage;
     // ccal_solve_dev: the starting point already sits in set 0 on the device - only mirror it into set 1
-    const double* poses = a.poses_on_device ? a.poses0 : a.stage + a.small_doubles;
+    const double* poses = a.poses_on_device ? a.poses0 : a.poses_src;
     for (int64_t e = t; e < a.np6; e += nt) { const double v = poses[e]; if (!a.poses_on_device) a.poses0[e] = v; a.poses1[e] = v; }
     if (blockIdx.x == 0) {
-        constexpr int NS = (int)(sizeof(DevState) / sizeof(double)), NCOL = (int)(CCAL_KMAX * sizeof(ColInfo) / sizeof(double));
-        const double* intr = a.poses_on_device ? a.intr0 : small;
-        for (int e = threadIdx.x; e < CCAL_PMAX; e += 256) { const double v = intr[e]; if (!a.poses_on_device) a.intr0[e] = v; a.intr1[e] = v; }
-        for (int e = threadIdx.x; e < NS; e += 256) reinterpret_cast<double*>(a.st)[e] = small[CCAL_PMAX + e];
-        for (int e = threadIdx.x; e < NCOL; e += 256) reinterpret_cast<double*>(a.cols)[e] = small[CCAL_PMAX + NS + e];
+        constexpr int NS = (int)(sizeof(DevState) / sizeof(double)), NC1 = (int)(sizeof(ColInfo) / sizeof(double));
+        for (int e = threadIdx.x; e < CCAL_PMAX; e += 256) {
+            const double v = a.poses_on_device ? a.intr0[e] : a.intr_h[e];
+            if (!a.poses_on_device) a.intr0[e] = v;
+            a.intr1[e] = v;
+        }
+        for (int e = threadIdx.x; e < NS; e += 256) reinterpret_cast<double*>(a.st)[e] = reinterpret_cast<const double*>(&a.st0)[e];
+        for (int e = threadIdx.x; e < a.n_cols * NC1; e += 256) reinterpret_cast<double*>(a.cols)[e] = reinterpret_cast<const double*>(a.col0)[e];
     }
 }
 hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s) {
@@ -1392,6 +1394,17 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
         const double* src = reinterpret_cast<const double*>(&S0);
         double* dst = reinterpret_cast<double*>(a.st);
         for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+    }
+    if (st->done && a.result_host) {
+        // this group finishes the solve: the accepted point goes straight to the caller's side of the bus.  The accepted poses
+        // were written by this group's Gram kernel (or an earlier one): complete at this kernel's start.  The accepted
+        // intrinsics: this kernel never writes set `cur` (candidates go to cur ^ 1), so global memory holds them
+        const int cur = st->cur;
+        const double* pi = a.intr[cur];
+        const double* pp = a.poses[cur];
+        for (int e = lane; e < CCAL_PMAX; e += 64) a.result_host[e] = pi[e];
+        for (int64_t e = lane; e < a.np6; e += 64) a.result_host[CCAL_PMAX + e] = pp[e];
+        __threadfence_system();
     }
     wsync();
     if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);

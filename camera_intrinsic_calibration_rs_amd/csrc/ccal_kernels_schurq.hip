@@ -21,7 +21,11 @@
 
 namespace ccal {
 
-constexpr int SQ_SLOTS = 16;       // frame slots per wavefront
+constexpr int SQ_SLOTS = 16;       // frame slots per full wavefront (four lanes each)
+// Slots per wavefront actually used: 16 (all 64 lanes) or 8 (lanes 32-63 leave at once).  625 wavefronts of 16 slots do not
+// even give every SIMD of the chip one wavefront, and each is a ~19 us chain (records in, then straight-line arithmetic): with
+// 8 slots a wavefront brings in half the bytes and twice as many wavefronts (1 250: all resident) overlap their phases.
+// CCAL_SCHURQ_SLOTS=8|16 overrides the launcher's choice.
 
 // entry e of a row-major lower triangle -> (i, j)
 __device__ __forceinline__ void sq_tri_decode(int e, int& i, int& j) {
@@ -44,17 +48,32 @@ template <int PE> struct SqLayout {
     static constexpr int CX = YL + 6 * K1;                               // C of the slot (6 x 6)
     static constexpr int DUM = CX + 36;                                  // one double per lane for sums nobody wants
     static constexpr int SS0 = DUM + 4;
-    static constexpr int SS = SS0 + ((2 - SS0 % 4) + 4) % 4;              // = 2 (mod 4): the 16 slots' 16-byte pieces of a broadcast read fall into 16 different bank groups
+    // Slot stride = 8 (mod 16) doubles.  What decides: the 16-byte stores and loads whose four lanes of a slot touch consecutive
+    // (staging, zeroing) or 48-byte-strided (rows of [B|g]^T, columns of Y) pieces - ds_write_b128 works in groups of 8 lanes = 2
+    // slots over 32 banks, ds_read_b128 in groups of 4 slots over 64: with the stride = 2 (mod 4) of round 3 the second slot of
+    // a group sat 16 bytes beside the first and three of its four pieces collided (model of every access of the kernel,
+    // tools/lds_bank_model.py: 46 % of the LDS cycles were conflicts, measured 42 %); at 64 bytes (mod 128) the pieces of a
+    // group tile the banks.  Broadcast reads (one address per slot) stay conflict-free.  CCAL_SQ_SS_OLD: the old stride (A/B)
+#ifdef CCAL_SQ_SS_OLD
+    static constexpr int SS = SS0 + ((2 - SS0 % 4) + 4) % 4;
+#else
+    static constexpr int SS = SS0 + ((8 - SS0 % 16) + 16) % 16;
+#endif
 };
 
+#ifndef CCAL_SCHURQ_DEFAULT_SLOTS
+#define CCAL_SCHURQ_DEFAULT_SLOTS 16
+#endif
 #ifdef CCAL_STAMPS      // diagnostic build: 100 MHz clock at the phase boundaries, parked behind the partial sums (tools/stamps_sq.py)
 #define SQ_STAMP(i) do { sq_stamps[i] = wall_clock64(); } while (0)
 #else
 #define SQ_STAMP(i) do { } while (0)
 #endif
 
-template <int PE>
+template <int PE, int SLOTS>
 __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
+    static_assert(SLOTS == 8 || SLOTS == 16, "8 or 16 slots per wavefront");
+    if (SLOTS < SQ_SLOTS && (int)threadIdx.x >= 4 * SLOTS) return;        // half-full wavefront: wave-level hand-offs only below
 #ifdef CCAL_STAMPS
     long long sq_stamps[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
@@ -67,10 +86,13 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (a.st && a.st->done) return;
     const int g_set = a.st ? schur_set(a.st) : 0;
-    const double* p_G = a.Gs[g_set];
+    // (an explicit global-address-space pointer: picked out of the argument block's array the compiler cannot prove where it
+    // points and emits flat_load, which also counts against the LDS counter)
+    typedef const __attribute__((address_space(1))) double* gptr_t;
+    const gptr_t p_G = (gptr_t)a.Gs[g_set];
     const double lambda = a.st ? schur_lambda(a.st) : a.lambda;
     const int lane = threadIdx.x, sl = lane >> 2, q = lane & 3;
-    const int s = blockIdx.x * SQ_SLOTS + sl;
+    const int s = blockIdx.x * SLOTS + sl;
     const bool has = s < a.n_slots;
     double* sb = smem + sl * Lt::SS;
     double* dum = sb + Lt::DUM + q;
@@ -88,18 +110,21 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     {
         constexpr int NH = HS / 2;                                      // 16-byte pieces of a head
         constexpr int TH = (NH + 3) / 4;
-        const double* r0 = p_G + d0;
-        const double* r1 = p_G + d1;
-        const double2* g0 = reinterpret_cast<const double2*>(r0);
-        const double2* g1 = reinterpret_cast<const double2*>(r1);
-        const double2 z2 = { 0.0, 0.0 };
+        const gptr_t r0 = p_G + d0;
+        const gptr_t r1 = p_G + d1;
+        typedef double dv2 __attribute__((ext_vector_type(2)));                       // (a plain vector: HIP's double2 class has no copy from address space 1)
+        typedef const __attribute__((address_space(1))) dv2* gptr2_t;
+        const gptr2_t g0 = (gptr2_t)r0;
+        const gptr2_t g1 = (gptr2_t)r1;
         double2* w = reinterpret_cast<double2*>(sb);
         {
             double2 h0[TH], e0[5];
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h0[t] = (has && c < NH) ? g0[c] : z2; }
+            // (always a load from a valid address, then a select of the VALUE, component by component: `cond ? g0[c] : z2` is
+            // compiled as a select of POINTERS into two address spaces - flat_load plus a scratch slot for the zero)
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; const dv2 v = g0[c < NH ? c : NH - 1]; const bool in = has && c < NH; h0[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; e0[t] = (has && c < 18) ? g0[gen_e_off(PE) / 2 + c] : z2; }
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; const dv2 v = g0[gen_e_off(PE) / 2 + (c < 18 ? c : 17)]; const bool in = has && c < 18; e0[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
             for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H0 / 2 + c] = h0[t]; }
 #pragma unroll
@@ -108,9 +133,9 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         {
             double2 h1[TH], e1[5];
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; h1[t] = (has && c < NH) ? g1[c] : z2; }
+            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; const dv2 v = g1[c < NH ? c : NH - 1]; const bool in = has && c < NH; h1[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; e1[t] = (has && c < 18) ? g1[gen_e_off(PE) / 2 + c] : z2; }
+            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; const dv2 v = g1[gen_e_off(PE) / 2 + (c < 18 ? c : 17)]; const bool in = has && c < 18; e1[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
             for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H1 / 2 + c] = h1[t]; }
 #pragma unroll
@@ -433,13 +458,13 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     // ---- the wavefront's 16 images in a fixed order -> one row of partial sums (k_reduce's layout: the full (K+1)^2 image,
     // lower triangle filled, then the extras)
     // (rows of the upper triangle are never written: the buffer is cleared once when the workspace is made)
-    for (int e = lane; e < ACCN; e += 64) {
+    for (int e = lane; e < ACCN; e += 4 * SLOTS) {
         int dst;
         if (e < NT) { int i, j; sq_tri_decode(e, i, j); dst = i * K1 + j; }
         else dst = K1 * K1 + (e - NT);
         double t = 0.0;
 #pragma unroll
-        for (int g = 0; g < SQ_SLOTS; g += 4)
+        for (int g = 0; g < SLOTS; g += 4)
             t += (smem[g * Lt::SS + Lt::IMG + e] + smem[(g + 1) * Lt::SS + Lt::IMG + e]) + (smem[(g + 2) * Lt::SS + Lt::IMG + e] + smem[(g + 3) * Lt::SS + Lt::IMG + e]);
         a.partial[(int64_t)dst * gridDim.x + blockIdx.x] = t;
     }
@@ -457,15 +482,24 @@ bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* c
     if (n_cams != 2 || peff[0] != peff[1] || peff[0] < 4 || peff[0] > 6) return false;
     return col_theta[0] == 0 && col_theta[1] == peff[0] && col_extr[1] == 2 * peff[0];
 }
-int schurq_rows(int n_slots) { return (std::max(n_slots, 1) + SQ_SLOTS - 1) / SQ_SLOTS; }
+// slots per wavefront: 8 by default (see SQ_SLOTS); CCAL_SCHURQ_SLOTS=16 for full wavefronts
+static int schurq_slots() {
+    static const int v = [] { const char* e = std::getenv("CCAL_SCHURQ_SLOTS"); const int n = e ? std::atoi(e) : 0; return (n == 8 || n == 16) ? n : CCAL_SCHURQ_DEFAULT_SLOTS; }();
+    return v;
+}
+int schurq_rows(int n_slots) { const int sp = schurq_slots(); return (std::max(n_slots, 1) + sp - 1) / sp; }
 
+template <int PE, int SLOTS>
+static hipError_t launch_schurq_s(const SchurArgs& a, int rows, hipStream_t s) {
+    const size_t lds = sizeof(double) * (size_t)SLOTS * SqLayout<PE>::SS;
+    static DynLdsGuard guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schurq<PE, SLOTS>), lds, guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_schurq<PE, SLOTS>), dim3(rows), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
 template <int PE>
 static hipError_t launch_schurq_t(const SchurArgs& a, int rows, hipStream_t s) {
-    const size_t lds = sizeof(double) * (size_t)SQ_SLOTS * SqLayout<PE>::SS;
-    static DynLdsGuard guard;
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schurq<PE>), lds, guard); e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_schurq<PE>, dim3(rows), dim3(64), lds, s, a);
-    return hipGetLastError();
+    return schurq_slots() == 8 ? launch_schurq_s<PE, 8>(a, rows, s) : launch_schurq_s<PE, 16>(a, rows, s);
 }
 
 hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, hipStream_t s) {

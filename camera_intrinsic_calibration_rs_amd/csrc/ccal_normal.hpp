@@ -86,8 +86,9 @@ struct FusedWs {
     bool state_is_eval = false; double state_eval_lambda = 0.0;     // d_state already says "first evaluation of set 0" with this damping
     bool fuse_elim = true;                     // the Gram kernels eliminate their frames' pose blocks in their tail (CCAL_FUSE_ELIM=0: separate launch)
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
-    double* h_stage = nullptr;                 // pinned staging [intr | state | cols | poses]
-    double* d_stage = nullptr;                 // its device image (one copy per solve, k_unpack1 distributes it)
+    double* h_stage = nullptr;                 // pinned staging of the caller's poses (read by k_unpack1 in place when small)
+    double* d_stage = nullptr;                 // their device image (large problems: one copy per solve, k_unpack1 distributes it)
+    double* h_result = nullptr;                // pinned, host-coherent: [intr | poses] written by the k_head that finishes a session-sized solve
     hipStream_t side = nullptr;                // result download: does not queue behind the early-exit groups
     bool tail_pending = false;                 // early-exit groups of the previous solve may still be in flight
 };

@@ -68,6 +68,7 @@ void normal_ws_destroy(ccal_problem* p) {
         for (void* q : fp) if (q) (void)hipFree(q);
         if (f->h_status) (void)hipHostFree(f->h_status);
         if (f->h_stage) (void)hipHostFree(f->h_stage);
+        if (f->h_result) (void)hipHostFree(f->h_result);
         if (f->d_stage) (void)hipFree(f->d_stage);
         if (f->side) (void)hipStreamDestroy(f->side);
         delete f;
@@ -86,6 +87,12 @@ int drain_pending_groups(ccal_problem* p) {
     if (w->fws) w->fws->tail_pending = false;
     return CCAL_OK;
 }
+
+// Session-sized solves (poses up to this many bytes: 2 048 frames) move their parameters without a copy operation: k_unpack1
+// reads the caller's poses from pinned host memory, the k_head that finishes the solve writes the result there.  Larger
+// problems stage through device copies (a kernel reading / writing half a megabyte across the bus one wavefront wide would
+// cost more than the DMA it saves).
+constexpr size_t kZeroCopyBytes = 96 * 1024;
 
 static int fused_ws_ensure(ccal_problem* p) {
     NormalWs* w = p->nws;
@@ -116,9 +123,11 @@ static int fused_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMemset(f->red, 0, (size_t)(f->RB1 + 7) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->d_state, sizeof(DevState)));
     HIP_TRY(ctx, hipHostMalloc((void**)&f->h_status, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
-    const size_t stage_bytes = ns * 6 * sizeof(double) + CCAL_PMAX * sizeof(double) + sizeof(DevState) + CCAL_KMAX * sizeof(ColInfo) + 64;
+    const size_t stage_bytes = std::max((ns * 6 + CCAL_PMAX) * sizeof(double) + 64, (size_t)(f->RB1 + 8) * sizeof(double));      // (ccal_build_normal stages the reduced sums here)
     HIP_TRY(ctx, hipHostMalloc((void**)&f->h_stage, stage_bytes, hipHostMallocDefault));
     HIP_TRY(ctx, hipMalloc((void**)&f->d_stage, stage_bytes));
+    if (ns * 6 * sizeof(double) <= kZeroCopyBytes)
+        HIP_TRY(ctx, hipHostMalloc((void**)&f->h_result, (ns * 6 + CCAL_PMAX) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
     HIP_TRY(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
     std::memset((void*)f->h_status, 0, sizeof(HostStatus));
     return CCAL_OK;
@@ -530,8 +539,9 @@ struct SolveJob {
 struct FusedJob : SolveJob {
     FusedWs* f = nullptr;
     FusedArgs fa; HeadArgs ha; bool schur_m = false, sharded = false;
-    double* h_intr = nullptr; double* h_poses = nullptr;
+    double* h_poses = nullptr;
     size_t np6 = 0;
+    bool zero_copy = false;           // session-sized ccal_solve: poses read from / result written to pinned host memory by the kernels
     using SolveJob::SolveJob;
     HostStatus* status() override { return f->h_status; }
     const DevState* dev_state() override { return f->d_state; }
@@ -547,21 +557,30 @@ struct FusedJob : SolveJob {
         static_assert(sizeof(ColInfo) % 8 == 0, "ColInfo is staged as doubles");
         if (f->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); f->tail_pending = false; }   // stale k_head must not publish into this solve
         np6 = (size_t)p->n_slots * 6;
-        const size_t small_doubles = CCAL_PMAX + sizeof(DevState) / sizeof(double) + CCAL_KMAX * sizeof(ColInfo) / sizeof(double);
-        h_intr = f->h_stage;
-        DevState* h_state = reinterpret_cast<DevState*>(h_intr + CCAL_PMAX);
-        ColInfo* h_cols = reinterpret_cast<ColInfo*>(h_state + 1);
-        h_poses = f->h_stage + small_doubles;
-        if (host_io) {
-            std::memcpy(h_poses, poses_io, np6 * sizeof(double));
-            std::memcpy(h_intr, intr_io, CCAL_PMAX * sizeof(double));
-        }
-        init_state(h_state, o);
-        build_cols(p, h_cols);
-        HIP_TRY(ctx, hipMemcpyAsync(f->d_stage, f->h_stage, (small_doubles + (host_io ? np6 : 0)) * sizeof(double), hipMemcpyHostToDevice, st));
+        h_poses = f->h_stage;
+        zero_copy = host_io && f->h_result != nullptr;
         {
-            UnpackArgs ua = { f->d_stage, (int64_t)small_doubles, (int64_t)np6, host_io ? 0 : 1, p->d_intr, p->d_intr_c, p->d_poses, p->d_poses_c,
-                              f->d_state, w->cols };
+            // state, column table and intrinsics travel in k_unpack1's argument block; the poses are read in place from
+            // pinned host memory (session sizes) or staged with one copy (large problems)
+            UnpackArgs ua = {};
+            init_state(&ua.st0, o);
+            if (K > kFusedMaxK) { ctx->err = "single-camera loop: more than 9 camera columns"; return CCAL_ERR_INVALID_ARG; }
+            ColInfo cols_all[CCAL_KMAX];
+            build_cols(p, cols_all);
+            for (int i = 0; i < K; ++i) ua.col0[i] = cols_all[i];
+            ua.n_cols = K;
+            ua.np6 = (int64_t)np6; ua.poses_on_device = host_io ? 0 : 1;
+            ua.intr0 = p->d_intr; ua.intr1 = p->d_intr_c; ua.poses0 = p->d_poses; ua.poses1 = p->d_poses_c;
+            ua.st = f->d_state; ua.cols = w->cols;
+            if (host_io) {
+                std::memcpy(ua.intr_h, intr_io, CCAL_PMAX * sizeof(double));
+                std::memcpy(h_poses, poses_io, np6 * sizeof(double));
+                if (zero_copy || np6 == 0) ua.poses_src = h_poses;
+                else {
+                    HIP_TRY(ctx, hipMemcpyAsync(f->d_stage, h_poses, np6 * sizeof(double), hipMemcpyHostToDevice, st));
+                    ua.poses_src = f->d_stage;
+                }
+            }
             f->state_is_eval = false;
             HIP_TRY(ctx, launch_unpack1(ua, st));
         }
@@ -574,6 +593,8 @@ struct FusedJob : SolveJob {
         ha.intr[0] = p->d_intr; ha.intr[1] = p->d_intr_c; ha.dc = w->dc; ha.K = K;
         ha.min_diag = o->lm_min_diagonal; ha.max_diag = o->lm_max_diagonal;
         ha.publish_all = o->verbose ? 1 : 0;
+        ha.result_host = zero_copy ? f->h_result : nullptr;
+        ha.poses[0] = p->d_poses; ha.poses[1] = p->d_poses_c; ha.np6 = (int64_t)np6;
         sharded = p->sharded();
         max_groups = max_groups_for(o);
         depth = groups_in_flight(p, "CCAL_FUSED_DEPTH");
@@ -618,11 +639,19 @@ struct FusedJob : SolveJob {
         R.lm_spec_hits = ds.hits; R.lm_spec_misses = ds.misses;
         R.initial_cost = ds.initial_cost; R.final_cost = ds.cur_cost;
         if (host_io) {
-            if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));
-            HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, dl));
-            HIP_TRY(ctx, hipStreamSynchronize(dl));
-            std::memcpy(poses_io, h_poses, np6 * sizeof(double));
-            std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
+            if (zero_copy && ds.done) {
+                // the k_head that set `done` wrote the result into pinned memory before it published the word this thread
+                // has just read: nothing to copy, nothing to wait for
+                std::memcpy(intr_io, const_cast<const double*>(f->h_result), CCAL_PMAX * sizeof(double));
+                std::memcpy(poses_io, const_cast<const double*>(f->h_result) + CCAL_PMAX, np6 * sizeof(double));
+            } else {
+                double* h_intr = h_poses + np6;
+                if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));
+                HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, dl));
+                HIP_TRY(ctx, hipStreamSynchronize(dl));
+                std::memcpy(poses_io, h_poses, np6 * sizeof(double));
+                std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
+            }
             if (p->one_focal) intr_io[1] = intr_io[0];           // fy = f (src/util.rs:467-470)
         }
         R.solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
