@@ -205,6 +205,10 @@ struct FusedArgs {
     // GEN, all cameras of a rig in ONE launch (same model and focal mode): the camera of every observation frame; `list` then
     // holds every camera's frames, `intr` / `extr` point at camera 0.  NULL: one camera per launch (`cam`)
     const int32_t* obs_cam;
+    // single-camera loop, experiment of round 4 (CCAL_PREPASS=1, off by default - it loses): a per-frame
+    // launch in front of the Gram kernel does the pose update and the exponential map and leaves the frame constants in
+    // fcbuf [n_obs][FC_N0P]; the Gram kernel's prologue is then one coalesced read per frame
+    int32_t prepass;
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:

@@ -258,7 +258,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
         const int64_t g0 = start + (cl < n ? cl : 0);
         pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
     }
-    {
+    if (!GEN && a.prepass) {
+        // k_prepass has updated the pose, written the pose block's model decrease and left R, t, J_l of this frame in fcbuf
+        if (lane_ok) for (int e = gl; e < FC_N0; e += LPF) fc[e] = a.fcbuf[(int64_t)fa_ * FC_N0P + e];
+    } else {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants; the lanes of
         // a group compute the same values, the G groups work on G frames at once
         const int slot = a.obs_slot[fa_];
@@ -609,6 +612,60 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
     G2_STAMPS_FLUSH;
 }
 
+// The per-frame pre-pass (experiment, FusedArgs::prepass): what k_gram2's prologue does per LANE GROUP, once per frame by one
+// thread - candidate pose from the stored elimination record and the camera step, its model decrease, exponential map and
+// left Jacobian - into fcbuf.
+__global__ __launch_bounds__(256) void k_prepass(const FusedArgs a) {
+    const DevState* st = a.st;
+    if (st->done || st->redo) return;
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= a.n_obs) return;
+    const int K = a.K, K1 = K + 1;
+    const int cur = st->cur, first = st->first;
+    const int es = first ? cur : (cur ^ 1);
+    const int slot = a.obs_slot[f];
+    double pose[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
+    double mc = 0.0;
+    if (!first) {
+        const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+        if (pf[0] != 0.0) {
+            double dp[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double* yr = pf + 21 + i * K1;
+                double t = yr[K];
+                for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                dp[i] = -t;
+            }
+#pragma unroll
+            for (int i = 5; i >= 0; --i) {
+                double t = dp[i];
+#pragma unroll
+                for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+                dp[i] = t * pf[i * (i + 1) / 2 + i];
+            }
+            const double lam = st->lambda_solve;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
+                const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
+                mc += dp[i] * (Dii * dp[i] - gp);
+                pose[i] += dp[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+    }
+    a.mc_f[f] = mc;
+    double fcr[FC_N0];
+    frame_setup<false>(pose, nullptr, fcr);
+    double* dst = a.fcbuf + (int64_t)f * FC_N0P;
+#pragma unroll
+    for (int i = 0; i < FC_N0; ++i) dst[i] = fcr[i];
+}
+
 #ifdef CCAL_G2_PROBE      // register-allocation probes (developer): a few instantiations, no launchers
 template __global__ void k_gram2<kEUCM, false, 12, false, false>(const FusedArgs);
 template __global__ void k_gram2<kKB4, false, 12, false, CCAL_G2_QUAD(kKB4)>(const FusedArgs);
@@ -633,6 +690,7 @@ static hipError_t launch_gram2_l(const FusedArgs& a, hipStream_t s) {
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
     const int fpb = G * CCAL_GRAMV_WPB;
     if (a.n_obs <= 0) return hipSuccess;
+    if (!GEN && a.prepass) hipLaunchKernelGGL(k_prepass, dim3((a.n_obs + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }

@@ -44,10 +44,11 @@ template <int PE> struct SqLayout {
     static constexpr int H0 = 0, E0 = HS, H1 = HS + 36, E1 = 2 * HS + 36;   // staging of the two records (E as stored: [M | N | J1 | SJ], ccal_fused.hpp)
     static constexpr int STG = 2 * HS + 72;
     static constexpr int IMG = 0;                                        // the slot's image of the reduced system: over the (dead) staging
-    static constexpr int YL = ((STG > ACCN ? STG : ACCN) + 1) & ~1;       // [B|g] of the slot, then Y: K1 columns of 6
+    static constexpr int ISH = 4;                                        // a slot's image starts 0 or ISH doubles into its area (sq_img_shift)
+    static constexpr int YL = ((STG > ACCN + ISH ? STG : ACCN + ISH) + 1) & ~1;       // [B|g] of the slot, then Y: K1 columns of 6
     static constexpr int CX = YL + 6 * K1;                               // C of the slot (6 x 6)
-    static constexpr int DUM = CX + 36;                                  // one double per lane for sums nobody wants
-    static constexpr int SS0 = DUM + 4;
+    static constexpr int DUM = (CX + 36 + 15) & ~15;                     // where stores nobody wants go: see dump() in the kernel
+    static constexpr int SS0 = DUM + 16 + 4 + ISH;
     // Slot stride = 8 (mod 16) doubles.  What decides: the 16-byte stores and loads whose four lanes of a slot touch consecutive
     // (staging, zeroing) or 48-byte-strided (rows of [B|g]^T, columns of Y) pieces - ds_write_b128 works in groups of 8 lanes = 2
     // slots over 32 banks, ds_read_b128 in groups of 4 slots over 64: with the stride = 2 (mod 4) of round 3 the second slot of
@@ -64,6 +65,12 @@ template <int PE> struct SqLayout {
 #ifndef CCAL_SCHURQ_DEFAULT_SLOTS
 #define CCAL_SCHURQ_DEFAULT_SLOTS 16
 #endif
+// Where a slot's image of the reduced system starts inside its area.  Every access of the image by the four lanes of a slot
+// is ROW-FIXED, COLUMN-CONSECUTIVE (the lanes own columns j = q + 4 t): four consecutive doubles per slot.  With the slot
+// stride = 8 (mod 16) the slots of an 8-byte store group (4 slots, 32 banks) sit at 0, 8, 0, 8 and those of a load group (8
+// slots, 64 banks) at 0, 8, 16, 24, 0, 8, 16, 24 doubles: this shift makes them 0, 8, 4, 12 and 0, 8, 20, 28, 4, 12, 16, 24 -
+// the groups tile the banks whatever the (common) offset inside the image.
+__host__ __device__ constexpr int sq_img_shift(int sl) { return 4 * (((sl >> 1) ^ (sl >> 2)) & 1); }
 #ifdef CCAL_STAMPS      // diagnostic build: 100 MHz clock at the phase boundaries, parked behind the partial sums (tools/stamps_sq.py)
 #define SQ_STAMP(i) do { sq_stamps[i] = wall_clock64(); } while (0)
 #else
@@ -95,7 +102,12 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     const int s = blockIdx.x * SLOTS + sl;
     const bool has = s < a.n_slots;
     double* sb = smem + sl * Lt::SS;
-    double* dum = sb + Lt::DUM + q;
+    // Stores of the lanes that have no entry in the row at hand (right of the diagonal) go to a dump - branch-free - and the
+    // dump address continues the valid lanes' pattern: "address = X + q (mod 16 doubles)" for all four lanes of the slot, so the
+    // store group tiles the banks whether a lane's value is wanted or not (a fixed dump address per lane collided with the valid
+    // lanes of other slots: the rest of the bank conflicts in the model, tools/lds_bank_model.py)
+    double* dq = sb + Lt::DUM + sq_img_shift(sl) + q;
+    auto dump = [&](const int X) { return dq + (X & 15); };
 
     // ---- the two records of the slot -> LDS (16 bytes per lane and load).  They sit side by side at (2 s + camera) x record size
     // (normal_ws_ensure): requested at once, no look-up first; a missing record is a hole of zeros.  The table only says
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     const bool live = p0 >= 0 || p1 >= 0;
     const double mc_s = (has && q == 0) ? a.mc_slot[s] : 0.0;          // model decrease of this slot's pose block for the step under decision
     // the camera | r blocks of the records (direct terms of the reduced system, wanted only once the products are done): this
-    // lane's rows i = q + 4 t of the lower triangles, held in registers from the staging on
+    // lane's COLUMNS j = q + 4 t of the lower triangles (rows i >= j), held in registers from the staging on
     double av[2][TR][K1c];
     {
         constexpr int NH = HS / 2;                                      // 16-byte pieces of a head
@@ -145,13 +157,13 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         // of the staging: 11.4 us against 8.4; as 8-byte loads straight into registers they arrive while the products run)
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            const int i = q + 4 * t;
+            const int j = q + 4 * t;
 #pragma unroll
-            for (int j = 0; j < K1c; ++j) {
-                if (j > 4 * t + 3) { av[0][t][j] = 0.0; av[1][t][j] = 0.0; continue; }      // compile time: j <= i impossible
-                const bool in = i < K1c && j <= i;
-                av[0][t][j] = (in && has) ? r0[HS + i * (i + 1) / 2 + j] : 0.0;      // packed lower triangle
-                av[1][t][j] = (in && has) ? r1[HS + i * (i + 1) / 2 + j] : 0.0;
+            for (int i = 0; i < K1c; ++i) {
+                if (i < 4 * t) { av[0][t][i] = 0.0; av[1][t][i] = 0.0; continue; }          // compile time: j <= i impossible
+                const bool in = j < K1c && j <= i;
+                av[0][t][i] = (in && has) ? r0[HS + i * (i + 1) / 2 + j] : 0.0;      // packed lower triangle, entry (i, j)
+                av[1][t][i] = (in && has) ? r1[HS + i * (i + 1) / 2 + j] : 0.0;
             }
         }
     }
@@ -316,7 +328,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     const bool go = live && ok;
     SQ_STAMP(3);
     double* pf = a.pf + (int64_t)(has ? s : 0) * a.PF;
-    double* img = sb + Lt::IMG;
+    double* img = sb + Lt::IMG + sq_img_shift(sl);
     // ---- the slot's image of the reduced system (over the staging, dead now): zero, then the direct terms
     {
         double2* w = reinterpret_cast<double2*>(img);
@@ -329,28 +341,32 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         if (live && !ok) img[Lt::XF] = 1.0;                  // failed pose block (all-reduced with the sums: every rank sees it)
     }
     // Direct terms: every entry has ONE writer (plain stores over the zeros), except (r, r) = cost, where the two records'
-    // entries meet in the same lane.  camera | r blocks of the records (rows i = q + 4 t): + hdiag, g_c, cost
+    // entries meet in the same lane.  camera | r blocks of the records, row by row (the row is compile time, the lanes hold its
+    // columns j = q + 4 t: consecutive addresses): + hdiag, g_c, cost
 #pragma unroll
-    for (int t = 0; t < TR; ++t) {
-        const int i = q + 4 * t;
+    for (int c = 0; c < 2; ++c) {
+        const int ct = c == 0 ? CT0 : CT1;
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int ct = c == 0 ? CT0 : CT1;
-            const int ii = i < PE ? ct + i : K, rowb = ii * (ii + 1) / 2;
+        for (int i = 0; i < K1c; ++i) {
+            const int ii = i < PE ? ct + i : K;              // the image's row (compile time)
 #pragma unroll
-            for (int j = 0; j < PE; ++j) {
-                if (j > 4 * t + 3) continue;                 // compile time: j <= i impossible
-                const double v = av[c][t][j];
-                const bool in = i < K1c && j <= i;
-                *(in ? img + rowb + ct + j : dum) = v;
-                *((in && i == PE) ? img + Lt::XG + ct + j : ((in && i == j) ? img + Lt::XH + ii : dum)) = v;
+            for (int t = 0; t < TR; ++t) {
+                if (4 * t > i) continue;                     // compile time: j <= i impossible
+                const int j = q + 4 * t;
+                const double v = av[c][t][i];
+                const bool in = j <= i && j < PE;            // (j == PE: the residual column - only (r, r), below)
+                *(in ? img + sq_tri(ii, 0) + ct + j : dump(sq_tri(ii, 0) + ct + 4 * t)) = v;
+                if (i < PE) { if (i / 4 == t) *((in && j == i) ? img + Lt::XH + ii : dump(Lt::XH + ii - (i & 3))) = v; }      // hdiag
+                else *(in ? img + Lt::XG + ct + j : dump(Lt::XG + ct + 4 * t)) = v;                                          // g_c
             }
         }
-        if (PE / 4 == t) {                                   // compile time: the row of r is among this t's rows
-            const double v = av[0][t][PE] + av[1][t][PE];
-            *(i == PE ? img + sq_tri(K, K) : dum) = v;
-            *(i == PE ? img + Lt::XC : dum) = v;
-        }
+    }
+    {
+        constexpr int t = PE / 4;                            // the lane whose column is the residual's: j == PE
+        const int j = q + 4 * t;
+        const double v = av[0][t][PE] + av[1][t][PE];
+        *(j == PE ? img + sq_tri(K, K) : dump(sq_tri(K, K) - (PE & 3))) = v;
+        *(j == PE ? img + Lt::XC : dump(Lt::XC - (PE & 3))) = v;
     }
     // camera 1: theta_1 (| r) x extrinsics, extrinsics x extrinsics
 #pragma unroll
@@ -360,8 +376,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int hi = i < PE ? CE + j : K, lo = i < PE ? col : CE + j;
-            *(i < K1c ? img + hi * (hi + 1) / 2 + lo : dum) = cross[t][j];
-            if (PE / 4 == t) *(i == PE ? img + Lt::XG + CE + j : dum) = cross[t][j];
+            *(i < K1c ? img + hi * (hi + 1) / 2 + lo : dump(sq_tri(CE + j, 0) + CT1 + 4 * t)) = cross[t][j];
+            if (PE / 4 == t) *(i == PE ? img + Lt::XG + CE + j : dump(Lt::XG + CE + j - (PE & 3))) = cross[t][j];
         }
     }
 #pragma unroll
@@ -371,8 +387,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         for (int jp = 0; jp < 6; ++jp) {
             if (jp < 4 * t) continue;                        // compile time: jp >= j impossible
             const bool in = j < 6 && jp >= j;
-            *(in ? img + sq_tri(CE + jp, 0) + CE + j : dum) = xx[t][jp];
-            if (jp <= 4 * t + 3) *((in && jp == j) ? img + Lt::XH + CE + j : dum) = xx[t][jp];
+            *(in ? img + sq_tri(CE + jp, 0) + CE + j : dump(sq_tri(CE + jp, 0) + CE + 4 * t)) = xx[t][jp];
+            if (jp <= 4 * t + 3) *((in && jp == j) ? img + Lt::XH + CE + j : dump(Lt::XH + CE + jp - (jp & 3))) = xx[t][jp];
         }
     }
     SQ_STAMP(4);
@@ -413,43 +429,42 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     }
     wsync();
     SQ_STAMP(5);
-    // ---- image -= Y^T Y: rows i = q + 4 t of the lower triangle, the columns j stream through (one read serves all of a lane's rows)
+    // ---- image -= Y^T Y: the lane owns COLUMNS j = q + 4 t (Y_j in registers), the rows i stream through (one broadcast read of Y_i
+    // serves the four lanes; the entries (i, j) they update are consecutive doubles of row i)
     {
-        double yi[TY][6];
-        int rowb[TY];
+        double yj[TY][6];
 #pragma unroll
         for (int t = 0; t < TY; ++t) {
-            const int i = q + 4 * t, ic = i < K1 ? i : 0;
-            const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * ic);
+            const int j = q + 4 * t, jc = j < K1 ? j : 0;
+            const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * jc);
             const double2 r0 = r[0], r1 = r[1], r2 = r[2];
-            yi[t][0] = r0.x; yi[t][1] = r0.y; yi[t][2] = r1.x; yi[t][3] = r1.y; yi[t][4] = r2.x; yi[t][5] = r2.y;
-            rowb[t] = i * (i + 1) / 2;
+            yj[t][0] = r0.x; yj[t][1] = r0.y; yj[t][2] = r1.x; yj[t][3] = r1.y; yj[t][4] = r2.x; yj[t][5] = r2.y;
         }
-        // software pipeline by hand: column j + 1 (Y_j and the direct terms under it) is read before column j is worked on -
-        // one writer per entry, plain read - modify - write (a ds_add_f64 per entry cost 32 cycles of the LDS pipe each)
+        // software pipeline by hand: row i + 1 (Y_i and the direct terms in it) is read before row i is worked on - one writer
+        // per entry, plain read - modify - write (a ds_add_f64 per entry cost 32 cycles of the LDS pipe each)
         double2 c0[2], c1[2], c2[2];
         double dv[2][TY];
-        auto fetch = [&](const int j, const int b) {
-            const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * j);
+        auto fetch = [&](const int i, const int b) {
+            const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * i);
             c0[b] = r[0]; c1[b] = r[1]; c2[b] = r[2];
 #pragma unroll
             for (int t = 0; t < TY; ++t) {
-                if (4 * t + 3 < j) continue;                 // compile time: every row of this t lies above column j
-                const int i = q + 4 * t;
-                dv[b][t] = *((i < K1 && j <= i) ? img + rowb[t] + j : dum);
+                if (4 * t > i) continue;                     // compile time: every column of this t lies right of the diagonal
+                const int j = q + 4 * t;
+                dv[b][t] = img[sq_tri(i, 0) + (j <= i ? j : i)];       // (right of the diagonal: the diagonal entry again - a broadcast, value unused)
             }
         };
         fetch(0, 0);
 #pragma unroll
-        for (int j = 0; j < K1; ++j) {
-            const int b = j & 1;
-            if (j + 1 < K1) fetch(j + 1, b ^ 1);
+        for (int i = 0; i < K1; ++i) {
+            const int b = i & 1;
+            if (i + 1 < K1) fetch(i + 1, b ^ 1);
 #pragma unroll
             for (int t = 0; t < TY; ++t) {
-                if (4 * t + 3 < j) continue;
-                const int i = q + 4 * t;
-                const double v = ((yi[t][0] * c0[b].x + yi[t][1] * c0[b].y) + (yi[t][2] * c1[b].x + yi[t][3] * c1[b].y)) + (yi[t][4] * c2[b].x + yi[t][5] * c2[b].y);
-                *((i < K1 && j <= i) ? img + rowb[t] + j : dum) = dv[b][t] - v;
+                if (4 * t > i) continue;
+                const int j = q + 4 * t;
+                const double v = ((yj[t][0] * c0[b].x + yj[t][1] * c0[b].y) + (yj[t][2] * c1[b].x + yj[t][3] * c1[b].y)) + (yj[t][4] * c2[b].x + yj[t][5] * c2[b].y);
+                *(j <= i ? img + sq_tri(i, 0) + j : dump(sq_tri(i, 0) + 4 * t)) = dv[b][t] - v;
             }
         }
     }
@@ -465,7 +480,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         double t = 0.0;
 #pragma unroll
         for (int g = 0; g < SLOTS; g += 4)
-            t += (smem[g * Lt::SS + Lt::IMG + e] + smem[(g + 1) * Lt::SS + Lt::IMG + e]) + (smem[(g + 2) * Lt::SS + Lt::IMG + e] + smem[(g + 3) * Lt::SS + Lt::IMG + e]);
+            t += (smem[g * Lt::SS + Lt::IMG + sq_img_shift(g) + e] + smem[(g + 1) * Lt::SS + Lt::IMG + sq_img_shift(g + 1) + e]) +
+                 (smem[(g + 2) * Lt::SS + Lt::IMG + sq_img_shift(g + 2) + e] + smem[(g + 3) * Lt::SS + Lt::IMG + sq_img_shift(g + 3) + e]);
         a.partial[(int64_t)dst * gridDim.x + blockIdx.x] = t;
     }
 #ifdef CCAL_STAMPS

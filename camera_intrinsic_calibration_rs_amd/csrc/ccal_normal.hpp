@@ -79,11 +79,12 @@ struct FusedWs {
     double* praw[2] = { nullptr, nullptr };
     double* partial = nullptr;
     double* red = nullptr;
-    double* fcbuf = nullptr;                   // [n_obs][40] frame constants of the evaluated point
+    double* fcbuf = nullptr;                   // -DCCAL_STAMPS builds only: in-kernel timestamps (NULL in the product build)
     double* mc_f = nullptr;                    // [n_obs] model decrease of each pose block
     double* cost_f = nullptr;                  // [n_obs] cost of each frame
     struct DevState* d_state = nullptr;
     bool state_is_eval = false; double state_eval_lambda = 0.0;     // d_state already says "first evaluation of set 0" with this damping
+    bool prepass = false;                      // CCAL_PREPASS=1: per-frame pre-pass launch in front of k_gram2 (experiment, off)
     bool fuse_elim = true;                     // the Gram kernels eliminate their frames' pose blocks in their tail (CCAL_FUSE_ELIM=0: separate launch)
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
     double* h_stage = nullptr;                 // pinned staging of the caller's poses (read by k_unpack1 in place when small)

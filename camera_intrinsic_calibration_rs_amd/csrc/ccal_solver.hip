@@ -114,7 +114,15 @@ static int fused_ws_ensure(ccal_problem* p) {
         HIP_TRY(ctx, hipMalloc((void**)&f->praw[i], no * f->PRAW * sizeof(double)));
         HIP_TRY(ctx, hipMemset(f->praw[i], 0, no * f->PRAW * sizeof(double)));
     }
-    HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, no * 40 * sizeof(double)));
+    // per-frame scratch: the frame constants of the pre-pass experiment (CCAL_PREPASS=1); diagnostic builds park in-kernel
+    // timestamps there (tools/stamps_*.py); the product path allocates nothing
+    { const char* e = std::getenv("CCAL_PREPASS"); f->prepass = e && e[0] == '1'; }
+#ifdef CCAL_STAMPS
+    const bool want_fcbuf = true;
+#else
+    const bool want_fcbuf = f->prepass;
+#endif
+    if (want_fcbuf) HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, std::max<size_t>(no * 40, 32768) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->mc_f, no * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->cost_f, no * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->partial, (size_t)f->RB1 * f->n_pw * sizeof(double)));
@@ -362,6 +370,7 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
     fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
+    fa.prepass = f->prepass ? 1 : 0;
     fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
     fa.part_cap = f->n_pw;
     return fa;

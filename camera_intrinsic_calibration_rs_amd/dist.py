@@ -1,7 +1,8 @@
-"""Frame-sharded multi-GPU solves: one process per GPU, frames sharded by slot range,
-ONE small all-reduce of the packed reduced camera system [A | hdiag | g_c | cost] per linear solve
-(plus a 2-double all-reduce of [cost(candidate), model-decrease]) over RCCL/xGMI.  Mode E needs no
-collective at all.
+"""Frame-sharded multi-GPU solves, one process per GPU: frames sharded by slot range, ONE small all-reduce of
+the packed sums of a step - [reduced camera system | cost | model decrease | failed blocks], 100 .. 400 doubles - per
+optimizer step, Gauss-Newton and Levenberg-Marquardt alike.  Mode E needs no collective at all.  The production transport is
+the library's own ncclAllReduce (Problem.set_rccl_comm); a single process reaches several GPUs through ccal_multi_*
+(engine.MultiContext / MultiProblem).  This module is the CALLBACK transport the tests drive with gloo:
 
 torch.distributed is plumbing only: the hook below wraps the library's device buffer as a tensor
 (zero copy) and calls all_reduce on the library's own HIP stream.

@@ -7,8 +7,8 @@ PE=6; K1c=PE+1; K=2*PE+6; K1=K+1; NT=K1*(K1+1)//2
 XH=NT; XG=NT+K; XC=NT+2*K; ACCN=XC+3
 HS=36+6*K1c; H0=0; E0=HS; H1=HS+36; E1=2*HS+36; STG=2*HS+72
 def layout(SS=None):
-    YL=((max(STG,ACCN))+1)&~1; CX=YL+6*K1; DUM=CX+36; SS0=DUM+4
-    ss=SS0+((2-SS0%4)+4)%4
+    YL=((max(STG,ACCN+4))+1)&~1; CX=YL+6*K1; DUM=(CX+36+15)&~15; SS0=DUM+16+4+4
+    ss=SS0+((8-SS0%16)+16)%16
     return dict(YL=YL,CX=CX,DUM=DUM,SS=SS if SS else ss)
 G128=[[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
 G128=G128+[[l+32 for l in g] for g in G128]
@@ -37,7 +37,7 @@ def cost(kind, addr_fn, active=lambda l: True):
         if any_active:
             cyc+=m; conf+=m-1
     return cyc, conf
-def evaluate(SS, verbose=False):
+def evaluate(SS, verbose=False, new=True):
     L=layout(SS); SS=L['SS']; YL=L['YL']; CX=L['CX']; DUM=L['DUM']
     tot=collections.Counter(); conf=collections.Counter()
     def add(name, kind, fn):
@@ -76,25 +76,40 @@ def evaluate(SS, verbose=False):
     # F zero image
     for t in range((ACCN//2+4)//4):
         add('F zero w128','w128', lambda l:(sl(l)*SS+2*(q(l)+4*t)) if q(l)+4*t<(ACCN+1)//2 else None)
-    # G direct terms (approx: av rows)
+    sh=(lambda s_: 4*(((s_>>1)^(s_>>2))&1)) if new else (lambda s_: 0)
     TR=(K1c+3)//4
-    for t in range(TR):
+    if new:
+        # lanes own columns j = q + 4 t; rows are compile time
         for c in range(2):
             ct=0 if c==0 else PE
-            for j in range(PE):
-                if j>4*t+3: continue
-                def f(l):
-                    i=q(l)+4*t
-                    ii=ct+i if i<PE else K
-                    return sl(l)*SS+(ii*(ii+1)//2+ct+j if (i<K1c and j<=i) else DUM+q(l))
-                add('G direct w64','w64', f)
+            for i in range(K1c):
+                ii=ct+i if i<PE else K
+                for t in range(TR):
+                    if 4*t>i: continue
+                    def f(l, ii=ii, ct=ct, i=i, t=t):
+                        j=q(l)+4*t
+                        X=ii*(ii+1)//2+ct+4*t
+                        return sl(l)*SS+sh(sl(l))+((ii*(ii+1)//2+ct+j) if (j<=i and j<PE) else DUM+(X&15)+q(l))
+                    add('G direct w64','w64', f)
+    else:
+        for t in range(TR):
+            for c in range(2):
+                ct=0 if c==0 else PE
+                for j in range(PE):
+                    if j>4*t+3: continue
+                    def f(l):
+                        i=q(l)+4*t
+                        ii=ct+i if i<PE else K
+                        return sl(l)*SS+(ii*(ii+1)//2+ct+j if (i<K1c and j<=i) else DUM+q(l))
+                    add('G direct w64','w64', f)
     for t in range(TR):
         for j in range(6):
             def f(l):
                 i=q(l)+4*t
                 col=PE+i if i<PE else K
                 hi=2*PE+j if i<PE else K; lo=col if i<PE else 2*PE+j
-                return sl(l)*SS+(hi*(hi+1)//2+lo if i<K1c else DUM+q(l))
+                X=(2*PE+j)*(2*PE+j+1)//2+PE+4*t
+                return sl(l)*SS+sh(sl(l))+(hi*(hi+1)//2+lo if i<K1c else DUM+(X&15)+q(l))
             add('G cross w64','w64', f)
     # H Y phase
     TY=(K1+3)//4
@@ -110,23 +125,34 @@ def evaluate(SS, verbose=False):
         for k in range(3):
             add('I col r128 bcast','r128', lambda l: sl(l)*SS+YL+6*j+2*k)
         for t in range(TY):
-            if 4*t+3<j: continue
-            def f(l):
-                i=q(l)+4*t
-                return sl(l)*SS+((i*(i+1)//2+j) if (i<K1 and j<=i) else DUM+q(l))
-            add('I dv r64','r64', f)
+            if new:
+                i=j                       # streamed row
+                if 4*t>i: continue
+                def f(l, i=i, t=t):
+                    jj=q(l)+4*t
+                    return sl(l)*SS+sh(sl(l))+((i*(i+1)//2+jj) if jj<=i else DUM+((i*(i+1)//2+4*t)&15)+q(l))
+                def fr(l, i=i, t=t):
+                    jj=q(l)+4*t
+                    return sl(l)*SS+sh(sl(l))+i*(i+1)//2+min(jj,i)
+            else:
+                if 4*t+3<j: continue
+                def f(l):
+                    i=q(l)+4*t
+                    return sl(l)*SS+((i*(i+1)//2+j) if (i<K1 and j<=i) else DUM+q(l))
+            add('I dv r64','r64', fr if new else f)
             add('I dv w64','w64', f)
     # J final
     for e0 in range(0,ACCN,64):
         for g in range(16):
-            add('J final r64','r64', lambda l:(g*SS+e0+l) if e0+l<ACCN else None)
+            add('J final r64','r64', lambda l, g=g:(g*SS+sh(g)+e0+l) if e0+l<ACCN else None)
     T=sum(tot.values()); C=sum(conf.values())
     if verbose:
         for k in tot: print(f"{k:22s} cycles {tot[k]:5d} conflicts {conf[k]:5d}")
         print("SS",SS,"total",T,"conflict",C, "frac %.3f"%(C/T))
     return T,C
 if __name__=='__main__':
-    evaluate(None, True)
+    print("round-3 form (rows owned, stride 386):"); evaluate(386, True, new=False)
+    print("round-4 form (columns owned, stride 8 mod 16, shifted images):"); evaluate(None, True)
     best=[]
     L=layout()
     for ss in range(L['SS']-2, L['SS']+40):
