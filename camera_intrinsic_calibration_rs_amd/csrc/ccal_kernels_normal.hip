@@ -620,7 +620,7 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
     int tab_entries = 0;
     if (!w->register_gram) for (int c = 0; c < p->n_cams; ++c) tab_entries += (p->cams[c].D + 1) * (p->cams[c].D + 1);
     const size_t lds = sizeof(double) * ((size_t)WS * WAVES_PER_BLOCK + tab_entries);
-    if (w->schurq) return launch_schurq(a, p->cams[0].Peff, w->n_rows, s);
+    if (w->schurq) return launch_schurq(a, p->cams[0].Peff, w->n_rows, w->schurq_slots, s);
     if (w->schur_wpb == 1) {           // 64 .. 127 columns: one wavefront per workgroup (record format only: normal_ws_ensure)
         const size_t lds1 = sizeof(double) * (size_t)WS;
         static DynLdsGuard lds_guard_big;

@@ -21,11 +21,11 @@
 
 namespace ccal {
 
-constexpr int SQ_SLOTS = 16;       // frame slots per full wavefront (four lanes each)
-// Slots per wavefront actually used: 16 (all 64 lanes) or 8 (lanes 32-63 leave at once).  625 wavefronts of 16 slots do not
-// even give every SIMD of the chip one wavefront, and each is a ~19 us chain (records in, then straight-line arithmetic): with
-// 8 slots a wavefront brings in half the bytes and twice as many wavefronts (1 250: all resident) overlap their phases.
-// CCAL_SCHURQ_SLOTS=8|16 overrides the launcher's choice.
+// Slots per wavefront: 16 with FOUR lanes each or 8 with EIGHT lanes each (LQ = 64 / SLOTS lanes share a slot's work by
+// "index = q (mod LQ)").  The kernel is a latency chain - one wavefront per SIMD (340 registers), ~3 300 straight-line
+// instructions at ~11 cycles each, measured: halving the LDS bank conflicts (43 % -> 11 % of the LDS cycles) did not move its
+// 20 us, and half-empty wavefronts of 8 four-lane slots take the same 17 us each (and two rounds: 31 us).  Eight lanes per
+// slot shorten the chain itself: every lane carries half the rows / columns.  CCAL_SCHURQ_SLOTS=8|16 picks the form.
 
 // entry e of a row-major lower triangle -> (i, j)
 __device__ __forceinline__ void sq_tri_decode(int e, int& i, int& j) {
@@ -37,7 +37,7 @@ __device__ __forceinline__ void sq_tri_decode(int e, int& i, int& j) {
 __host__ __device__ constexpr int sq_tri(int i, int j) { return i * (i + 1) / 2 + j; }
 
 // per-slot LDS area (doubles)
-template <int PE> struct SqLayout {
+template <int PE, int LQ> struct SqLayout {
     static constexpr int K1c = PE + 1, K = 2 * PE + 6, K1 = K + 1, NT = K1 * (K1 + 1) / 2;
     static constexpr int XH = NT, XG = NT + K, XC = NT + 2 * K, XM = XC + 1, XF = XC + 2, ACCN = XC + 3;
     static constexpr int HS = 36 + 6 * K1c;                              // record head: C | [B|g]^T
@@ -48,7 +48,7 @@ template <int PE> struct SqLayout {
     static constexpr int YL = ((STG > ACCN + ISH ? STG : ACCN + ISH) + 1) & ~1;       // [B|g] of the slot, then Y: K1 columns of 6
     static constexpr int CX = YL + 6 * K1;                               // C of the slot (6 x 6)
     static constexpr int DUM = (CX + 36 + 15) & ~15;                     // where stores nobody wants go: see dump() in the kernel
-    static constexpr int SS0 = DUM + 16 + 4 + ISH;
+    static constexpr int SS0 = DUM + 16 + LQ + ISH;
     // Slot stride = 8 (mod 16) doubles.  What decides: the 16-byte stores and loads whose four lanes of a slot touch consecutive
     // (staging, zeroing) or 48-byte-strided (rows of [B|g]^T, columns of Y) pieces - ds_write_b128 works in groups of 8 lanes = 2
     // slots over 32 banks, ds_read_b128 in groups of 4 slots over 64: with the stride = 2 (mod 4) of round 3 the second slot of
@@ -77,19 +77,21 @@ __host__ __device__ constexpr int sq_img_shift(int sl) { return 4 * (((sl >> 1) 
 #define SQ_STAMP(i) do { } while (0)
 #endif
 
+// (eight lanes per slot: 1 250 wavefronts at 10 000 slots - two per SIMD, i.e. at most 256 registers, or half of them wait for a
+// second round)
 template <int PE, int SLOTS>
-__global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
+__global__ __launch_bounds__(64, SLOTS == 8 ? 2 : 1) void k_schurq(const SchurArgs a) {
     static_assert(SLOTS == 8 || SLOTS == 16, "8 or 16 slots per wavefront");
-    if (SLOTS < SQ_SLOTS && (int)threadIdx.x >= 4 * SLOTS) return;        // half-full wavefront: wave-level hand-offs only below
+    constexpr int LQ = 64 / SLOTS;                          // lanes per slot
 #ifdef CCAL_STAMPS
     long long sq_stamps[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     SQ_STAMP(0);
-    using Lt = SqLayout<PE>;
+    using Lt = SqLayout<PE, LQ>;
     constexpr int K1c = Lt::K1c, K = Lt::K, K1 = Lt::K1, NT = Lt::NT, HS = Lt::HS, ACCN = Lt::ACCN;
     constexpr int CT0 = 0, CT1 = PE, CE = 2 * PE;
-    constexpr int TR = (K1c + 3) / 4;                       // rows of a record's [B|g]^T per lane
-    constexpr int TY = (K1 + 3) / 4;                        // columns / rows of the slot's Y per lane
+    constexpr int TR = (K1c + LQ - 1) / LQ;                       // rows of a record's [B|g]^T per lane
+    constexpr int TY = (K1 + LQ - 1) / LQ;                        // columns / rows of the slot's Y per lane
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if (a.st && a.st->done) return;
     const int g_set = a.st ? schur_set(a.st) : 0;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     typedef const __attribute__((address_space(1))) double* gptr_t;
     const gptr_t p_G = (gptr_t)a.Gs[g_set];
     const double lambda = a.st ? schur_lambda(a.st) : a.lambda;
-    const int lane = threadIdx.x, sl = lane >> 2, q = lane & 3;
+    const int lane = threadIdx.x, sl = lane / LQ, q = lane % LQ;
     const int s = blockIdx.x * SLOTS + sl;
     const bool has = s < a.n_slots;
     double* sb = smem + sl * Lt::SS;
@@ -119,53 +121,59 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     // the camera | r blocks of the records (direct terms of the reduced system, wanted only once the products are done): this
     // lane's COLUMNS j = q + 4 t of the lower triangles (rows i >= j), held in registers from the staging on
     double av[2][TR][K1c];
+    const gptr_t r0 = p_G + d0;
+    const gptr_t r1 = p_G + d1;
+    // Four lanes per slot: requested with the staging, as 8-byte loads straight into registers they arrive while the products
+    // run (through 16-byte pieces into LDS they sat on the staging's critical path: 11.4 us against 8.4).  Eight lanes per slot
+    // (two wavefronts per SIMD: 256 registers): requested AFTER the products, they arrive behind the factorisation - held across
+    // the products they cost 130 bytes of scratch
+    constexpr bool AV_LATE = LQ == 8;
+    auto load_av = [&]() {
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const int j = q + LQ * t;
+#pragma unroll
+            for (int i = 0; i < K1c; ++i) {
+                if (i < LQ * t) { av[0][t][i] = 0.0; av[1][t][i] = 0.0; continue; }          // compile time: j <= i impossible
+                const bool in = j < K1c && j <= i;
+                av[0][t][i] = (in && has) ? r0[HS + i * (i + 1) / 2 + j] : 0.0;      // packed lower triangle, entry (i, j)
+                av[1][t][i] = (in && has) ? r1[HS + i * (i + 1) / 2 + j] : 0.0;
+            }
+        }
+    };
     {
         constexpr int NH = HS / 2;                                      // 16-byte pieces of a head
-        constexpr int TH = (NH + 3) / 4;
-        const gptr_t r0 = p_G + d0;
-        const gptr_t r1 = p_G + d1;
+        constexpr int TH = (NH + LQ - 1) / LQ, TE = (18 + LQ - 1) / LQ;
         typedef double dv2 __attribute__((ext_vector_type(2)));                       // (a plain vector: HIP's double2 class has no copy from address space 1)
         typedef const __attribute__((address_space(1))) dv2* gptr2_t;
         const gptr2_t g0 = (gptr2_t)r0;
         const gptr2_t g1 = (gptr2_t)r1;
         double2* w = reinterpret_cast<double2*>(sb);
         {
-            double2 h0[TH], e0[5];
+            double2 h0[TH], e0[TE];
 #pragma unroll
             // (always a load from a valid address, then a select of the VALUE, component by component: `cond ? g0[c] : z2` is
             // compiled as a select of POINTERS into two address spaces - flat_load plus a scratch slot for the zero)
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; const dv2 v = g0[c < NH ? c : NH - 1]; const bool in = has && c < NH; h0[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
+            for (int t = 0; t < TH; ++t) { const int c = q + LQ * t; const dv2 v = g0[c < NH ? c : NH - 1]; const bool in = has && c < NH; h0[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; const dv2 v = g0[gen_e_off(PE) / 2 + (c < 18 ? c : 17)]; const bool in = has && c < 18; e0[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
+            for (int t = 0; t < TE; ++t) { const int c = q + LQ * t; const dv2 v = g0[gen_e_off(PE) / 2 + (c < 18 ? c : 17)]; const bool in = has && c < 18; e0[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H0 / 2 + c] = h0[t]; }
+            for (int t = 0; t < TH; ++t) { const int c = q + LQ * t; if (c < NH) w[Lt::H0 / 2 + c] = h0[t]; }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; if (c < 18) w[Lt::E0 / 2 + c] = e0[t]; }
+            for (int t = 0; t < TE; ++t) { const int c = q + LQ * t; if (c < 18) w[Lt::E0 / 2 + c] = e0[t]; }
         }
         {
-            double2 h1[TH], e1[5];
+            double2 h1[TH], e1[TE];
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; const dv2 v = g1[c < NH ? c : NH - 1]; const bool in = has && c < NH; h1[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
+            for (int t = 0; t < TH; ++t) { const int c = q + LQ * t; const dv2 v = g1[c < NH ? c : NH - 1]; const bool in = has && c < NH; h1[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; const dv2 v = g1[gen_e_off(PE) / 2 + (c < 18 ? c : 17)]; const bool in = has && c < 18; e1[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
+            for (int t = 0; t < TE; ++t) { const int c = q + LQ * t; const dv2 v = g1[gen_e_off(PE) / 2 + (c < 18 ? c : 17)]; const bool in = has && c < 18; e1[t] = make_double2(in ? v.x : 0.0, in ? v.y : 0.0); }
 #pragma unroll
-            for (int t = 0; t < TH; ++t) { const int c = q + 4 * t; if (c < NH) w[Lt::H1 / 2 + c] = h1[t]; }
+            for (int t = 0; t < TH; ++t) { const int c = q + LQ * t; if (c < NH) w[Lt::H1 / 2 + c] = h1[t]; }
 #pragma unroll
-            for (int t = 0; t < 5; ++t) { const int c = q + 4 * t; if (c < 18) w[Lt::E1 / 2 + c] = e1[t]; }
+            for (int t = 0; t < TE; ++t) { const int c = q + LQ * t; if (c < 18) w[Lt::E1 / 2 + c] = e1[t]; }
         }
-        // (the A blocks through 16-byte pieces into LDS - 8 wide loads instead of 2 x 28 narrow ones - put them on the critical path
-        // of the staging: 11.4 us against 8.4; as 8-byte loads straight into registers they arrive while the products run)
-#pragma unroll
-        for (int t = 0; t < TR; ++t) {
-            const int j = q + 4 * t;
-#pragma unroll
-            for (int i = 0; i < K1c; ++i) {
-                if (i < 4 * t) { av[0][t][i] = 0.0; av[1][t][i] = 0.0; continue; }          // compile time: j <= i impossible
-                const bool in = j < K1c && j <= i;
-                av[0][t][i] = (in && has) ? r0[HS + i * (i + 1) / 2 + j] : 0.0;      // packed lower triangle, entry (i, j)
-                av[1][t][i] = (in && has) ? r1[HS + i * (i + 1) / 2 + j] : 0.0;
-            }
-        }
+        if constexpr (!AV_LATE) load_av();
     }
     wsync();
     SQ_STAMP(1);
@@ -175,8 +183,9 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     double racc[6] = { 0, 0, 0, 0, 0, 0 };                  // [B|g] column r: both cameras' row r meet in the same lane
     double cmb[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };          // this lane's 3 x 3 block (rh, ch) of the slot's C
     double cross[TR][6];                                    // camera 1: rows of [B|g]^T times E_x -> theta_1 (| r) x extrinsics
-    double xx[2][6];                                        // E_x^T (C E_x) columns j = q, q + 4
-    const int rh = q >> 1, ch = q & 1;
+    constexpr int TX = (6 + LQ - 1) / LQ;                   // extrinsic columns per lane
+    double xx[TX][6];                                        // E_x^T (C E_x) columns j = q, q + 4
+    const int rh = (q & 3) >> 1, ch = q & 1;          // (eight lanes per slot: lanes q and q + 4 do the same block)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const double* H = sb + (c == 0 ? Lt::H0 : Lt::H1);
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         // rows i = q + 4 t of [B|g]^T: E_p^T b_i -> column theta_c,i of the slot's [B|g] (i = PE: the r column)
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            const int i = q + 4 * t, ic = i < K1c ? i : 0;
+            const int i = q + LQ * t, ic = i < K1c ? i : 0;
             const double2* r = reinterpret_cast<const double2*>(H + 36 + 6 * ic);
             const double2 r0 = r[0], r1 = r[1], r2 = r[2];
             const double bi[6] = { r0.x, r0.y, r1.x, r1.y, r2.x, r2.y };
@@ -247,11 +256,11 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         }
         if (c == 1) {
             // columns j = q, q + 4 of E_x: z = C E_x[:, j];  E_p^T z -> extrinsics column of [B|g];  E_x^T z -> extrinsics block
-            double z[2][6];
-            double exj[2][6];
+            double z[TX][6];
+            double exj[TX][6];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int j = q + 4 * t, jr = j < 3 ? j : 0;             // column j of E_x: rotation columns stored, translation columns unit
+            for (int t = 0; t < TX; ++t) {
+                const int j = q + LQ * t, jr = j < 3 ? j : 0;             // column j of E_x: rotation columns stored, translation columns unit
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     exj[t][k] = j < 3 ? Ec[18 + 3 * jr + k] : 0.0;
@@ -263,12 +272,12 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
                 const double2* r = reinterpret_cast<const double2*>(H + 6 * m);
                 const double2 r0 = r[0], r1 = r[1], r2 = r[2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TX; ++t)
                     z[t][m] = ((r0.x * exj[t][0] + r0.y * exj[t][1]) + (r1.x * exj[t][2] + r1.y * exj[t][3])) + (r2.x * exj[t][4] + r2.y * exj[t][5]);
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const int j = q + 4 * t;
+            for (int t = 0; t < TX; ++t) {
+                const int j = q + LQ * t;
                 double y[6];
 #pragma unroll
                 for (int b = 0; b < 3; ++b) {
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             }
         }
     }
-    if (q == (PE & 3)) {                                    // the lane that had row r of both records
+    if (q == (PE % LQ)) {                                    // the lane that had row r of both records
         double2* yo = reinterpret_cast<double2*>(sb + Lt::YL + 6 * K);
         yo[0] = double2{ racc[0], racc[1] }; yo[1] = double2{ racc[2], racc[3] }; yo[2] = double2{ racc[4], racc[5] };
     }
@@ -293,6 +302,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) sb[Lt::CX + (3 * rh + m) * 6 + 3 * ch + n] = cmb[3 * m + n];
+    if constexpr (AV_LATE) load_av();
     wsync();
     SQ_STAMP(2);
 
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     {
         double2* w = reinterpret_cast<double2*>(img);
 #pragma unroll
-        for (int t = 0; t < (ACCN / 2 + 4) / 4; ++t) { const int c = q + 4 * t; if (c < (ACCN + 1) / 2) w[c] = double2{ 0.0, 0.0 }; }
+        for (int t = 0; t < ((ACCN + 1) / 2 + LQ - 1) / LQ; ++t) { const int c = q + LQ * t; if (c < (ACCN + 1) / 2) w[c] = double2{ 0.0, 0.0 }; }
     }
     wsync();
     if (q == 0) {
@@ -351,52 +361,52 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             const int ii = i < PE ? ct + i : K;              // the image's row (compile time)
 #pragma unroll
             for (int t = 0; t < TR; ++t) {
-                if (4 * t > i) continue;                     // compile time: j <= i impossible
-                const int j = q + 4 * t;
+                if (LQ * t > i) continue;                    // compile time: j <= i impossible
+                const int j = q + LQ * t;
                 const double v = av[c][t][i];
                 const bool in = j <= i && j < PE;            // (j == PE: the residual column - only (r, r), below)
-                *(in ? img + sq_tri(ii, 0) + ct + j : dump(sq_tri(ii, 0) + ct + 4 * t)) = v;
-                if (i < PE) { if (i / 4 == t) *((in && j == i) ? img + Lt::XH + ii : dump(Lt::XH + ii - (i & 3))) = v; }      // hdiag
-                else *(in ? img + Lt::XG + ct + j : dump(Lt::XG + ct + 4 * t)) = v;                                          // g_c
+                *(in ? img + sq_tri(ii, 0) + ct + j : dump(sq_tri(ii, 0) + ct + LQ * t)) = v;
+                if (i < PE) { if (i / LQ == t) *((in && j == i) ? img + Lt::XH + ii : dump(Lt::XH + ii - (i % LQ))) = v; }      // hdiag
+                else *(in ? img + Lt::XG + ct + j : dump(Lt::XG + ct + LQ * t)) = v;                                          // g_c
             }
         }
     }
     {
-        constexpr int t = PE / 4;                            // the lane whose column is the residual's: j == PE
-        const int j = q + 4 * t;
+        constexpr int t = PE / LQ;                            // the lane whose column is the residual's: j == PE
+        const int j = q + LQ * t;
         const double v = av[0][t][PE] + av[1][t][PE];
-        *(j == PE ? img + sq_tri(K, K) : dump(sq_tri(K, K) - (PE & 3))) = v;
-        *(j == PE ? img + Lt::XC : dump(Lt::XC - (PE & 3))) = v;
+        *(j == PE ? img + sq_tri(K, K) : dump(sq_tri(K, K) - (PE % LQ))) = v;
+        *(j == PE ? img + Lt::XC : dump(Lt::XC - (PE % LQ))) = v;
     }
     // camera 1: theta_1 (| r) x extrinsics, extrinsics x extrinsics
 #pragma unroll
     for (int t = 0; t < TR; ++t) {
-        const int i = q + 4 * t;
+        const int i = q + LQ * t;
         const int col = i < PE ? CT1 + i : K;                // i == PE: row r of the system (g_c of the extrinsic columns)
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int hi = i < PE ? CE + j : K, lo = i < PE ? col : CE + j;
-            *(i < K1c ? img + hi * (hi + 1) / 2 + lo : dump(sq_tri(CE + j, 0) + CT1 + 4 * t)) = cross[t][j];
-            if (PE / 4 == t) *(i == PE ? img + Lt::XG + CE + j : dump(Lt::XG + CE + j - (PE & 3))) = cross[t][j];
+            *(i < K1c ? img + hi * (hi + 1) / 2 + lo : dump(sq_tri(CE + j, 0) + CT1 + LQ * t)) = cross[t][j];
+            if (PE / LQ == t) *(i == PE ? img + Lt::XG + CE + j : dump(Lt::XG + CE + j - (PE % LQ))) = cross[t][j];
         }
     }
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int j = q + 4 * t;
+    for (int t = 0; t < TX; ++t) {
+        const int j = q + LQ * t;
 #pragma unroll
         for (int jp = 0; jp < 6; ++jp) {
-            if (jp < 4 * t) continue;                        // compile time: jp >= j impossible
+            if (jp < LQ * t) continue;                        // compile time: jp >= j impossible
             const bool in = j < 6 && jp >= j;
-            *(in ? img + sq_tri(CE + jp, 0) + CE + j : dump(sq_tri(CE + jp, 0) + CE + 4 * t)) = xx[t][jp];
-            if (jp <= 4 * t + 3) *((in && jp == j) ? img + Lt::XH + CE + j : dump(Lt::XH + CE + jp - (jp & 3))) = xx[t][jp];
+            *(in ? img + sq_tri(CE + jp, 0) + CE + j : dump(sq_tri(CE + jp, 0) + CE + LQ * t)) = xx[t][jp];
+            if (jp <= LQ * t + LQ - 1) *((in && jp == j) ? img + Lt::XH + CE + j : dump(Lt::XH + CE + jp - (jp % LQ))) = xx[t][jp];
         }
     }
     SQ_STAMP(4);
     // ---- Y = L^-1 [B | g_p], columns c = q + 4 t, in place; the slot's record for k_backsub
-    if (has && !go) for (int e = q; e < a.PF; e += 4) pf[e] = 0.0;          // no observations or a failed block
+    if (has && !go) for (int e = q; e < a.PF; e += LQ) pf[e] = 0.0;          // no observations or a failed block
 #pragma unroll
     for (int t = 0; t < TY; ++t) {
-        const int c = q + 4 * t, cc = c < K1 ? c : 0;
+        const int c = q + LQ * t, cc = c < K1 ? c : 0;
         double2* yp = reinterpret_cast<double2*>(sb + Lt::YL + 6 * cc);
         const double2 b0 = yp[0], b1 = yp[1], b2 = yp[2];
         const double bc[6] = { b0.x, b0.y, b1.x, b1.y, b2.x, b2.y };
@@ -423,9 +433,9 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     if (go) {
         // L (21) and diag C (6): every lane holds them; lane q stores entries q, q + 4, ...
 #pragma unroll
-        for (int e = 0; e < 21; ++e) if ((e & 3) == q) pf[e] = L[e];
+        for (int e = 0; e < 21; ++e) if ((e % LQ) == q) pf[e] = L[e];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) if ((e & 3) == q) pf[21 + 6 * K1 + 6 + e] = dC[e];
+        for (int e = 0; e < 6; ++e) if ((e % LQ) == q) pf[21 + 6 * K1 + 6 + e] = dC[e];
     }
     wsync();
     SQ_STAMP(5);
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
         double yj[TY][6];
 #pragma unroll
         for (int t = 0; t < TY; ++t) {
-            const int j = q + 4 * t, jc = j < K1 ? j : 0;
+            const int j = q + LQ * t, jc = j < K1 ? j : 0;
             const double2* r = reinterpret_cast<const double2*>(sb + Lt::YL + 6 * jc);
             const double2 r0 = r[0], r1 = r[1], r2 = r[2];
             yj[t][0] = r0.x; yj[t][1] = r0.y; yj[t][2] = r1.x; yj[t][3] = r1.y; yj[t][4] = r2.x; yj[t][5] = r2.y;
@@ -449,8 +459,8 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             c0[b] = r[0]; c1[b] = r[1]; c2[b] = r[2];
 #pragma unroll
             for (int t = 0; t < TY; ++t) {
-                if (4 * t > i) continue;                     // compile time: every column of this t lies right of the diagonal
-                const int j = q + 4 * t;
+                if (LQ * t > i) continue;                    // compile time: every column of this t lies right of the diagonal
+                const int j = q + LQ * t;
                 dv[b][t] = img[sq_tri(i, 0) + (j <= i ? j : i)];       // (right of the diagonal: the diagonal entry again - a broadcast, value unused)
             }
         };
@@ -461,10 +471,10 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
             if (i + 1 < K1) fetch(i + 1, b ^ 1);
 #pragma unroll
             for (int t = 0; t < TY; ++t) {
-                if (4 * t > i) continue;
-                const int j = q + 4 * t;
+                if (LQ * t > i) continue;
+                const int j = q + LQ * t;
                 const double v = ((yj[t][0] * c0[b].x + yj[t][1] * c0[b].y) + (yj[t][2] * c1[b].x + yj[t][3] * c1[b].y)) + (yj[t][4] * c2[b].x + yj[t][5] * c2[b].y);
-                *(j <= i ? img + sq_tri(i, 0) + j : dump(sq_tri(i, 0) + 4 * t)) = dv[b][t] - v;
+                *(j <= i ? img + sq_tri(i, 0) + j : dump(sq_tri(i, 0) + LQ * t)) = dv[b][t] - v;
             }
         }
     }
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(64) void k_schurq(const SchurArgs a) {
     // ---- the wavefront's 16 images in a fixed order -> one row of partial sums (k_reduce's layout: the full (K+1)^2 image,
     // lower triangle filled, then the extras)
     // (rows of the upper triangle are never written: the buffer is cleared once when the workspace is made)
-    for (int e = lane; e < ACCN; e += 4 * SLOTS) {
+    for (int e = lane; e < ACCN; e += 64) {
         int dst;
         if (e < NT) { int i, j; sq_tri_decode(e, i, j); dst = i * K1 + j; }
         else dst = K1 * K1 + (e - NT);
@@ -498,31 +508,33 @@ bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* c
     if (n_cams != 2 || peff[0] != peff[1] || peff[0] < 4 || peff[0] > 6) return false;
     return col_theta[0] == 0 && col_theta[1] == peff[0] && col_extr[1] == 2 * peff[0];
 }
-// slots per wavefront: 8 by default (see SQ_SLOTS); CCAL_SCHURQ_SLOTS=16 for full wavefronts
-static int schurq_slots() {
-    static const int v = [] { const char* e = std::getenv("CCAL_SCHURQ_SLOTS"); const int n = e ? std::atoi(e) : 0; return (n == 8 || n == 16) ? n : CCAL_SCHURQ_DEFAULT_SLOTS; }();
-    return v;
+// slots per wavefront (16: four lanes per slot, 8: eight lanes per slot), read when a problem's workspace is created;
+// CCAL_SCHURQ_SLOTS=8|16 overrides
+int schurq_slots_per_wave() {
+    const char* e = std::getenv("CCAL_SCHURQ_SLOTS");
+    const int n = e ? std::atoi(e) : 0;
+    return (n == 8 || n == 16) ? n : CCAL_SCHURQ_DEFAULT_SLOTS;
 }
-int schurq_rows(int n_slots) { const int sp = schurq_slots(); return (std::max(n_slots, 1) + sp - 1) / sp; }
+int schurq_rows(int n_slots, int slots_per_wave) { return (std::max(n_slots, 1) + slots_per_wave - 1) / slots_per_wave; }
 
 template <int PE, int SLOTS>
 static hipError_t launch_schurq_s(const SchurArgs& a, int rows, hipStream_t s) {
-    const size_t lds = sizeof(double) * (size_t)SLOTS * SqLayout<PE>::SS;
+    const size_t lds = sizeof(double) * (size_t)SLOTS * SqLayout<PE, 64 / SLOTS>::SS;
     static DynLdsGuard guard;
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schurq<PE, SLOTS>), lds, guard); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_schurq<PE, SLOTS>), dim3(rows), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 template <int PE>
-static hipError_t launch_schurq_t(const SchurArgs& a, int rows, hipStream_t s) {
-    return schurq_slots() == 8 ? launch_schurq_s<PE, 8>(a, rows, s) : launch_schurq_s<PE, 16>(a, rows, s);
+static hipError_t launch_schurq_t(const SchurArgs& a, int rows, int slots_per_wave, hipStream_t s) {
+    return slots_per_wave == 8 ? launch_schurq_s<PE, 8>(a, rows, s) : launch_schurq_s<PE, 16>(a, rows, s);
 }
 
-hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, hipStream_t s) {
+hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, int slots_per_wave, hipStream_t s) {
     switch (peff) {
-        case 4: return launch_schurq_t<4>(a, rows, s);
-        case 5: return launch_schurq_t<5>(a, rows, s);
-        case 6: return launch_schurq_t<6>(a, rows, s);
+        case 4: return launch_schurq_t<4>(a, rows, slots_per_wave, s);
+        case 5: return launch_schurq_t<5>(a, rows, slots_per_wave, s);
+        case 6: return launch_schurq_t<6>(a, rows, slots_per_wave, s);
     }
     return hipErrorInvalidValue;
 }

@@ -39,6 +39,7 @@ struct NormalWs {
     int K = 0, RB = 0, PF = 0, n_pw = 0;
     int schur_wpb = 4;                         // wavefronts per workgroup of k_schur: 1 for reduced systems of 64 .. 127 columns
     bool schurq = false;                       // two cameras with equal blocks: elimination with four lanes per slot (k_schurq) instead of k_schur<true>
+    int schurq_slots = 16;                     // k_schurq: frame slots per wavefront (16 = four lanes each, 8 = eight lanes each)
     int n_rows = 0;                            // rows of partial sums the elimination kernel in use writes = what k_reduce adds up
     double* G[2] = { nullptr, nullptr };       // per-observation-frame Gram blocks (current / candidate)
     double* cost_o[2] = { nullptr, nullptr };  // per-observation-frame cost
@@ -129,8 +130,9 @@ hipError_t launch_gram_dev_all(const ccal_problem* p, const DevState* st, hipStr
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
                         const DevState* st = nullptr);
 bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* col_extr);      // ccal_kernels_schurq.hip
-int schurq_rows(int n_slots);
-hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, hipStream_t s);
+int schurq_slots_per_wave();                    // 16 (four lanes per slot) or 8 (eight lanes per slot)
+int schurq_rows(int n_slots, int slots_per_wave);
+hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, int slots_per_wave, hipStream_t s);
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st = nullptr);
 hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, double max_diag, hipStream_t s, DevState* st = nullptr,
                         HostStatus* hs = nullptr, int seq = 0, bool publish_all = false);

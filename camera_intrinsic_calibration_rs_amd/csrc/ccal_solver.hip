@@ -187,7 +187,8 @@ int normal_ws_ensure(ccal_problem* p) {
         const char* e = std::getenv("CCAL_SCHURQ");
         w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && (e ? e[0] != '0' : p->n_slots >= 6000);
     }
-    w->n_rows = w->schurq ? schurq_rows(p->n_slots) : n_pw / w->schur_wpb;
+    w->schurq_slots = schurq_slots_per_wave();
+    w->n_rows = w->schurq ? schurq_rows(p->n_slots, w->schurq_slots) : n_pw / w->schur_wpb;
     // cameras of one model (and the problem's one focal mode): their blocks go through ONE launch (CCAL_MERGE_GRAM=0: one per camera)
     {
         bool same = p->n_cams > 1;

@@ -559,14 +559,17 @@ def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal
     assert (seen.sum(1) == 1).any() and (~seen[:, 0]).any() and (~seen[:, 1]).any()
     op = oracle.OracleProblem.from_synth(sp)
     probs = {}
-    for name, env in (("fast", {"CCAL_SCHURQ": "1", "CCAL_MERGE_GRAM": "1"}), ("generic", {"CCAL_SCHURQ": "0", "CCAL_MERGE_GRAM": "0"}),
+    # k_schurq in both forms: 16 slots per wavefront with four lanes each, 8 slots with eight lanes each
+    for name, env in (("fast", {"CCAL_SCHURQ": "1", "CCAL_MERGE_GRAM": "1", "CCAL_SCHURQ_SLOTS": "16"}),
+                      ("fast8", {"CCAL_SCHURQ": "1", "CCAL_MERGE_GRAM": "1", "CCAL_SCHURQ_SLOTS": "8"}),
+                      ("generic", {"CCAL_SCHURQ": "0", "CCAL_MERGE_GRAM": "0"}),
                       ("merged_only", {"CCAL_SCHURQ": "0", "CCAL_MERGE_GRAM": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         g = Problem.from_synth(gpu_ctx, sp)
         g.build_normal(sp.intr0, sp.poses0, sp.extr0)                   # the workspace (and the choice of kernels) is made here
         probs[name] = g
-    monkeypatch.delenv("CCAL_SCHURQ"); monkeypatch.delenv("CCAL_MERGE_GRAM")
+    monkeypatch.delenv("CCAL_SCHURQ"); monkeypatch.delenv("CCAL_MERGE_GRAM"); monkeypatch.delenv("CCAL_SCHURQ_SLOTS")
     for lam in (0.0, 1e-3):
         So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
         for g in probs.values():
