@@ -340,7 +340,7 @@ def main():
                 extra["concurrent_sessions"] = {"error": repr(e)}
             # BASELINE configs[4] shape: a two-camera rig with extrinsics (calib_all_camera_with_extrinsics, src/util.rs:567),
             # both cameras seeing every frame slot - the general loop: 13-column Gram at the composed pose (ONE launch for both
-            # cameras: they share the model), per-slot expansion + elimination (k_schurq from 6 000 slots for UCM / EUCM, else
+            # cameras: they share the model), per-slot expansion + elimination (k_schurq from 1 000 slots for UCM / EUCM, else
             # k_schur), K = 2 P_eff + 6
             if not args.no_rig:
                 sp2 = synth.make_problem(args.frames, args.model, n_cams=2)
@@ -358,7 +358,7 @@ def main():
                     torch.cuda.synchronize()
                 extra["two_cameras"] = {
                     "frames": sp2.n_slots, "corners": sp2.n_corners, "K": p2.K, "build_ms": a.elapsed_time(b) / 100,
-                    "build_kernels": "register Gram kernel (GEN records, both cameras in one launch) + k_schurq (UCM / EUCM, >= 6 000 slots; "
+                    "build_kernels": "register Gram kernel (GEN records, both cameras in one launch) + k_schurq (UCM / EUCM, >= 1 000 slots; "
                                      "else k_schur) + k_reduce",
                     "gn": solve_stats(p2, sp2, 0, False), "lm": solve_stats(p2, sp2, 1, False),
                     "gn_device_resident": solve_stats(p2, sp2, 0, True), "lm_device_resident": solve_stats(p2, sp2, 1, True)}

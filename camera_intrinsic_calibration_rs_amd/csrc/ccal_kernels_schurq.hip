@@ -62,9 +62,6 @@ template <int PE, int LQ> struct SqLayout {
 #endif
 };
 
-#ifndef CCAL_SCHURQ_DEFAULT_SLOTS
-#define CCAL_SCHURQ_DEFAULT_SLOTS 16
-#endif
 // Where a slot's image of the reduced system starts inside its area.  Every access of the image by the four lanes of a slot
 // is ROW-FIXED, COLUMN-CONSECUTIVE (the lanes own columns j = q + 4 t): four consecutive doubles per slot.  With the slot
 // stride = 8 (mod 16) the slots of an 8-byte store group (4 slots, 32 banks) sit at 0, 8, 0, 8 and those of a load group (8
@@ -508,12 +505,16 @@ bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* c
     if (n_cams != 2 || peff[0] != peff[1] || peff[0] < 4 || peff[0] > 6) return false;
     return col_theta[0] == 0 && col_theta[1] == peff[0] && col_extr[1] == 2 * peff[0];
 }
-// slots per wavefront (16: four lanes per slot, 8: eight lanes per slot), read when a problem's workspace is created;
+// slots per wavefront (16: four lanes per slot, 8: eight lanes per slot), chosen when a problem's workspace is created.
+// Measured (two EUCM cameras, whole build, us; eight | four lanes | generic k_schur): 1 000 slots 27.5 | 30.6 | 28.2; 3 000: 37.6 |
+// 40.0 | 42.6; 6 000: 56.1 | 57.3 | 63.8; 10 000: 71.6 | 71.8; 20 000: 134.5 | 135.9; two one-focal UCM cameras x 10 000: 64.4 | 62.9 -
+// the eight-lane form's shorter chain wins while its wavefronts (twice as many) still get a SIMD to themselves.
 // CCAL_SCHURQ_SLOTS=8|16 overrides
-int schurq_slots_per_wave() {
+int schurq_slots_per_wave(int n_slots) {
     const char* e = std::getenv("CCAL_SCHURQ_SLOTS");
     const int n = e ? std::atoi(e) : 0;
-    return (n == 8 || n == 16) ? n : CCAL_SCHURQ_DEFAULT_SLOTS;
+    if (n == 8 || n == 16) return n;
+    return n_slots <= 8192 ? 8 : 16;
 }
 int schurq_rows(int n_slots, int slots_per_wave) { return (std::max(n_slots, 1) + slots_per_wave - 1) / slots_per_wave; }
 

@@ -130,7 +130,7 @@ hipError_t launch_gram_dev_all(const ccal_problem* p, const DevState* st, hipStr
 hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double min_diag, double max_diag, hipStream_t s,
                         const DevState* st = nullptr);
 bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* col_extr);      // ccal_kernels_schurq.hip
-int schurq_slots_per_wave();                    // 16 (four lanes per slot) or 8 (eight lanes per slot)
+int schurq_slots_per_wave(int n_slots);         // 16 (four lanes per slot) or 8 (eight lanes per slot)
 int schurq_rows(int n_slots, int slots_per_wave);
 hipError_t launch_schurq(const SchurArgs& a, int peff, int rows, int slots_per_wave, hipStream_t s);
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st = nullptr);

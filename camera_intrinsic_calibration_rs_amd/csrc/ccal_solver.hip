@@ -178,16 +178,17 @@ int normal_ws_ensure(ccal_problem* p) {
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
     { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || w->schur_wpb == 1; }      // the matrix-core pair: four-wavefront elimination only
-    // two cameras with equal blocks and enough slots to fill the chip with 16 per wavefront: k_schurq (10 000 slots: 21 against
-    // 29.6 us; 5 000: equal; 1 000: 7 us slower - 63 wavefronts, each a 19 us critical path);  CCAL_SCHURQ=1 / 0 forces it /
-    // the generic k_schur<true>, which every other rig takes
+    // two cameras with equal blocks: k_schurq from 1 000 slots (round 4, with its eight-lanes-per-slot form up to 8 192 slots; whole
+    // build against the generic k_schur<true>: 1 000 slots 27.5 against 28.2 us, 3 000: 37.6 / 42.6, 6 000: 56.1 / 63.8, 10 000: 71.7
+    // with k_schur at 81); below that the generic kernel's many short wavefronts win.  CCAL_SCHURQ=1 / 0 forces it / the generic
+    // k_schur<true>, which every other rig takes
     {
         int pe[CCAL_MAX_CAMS], ct[CCAL_MAX_CAMS], ce[CCAL_MAX_CAMS];
         for (int c = 0; c < p->n_cams; ++c) { pe[c] = p->cams[c].Peff; ct[c] = p->cams[c].col_theta; ce[c] = p->cams[c].col_extr; }
         const char* e = std::getenv("CCAL_SCHURQ");
-        w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && (e ? e[0] != '0' : p->n_slots >= 6000);
+        w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && (e ? e[0] != '0' : p->n_slots >= 1000);
     }
-    w->schurq_slots = schurq_slots_per_wave();
+    w->schurq_slots = schurq_slots_per_wave(p->n_slots);
     w->n_rows = w->schurq ? schurq_rows(p->n_slots, w->schurq_slots) : n_pw / w->schur_wpb;
     // cameras of one model (and the problem's one focal mode): their blocks go through ONE launch (CCAL_MERGE_GRAM=0: one per camera)
     {

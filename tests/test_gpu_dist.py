@@ -151,7 +151,7 @@ def _gpu_worker(rank, world, port, model, n_cams, method, n_frames, q):
 def test_two_ranks_on_the_device_path(model, n_cams, method, fast, monkeypatch):
     """Frame-sharded solve, two ranks, HIP kernels on both: identical camera block on both ranks (bit for bit), the same
     collective sequence on both ranks, and the single-process solve of the whole problem up to summation order.
-    fast: the two-camera rig's shards through k_schurq (forced: the shards are far below its 6 000-slot threshold) and the
+    fast: the two-camera rig's shards through k_schurq (forced: the shards are far below its 1 000-slot threshold) and the
     merged Gram launch - their partial sums feed the same all-reduce."""
     import torch.multiprocessing as mp
     if fast:

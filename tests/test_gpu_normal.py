@@ -549,7 +549,7 @@ def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatc
 @pytest.mark.parametrize("model", ["ucm", "eucm", "kb4", "opencv5"])
 @pytest.mark.parametrize("one_focal", [False, True])
 def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal, monkeypatch):
-    """A rig of two cameras of one model takes, above 6 000 slots, the compile-time structured elimination k_schurq (four lanes
+    """A rig of two cameras of one model takes, above 1 000 slots, the compile-time structured elimination k_schurq (four or eight lanes
     per slot; UCM and EUCM: P_eff = 4 .. 6) and ONE launch of the register Gram kernel for both cameras.  Forced here on a small rig - 0.4 rad
     extrinsic rotation, slots seen by one camera only, ragged corner sets - against the oracle and against
     the generic pair (k_schur, one Gram launch per camera): normal equations, GN, LM."""
