@@ -136,11 +136,22 @@ SYMBOLS = [
     ("ccal_validation", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
 ]
 
+LEGACY_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libccal_hip_legacy.so")
 _lib = None
+_legacy = None
 
 
 class CcalLibraryMissing(RuntimeError):
     pass
+
+
+def _bind(path, mode):
+    lib = C.CDLL(path, mode=mode)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)   # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
 
 
 def load():
@@ -152,10 +163,17 @@ def load():
         raise CcalLibraryMissing(
             f"{LIB_PATH} not found: the HIP engine is not built (run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `make -C camera_intrinsic_calibration_rs_amd/csrc`).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
-    for name, res, args in SYMBOLS:
-        fn = getattr(lib, name)   # AttributeError if the export is missing
-        fn.restype = res
-        fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _bind(LIB_PATH, C.RTLD_GLOBAL)
+    return _lib
+
+
+def load_legacy():
+    """TEST INFRASTRUCTURE: the second build of the library that still carries the superseded matrix-core kernels
+    (-DCCAL_LEGACY_KERNELS: k_gram1, k_gram, k_schur<false>; CCAL_GRAM=mfma / CCAL_GENERAL_GRAM=mfma select them there) - the
+    independent second implementation some parity tests hold the product kernels against.  engine.Context(lib=load_legacy())."""
+    global _legacy
+    if _legacy is None:
+        if not os.path.exists(LEGACY_LIB_PATH):
+            raise CcalLibraryMissing(f"{LEGACY_LIB_PATH} not found (make -C camera_intrinsic_calibration_rs_amd/csrc)")
+        _legacy = _bind(LEGACY_LIB_PATH, C.RTLD_LOCAL)
+    return _legacy

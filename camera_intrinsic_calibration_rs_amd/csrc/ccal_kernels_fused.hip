@@ -52,6 +52,8 @@ hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+#ifdef CCAL_LEGACY_KERNELS      // the matrix-core Gram kernel of round 1: superseded by the register kernels for every model; kept in
+                                // libccal_hip_legacy.so as the independent second implementation the parity tests hold the product kernels against
 // ---------------------------------------------------------------------------------------------
 // k_gram1
 // ---------------------------------------------------------------------------------------------
@@ -205,6 +207,8 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
     if (lane == 0) a.cost_f[f] = G[D * 16 + D];
     if (lane < 9) rec[praw_jl_off(K) + lane] = fc[FC_A + lane];      // the frame's left Jacobian: k_schur1(m) maps phi -> rvec with it
 }
+
+#endif  // CCAL_LEGACY_KERNELS
 
 // ---------------------------------------------------------------------------------------------
 // k_gram1v: the same per-frame record as k_gram1, without the LDS transposition the matrix cores need.
@@ -946,6 +950,7 @@ hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a0,
     if (use_gram2(model, a0.n_obs)) return launch_gram2_general(model, one_focal, a0, s);
     FusedArgs a = a0; a.fuse_elim = 0; return launch_gram1v_m<true>(model, one_focal, a, s);
 }
+#ifdef CCAL_LEGACY_KERNELS
 template <int MODEL, bool OF>
 static hipError_t launch_gram1_t(const FusedArgs& a, hipStream_t s) {
     constexpr int WS = FC_N0P + GRAM_TILE_CORNERS * 34;
@@ -968,6 +973,10 @@ hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream
         default: return hipErrorInvalidValue;
     }
 }
+
+#else
+hipError_t launch_gram1(int, bool, const FusedArgs&, hipStream_t) { return hipErrorNotSupported; }      // not in the product build
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_schur1: persistent wavefronts over frames (problems too large for one pass of k_schur1m).  Works on the set and

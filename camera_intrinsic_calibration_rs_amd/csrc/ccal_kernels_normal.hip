@@ -29,6 +29,7 @@ struct GramArgs {
     const double* intr2; const double* poses2; const double* extr2; double* G2; double* cost_o2;
 };
 
+#ifdef CCAL_LEGACY_KERNELS      // matrix-core Gram of the general loop (19-column blocks): libccal_hip_legacy.so only
 // ---------------------------------------------------------------------------------------------
 // k_gram: one wavefront per observation frame.  Every lane evaluates one corner's two weighted
 // rows sqrt(w) [J | r] (NC = D + 1 columns), the wave stages them in LDS as a [rows][16 T] image and
@@ -222,6 +223,8 @@ static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
     return hipGetLastError();
 }
 
+#endif  // CCAL_LEGACY_KERNELS
+
 #define CCAL_DISPATCH(FN, model, of, other, ...)                                                     \
     do {                                                                                             \
         const int key_ = (model) * 4 + ((of) ? 2 : 0) + ((other) ? 1 : 0);                           \
@@ -239,6 +242,10 @@ static hipError_t launch_gram_t(const GramArgs& ga, hipStream_t s) {
     } while (0)
 
 hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipStream_t s) {
+#ifndef CCAL_LEGACY_KERNELS
+    (void)p; (void)cam; (void)cand; (void)gbuf; (void)s;
+    return hipErrorNotSupported;          // the matrix-core pair is not in the product build (normal_ws_ensure never selects it)
+#else
     const NormalWs* w = p->nws;
     GramArgs ga = {};
     KArgs& a = ga.k;
@@ -249,6 +256,7 @@ hipError_t launch_gram(const ccal_problem* p, int cam, bool cand, int gbuf, hipS
     a.huber_delta = p->huber_delta; a.rt = model_rt(p->ctx);
     ga.goff = w->d_goff; ga.G = w->G[gbuf]; ga.cost_o = w->cost_o[gbuf];
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
+#endif
 }
 // device-resident loop: set 0 = (p->d_*, G[w->cur]), set 1 = (p->d_*_c, G[w->cur ^ 1])
 hipError_t launch_gram_dev_all(const ccal_problem* p, const DevState* st, hipStream_t s) {
@@ -295,6 +303,9 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
         fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
         return launch_gram1v_general(p->cams[cam].model, p->one_focal, fa, s);
     }
+#ifndef CCAL_LEGACY_KERNELS
+    return hipErrorNotSupported;
+#else
     GramArgs ga = {};
     KArgs& a = ga.k;
     a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
@@ -306,6 +317,7 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
     ga.goff = w->d_goff; ga.G = w->G[w->cur]; ga.cost_o = w->cost_o[w->cur]; ga.G2 = w->G[w->cur ^ 1]; ga.cost_o2 = w->cost_o[w->cur ^ 1];
     ga.st = st;
     CCAL_DISPATCH(launch_gram_t, p->cams[cam].model, p->one_focal, cam > 0, ga, s);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -636,9 +648,14 @@ hipError_t launch_schur(const ccal_problem* p, int gbuf, double lambda, double m
         hipLaunchKernelGGL((k_schur<true, 4>), dim3(blocks), dim3(256), lds, s, a);
         return hipGetLastError();
     }
+#ifdef CCAL_LEGACY_KERNELS          // the table-driven elimination of the matrix-core Gram's 16 x 16 / 32-stride tiles
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_schur<false, 4>), lds, lds_guard); e != hipSuccess) return e;
     hipLaunchKernelGGL((k_schur<false, 4>), dim3(blocks), dim3(256), lds, s, a);
     return hipGetLastError();
+#else
+    (void)lds_guard;
+    return hipErrorNotSupported;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -177,7 +177,11 @@ int normal_ws_ensure(ccal_problem* p) {
     // Register Gram kernels + record format for every camera (k_gram1v / k_gram1w, GEN; k_schur expands the records).
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
+#ifdef CCAL_LEGACY_KERNELS
     { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || w->schur_wpb == 1; }      // the matrix-core pair: four-wavefront elimination only
+#else
+    w->register_gram = true;               // (the matrix-core pair lives in libccal_hip_legacy.so only)
+#endif
     // two cameras with equal blocks: k_schurq from 1 000 slots (round 4, with its eight-lanes-per-slot form up to 8 192 slots; whole
     // build against the generic k_schur<true>: 1 000 slots 27.5 against 28.2 us, 3 000: 37.6 / 42.6, 6 000: 56.1 / 63.8, 10 000: 71.7
     // with k_schur at 81); below that the generic kernel's many short wavefronts win.  CCAL_SCHURQ=1 / 0 forces it / the generic
@@ -391,7 +395,9 @@ static bool fused_use_schur1m(const ccal_problem* p, FusedArgs& fa) {
 // 256 products where the triangle needs <= 136.  CCAL_GRAM=mfma selects the matrix-core kernel (k_gram1).
 static bool fused_use_valu_gram(const ccal_problem* p) {
     (void)p;
+#ifdef CCAL_LEGACY_KERNELS
     if (const char* g = std::getenv("CCAL_GRAM")) return g[0] != 'm';
+#endif
     return true;
 }
 // Gram + elimination of one group on the single-camera path (fa.n_part = the number of partial sums per entry)

@@ -35,8 +35,8 @@ def _dp(a: Optional[np.ndarray]):
 class Context:
     """One GPU + one HIP stream (ccal_ctx)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
-        self.lib = _ffi.load()
+    def __init__(self, device: int = 0, stream: int | None = None, lib=None):
+        self.lib = lib if lib is not None else _ffi.load()      # lib: another build of the library (tests: _ffi.load_legacy())
         h = C.c_void_p()
         rc = self.lib.ccal_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
         if rc != _ffi.OK:

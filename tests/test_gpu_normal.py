@@ -500,6 +500,19 @@ RIG_EXTR = {3: [[0.0] * 6, [0.3, -0.25, 0.2, -0.1, 0.02, 0.01], [-0.2, 0.35, -0.
             2: [[0.0] * 6, [0.12, -0.1, 0.3, -0.1, 0.02, 0.01]]}
 
 
+_LEGACY_CTX = None
+
+
+def _legacy_ctx():
+    """A context of the SECOND build of the library (-DCCAL_LEGACY_KERNELS): the superseded matrix-core kernels are not in the
+    product library; the tests that hold the product kernels against them load both builds side by side."""
+    global _LEGACY_CTX
+    if _LEGACY_CTX is None:
+        from camera_intrinsic_calibration_rs_amd.engine import Context
+        _LEGACY_CTX = Context(0, lib=_ffi.load_legacy())
+    return _LEGACY_CTX
+
+
 @pytest.mark.parametrize("models", [("eucm", "kb4", "ucm"), ("opencv5", "opencv5"), ("kb4", "eucm")])
 @pytest.mark.parametrize("one_focal", [False, True])
 def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatch):
@@ -514,7 +527,7 @@ def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatc
     assert (~seen[:, 0]).any() and (seen.sum(1) == 1).any()            # the cases the test is about are present
     gp, op = _pair(gpu_ctx, oracle, sp)
     monkeypatch.setenv("CCAL_GENERAL_GRAM", "mfma")
-    gm = Problem.from_synth(gpu_ctx, sp)
+    gm = Problem.from_synth(_legacy_ctx(), sp)                          # the matrix-core pair lives in libccal_hip_legacy.so only
     gm.build_normal(sp.intr0, sp.poses0, sp.extr0)                      # workspace (and the choice) made under the switch
     monkeypatch.delenv("CCAL_GENERAL_GRAM")
     for lam in (0.0, 1e-3):
@@ -641,7 +654,7 @@ def test_matrix_core_gram_switch(gpu_ctx, oracle, model, one_focal, frames, monk
     """CCAL_GRAM=mfma: the single-camera loop through the matrix-core Gram kernel (k_gram1: v_mfma_f64_16x16x4_f64 on LDS-staged
     rows) and the separate elimination launch - the second implementation behind the developer switch stays correct."""
     sp = synth.make_problem(frames, model, xy_same_focal=one_focal, ragged=True, outlier_frac=0.02)
-    gp, op = _pair(gpu_ctx, oracle, sp)
+    gp, op = _pair(_legacy_ctx(), oracle, sp)                           # k_gram1 is compiled into libccal_hip_legacy.so only
     monkeypatch.setenv("CCAL_GRAM", "mfma")
     S, b, c = gp.build_normal(sp.intr0, sp.poses0, lam=1e-3)
     So, bo, co = op.build_normal(sp.intr0, sp.poses0, lam=1e-3)
