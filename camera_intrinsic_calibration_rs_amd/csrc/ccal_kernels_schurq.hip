@@ -336,16 +336,13 @@ __global__ __launch_bounds__(64, SLOTS == 8 ? 2 : 1) void k_schurq(const SchurAr
     SQ_STAMP(3);
     double* pf = a.pf + (int64_t)(has ? s : 0) * a.PF;
     double* img = sb + Lt::IMG + sq_img_shift(sl);
-    // ---- the slot's image of the reduced system (over the staging, dead now): zero, then the direct terms
-    {
-        double2* w = reinterpret_cast<double2*>(img);
-#pragma unroll
-        for (int t = 0; t < ((ACCN + 1) / 2 + LQ - 1) / LQ; ++t) { const int c = q + LQ * t; if (c < (ACCN + 1) / 2) w[c] = double2{ 0.0, 0.0 }; }
-    }
-    wsync();
+    // ---- the slot's image of the reduced system (over the staging, dead now): the direct terms.  The image is NOT cleared
+    // first (round 4): every entry of the triangle is written by the Y^T Y pass below, which knows - at compile time per row and
+    // column block - where no direct term was stored (theta_1 x theta_0, extrinsics x theta_0: camera 0 has no share in camera 1's
+    // blocks) and starts from 0 there instead of reading; every extra (hdiag, g_c, cost, model decrease, failed) has its writer
     if (q == 0) {
-        if (has) img[Lt::XM] = mc_s;
-        if (live && !ok) img[Lt::XF] = 1.0;                  // failed pose block (all-reduced with the sums: every rank sees it)
+        img[Lt::XM] = has ? mc_s : 0.0;
+        img[Lt::XF] = (live && !ok) ? 1.0 : 0.0;             // failed pose block (all-reduced with the sums: every rank sees it)
     }
     // Direct terms: every entry has ONE writer (plain stores over the zeros), except (r, r) = cost, where the two records'
     // entries meet in the same lane.  camera | r blocks of the records, row by row (the row is compile time, the lanes hold its
@@ -458,7 +455,11 @@ __global__ __launch_bounds__(64, SLOTS == 8 ? 2 : 1) void k_schurq(const SchurAr
             for (int t = 0; t < TY; ++t) {
                 if (LQ * t > i) continue;                    // compile time: every column of this t lies right of the diagonal
                 const int j = q + LQ * t;
-                dv[b][t] = img[sq_tri(i, 0) + (j <= i ? j : i)];       // (right of the diagonal: the diagonal entry again - a broadcast, value unused)
+                // rows of theta_1 and of the extrinsics have no direct term in the theta_0 columns (j < PE): nothing was stored there
+                const bool row_all = i < PE || i == K;       // compile time
+                if (!row_all && LQ * t + LQ - 1 < PE) { dv[b][t] = 0.0; continue; }
+                const double rd = img[sq_tri(i, 0) + (j <= i ? j : i)];       // (right of the diagonal: the diagonal entry again - a broadcast, value unused)
+                dv[b][t] = (row_all || LQ * t >= PE || j >= PE) ? rd : 0.0;
             }
         };
         fetch(0, 0);
