@@ -604,6 +604,13 @@ def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal
             assert (np.abs(intr - intr_o) / np.maximum(np.abs(intr_o), 1e-3)).max() <= 1e-6
             np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
             np.testing.assert_allclose(extr, extr_o, rtol=0, atol=1e-7)
+    # k_schurq's record buffers keep HOLES (slots one camera did not see) and never-written rows of the partial sums that must
+    # stay zero for good: after GN and LM solves on both parameter sets the normal equations still match the oracle's
+    So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=1e-3)
+    for g in probs.values():
+        S, b, cost = g.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=1e-3)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
     for g in probs.values():
         g.close()
 
