@@ -130,6 +130,8 @@ SYMBOLS = [
     ("ccal_multi_upload_params", C.c_int, [_vp, _dp, _dp, _dp]),
     ("ccal_multi_eval_dev", C.c_int, [_vp, C.c_int, C.POINTER(_vp), C.POINTER(_vp)]),
     ("ccal_multi_solve", C.c_int, [_vp, C.POINTER(SolverOpts), _dp, _dp, _dp, C.POINTER(Report)]),
+    ("ccal_multi_validation", C.c_int, [_vp, C.c_int, _dp, _dp, _dp, _dp, _dp]),
+    ("ccal_multi_reprojection_errors", C.c_int, [_vp, _dp, _dp, _dp, _dp, _lp]),
     ("ccal_convert_model", C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_double, C.c_int,
                                      C.POINTER(SolverOpts), C.POINTER(Report)]),
     ("ccal_reprojection_errors", C.c_int, [_vp, _dp, _dp, _dp, _dp]),

@@ -492,19 +492,17 @@ def init_ucm(frame_feature0: FrameFeature, frame_feature1: FrameFeature, rtvec0:
 
 
 def validation(cam_idx: int, final_result: GenericModel, rtvec_list: Dict[int, RvecTvec],
-               detected_feature_frames: Sequence[Optional[FrameFeature]], ctx: Optional[Context] = None
-               ) -> Tuple[float, float]:
-    """util::validation (src/util.rs:721-795): (avg of the lowest 99 %, median) reprojection error in px."""
+               detected_feature_frames: Sequence[Optional[FrameFeature]], ctx: Optional[Context] = None,
+               devices: Optional[Sequence[int]] = None) -> Tuple[float, float]:
+    """util::validation (src/util.rs:721-795): (avg of the lowest 99 %, median) reprojection error in px.
+    `devices`: the errors are evaluated shard by shard on the listed GPUs, the statistics are the same bits."""
     valid = [i for i in sorted(rtvec_list.keys()) if detected_feature_frames[i] is not None]
     slots, obs_cam, obs_slot, offs, X, U = _flatten([detected_feature_frames], [valid])
     d, keep = make_desc(1, [final_result.model_id], [final_result.width()], [final_result.height()], False,
                         len(slots), obs_cam, obs_slot, offs, X[:, 0], X[:, 1], X[:, 2], U[:, 0], U[:, 1], 1.0)
-    prob = Problem(_ctx(ctx), d, keep)
-    try:
+    with _Opened(ctx, devices, d, keep) as prob:
         poses = np.stack([rtvec_list[i].as6() for i in slots])
         return prob.validation(0, _intr_matrix([final_result]), poses, None)
-    finally:
-        prob.close()
 
 
 class ReprojectionFactor:

@@ -358,8 +358,9 @@ int ccal_eval(ccal_problem* p, const double* intr, const double* poses, const do
     return CCAL_OK;
 }
 
-int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr, double* err_out) {
-    if (!p || !intr || (!poses && p->n_slots) || (!extr && p->n_cams > 1) || !err_out) return CCAL_ERR_INVALID_ARG;
+}  // extern "C"
+namespace ccal {
+int reprojection_errors_dev(ccal_problem* p, const double* intr, const double* poses, const double* extr) {
     ccal_ctx* ctx = p->ctx;
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
@@ -369,6 +370,16 @@ int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* 
         a.err_out = p->d_err;
         HIP_TRY(ctx, launch_reproj_err(p, c, a, ctx->stream));
     }
+    return CCAL_OK;
+}
+}  // namespace ccal
+extern "C" {
+
+int ccal_reprojection_errors(ccal_problem* p, const double* intr, const double* poses, const double* extr, double* err_out) {
+    if (!p || !intr || (!poses && p->n_slots) || (!extr && p->n_cams > 1) || !err_out) return CCAL_ERR_INVALID_ARG;
+    ccal_ctx* ctx = p->ctx;
+    int rc = reprojection_errors_dev(p, intr, poses, extr);
+    if (rc != CCAL_OK) return rc;
     if (p->n_corners) HIP_TRY(ctx, hipMemcpyAsync(err_out, p->d_err, sizeof(double) * p->n_corners, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CCAL_OK;

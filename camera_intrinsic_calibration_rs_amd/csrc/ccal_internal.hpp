@@ -133,6 +133,10 @@ int rccl_allreduce_sum(ccal_ctx* ctx, void* comm, double* buf, size_t count, hip
 int drain_pending_groups(ccal_problem* p);
 // ccal_kernels_stats.hip
 hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
+hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s);
+hipError_t sorted_stats_device(double* d_vals, int64_t n, double* avg_99, double* median, hipStream_t s);
+// ccal_api.hip: reprojection errors of every corner at the given parameters into p->d_err (device); ccal_multi.hip uses it per shard
+int reprojection_errors_dev(ccal_problem* p, const double* intr, const double* poses, const double* extr);
 // ccal_kernels_init.hip
 hipError_t launch_pose_init(const ccal_problem* p, int cam, const double* d_intr, double* d_poses_obs, int32_t* d_valid,
                             int min_points, hipStream_t s);

@@ -19,27 +19,52 @@ __global__ __launch_bounds__(256) void k_scale(double* v, int64_t n, double inv)
     if (i < n) v[i] *= inv;
 }
 
-// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`.
-hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
+// One camera's errors out of the per-corner errors of the whole problem (device), packed in observation-frame order into a fresh
+// device buffer (*d_out, *n_out doubles; the caller frees it).  A camera without corners: *d_out = NULL, *n_out = 0.
+hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s) {
+    *d_out = nullptr; *n_out = 0;
     const CamLayout& cl = p->cams[cam];
     const int n_list = (int)cl.obs.size();
     std::vector<int64_t> dst(n_list + 1, 0);
     for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
     const int64_t n = dst[n_list];
+    if (n <= 0) return hipSuccess;
+    int64_t* d_dst = nullptr; double* d_a = nullptr;
+    hipError_t e = hipMalloc((void**)&d_dst, (n_list + 1) * sizeof(int64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_a, n * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst.data(), (n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) { hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);       // (dst is a host vector of this frame)
+    if (d_dst) (void)hipFree(d_dst);
+    if (e != hipSuccess) { if (d_a) (void)hipFree(d_a); return e; }
+    *d_out = d_a; *n_out = n;
+    return hipSuccess;
+}
+
+// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`.
+hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
+    double* d_a = nullptr; int64_t n = 0;
+    hipError_t e = camera_errors_device(p, cam, d_err, &d_a, &n, s);
+    if (e != hipSuccess) return e;
     if (n <= 0) return hipErrorInvalidValue;
-    int64_t* d_dst = nullptr; double *d_a = nullptr, *d_b = nullptr, *d_sum = nullptr; void* d_tmp = nullptr;
+    e = sorted_stats_device(d_a, n, avg_99, median, s);
+    (void)hipFree(d_a);
+    return e;
+}
+
+// median = e[len / 2] and avg_99 = sum_{i < len * 99 / 100} e_i / (len * 99 / 100) of n non-negative values on the device (d_a is
+// used as the sort's input buffer).  The multi-GPU form gathers the shards' values into one buffer and calls this: same values,
+// same sorted order, same reduction - the same bits as on one GPU.
+hipError_t sorted_stats_device(double* d_a, int64_t n, double* avg_99, double* median, hipStream_t s) {
+    if (n <= 0) return hipErrorInvalidValue;
+    double *d_b = nullptr, *d_sum = nullptr; void* d_tmp = nullptr;
     hipError_t e;
 #define TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
     size_t tmp_sort = 0, tmp_red = 0, tmp_bytes = 0;
     const int64_t n99 = n * 99 / 100;
     double h[2] = { 0.0, 0.0 };
-    TRY(hipMalloc((void**)&d_dst, (n_list + 1) * sizeof(int64_t)));
-    TRY(hipMalloc((void**)&d_a, n * sizeof(double)));
     TRY(hipMalloc((void**)&d_b, n * sizeof(double)));
     TRY(hipMalloc((void**)&d_sum, sizeof(double)));
-    TRY(hipMemcpyAsync(d_dst, dst.data(), (n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a);
-    TRY(hipGetLastError());
     TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, d_a, d_b, (int)n, 0, 64, s));
     TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_red, d_b, d_sum, (int)std::max<int64_t>(n99, 1), s));
     tmp_bytes = std::max(tmp_sort, tmp_red);
@@ -56,8 +81,6 @@ hipError_t validation_stats_device(const ccal_problem* p, int cam, const double*
     *median = h[0]; *avg_99 = h[1];
 done:
 #undef TRY
-    if (d_dst) (void)hipFree(d_dst);
-    if (d_a) (void)hipFree(d_a);
     if (d_b) (void)hipFree(d_b);
     if (d_sum) (void)hipFree(d_sum);
     if (d_tmp) (void)hipFree(d_tmp);

@@ -428,6 +428,71 @@ int ccal_multi_init_poses(ccal_multi_problem* mp, const double* intr, int min_po
     CCAL_API_CATCH((ccal_ctx*)nullptr)
 }
 
+// validation() over the shards (src/util.rs:721-795): every shard evaluates its corners' errors on its GPU; the camera's errors of
+// all shards meet on the first shard's GPU, where the single-GPU statistics code sorts and sums them - the same values, the same
+// sorted order, the same reduction: the same bits as ccal_validation on one GPU.
+int ccal_multi_validation(ccal_multi_problem* mp, int cam, const double* intr, const double* poses, const double* extr,
+                          double* avg_99_percent, double* median) {
+    if (!mp || cam < 0 || cam >= mp->n_cams || !intr || (!poses && mp->n_slots) || (!extr && mp->n_cams > 1) || !avg_99_percent || !median) return CCAL_ERR_INVALID_ARG;
+    ccal_multi* m = mp->m;
+    CCAL_API_TRY
+    const int n = (int)mp->shard.size();
+    std::vector<double*> d_part((size_t)n, nullptr);
+    std::vector<int64_t> cnt((size_t)n, 0);
+    std::vector<int> rc((size_t)n, CCAL_OK);
+    for_each_shard(n, [&](int r) {
+        ccal_problem* p = mp->shard[(size_t)r];
+        rc[(size_t)r] = reprojection_errors_dev(p, intr, poses ? poses + 6 * (size_t)mp->first[(size_t)r] : nullptr, extr);
+        if (rc[(size_t)r] == CCAL_OK && camera_errors_device(p, cam, p->d_err, &d_part[(size_t)r], &cnt[(size_t)r], p->ctx->stream) != hipSuccess) rc[(size_t)r] = CCAL_ERR_HIP;
+    });
+    int64_t total = 0;
+    int bad = CCAL_OK;
+    for (int r = 0; r < n; ++r) { total += cnt[(size_t)r]; if (rc[(size_t)r] != CCAL_OK && bad == CCAL_OK) bad = rc[(size_t)r]; }
+    double* d_all = nullptr;
+    ccal_ctx* c0 = m->ctx[0];
+    if (bad == CCAL_OK && total <= 0) { bad = CCAL_ERR_INVALID_ARG; m->err = "camera has no observations"; }
+    if (bad == CCAL_OK && (hipSetDevice(c0->device) != hipSuccess || hipMalloc((void**)&d_all, (size_t)total * sizeof(double)) != hipSuccess)) bad = CCAL_ERR_HIP;
+    if (bad == CCAL_OK) {
+        int64_t at = 0;
+        for (int r = 0; r < n && bad == CCAL_OK; ++r) {          // shard order = slot order: the single-GPU gather's order
+            if (!cnt[(size_t)r]) continue;
+            if (hipMemcpy(d_all + at, d_part[(size_t)r], (size_t)cnt[(size_t)r] * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) bad = CCAL_ERR_HIP;
+            at += cnt[(size_t)r];
+        }
+    }
+    if (bad == CCAL_OK && sorted_stats_device(d_all, total, avg_99_percent, median, c0->stream) != hipSuccess) bad = CCAL_ERR_HIP;
+    for (int r = 0; r < n; ++r) if (d_part[(size_t)r]) { (void)hipSetDevice(mp->shard[(size_t)r]->ctx->device); (void)hipFree(d_part[(size_t)r]); }
+    if (d_all) { (void)hipSetDevice(c0->device); (void)hipFree(d_all); }
+    if (bad == CCAL_ERR_HIP) m->err = "ccal_multi_validation: a HIP call failed";
+    return bad;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+
+// Per-corner reprojection errors in the CALLER's corner order (the order of the description handed to ccal_multi_problem_create).
+int ccal_multi_reprojection_errors(ccal_multi_problem* mp, const double* intr, const double* poses, const double* extr, double* err_out,
+                                   const int64_t* obs_offsets /* the description's [n_obs + 1] */) {
+    if (!mp || !intr || (!poses && mp->n_slots) || (!extr && mp->n_cams > 1) || !err_out || !obs_offsets) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    const int n = (int)mp->shard.size();
+    std::vector<int> rc((size_t)n, CCAL_OK);
+    std::vector<std::vector<double>> part((size_t)n);
+    for (int r = 0; r < n; ++r) part[(size_t)r].assign((size_t)std::max<int64_t>(ccal_num_corners(mp->shard[(size_t)r]), 1), 0.0);
+    for_each_shard(n, [&](int r) {
+        rc[(size_t)r] = ccal_reprojection_errors(mp->shard[(size_t)r], intr, poses ? poses + 6 * (size_t)mp->first[(size_t)r] : nullptr, extr, part[(size_t)r].data());
+    });
+    for (int r = 0; r < n; ++r) {
+        if (rc[(size_t)r] != CCAL_OK) return mfail(mp->m, rc[(size_t)r], ccal_last_error(mp->m->ctx[(size_t)r]));
+        int64_t at = 0;
+        for (int32_t o : mp->obs_of[(size_t)r]) {
+            const int64_t c = obs_offsets[o + 1] - obs_offsets[o];
+            std::memcpy(err_out + obs_offsets[o], &part[(size_t)r][(size_t)at], (size_t)c * sizeof(double));
+            at += c;
+        }
+    }
+    return CCAL_OK;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+
 int ccal_multi_solve(ccal_multi_problem* mp, const ccal_solver_opts* o, double* intr_io, double* poses_io, double* extr_io, ccal_report* rep) {
     if (!mp || !o || !intr_io || (!poses_io && mp->n_slots) || (!extr_io && mp->n_cams > 1)) return CCAL_ERR_INVALID_ARG;
     ccal_multi* m = mp->m;

@@ -257,6 +257,23 @@ class MultiProblem:
                                                    used.ctypes.data_as(C.POINTER(C.c_int32))), "ccal_multi_init_poses")
         return poses[:self.n_obs], used[:self.n_obs]
 
+    def validation(self, cam, intr, poses, extr=None):
+        """validation() statistics (avg of the lowest 99 %, median) over the shards: bit-identical to Problem.validation."""
+        intr, poses, extr = self._params(intr, poses, extr)
+        a = C.c_double(); m = C.c_double()
+        self._check(self.lib.ccal_multi_validation(self.handle, cam, _dp(intr), _dp(poses), _dp(extr), C.byref(a), C.byref(m)),
+                    "ccal_multi_validation")
+        return a.value, m.value
+
+    def reprojection_errors(self, intr, poses, extr=None):
+        """Per-corner Euclidean reprojection errors in the corner order of the description this problem was made from."""
+        intr, poses, extr = self._params(intr, poses, extr)
+        offs = self._keep["obs_offsets"]
+        e = np.empty(int(offs[-1]))
+        self._check(self.lib.ccal_multi_reprojection_errors(self.handle, _dp(intr), _dp(poses), _dp(extr), _dp(e),
+                                                            offs.ctypes.data_as(C.POINTER(C.c_int64))), "ccal_multi_reprojection_errors")
+        return e
+
     def solve(self, intr, poses, extr=None, opts: _ffi.SolverOpts | None = None, raise_on_error=True):
         """ccal_multi_solve: ONE call, every GPU of the set; poses in the caller's slot order."""
         intr, poses, extr = self._params(intr, poses, extr)

@@ -312,6 +312,12 @@ int ccal_multi_disable_distortions(ccal_multi_problem* mp, int n_disabled, doubl
 int ccal_multi_init_poses(ccal_multi_problem* mp, const double* intr, int min_points, double* poses_obs, int32_t* n_used);
 int ccal_multi_upload_params(ccal_multi_problem* mp, const double* intr, const double* poses /* [n_slots][6], all slots */, const double* extr);
 int ccal_multi_eval_dev(ccal_multi_problem* mp, int apply_loss, double* const* r_dev, double* const* J_dev);   /* per shard device buffers; no collective */
+/* validation() (src/util.rs:721-795) over the shards: the same statistics, bit for bit, as ccal_validation on one GPU */
+int ccal_multi_validation(ccal_multi_problem* mp, int cam, const double* intr, const double* poses, const double* extr,
+                          double* avg_99_percent, double* median);
+int ccal_multi_reprojection_errors(ccal_multi_problem* mp, const double* intr, const double* poses, const double* extr,
+                                   double* err_out /* [n_corners], the description's corner order */,
+                                   const int64_t* obs_offsets /* the description's obs_offsets [n_obs + 1] */);
 int ccal_multi_solve(ccal_multi_problem* mp, const ccal_solver_opts* opts,
                      double* intr_io, double* poses_io /* [n_slots][6], all slots */, double* extr_io, ccal_report* report);
 

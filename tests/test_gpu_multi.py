@@ -70,7 +70,10 @@ def _child_multi(q, devices, cases):
             i2, p2, e2, r2 = mpb.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method), raise_on_error=False)
             out.append((i2, p2, e2, (r2.status, r2.iterations, r2.lm_accepted, r2.lm_rejected, r2.lm_spec_misses, r2.final_cost, r2.initial_cost)))
         po2, nu2 = mpb.init_poses(sp.intr0)
-        results.append(dict(transport=mc.transport, ranges=ranges, n_slots=sp.n_slots,
+        # validation() statistics and per-corner errors over the shards against the single-GPU entry points (same bits)
+        val = [(full.validation(c, i1, p1, e1), mpb.validation(c, i1, p1, e1)) for c in range(n_cams)] if r1.status in (0, 5) else []
+        errs = (full.reprojection_errors(i1, p1, e1), mpb.reprojection_errors(i1, p1, e1)) if r1.status in (0, 5) else None
+        results.append(dict(transport=mc.transport, ranges=ranges, n_slots=sp.n_slots, val=val, errs=errs,
                             single=(i1, p1, e1, (r1.status, r1.iterations, r1.lm_accepted, r1.lm_rejected, r1.lm_spec_misses, r1.final_cost, r1.initial_cost)),
                             multi=out, init=(po1, nu1, po2, nu2)))
         mpb.close(); full.close()
@@ -120,6 +123,10 @@ def _check_against_single(res, n_slots, expect_transport, method):
     po1, nu1, po2, nu2 = res["init"]
     np.testing.assert_array_equal(nu1, nu2)                 # pose initialisation is per frame: the same bits, caller's order
     np.testing.assert_array_equal(po1, po2)
+    for one, many in res["val"]:
+        assert one == many                                  # the same values meet one sort and one reduction: bit for bit
+    if res["errs"] is not None:
+        np.testing.assert_array_equal(res["errs"][0], res["errs"][1])
 
 
 PLAIN = [("plain", "eucm", 1, 0, False), ("plain", "eucm", 1, 1, False), ("plain", "kb4", 1, 0, True), ("plain", "eucm", 2, 0, False),
