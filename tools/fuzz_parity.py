@@ -5,13 +5,17 @@ import argparse, json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from camera_intrinsic_calibration_rs_amd import synth, _ffi
-from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts, CcalError
+from camera_intrinsic_calibration_rs_amd.engine import Context, MultiContext, MultiProblem, Problem, default_opts, CcalError
 from oracle import binding as ob
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=60.0)
 ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--shards", type=int, default=0, help="also solve every case through ccal_multi_solve over this many shards of GPU 0 "
+                "(in-process transport) and hold it against the unsharded device solve: verdict, iterations, intrinsics")
 args = ap.parse_args()
+mctx = MultiContext([0] * args.shards) if args.shards > 1 else None
+worst_sh = {"intr": 0.0, "poses": 0.0}; n_sh = 0
 rng = np.random.default_rng(args.seed)
 ctx = Context(0)
 t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []; both_none = []
@@ -48,7 +52,8 @@ while time.time() - t0 < args.seconds:
         lam = float(rng.choice([0.0, 1e-4]))
         S, b, c = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam); So, bo, co = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
         worst["S"] = max(worst["S"], float(np.abs(S - So).max() / np.abs(So).max()))
-        if rng.integers(0, 2):
+        bounds = bool(rng.integers(0, 2))
+        if bounds:
             gp.apply_reference_bounds(); op.apply_reference_bounds()
         method = int(rng.integers(0, 2))
         o = default_opts(method)
@@ -57,6 +62,24 @@ while time.time() - t0 < args.seconds:
         except CcalError as e:
             g = None; gs = (e.code, -1)
         orc = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=o); os_ = (orc[3].status, orc[3].iterations)
+        if mctx is not None:
+            mp = MultiProblem.from_synth(mctx, sp)
+            if bounds:
+                mp.apply_reference_bounds()
+            try:
+                m = mp.solve(sp.intr0, sp.poses0, sp.extr0, opts=o); ms = (m[3].status, m[3].iterations)
+            except CcalError as e:
+                m = None; ms = (e.code, -1)
+            mp.close(); n_sh += 1
+            if ms[0] != gs[0] or (gs[0] == 0 and ms[1] != gs[1]):
+                # a verdict that differs between the sharded and the unsharded DEVICE solve (summation order can move a marginal
+                # convergence test by one iteration on a flat optimum: reported, judged with the deviations below)
+                fails.append(dict(case=case, what="sharded vs unsharded verdict", sharded=ms, unsharded=gs, method=method))
+            elif gs[0] == 0:
+                dsi = float((np.abs(m[0] - g[0]) / np.maximum(np.abs(g[0]), 1e-3)).max()); dsp = float(np.abs(m[1] - g[1]).max())
+                worst_sh["intr"] = max(worst_sh["intr"], dsi); worst_sh["poses"] = max(worst_sh["poses"], dsp)
+                if dsi > 1e-7 or dsp > 1e-7:
+                    fails.append(dict(case=case, what="sharded vs unsharded result", d_intr=dsi, d_poses=dsp, method=method))
         if g is None or gs[0] != 0 or os_[0] != 0:
             if (gs[0] == 0) != (os_[0] == 0):
                 fails.append(dict(case=case, what="one side solved, the other did not", gpu=gs, oracle=os_))
@@ -72,5 +95,5 @@ while time.time() - t0 < args.seconds:
     except Exception as e:  # noqa: BLE001
         fails.append(dict(case=case, what="exception", err=repr(e)))
     gp.close(); n += 1
-print(json.dumps(dict(cases=n, worst=worst, n_fail=len(fails), fails=fails[:6], n_both_none_different_code=len(both_none),
+print(json.dumps(dict(cases=n, worst=worst, sharded_cases=n_sh, shards=args.shards, worst_sharded_vs_unsharded=worst_sh, n_fail=len(fails), fails=fails[:6], n_both_none_different_code=len(both_none),
                       both_none=both_none[:3]), indent=1))
