@@ -1016,9 +1016,13 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
     }
     std::vector<int> rc((size_t)n, CCAL_ERR_HIP);
     std::vector<ccal_report> reps((size_t)n);
+    // test hook (tests/test_gpu_multi.py): CCAL_TEST_FAIL_SHARD=r makes shard r fail before it enqueues anything - its peers are
+    // then inside the step's collective with no partner, which is what the transport's abort / timeout path is for
+    const int fail_shard = [] { const char* e = std::getenv("CCAL_TEST_FAIL_SHARD"); return e ? std::atoi(e) : -1; }();
     auto run = [&](int i) noexcept {
         try {
-            rc[i] = solve_entry(ps[i], o, true, &intr[i * ni], poses_io ? poses_io[i] : nullptr, &extr[i * ne], &reps[i]);
+            if (i == fail_shard) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "injected failure (CCAL_TEST_FAIL_SHARD)"); }
+            else rc[i] = solve_entry(ps[i], o, true, &intr[i * ni], poses_io ? poses_io[i] : nullptr, &extr[i * ne], &reps[i]);
         } catch (const std::bad_alloc&) { rc[i] = CCAL_ERR_NO_MEMORY; note_error(ps[i]->ctx, "out of host memory");
         } catch (...) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "C++ exception in ccal_solve_sharded"); }
         if (!verdict(rc[i]) && inproc) inproc_abort(inproc);      // the peers wait for this rank in the host barrier

@@ -245,3 +245,37 @@ def test_calib_camera_over_several_shards(devset):
         assert sorted(posa) == sorted(posb) and 7 not in posb
         for k in posa:
             np.testing.assert_allclose(posb[k], posa[k], rtol=0, atol=1e-9)
+
+
+def _child_abort(q, devices):
+    """A shard that fails must not hang its peers: the in-process transport's abort releases them, the call returns an error, and
+    the SAME device set solves again afterwards (ccal_multi_solve drains the devices and resets the transport)."""
+    sys.path.insert(0, ROOT)
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.engine import CcalError, MultiContext, MultiProblem, default_opts
+    sp = synth.make_problem(30, "eucm", seed=3)
+    mc = MultiContext(devices)
+    mpb = MultiProblem.from_synth(mc, sp)
+    ok0 = mpb.solve(sp.intr0, sp.poses0, opts=default_opts(0))
+    codes = []
+    for bad in range(len(devices)):
+        os.environ["CCAL_TEST_FAIL_SHARD"] = str(bad)
+        try:
+            mpb.solve(sp.intr0, sp.poses0, opts=default_opts(0, timeout_s=20))
+            codes.append(0)
+        except CcalError as e:
+            codes.append(e.code)
+        finally:
+            del os.environ["CCAL_TEST_FAIL_SHARD"]
+        again = mpb.solve(sp.intr0, sp.poses0, opts=default_opts(0))
+        codes.append((again[3].status, bool(np.array_equal(again[0], ok0[0]) and np.array_equal(again[1], ok0[1]))))
+    q.put(dict(codes=codes, err=mc.last_error()))
+    mpb.close(); mc.close()
+
+
+def test_a_failing_shard_does_not_hang_the_others():
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    res = _run_child(_child_abort, ([0, 0, 0],), timeout=240)
+    for k in range(3):
+        assert res["codes"][2 * k] == _ffi.ERR_HIP                       # the call comes back with an error, promptly
+        assert res["codes"][2 * k + 1] == (0, True)                      # and the device set still solves, bit for bit as before
