@@ -246,9 +246,10 @@ int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out) {
             m->comms.assign((size_t)n_dev, nullptr);
             std::string err;
             const int rc = rccl_comm_init_all(device_ids, n_dev, m->comms.data(), &err);
-            if (rc != CCAL_OK) { m->comms.clear(); return bail(rc); }
-            m->transport = CCAL_TRANSPORT_RCCL;
-        } else {
+            if (rc == CCAL_OK) m->transport = CCAL_TRANSPORT_RCCL;
+            else m->comms.clear();                         // (falls through to the in-process transport: peer access may still do)
+        }
+        if (m->transport == CCAL_TRANSPORT_NONE) {
             std::string err;
             m->inproc = inproc_create(n_dev, device_ids, &err);
             if (!m->inproc) return bail(CCAL_ERR_UNSUPPORTED);

@@ -499,6 +499,9 @@ struct SolveJob {
     long spins = 0;
     bool finished = false, enqueued_any = false;
     double timeout_s = 30.0;
+    // single-process sharded solves: raised by the first shard that fails with something other than the solver's verdicts; its
+    // peers - whose collectives will never find their partner - stop waiting at their next look instead of at the timeout
+    const std::atomic<int>* cancel = nullptr;
     SolveJob(ccal_problem* p_, const ccal_solver_opts* o_, bool hio, double* i, double* po, double* e)
         : p(p_), o(o_), host_io(hio), intr_io(i), poses_io(po), extr_io(e), ctx(p_->ctx), w(p_->nws), st(p_->ctx->stream) {}
     virtual ~SolveJob() {}
@@ -525,6 +528,7 @@ struct SolveJob {
     int poll(bool* fin) {
         *fin = finished;
         if (finished) return CCAL_OK;
+        if (cancel && cancel->load(std::memory_order_acquire)) { ctx->err = "sharded solve: a peer shard failed"; return fail_enqueued(CCAL_ERR_HIP); }
         int rc = fill();
         if (rc != CCAL_OK) return rc;
         if (pending.empty()) { finished = true; *fin = true; return CCAL_OK; }
@@ -859,12 +863,13 @@ static std::unique_ptr<SolveJob> make_job(ccal_problem* p, const ccal_solver_opt
     return std::unique_ptr<SolveJob>(new GeneralJob(p, o, host_io, intr_io, poses_io, extr_io));
 }
 static int solve_entry(ccal_problem* p, const ccal_solver_opts* o, bool host_io, double* intr_io, double* poses_io, double* extr_io,
-                       ccal_report* rep) {
+                       ccal_report* rep, const std::atomic<int>* cancel = nullptr) {
     ccal_ctx* ctx = p->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     auto job = make_job(p, o, host_io, intr_io, poses_io, extr_io);
+    job->cancel = cancel;
     if ((rc = job->begin()) != CCAL_OK) return rc;
     bool fin = false;
     while (!fin) if ((rc = job->poll(&fin)) != CCAL_OK) return rc;
@@ -1019,13 +1024,20 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
     // test hook (tests/test_gpu_multi.py): CCAL_TEST_FAIL_SHARD=r makes shard r fail before it enqueues anything - its peers are
     // then inside the step's collective with no partner, which is what the transport's abort / timeout path is for
     const int fail_shard = [] { const char* e = std::getenv("CCAL_TEST_FAIL_SHARD"); return e ? std::atoi(e) : -1; }();
+    std::atomic<int> cancel{0};
     auto run = [&](int i) noexcept {
         try {
             if (i == fail_shard) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "injected failure (CCAL_TEST_FAIL_SHARD)"); }
-            else rc[i] = solve_entry(ps[i], o, true, &intr[i * ni], poses_io ? poses_io[i] : nullptr, &extr[i * ne], &reps[i]);
+            else rc[i] = solve_entry(ps[i], o, true, &intr[i * ni], poses_io ? poses_io[i] : nullptr, &extr[i * ne], &reps[i], &cancel);
         } catch (const std::bad_alloc&) { rc[i] = CCAL_ERR_NO_MEMORY; note_error(ps[i]->ctx, "out of host memory");
         } catch (...) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "C++ exception in ccal_solve_sharded"); }
-        if (!verdict(rc[i]) && inproc) inproc_abort(inproc);      // the peers wait for this rank in the host barrier
+        if (!verdict(rc[i])) {
+            // this shard has left the shared sequence of collectives: its peers must not wait for it - neither in the in-process
+            // transport's host barrier nor, with RCCL, for a step whose ncclAllReduce will never find its partner (the caller
+            // aborts the communicators once every thread is back)
+            cancel.store(1, std::memory_order_release);
+            if (inproc) inproc_abort(inproc);
+        }
     };
     std::vector<ccal_ctx_worker*> busy;
     busy.reserve((size_t)n);
@@ -1042,7 +1054,9 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
     }
     run(0);
     for (ccal_ctx_worker* wk : busy) wk->wait();
+    // the shard that failed FIRST is the one to report (its peers then gave up with "a peer shard failed")
     int first_bad = -1;
+    for (int i = 0; i < n && first_bad < 0; ++i) if (!verdict(rc[i]) && ps[i]->ctx->err != "sharded solve: a peer shard failed") first_bad = i;
     for (int i = 0; i < n && first_bad < 0; ++i) if (!verdict(rc[i])) first_bad = i;
     if (first_bad >= 0) {
         if (first_bad != 0) note_error(ps[0]->ctx, (std::string("shard ") + std::to_string(first_bad) + ": " + ps[first_bad]->ctx->err).c_str());

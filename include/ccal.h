@@ -278,7 +278,10 @@ int ccal_solve_batch(ccal_problem** problems, int n, const ccal_solver_opts* opt
  *   different and RCCL can be resolved, the in-process transport otherwise (a device listed twice: two shards on one GPU).
  *   ccal_multi_problem_create takes the SAME description as ccal_problem_create and cuts it into contiguous slot ranges
  *   balanced by corner count; poses / poses_obs / n_used keep the caller's slot and observation-frame order.
- * Errors: as for sharded solves above.  After an error other than the solver's verdicts a ccal_multi with the in-process
+ * Threading: like a ccal_ctx, a ccal_multi (and its problems) is single-caller; the host threads that drive the devices inside a
+ * call are the library's own.
+ * Errors: as for sharded solves above.  A shard that fails raises a flag its peers see at their next look at the status word: they
+ * stop waiting at once (not at the timeout).  After an error other than the solver's verdicts a ccal_multi with the in-process
  * transport recovers by itself; with RCCL its communicators are aborted and every later ccal_multi_solve on it fails
  * (CCAL_ERR_HIP): destroy it and create a new one. */
 #define CCAL_MULTI_MAX_DEVICES 16
