@@ -62,3 +62,11 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("load() must raise when the HIP library is missing")
+
+
+def test_integration_stub_lists_every_entry_point():
+    """INTEGRATION.md's Rust `extern "C"` block (what a maintainer of the reference pastes into src/gpu/ffi.rs) names every
+    function include/ccal.h declares."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [d for d in _declared() if f"fn {d}(" not in doc]
+    assert not missing, missing
