@@ -232,8 +232,21 @@ def _child_api(q, devices):
     many = api.calib_camera(frames, cam, False, 0, False, devices=devices)
     ff = api.calib_camera(frames, cam, True, 0, True)
     ffm = api.calib_camera(frames, cam, True, 0, True, devices=devices)
+    # the joint two-camera solve (calib_all_camera_with_extrinsics, src/util.rs:567-715) and validation() over the same shards
+    rig = synth.make_problem(30, "eucm", n_cams=2, seed=10, ragged=True)
+    fr = [api.frames_from_synth(rig, c) for c in range(2)]
+    cams = [api.GenericModel("eucm", rig.intr0[c, :6], 512, 512) for c in range(2)]
+    per_cam = [api.calib_camera(fr[c], cams[c], False, 0, False) for c in range(2)]
+    rt = [pc[1] for pc in per_cam]
+    t_i_0 = api.init_camera_extrinsic(rt)
+    j1 = api.calib_all_camera_with_extrinsics([pc[0] for pc in per_cam], t_i_0, rt, fr, False, 0, False)
+    jm = api.calib_all_camera_with_extrinsics([pc[0] for pc in per_cam], t_i_0, rt, fr, False, 0, False, devices=devices)
+    v1 = api.validation(0, j1[0][0], j1[2], fr[0])
+    vm = api.validation(0, j1[0][0], j1[2], fr[0], devices=devices)
     q.put(dict(one=(one[0].params(), {k: v.as6() for k, v in one[1].items()}), many=(many[0].params(), {k: v.as6() for k, v in many[1].items()}),
-               ff=(ff[0].params(), {k: v.as6() for k, v in ff[1].items()}), ffm=(ffm[0].params(), {k: v.as6() for k, v in ffm[1].items()})))
+               ff=(ff[0].params(), {k: v.as6() for k, v in ff[1].items()}), ffm=(ffm[0].params(), {k: v.as6() for k, v in ffm[1].items()}),
+               joint=([m.params() for m in j1[0]], [t.as6() for t in j1[1]]), joint_multi=([m.params() for m in jm[0]], [t.as6() for t in jm[1]]),
+               val=(v1, vm)))
 
 
 @pytest.mark.parametrize("devset", _device_sets()[:1] + _device_sets()[2:], ids=lambda d: d[0])
@@ -245,6 +258,11 @@ def test_calib_camera_over_several_shards(devset):
         assert sorted(posa) == sorted(posb) and 7 not in posb
         for k in posa:
             np.testing.assert_allclose(posb[k], posa[k], rtol=0, atol=1e-9)
+    for a1, a2 in zip(res["joint"][0], res["joint_multi"][0]):
+        np.testing.assert_allclose(a2, a1, rtol=1e-9, atol=1e-12)
+    for a1, a2 in zip(res["joint"][1], res["joint_multi"][1]):
+        np.testing.assert_allclose(a2, a1, rtol=0, atol=1e-10)
+    assert res["val"][0] == res["val"][1]
 
 
 def _child_abort(q, devices):
