@@ -237,10 +237,12 @@ int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out) {
         const int rc = ccal_ctx_create(device_ids[i], nullptr, &m->ctx[i]);
         if (rc != CCAL_OK) return bail(rc);
     }
-    if (n_dev > 1) {
+    const char* force = std::getenv("CCAL_MULTI_TRANSPORT");              // developer switch: "inproc" keeps RCCL out of it; "rccl" asks
+                                                                          // for communicators even for ONE device (the 1-GPU test box
+                                                                          // runs ncclCommInitAll and the library-issued collective so)
+    if (n_dev > 1 || (force && force[0] == 'r')) {
         bool distinct = true;
         for (int i = 0; i < n_dev; ++i) for (int k = 0; k < i; ++k) distinct = distinct && device_ids[i] != device_ids[k];
-        const char* force = std::getenv("CCAL_MULTI_TRANSPORT");          // developer switch: "inproc" keeps RCCL out of it
         const bool want_rccl = distinct && ccal_rccl_available() && !(force && force[0] == 'i');
         if (want_rccl) {
             m->comms.assign((size_t)n_dev, nullptr);
@@ -249,7 +251,7 @@ int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out) {
             if (rc == CCAL_OK) m->transport = CCAL_TRANSPORT_RCCL;
             else m->comms.clear();                         // (falls through to the in-process transport: peer access may still do)
         }
-        if (m->transport == CCAL_TRANSPORT_NONE) {
+        if (m->transport == CCAL_TRANSPORT_NONE && n_dev > 1) {
             std::string err;
             m->inproc = inproc_create(n_dev, device_ids, &err);
             if (!m->inproc) return bail(CCAL_ERR_UNSUPPORTED);

@@ -297,3 +297,33 @@ def test_a_failing_shard_does_not_hang_the_others():
     for k in range(3):
         assert res["codes"][2 * k] == _ffi.ERR_HIP                       # the call comes back with an error, promptly
         assert res["codes"][2 * k + 1] == (0, True)                      # and the device set still solves, bit for bit as before
+
+
+def _child_rccl_one(q):
+    """ncclCommInitAll + the library-issued ncclAllReduce on the one GPU of the box: ccal_multi_create([0]) under
+    CCAL_MULTI_TRANSPORT=rccl makes a 1-rank communicator the way it makes n of them on a multi-GPU node."""
+    sys.path.insert(0, ROOT)
+    os.environ["CCAL_MULTI_TRANSPORT"] = "rccl"
+    from camera_intrinsic_calibration_rs_amd import _ffi, synth
+    from camera_intrinsic_calibration_rs_amd.engine import Context, MultiContext, MultiProblem, Problem, default_opts
+    out = []
+    mc = MultiContext([0])
+    for model, n_cams, method in (("eucm", 1, 0), ("eucm", 2, 1)):
+        sp = synth.make_problem(40, model, n_cams=n_cams, seed=12, ragged=True)
+        full = Problem.from_synth(Context(0), sp)
+        a = full.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        mpb = MultiProblem.from_synth(mc, sp)
+        b = mpb.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+        out.append((a[0], a[1], a[3].iterations, a[3].final_cost, b[0], b[1], b[3].iterations, b[3].final_cost))
+        mpb.close(); full.close()
+    q.put(dict(transport=mc.transport, out=out))
+    mc.close()
+
+
+def test_in_process_rccl_communicators_on_one_gpu():
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    res = _run_child(_child_rccl_one, ())
+    assert res["transport"] == _ffi.TRANSPORT_RCCL
+    for ia, pa, ita, ca, ib, pb, itb, cb in res["out"]:
+        assert ita == itb and ca == cb                       # a 1-rank sum is the identity: bit for bit
+        np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(pa, pb)
