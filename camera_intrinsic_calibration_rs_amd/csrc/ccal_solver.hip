@@ -1024,7 +1024,7 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
     // test hook (tests/test_gpu_multi.py): CCAL_TEST_FAIL_SHARD=r makes shard r fail before it enqueues anything - its peers are
     // then inside the step's collective with no partner, which is what the transport's abort / timeout path is for
     const int fail_shard = [] { const char* e = std::getenv("CCAL_TEST_FAIL_SHARD"); return e ? std::atoi(e) : -1; }();
-    std::atomic<int> cancel{0};
+    std::atomic<int> cancel{0}, first_failed{-1};        // first_failed: the shard that raised `cancel` (its peers fail BECAUSE of it)
     auto run = [&](int i) noexcept {
         try {
             if (i == fail_shard) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "injected failure (CCAL_TEST_FAIL_SHARD)"); }
@@ -1035,7 +1035,8 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
             // this shard has left the shared sequence of collectives: its peers must not wait for it - neither in the in-process
             // transport's host barrier nor, with RCCL, for a step whose ncclAllReduce will never find its partner (the caller
             // aborts the communicators once every thread is back)
-            cancel.store(1, std::memory_order_release);
+            int none = 0;
+            if (cancel.compare_exchange_strong(none, 1, std::memory_order_acq_rel)) first_failed.store(i, std::memory_order_release);
             if (inproc) inproc_abort(inproc);
         }
     };
@@ -1055,8 +1056,7 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
     run(0);
     for (ccal_ctx_worker* wk : busy) wk->wait();
     // the shard that failed FIRST is the one to report (its peers then gave up with "a peer shard failed")
-    int first_bad = -1;
-    for (int i = 0; i < n && first_bad < 0; ++i) if (!verdict(rc[i]) && ps[i]->ctx->err != "sharded solve: a peer shard failed") first_bad = i;
+    int first_bad = first_failed.load(std::memory_order_acquire);
     for (int i = 0; i < n && first_bad < 0; ++i) if (!verdict(rc[i])) first_bad = i;
     if (first_bad >= 0) {
         if (first_bad != 0) note_error(ps[0]->ctx, (std::string("shard ") + std::to_string(first_bad) + ": " + ps[first_bad]->ctx->err).c_str());
