@@ -1337,6 +1337,15 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
     const bool lm = st->method == CCAL_METHOD_LM;
     if (lane == 0) hs.solve = optimizer_decide(st, Ad[K * K1 + K], red[2 * K1 * K1], red[2 * K1 * K1 + 1] > 0.0, a.seq) ? 1 : 0;
     wsync();
+    // A group that does NOT finish the solve tells the host so as soon as that is certain - after the decision for a group that
+    // does not solve (a re-elimination follows), after the camera factorisation otherwise (Gauss-Newton ends the solve there when
+    // the system is not positive definite: what the host reads for a group must not depend on WHEN it looks, or sharded ranks
+    // would enqueue different numbers of collectives).  The word only says "group seq has decided, go on": the host answers by
+    // enqueueing a later group behind the ones already in the stream, nothing it does depends on what this kernel still writes,
+    // and the store's trip across the bus overlaps the rest of the kernel instead of sitting in front of its end.  A finishing
+    // group publishes last (its report and result must be complete first); so does a verbose solve's full report.
+    bool early_publish = false;
+    if (!st->done && !a.publish_all && !hs.solve) { early_publish = true; if (lane == 0) a.hs->word = status_word(a.seq, 0, 0); }
     if (hs.solve) {
         const double lambda = st->lambda;
         const int cur = st->cur;
@@ -1374,6 +1383,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             }
             if (lane < K) a.dc[lane] = 0.0;
         }
+        if (!st->done && !a.publish_all) { early_publish = true; if (lane == 0) a.hs->word = status_word(a.seq, 0, 0); }      // (st->done: set just above, GN only)
         if (!bad || lm) {
             // candidate intrinsics = clamp(x + dc) into the other set; model decrease of the camera block
             double* dst = a.intr[cur ^ 1];
@@ -1416,7 +1426,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
         __threadfence_system();
     }
     wsync();
-    if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
+    if (lane == 0 && !early_publish) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
 }
 // ccal_build_normal_dev on a single camera: evaluate set 0 as a first evaluation (no pose update) with this damping
 __global__ void k_state_eval(DevState* st, double lambda) {
