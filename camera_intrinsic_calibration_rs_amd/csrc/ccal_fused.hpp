@@ -182,6 +182,86 @@ __device__ __forceinline__ double schur_lambda(const DevState* st) {
     return (st->method == CCAL_METHOD_LM && !st->first && !st->redo) ? st->lambda_spec : st->lambda;
 }
 
+// Single-launch groups (round 4; session sizes - the launcher decides, fused_iter_rows): k_gram1v<.., ITER> sums the PREVIOUS
+// launch's rows of partial sums itself (every workgroup, the same rows in the same order), takes the decision and solves the
+// camera system in front of its own evaluation (every workgroup the same arithmetic on the same sums: the same decision, the
+// same candidate, bit for bit; workgroup 0 alone writes state, candidate, status word and result).  A group is ONE launch
+// instead of Gram + reduce + head: two kernel boundaries (~3 us each) less per step.  What a launch reads and what the same
+// launch's workgroup 0 writes must not alias - another workgroup may start later: the state and the rows alternate between
+// two buffers by launch number.
+struct IterArgs {
+    int32_t on;                    // this launch is of the single-launch form
+    int32_t skip_head;             // the solve's first launch: no sums to decide on yet, the state passes through
+    int32_t seq, publish_all;
+    const DevState* st_in; DevState* st_out;
+    const double* partial_in; int32_t n_part_in;       // the previous launch's rows (this launch's go to FusedArgs::partial)
+    HostStatus* hs; const ColInfo* cols; double* dc_out;
+    double* result_host; int64_t np6;                  // see HeadArgs
+};
+
+// A workgroup's row of partial sums in the single-launch form: the two symmetric blocks as their upper triangles (the mirrored
+// entries are the same sums bit for bit: 58 doubles instead of 100 for six camera columns - every workgroup reads every row),
+//   [A_dir (i <= j) | Y^T Y (i <= j) | mc_pose | failed pose blocks]
+__host__ __device__ constexpr int iter_row_len(int K) { return (K + 1) * (K + 2) + 2; }
+// packed entry -> entry of the full row [A_dir (K1 x K1) | Y^T Y (K1 x K1) | mc_pose | failed] (fused_red_size)
+__host__ __device__ inline int iter_row_src(int K, int pe) {
+    const int K1 = K + 1, T = K1 * (K1 + 1) / 2, NA = K1 * K1;
+    if (pe >= 2 * T) return 2 * NA + (pe - 2 * T);
+    const int blk = pe >= T ? 1 : 0;
+    int t = pe - blk * T, i = 0;
+    while (t >= K1 - i) { t -= K1 - i; ++i; }            // row i holds K1 - i entries (j = i .. K)
+    return blk * NA + i * K1 + (i + t);
+}
+// Every workgroup (256 threads) of a single-launch group sums ALL rows of the launch before - the same rows in the same order in
+// every workgroup: lane = packed entry, the four wavefronts take the four contiguous quarters of the rows, 48 loads in flight per
+// lane (with 150 workgroups on the same lines an L2 round trip is ~1.3 us: the loop of reduce_partial_rows - four loads, wait,
+// add - took 5.3 us for 157 rows), four interleaved accumulators, combined in a fixed order; the full (mirrored) layout goes to
+// `red` in LDS, where head_wave expects it.
+template <int K>
+__device__ __forceinline__ void iter_reduce_rows(const double* partial, const int n_rows, double* red, double (*sh)[(iter_row_len(K) + 63) / 64][64]) {
+    constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, K1 = K + 1, NA = K1 * K1, B = NCH == 1 ? 48 : 24;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (n_rows + 3) >> 2, r0 = wv * per, r1 = min(n_rows, r0 + per);
+    double v[NCH][4];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { v[c][0] = 0.0; v[c][1] = 0.0; v[c][2] = 0.0; v[c][3] = 0.0; }
+    for (int r = r0; r < r1; r += B) {
+        double t[NCH][B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            const double* row = partial + (int64_t)min(r + i, r1 - 1) * PROW;       // (past the end: a valid row, not added)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) t[c][i] = row[min(c * 64 + lane, PROW - 1)];
+        }
+#pragma unroll
+        for (int i = 0; i < B; ++i) {
+            if (r + i < r1) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) v[c][i & 3] += t[c][i];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) sh[wv][c][lane] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int pe = c * 64 + lane;
+            if (pe < PROW) {
+                const double sum = (sh[0][c][lane] + sh[1][c][lane]) + (sh[2][c][lane] + sh[3][c][lane]);
+                const int e = iter_row_src(K, pe);
+                red[e] = sum;
+                if (e < 2 * NA) {                      // the mirrored entry
+                    const int blk = e >= NA ? 1 : 0, q = e - blk * NA, i = q / K1, j = q - i * K1;
+                    red[blk * NA + j * K1 + i] = sum;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 struct FusedArgs {
     const float* x; const float* y; const float* z; const float* u; const float* v;
     const int64_t* obs_off; const int32_t* obs_slot;
@@ -209,6 +289,7 @@ struct FusedArgs {
     // launch in front of the Gram kernel does the pose update and the exponential map and leaves the frame constants in
     // fcbuf [n_obs][FC_N0P]; the Gram kernel's prologue is then one coalesced read per frame
     int32_t prepass;
+    IterArgs it;
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:
@@ -282,6 +363,9 @@ struct UnpackArgs {               // the starting point of a single-camera solve
 hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
+// rows of partial sums (= workgroups) a single-launch group of this problem would have; 0: that form does not apply
+int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K);
+hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s);  // k_gram1v<.., ITER>; a.it filled in
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
 // ccal_kernels_gram2.hip: a corner's two rows on two lanes (row-local columns), same records, same fused tail
 hipError_t launch_gram2(int model, bool one_focal, FusedArgs& a, hipStream_t s);

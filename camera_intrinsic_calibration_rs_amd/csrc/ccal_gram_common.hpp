@@ -117,9 +117,10 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
 
 // Fused elimination (single-camera loop, k_gram1w): the wavefront that built G frames' Grams eliminates their pose blocks
 // itself - records in LDS at red + g GS (what k_schur1m loads from HBM), LPF lanes per frame - and writes ONE row of
-// partial sums per wavefront, [A_dir | Y^T Y | model decrease | failed blocks], frames added in a fixed order.
+// partial sums per wavefront, [A_dir | Y^T Y | model decrease | failed blocks], frames added in a fixed order, to `row`
+// (the wavefront's row of FusedArgs::partial; single-launch groups: a row in LDS that the workgroup adds up).
 template <int K, int LPF>
-__device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const DevState* st, double* red, const int wave_global,
+__device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const double lambda, double* red, double* row,
                                                 const int grp, const int gl, const bool lane_ok, const bool active, const int slot,
                                                 const int set, const double mcv) {
     constexpr int G = 64 / LPF, K1 = K + 1, NA = K1 * K1;
@@ -130,7 +131,7 @@ __device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const DevSta
     double accA[NQ], accY[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
-    const bool ok = eliminate_frame<K, LPF>(R, Ym, gl, active, schur_lambda(st), a.min_diag, a.max_diag,
+    const bool ok = eliminate_frame<K, LPF>(R, Ym, gl, active, lambda, a.min_diag, a.max_diag,
                                            a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY);
     wsync();
     if (lane_ok) {
@@ -147,7 +148,7 @@ __device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const DevSta
         double t = 0.0;
 #pragma unroll
         for (int g = 0; g < G; ++g) t += red[g * GS + e];
-        a.partial[(int64_t)wave_global * (2 * NA + 2) + e] = t;
+        row[e] = t;
     }
 }
 

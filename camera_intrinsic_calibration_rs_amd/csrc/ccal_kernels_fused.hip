@@ -21,6 +21,7 @@
 #include "ccal_device.hpp"
 #include "ccal_fused.hpp"
 #include "ccal_gram_common.hpp"
+#include "ccal_head.hpp"
 
 namespace ccal {
 
@@ -264,8 +265,14 @@ template <bool OF> __device__ constexpr bool nz_v(int i) { return OF ? (i != 1) 
 // stands (k_backsub has formed it) and composed with the camera's extrinsics (frame_setup_composed): the six pose columns
 // are those of the COMPOSED pose, in the phi basis, for every camera; the record goes to the observation frame's place in
 // the Gram buffer (a.rec_off) together with the blocks of the matrix that expands it to the block's reference columns.
-template <int MODEL, bool OF, int LPF, bool GEN>
-__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedArgs a) {
+// ITER (single-camera loop, session sizes; IterArgs in ccal_fused.hpp): a group in ONE launch - four wavefronts per workgroup;
+// in front of the evaluation every workgroup sums the previous launch's rows (reduce_partial_rows: k_head's order), its first
+// wavefront decides and solves the camera system (head_wave), and the evaluation takes state, camera step and candidate
+// intrinsics from LDS; behind it the four wavefronts' rows of partial sums are added in LDS: one row per workgroup.
+template <int MODEL, bool OF, int LPF, bool GEN, bool ITER = false>
+__global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(const FusedArgs a) {
+    static_assert(!(ITER && GEN), "single-launch groups: single-camera loop only");
+    constexpr int WPB = ITER ? 4 : CCAL_GRAMV_WPB;
     constexpr int G = 64 / LPF;                     // frames per wavefront
     constexpr int D = block_dim(MODEL, OF, false);
     constexpr int K = D - 6, K1 = K + 1;
@@ -276,29 +283,90 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
     constexpr int WSL = G * FC_N0P + 64 * LS;           // per wave: G frames' constants | reduction buffer
     constexpr int NQ = (G * HALF + 63) / 64;        // (frame, entry) sums per lane and round
     extern __shared__ double smem[];
-    const DevState* st = a.st;
+#ifdef CCAL_STAMPS          // diagnostic build (tools/stamps_g1v.py): the phases of every wavefront, 8 stamps per wavefront in the per-frame scratch
+    long long ts[12] = {};
+    ts[0] = wall_clock64();
+#define G1V_STAMP(i) ts[i] = wall_clock64()
+#else
+#define G1V_STAMP(i)
+#endif
+    // what the evaluation needs of the optimizer state, in registers (the single-launch form decides in this kernel: LDS; else global)
+    struct { int done, redo, cur, first, method; double lambda_solve, lam_schur; } g;
+    constexpr int PROW = ITER ? iter_row_len(D - 6) : 1;       // ITER: a workgroup's row of partial sums, symmetric blocks packed
+    __shared__ double it_rows[ITER ? 4 : 1][ITER ? fused_red_size(D - 6) : 1];
+    __shared__ typename std::conditional<ITER, HeadShared, int>::type hsh;
+    bool from_lds = false;                          // ITER, not the first launch: state, camera step and candidate are in hsh
+    if constexpr (ITER) {
+        const IterArgs& it = a.it;
+        if (!it.skip_head) {
+            // (the rows are summed also for a solve that has finished: asking first would put a memory round trip in front of every group's loads)
+            __shared__ double shr[4][(PROW + 63) / 64][64];
+            iter_reduce_rows<D - 6>(it.partial_in, it.n_part_in, hsh.red, shr);
+            G1V_STAMP(7);                                   // the previous launch's rows are summed
+            HeadIO io;
+            io.st_in = it.st_in; io.st_out = it.st_out; io.hs = it.hs; io.red_g = nullptr; io.cols = it.cols;
+            io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = it.dc_out; io.K = D - 6; io.seq = it.seq;
+            io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = it.publish_all;
+            const bool writer = blockIdx.x == 0;
+            if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer);
+            __syncthreads();
+            G1V_STAMP(8);                                   // decided, camera system solved
+            head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer);
+            G1V_STAMP(9);
+            from_lds = true;
+            const DevState& S = hsh.S0;
+            g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;
+            g.lambda_solve = S.lambda_solve; g.lam_schur = schur_lambda(&S);
+        } else {
+            // the solve's first launch: the starting state passes through to the buffer the next launch reads
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                const double* src = reinterpret_cast<const double*>(it.st_in);
+                double* dst = reinterpret_cast<double*>(it.st_out);
+                for (int e = threadIdx.x; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+                if (threadIdx.x == 0) it.hs->word = status_word(it.seq, 0, 0);
+            }
+            const DevState* st = it.st_in;
+            g.done = st->done; g.redo = st->redo; g.cur = st->cur; g.first = st->first; g.method = st->method;
+            g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
+        }
+    } else {
+        const DevState* st = a.st;
+        g.done = st->done; g.redo = st->redo; g.cur = st->cur; g.first = st->first; g.method = st->method;
+        g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
+    }
+    // the four wavefronts' rows -> the workgroup's row (fixed order), the two symmetric blocks as their upper triangles
+    auto iter_row_out = [&]() {
+        if constexpr (ITER) {
+            __syncthreads();
+            if (threadIdx.x < 64) for (int pe = threadIdx.x; pe < PROW; pe += 64) {
+                const int e = iter_row_src(D - 6, pe);
+                a.partial[(int64_t)blockIdx.x * PROW + pe] = ((it_rows[0][e] + it_rows[1][e]) + it_rows[2][e]) + it_rows[3][e];
+            }
+        }
+    };
     // fused elimination (launch_gram1v_t decides): no separate elimination launch; a re-elimination group then runs here too
     const bool fuse = !GEN && a.fuse_elim != 0;
     // the records in HBM are what a re-elimination group reads: Gauss-Newton never has one, so a fused GN group skips the stores
-    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
-    if (st->done || (st->redo && !fuse)) return;            // finished, or a re-elimination group without fusion (no evaluation)
+    const bool keep_rec = GEN || !fuse || g.method == CCAL_METHOD_LM;
+    if (g.done || (g.redo && !fuse)) return;            // finished, or a re-elimination group without fusion (no evaluation)
+    G1V_STAMP(1);                                           // the state has arrived
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
     const bool lane_ok = lane < G * LPF;
     const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
-    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
+    const int f = (blockIdx.x * WPB + wave) * G + grp;
     const bool active = lane_ok && f < a.n_obs;
     const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
     const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
     double* red = fcw + G * FC_N0P;
-    const int cur = st->cur, first = st->first;
+    const int cur = g.cur, first = g.first;
     const int es = first ? cur : (cur ^ 1);
     if constexpr (!GEN) {
         constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
         static_assert(G * GS_ <= 64 * LS, "the frames' records fit the reduction buffer");
-        if (st->redo) {
+        if (g.redo) {
             // re-elimination group (LM: rejected step or missed speculation): the accepted set's stored records, new damping
             double* R = red + grp * GS_;
             double mcv = 0.0;
@@ -310,13 +378,18 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
                 if (gl == 0) mcv = a.mc_f[f];
             }
             wsync();
-            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_r, cur, mcv);
+            gram_fused_tail<K, LPF>(a, g.lam_schur, red, ITER ? it_rows[wave] : a.partial + (int64_t)(blockIdx.x * WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
+            iter_row_out();
             return;
         }
     }
-    const double* th_g = a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0);
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.rt, th);
+    if constexpr (ITER) {
+        if (from_lds) load_theta<MODEL, OF>(hsh.cand, a.rt, th);           // the candidate this launch has just formed
+        else load_theta<MODEL, OF>(a.intr[es], a.rt, th);
+    } else {
+        load_theta<MODEL, OF>(a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0), a.rt, th);
+    }
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
     float pX, pY, pZ, pU, pV;
@@ -334,6 +407,14 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         double mc = 0.0;
         if (!GEN && !first) {
             const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+            double dcr[K];                                  // the camera step
+            if constexpr (ITER) {
+#pragma unroll
+                for (int j = 0; j < K; ++j) dcr[j] = hsh.x[j];    // (not the first launch: this launch's own solve)
+            } else {
+#pragma unroll
+                for (int j = 0; j < K; ++j) dcr[j] = a.dc[j];
+            }
             if (pf[0] != 0.0) {
                 double dp[6];
 #pragma unroll
@@ -341,7 +422,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
                     const double* yr = pf + 21 + i * K1;
                     double t = yr[K];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                    for (int j = 0; j < K; ++j) t += yr[j] * dcr[j];
                     dp[i] = -t;
                 }
 #pragma unroll
@@ -351,7 +432,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
                     for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
                     dp[i] = t * pf[i * (i + 1) / 2 + i];
                 }
-                const double lam = st->lambda_solve;
+                const double lam = g.lambda_solve;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
@@ -395,6 +476,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         }
     }
     wsync();
+    G1V_STAMP(2);                                           // prologue done: frame constants in LDS
 
     double acc[NE];
 #pragma unroll
@@ -434,6 +516,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
         }
     }
 
+    G1V_STAMP(3);                                           // corner loop done
     // 16 partial Grams per frame -> one, through LDS, in two halves of the triangle
     double res[2][NQ];
 #pragma unroll
@@ -455,8 +538,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             res[h][q] = sum;
         }
     }
+    G1V_STAMP(4);                                           // lane sums reduced
     // scatter the upper triangle into the compact record  C (21) | [B|g] (6 x K1) | A (K1 x K1)
-    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
+    const int fbase = (blockIdx.x * WPB + wave) * G;
     // fused elimination: what its tail needs from memory is requested now, behind the reductions
     int slot_t = 0;
     double mc_t = 0.0;
@@ -496,9 +580,15 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 1) void k_gram1v(const FusedAr
             constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
             if (lane_ok) for (int e = gl; e < 9; e += LPF) red[grp * GS_ + praw_jl_off(K) + e] = fc[FC_A + e];
             wsync();
-            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_t, es, mc_t);
+            G1V_STAMP(5);                                   // record assembled (LDS and / or HBM)
+            gram_fused_tail<K, LPF>(a, g.lam_schur, red, ITER ? it_rows[wave] : a.partial + (int64_t)(blockIdx.x * WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t);
+            iter_row_out();
         }
     }
+#ifdef CCAL_STAMPS
+    if (!GEN && lane == 0) { ts[6] = wall_clock64(); const int wg = blockIdx.x * WPB + wave; for (int i = 0; i < 10; ++i) a.fcbuf[16 * wg + i] = (double)ts[i]; }
+#endif
+#undef G1V_STAMP
 }
 
 // k_gram1w: k_gram1v with two wavefronts per SIMD.  k_gram1v needs 256 VGPRs + 66 AGPRs (91 accumulators and the
@@ -565,7 +655,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
                 if (gl == 0) mcv = a.mc_f[f];
             }
             wsync();
-            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_r, cur, mcv);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
             return;
         }
     }
@@ -820,7 +910,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
         if (fuse) {
             // the records are in LDS as well (written along with the global stores above): the elimination right here
             wsync();
-            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_t, es, mc_t);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t);
         }
     }
 #ifdef CCAL_STAMPS
@@ -930,6 +1020,77 @@ static hipError_t launch_gram1v_m(int model, bool one_focal, FusedArgs& a, hipSt
         default: return hipErrorInvalidValue;
     }
 }
+// ---- single-launch groups (k_gram1v<.., ITER>) ----
+constexpr int kIterWpb = 4;
+constexpr size_t kLdsPerCu = 160 * 1024;
+template <int MODEL, bool OF, int LPF>
+static size_t iter_lds_bytes() {
+    constexpr int G = 64 / LPF, NC = block_dim(MODEL, OF, false) + 1, NE = NC * (NC + 1) / 2, HALF = (NE + 1) / 2;
+    constexpr int WSL = G * FC_N0P + 64 * (HALF | 1);
+    return sizeof(double) * WSL * kIterWpb;
+}
+template <int MODEL, bool OF, int LPF>
+static hipError_t launch_gram_iter_l(FusedArgs& a, hipStream_t s) {
+    constexpr int G = 64 / LPF;
+    const size_t lds = iter_lds_bytes<MODEL, OF, LPF>();
+    void (*kern)(const FusedArgs) = k_gram1v<MODEL, OF, LPF, false, true>;
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
+    const int fpb = G * kIterWpb;
+    a.fuse_elim = 1; a.elim_fused = 1;
+    a.n_part = (a.n_obs + fpb - 1) / fpb;
+    hipLaunchKernelGGL(kern, dim3(a.n_part), dim3(64 * kIterWpb), lds, s, a);
+    return hipGetLastError();
+}
+// static LDS of the ITER form beside the dynamic part: HeadShared + the reduction's 4 x 64 + the four rows
+template <int MODEL, bool OF>
+static constexpr size_t iter_static_lds() { return sizeof(HeadShared) + 4 * 2 * 64 * 8 + 4 * 8 * (size_t)fused_red_size(block_dim(MODEL, OF, false) - 6) + 256; }
+template <int MODEL, bool OF>
+static int iter_rows_t(int n_obs, int avg_corners, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
+    // CCAL_ITER_ROWS: most rows (= workgroups, each of which reads every row of the launch before) for which a group is one
+    // launch; 0 = never.  One wavefront per SIMD, every workgroup resident at once: <= 256 workgroups.
+    static const int max_rows = [] { const char* e = std::getenv("CCAL_ITER_ROWS"); return e ? std::min(std::atoi(e), 256) : 256; }();
+    if (n_obs <= 0 || max_rows <= 0) return 0;
+    const int lpf = gram_lanes_per_frame(n_obs, avg_corners, 1024);
+    const int g = 64 / lpf, rows = (n_obs + g * kIterWpb - 1) / (g * kIterWpb);
+    if (rows > max_rows) return 0;
+    size_t lds = 0;
+    switch (lpf) {
+#define CCAL_IT_CASE(L) case L: lds = iter_lds_bytes<MODEL, OF, L>(); if (launch && lds + iter_static_lds<MODEL, OF>() <= kLdsPerCu) *err = launch_gram_iter_l<MODEL, OF, L>(*a, s); break;
+        CCAL_IT_CASE(6) CCAL_IT_CASE(8) CCAL_IT_CASE(12) CCAL_IT_CASE(16) CCAL_IT_CASE(32) CCAL_IT_CASE(64)
+#undef CCAL_IT_CASE
+        default: return 0;
+    }
+    if (lds + iter_static_lds<MODEL, OF>() > kLdsPerCu) return 0;
+    return rows;
+}
+static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
+    switch (model * 2 + (one_focal ? 1 : 0)) {
+        case 0: return iter_rows_t<kUCM, false>(n_obs, avg_corners, launch, a, s, err);
+        case 1: return iter_rows_t<kUCM, true>(n_obs, avg_corners, launch, a, s, err);
+        case 2: return iter_rows_t<kEUCM, false>(n_obs, avg_corners, launch, a, s, err);
+        case 3: return iter_rows_t<kEUCM, true>(n_obs, avg_corners, launch, a, s, err);
+        case 4: return iter_rows_t<kKB4, false>(n_obs, avg_corners, launch, a, s, err);
+        case 5: return iter_rows_t<kKB4, true>(n_obs, avg_corners, launch, a, s, err);
+        case 6: return iter_rows_t<kOCV5, false>(n_obs, avg_corners, launch, a, s, err);
+        case 7: return iter_rows_t<kOCV5, true>(n_obs, avg_corners, launch, a, s, err);
+        default: return 0;
+    }
+}
+int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K) {
+    if (K != block_dim(model, one_focal, false) - 6) return 0;      // (the kernel's compile-time column count is the problem's)
+    // OPENCV5: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch
+    // form (112-double rows: two chunks per lane to sum, 4.9 us).  CCAL_ITER_OCV5=1 forces the single-launch form.
+    static const bool ocv5 = [] { const char* e = std::getenv("CCAL_ITER_OCV5"); return e && e[0] == '1'; }();
+    if (model == kOCV5 && !ocv5) return 0;
+    return iter_rows_m(model, one_focal, n_obs, avg_corners, false, nullptr, nullptr, nullptr);
+}
+hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
+    hipError_t err = hipErrorInvalidValue;
+    const int rows = iter_rows_m(model, one_focal, a.n_obs, a.avg_corners, true, &a, s, &err);
+    return rows > 0 ? err : hipErrorInvalidValue;
+}
+
 // single-camera loop; a.fuse_elim in: fusion allowed, out: fusion done (then a.n_part = rows of partial sums, a.elim_fused = 1)
 // Which register Gram kernel.  k_gram2 (the block's rows traded between lane halves, ccal_kernels_gram2.hip) where it
 // measured faster (10 000 / 2 500 frames, us per build, k_gram2 vs k_gram1v|w): OPENCV5 47.1 / 25.6 vs 51.2 / 27.3, EUCM 35.8 /
@@ -984,15 +1145,6 @@ hipError_t launch_gram1(int, bool, const FusedArgs&, hipStream_t) { return hipEr
 // re-elimination group - the accepted set, whose records an LM rejection left untouched.
 // Per workgroup partial sums: [A_dir | Y^T Y | model decrease of the pose blocks | pose blocks that failed].
 // ---------------------------------------------------------------------------------------------
-struct HeadShared {               // LDS of the decision / solve step
-    DevState S0;
-    double red[2 * 100 + 2];
-    double S[10 * 11];
-    double x[10];
-    double cur_intr[CCAL_PMAX];   // current intrinsics (full layout)
-    int fx[10];                   // fixed flags of the camera columns
-    int bad, solve;
-};
 
 template <int K>
 __global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
@@ -1247,186 +1399,28 @@ hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s) {
 // red = [A_dir (K1*K1) | Y^T Y (K1*K1) | mc_pose | failed pose blocks]
 // The optimizer state is staged in LDS once (the global copy is touched twice per launch).
 // ---------------------------------------------------------------------------------------------
-// S (LDS, row stride 11) x = rhs (LDS) by Cholesky, entirely in registers of every lane; lane 0 writes x back.
-template <int K>
-__device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
-    double M[K * K], v[K];
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        v[i] = x[i];
-#pragma unroll
-        for (int j = 0; j <= i; ++j) M[i * K + j] = S[i * 11 + j];
-    }
-    bool ok = true;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-        double d = M[j * K + j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) d -= M[j * K + k] * M[j * K + k];
-        ok = ok && (d > 0.0) && (d < 1.7e308);
-        double sq, rs;
-        fast_sqrt_rsqrt(ok ? d : 1.0, sq, rs);
-        M[j * K + j] = rs;                               // inverted diagonal
-#pragma unroll
-        for (int i = j + 1; i < K; ++i) {
-            double t = M[i * K + j];
-#pragma unroll
-            for (int k = 0; k < j; ++k) t -= M[i * K + k] * M[j * K + k];
-            M[i * K + j] = t * rs;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < K; ++i) {
-        double t = v[i];
-#pragma unroll
-        for (int k = 0; k < i; ++k) t -= M[i * K + k] * v[k];
-        v[i] = t * M[i * K + i];
-    }
-#pragma unroll
-    for (int i = K - 1; i >= 0; --i) {
-        double t = v[i];
-#pragma unroll
-        for (int k = i + 1; k < K; ++k) t -= M[k * K + i] * v[k];
-        v[i] = t * M[i * K + i];
-    }
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int i = 0; i < K; ++i) x[i] = v[i];
-    }
-    return ok;
-}
-
 __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
     __shared__ HeadShared hs;
-    DevState& S0 = hs.S0;
-    double* red = hs.red; double* S = hs.S; double* x = hs.x; int& bad = hs.bad;
-    const int K = a.K, K1 = K + 1;
     if (a.partial) {
         // single-GPU loop: the partial sums of the elimination kernel are added up here in k_reduce1's order (a launch and a
-        // kernel boundary less per group); then wavefront 0 goes on alone
+        // kernel boundary less per group); then wavefront 0 decides alone
         if (a.st->done) { if (threadIdx.x == 0) publish_host_status(a.hs, a.st, a.seq, a.publish_all != 0); return; }
         __shared__ double shr[4][64];
-        const int rb = fused_red_size(K);
+        const int rb = fused_red_size(a.K);
         for (int e0 = 0; e0 < rb; e0 += 64) {
             const int e = e0 + (threadIdx.x & 63);
             const double t = reduce_partial_rows(a.partial, a.n_part, rb, e, shr);
-            if (threadIdx.x < 64 && e < rb) red[e] = t;
+            if (threadIdx.x < 64 && e < rb) hs.red[e] = t;
         }
         __syncthreads();
-        if (threadIdx.x >= 64) return;          // from here on ONE wavefront is left: wave-level hand-offs (wsync), no workgroup barrier
     }
-    const int lane = threadIdx.x;
-    // everything the solve needs from global memory is requested up front, next to the state: one memory latency
-    // instead of a chain of three (state -> column info -> intrinsics)
-    ColInfo ci = {};
-    double intr_a = 0.0, intr_b = 0.0;
-    if (lane < K) ci = a.cols[lane];
-    if (lane < CCAL_PMAX) { intr_a = a.intr[0][lane]; intr_b = a.intr[1][lane]; }
-    {   // stage state + reduced sums
-        const double* src = reinterpret_cast<const double*>(a.st);
-        double* dst = reinterpret_cast<double*>(&S0);
-        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
-        if (!a.partial) for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red[e];
-        if (lane < K) hs.fx[lane] = ci.fixed;
-    }
-    wsync();
-    DevState* st = &S0;
-    if (st->done) { if (lane == 0) publish_host_status(a.hs, st, a.seq, a.publish_all != 0); return; }     // the host still waits for this group's number
-    const double* Ad = red;
-    const double* Yt = red + K1 * K1;
-    const bool lm = st->method == CCAL_METHOD_LM;
-    if (lane == 0) hs.solve = optimizer_decide(st, Ad[K * K1 + K], red[2 * K1 * K1], red[2 * K1 * K1 + 1] > 0.0, a.seq) ? 1 : 0;
-    wsync();
-    // A group that does NOT finish the solve tells the host so as soon as that is certain - after the decision for a group that
-    // does not solve (a re-elimination follows), after the camera factorisation otherwise (Gauss-Newton ends the solve there when
-    // the system is not positive definite: what the host reads for a group must not depend on WHEN it looks, or sharded ranks
-    // would enqueue different numbers of collectives).  The word only says "group seq has decided, go on": the host answers by
-    // enqueueing a later group behind the ones already in the stream, nothing it does depends on what this kernel still writes,
-    // and the store's trip across the bus overlaps the rest of the kernel instead of sitting in front of its end.  A finishing
-    // group publishes last (its report and result must be complete first); so does a verbose solve's full report.
-    bool early_publish = false;
-    if (!st->done && !a.publish_all && !hs.solve) { early_publish = true; if (lane == 0) a.hs->word = status_word(a.seq, 0, 0); }
-    if (hs.solve) {
-        const double lambda = st->lambda;
-        const int cur = st->cur;
-        if (lane == 0) bad = 0;
-        for (int e = lane; e < K * K; e += 64) {
-            const int i = e / K, j = e - i * K;
-            double v = Ad[i * K1 + j] - Yt[i * K1 + j];
-            const bool fi = hs.fx[i] != 0, fj = hs.fx[j] != 0;
-            if (fi || fj) v = (i == j) ? 1.0 : 0.0;
-            else if (i == j && lambda > 0.0) v += lambda * clampd1(Ad[i * K1 + i], a.min_diag, a.max_diag);
-            S[i * 11 + j] = v;
-        }
-        if (lane < K) x[lane] = ci.fixed ? 0.0 : -(Ad[lane * K1 + K] - Yt[lane * K1 + K]);
-        wsync();
-        // K <= 9: Cholesky + both triangular solves in registers (every lane the same wave-uniform work, no
-        // LDS round trips or barriers inside the factorisation)
-        {
-            bool okc = true;
-            switch (K) {
-                case 4: okc = chol_solve_reg<4>(S, x); break;
-                case 5: okc = chol_solve_reg<5>(S, x); break;
-                case 6: okc = chol_solve_reg<6>(S, x); break;
-                case 7: okc = chol_solve_reg<7>(S, x); break;
-                case 8: okc = chol_solve_reg<8>(S, x); break;
-                default: okc = chol_solve_reg<9>(S, x); break;
-            }
-            if (lane == 0 && !okc) bad = 1;
-        }
-        wsync();
-        if (bad) {
-            if (lane == 0) {
-                if (!lm) { st->done = CCAL_ERR_NOT_PD + 1; if (!st->done_seq) st->done_seq = a.seq; }
-                else st->cam_failed = 1;             // LM: the next decision rejects and shrinks the radius
-                st->mc_cam = 0.0; st->lambda_solve = lambda;
-            }
-            if (lane < K) a.dc[lane] = 0.0;
-        }
-        if (!st->done && !a.publish_all) { early_publish = true; if (lane == 0) a.hs->word = status_word(a.seq, 0, 0); }      // (st->done: set just above, GN only)
-        if (!bad || lm) {
-            // candidate intrinsics = clamp(x + dc) into the other set; model decrease of the camera block
-            double* dst = a.intr[cur ^ 1];
-            const double keep = cur ? intr_b : intr_a;          // current intrinsics, full layout, element `lane`
-            if (lane < CCAL_PMAX) { dst[lane] = keep; hs.cur_intr[lane] = keep; }
-            wsync();
-            double mc = 0.0;
-            if (lane < K && !bad) {
-                const double d = x[lane];
-                a.dc[lane] = d;
-                const double Dii = lambda > 0.0 ? lambda * clampd1(Ad[lane * K1 + lane], a.min_diag, a.max_diag) : 0.0;
-                if (!ci.fixed) {
-                    mc = d * (Dii * d - Ad[lane * K1 + K]);
-                    double v = hs.cur_intr[ci.dst] + d;
-                    if (ci.has_bound) v = fmin(fmax(v, ci.lo), ci.hi);
-                    dst[ci.dst] = v;
-                    if (ci.dst2 >= 0) dst[ci.dst2] = v;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mc += __shfl_down(mc, off, 64);
-            if (lane == 0 && !bad) { st->mc_cam = mc; st->lambda_solve = lambda; }
-        }
-    }
-    wsync();
-    {   // write the state back, then publish
-        const double* src = reinterpret_cast<const double*>(&S0);
-        double* dst = reinterpret_cast<double*>(a.st);
-        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
-    }
-    if (st->done && a.result_host) {
-        // this group finishes the solve: the accepted point goes straight to the caller's side of the bus.  The accepted poses
-        // were written by this group's Gram kernel (or an earlier one): complete at this kernel's start.  The accepted
-        // intrinsics: this kernel never writes set `cur` (candidates go to cur ^ 1), so global memory holds them
-        const int cur = st->cur;
-        const double* pi = a.intr[cur];
-        const double* pp = a.poses[cur];
-        for (int e = lane; e < CCAL_PMAX; e += 64) a.result_host[e] = pi[e];
-        for (int64_t e = lane; e < a.np6; e += 64) a.result_host[CCAL_PMAX + e] = pp[e];
-        __threadfence_system();
-    }
-    wsync();
-    if (lane == 0 && !early_publish) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
+    HeadIO io;
+    io.st_in = a.st; io.st_out = a.st; io.hs = a.hs; io.red_g = a.partial ? nullptr : a.red; io.cols = a.cols;
+    io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = a.dc; io.K = a.K; io.seq = a.seq;
+    io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = a.publish_all;
+    if (threadIdx.x < 64) head_wave(io, hs, (int)threadIdx.x, true);
+    __syncthreads();
+    head_finish(io, hs, a.result_host, a.poses[0], a.poses[1], a.np6, true);
 }
 // ccal_build_normal_dev on a single camera: evaluate set 0 as a first evaluation (no pose update) with this damping
 __global__ void k_state_eval(DevState* st, double lambda) {
@@ -1439,7 +1433,7 @@ hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s) {
     return hipGetLastError();
 }
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(k_head, dim3(1), dim3(a.partial ? 256 : 64), 0, s, a);
+    hipLaunchKernelGGL(k_head, dim3(1), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

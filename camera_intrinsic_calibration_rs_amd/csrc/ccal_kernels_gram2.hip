@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
                 if (gl == 0) mcv = a.mc_f[f];
             }
             wsync();
-            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_r, cur, mcv);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
             return;
         }
     }
@@ -605,7 +605,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
         if (fuse) {
             if (keep_rec) wsync();                                     // the tail reuses the records' rows
             G2_STAMP(4);
-            gram_fused_tail<K, LPF>(a, st, red, blockIdx.x * CCAL_GRAMV_WPB + wave, grp, gl, lane_ok, active, slot_t, es, mc_t);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t);
         }
     }
     G2_STAMP(5);

@@ -129,7 +129,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMemset(f->partial, 0, (size_t)f->RB1 * f->n_pw * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&f->red, (size_t)(f->RB1 + 7) * sizeof(double)));
     HIP_TRY(ctx, hipMemset(f->red, 0, (size_t)(f->RB1 + 7) * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&f->d_state, sizeof(DevState)));
+    HIP_TRY(ctx, hipMalloc((void**)&f->d_state, 3 * sizeof(DevState)));       // [0] the loops' state; [1], [2]: single-launch groups alternate
     HIP_TRY(ctx, hipHostMalloc((void**)&f->h_status, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
     const size_t stage_bytes = std::max((ns * 6 + CCAL_PMAX) * sizeof(double) + 64, (size_t)(f->RB1 + 8) * sizeof(double));      // (ccal_build_normal stages the reduced sums here)
     HIP_TRY(ctx, hipHostMalloc((void**)&f->h_stage, stage_bytes, hipHostMallocDefault));
@@ -560,12 +560,17 @@ struct SolveJob {
 struct FusedJob : SolveJob {
     FusedWs* f = nullptr;
     FusedArgs fa; HeadArgs ha; bool schur_m = false, sharded = false;
+    // single-launch groups (k_gram1v<.., ITER>, IterArgs): launch s reads state buffer s & 1 and the rows of launch s - 1,
+    // writes state buffer (s + 1) & 1 and its own rows into the other half of the partial-sum buffer
+    int iter_rows = 0;
+    DevState* iter_state(int s) const { return f->d_state + 1 + (s & 1); }
+    double* iter_partial(int s) const { return f->partial + (size_t)(s & 1) * iter_rows * f->RB1; }
     double* h_poses = nullptr;
     size_t np6 = 0;
     bool zero_copy = false;           // session-sized ccal_solve: poses read from / result written to pinned host memory by the kernels
     using SolveJob::SolveJob;
     HostStatus* status() override { return f->h_status; }
-    const DevState* dev_state() override { return f->d_state; }
+    const DevState* dev_state() override { return iter_rows ? iter_state(seq + 1) : f->d_state; }     // (read once the stream has drained)
     void mark_tail_pending() override { if (f) f->tail_pending = true; }
     int begin() override {
         int rc = fused_ws_ensure(p);
@@ -580,6 +585,13 @@ struct FusedJob : SolveJob {
         np6 = (size_t)p->n_slots * 6;
         h_poses = f->h_stage;
         zero_copy = host_io && f->h_result != nullptr;
+        fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
+        sharded = p->sharded();
+        iter_rows = 0;
+        if (!sharded && f->fuse_elim && !f->prepass && fused_use_valu_gram(p)) {
+            const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K);
+            if (rows > 0 && 2 * rows <= f->n_pw) iter_rows = rows;
+        }
         {
             // state, column table and intrinsics travel in k_unpack1's argument block; the poses are read in place from
             // pinned host memory (session sizes) or staged with one copy (large problems)
@@ -592,7 +604,7 @@ struct FusedJob : SolveJob {
             ua.n_cols = K;
             ua.np6 = (int64_t)np6; ua.poses_on_device = host_io ? 0 : 1;
             ua.intr0 = p->d_intr; ua.intr1 = p->d_intr_c; ua.poses0 = p->d_poses; ua.poses1 = p->d_poses_c;
-            ua.st = f->d_state; ua.cols = w->cols;
+            ua.st = iter_rows ? iter_state(1) : f->d_state; ua.cols = w->cols;
             if (host_io) {
                 std::memcpy(ua.intr_h, intr_io, CCAL_PMAX * sizeof(double));
                 std::memcpy(h_poses, poses_io, np6 * sizeof(double));
@@ -607,7 +619,6 @@ struct FusedJob : SolveJob {
         }
         enqueued_any = true;          // from here on an error exit leaves kernels in flight: the next solve / the destructor drains
         f->h_status->word = 0;
-        fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
         schur_m = fused_use_schur1m(p, fa);
         ha = HeadArgs{};
         ha.st = f->d_state; ha.hs = f->h_status; ha.red = f->red; ha.cols = w->cols;
@@ -616,8 +627,7 @@ struct FusedJob : SolveJob {
         ha.publish_all = o->verbose ? 1 : 0;
         ha.result_host = zero_copy ? f->h_result : nullptr;
         ha.poses[0] = p->d_poses; ha.poses[1] = p->d_poses_c; ha.np6 = (int64_t)np6;
-        sharded = p->sharded();
-        max_groups = max_groups_for(o);
+        max_groups = max_groups_for(o) + (iter_rows ? 1 : 0);          // (single-launch groups: the decision on launch s is taken in launch s + 1)
         depth = groups_in_flight(p, "CCAL_FUSED_DEPTH");
         timeout_s = wait_timeout(p, o);
         return fill();
@@ -625,6 +635,20 @@ struct FusedJob : SolveJob {
     int enqueue() override {          // one group: evaluation + elimination + ONE collective + decision/solve
         // CCAL_HEAD_REDUCE_ROWS=0 (developer switch): always the separate reduce launch
         static const int head_reduce_max_rows = [] { const char* e = std::getenv("CCAL_HEAD_REDUCE_ROWS"); return e ? std::min(std::atoi(e), kHeadReduceRows) : kHeadReduceRows; }();
+        if (iter_rows) {
+            // session sizes on one GPU: the whole group is ONE launch - the Gram kernel sums the previous launch's rows, decides
+            // and solves the camera system in front of its own evaluation (every workgroup the same arithmetic, workgroup 0 writes)
+            const int sq = ++seq;
+            IterArgs& it = fa.it;
+            it.on = 1; it.skip_head = sq == 1 ? 1 : 0; it.seq = sq; it.publish_all = o->verbose ? 1 : 0;
+            it.st_in = iter_state(sq); it.st_out = iter_state(sq + 1);
+            it.partial_in = iter_partial(sq - 1); it.n_part_in = iter_rows; fa.partial = iter_partial(sq);
+            it.hs = f->h_status; it.cols = w->cols; it.dc_out = w->dc;
+            it.result_host = zero_copy ? f->h_result : nullptr; it.np6 = (int64_t)np6;
+            HIP_TRYN(ctx, launch_gram_iter(p->cams[0].model, p->one_focal, fa, st));
+            if (fa.n_part != iter_rows) { ctx->err = "single-launch group: row count changed"; return -CCAL_ERR_INVALID_ARG; }
+            return sq;
+        }
         if (sharded) {
             // Gram -> elimination -> reduce -> all-reduce of the packed sums -> head
             HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));

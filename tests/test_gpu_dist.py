@@ -1,6 +1,6 @@
 """GPU: the sharded-solve paths of ccal_solve on the one GPU of the box.
   * native RCCL inside the library (ccal_set_rccl_comm; communicator created through ccal_rccl_comm_create) on a
-    1-rank communicator: bit-identical to the unsharded solve, groups enqueued ahead like on a single GPU;
+    1-rank communicator: the unsharded solve's result (bit-identical on the general path), groups enqueued ahead like on a single GPU;
   * the callback path (ccal_set_allreduce) with torch.distributed's RCCL on a 1-rank group: exact collective counts
     (ONE all-reduce per group, Gauss-Newton and Levenberg-Marquardt alike);
   * two ranks on the device path (both processes on cuda:0, gloo moving the device buffers).
@@ -35,9 +35,15 @@ def test_native_rccl_single_rank(model, n_cams):
             got = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
             assert ref[3].status == got[3].status == 0
             assert (ref[3].iterations, ref[3].lm_accepted, ref[3].lm_rejected) == (got[3].iterations, got[3].lm_accepted, got[3].lm_rejected)
-            for a, b in zip(ref[:3], got[:3]):          # a 1-rank sum is the identity: bit for bit
-                np.testing.assert_array_equal(a, b)
-            assert ref[3].final_cost == got[3].final_cost
+            for a, b in zip(ref[:3], got[:3]):
+                if n_cams > 1:                          # a 1-rank sum is the identity: bit for bit
+                    np.testing.assert_array_equal(a, b)
+                else:
+                    # single camera: the unsharded solve of a session-sized problem runs single-launch groups (k_gram1v<.., ITER>:
+                    # four wavefronts' rows added per workgroup, then the workgroups' rows), the sharded one Gram -> reduce ->
+                    # all-reduce -> head: the same sums in another order
+                    np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13)
+            assert ref[3].final_cost == pytest.approx(got[3].final_cost, rel=1e-12)
         gp.set_rccl_comm(None)
         gp.close()
     finally:
