@@ -217,12 +217,14 @@ __host__ __device__ inline int iter_row_src(int K, int pe) {
 // lane (with 150 workgroups on the same lines an L2 round trip is ~1.3 us: the loop of reduce_partial_rows - four loads, wait,
 // add - took 5.3 us for 157 rows), four interleaved accumulators, combined in a fixed order; the full (mirrored) layout goes to
 // `red` in LDS, where head_wave expects it.
+// Two halves, so that the caller can put loads of its own between them (issued while these sums' loads are in flight, consumed
+// after the decision): iter_reduce_load = this wavefront's quarter of the rows into four accumulators per 64 packed entries;
+// iter_reduce_combine = the four wavefronts' sums through LDS (two workgroup barriers).
 template <int K>
-__device__ __forceinline__ void iter_reduce_rows(const double* partial, const int n_rows, double* red, double (*sh)[(iter_row_len(K) + 63) / 64][64]) {
-    constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, K1 = K + 1, NA = K1 * K1, B = NCH == 1 ? 48 : 24;
+__device__ __forceinline__ void iter_reduce_load(const double* partial, const int n_rows, double (*v)[4]) {
+    constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, B = NCH == 1 ? 48 : 24;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per = (n_rows + 3) >> 2, r0 = wv * per, r1 = min(n_rows, r0 + per);
-    double v[NCH][4];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { v[c][0] = 0.0; v[c][1] = 0.0; v[c][2] = 0.0; v[c][3] = 0.0; }
     for (int r = r0; r < r1; r += B) {
@@ -241,6 +243,11 @@ __device__ __forceinline__ void iter_reduce_rows(const double* partial, const in
             }
         }
     }
+}
+template <int K>
+__device__ __forceinline__ void iter_reduce_combine(const double (*v)[4], double* red, double (*sh)[(iter_row_len(K) + 63) / 64][64]) {
+    constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, K1 = K + 1, NA = K1 * K1;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) sh[wv][c][lane] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
     __syncthreads();

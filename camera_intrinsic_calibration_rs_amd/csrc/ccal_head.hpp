@@ -77,26 +77,36 @@ __device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
 }
 
 
+// What head_wave reads from global memory, one element per lane - requested ahead of whatever the caller does first (the
+// single-launch form: the sum over the previous launch's rows), so that the decision does not start with a memory round trip.
+struct HeadPre { ColInfo ci; double intr_a, intr_b, stw; };
+__device__ __forceinline__ HeadPre head_prefetch(const HeadIO& a, const int lane) {
+    HeadPre p;
+    p.ci = ColInfo{}; p.intr_a = 0.0; p.intr_b = 0.0; p.stw = 0.0;
+    if (lane < a.K) p.ci = a.cols[lane];
+    if (lane < CCAL_PMAX) { p.intr_a = a.intr[0][lane]; p.intr_b = a.intr[1][lane]; }
+    static_assert(sizeof(DevState) / sizeof(double) <= 64, "one element of the state per lane");
+    if (lane < (int)(sizeof(DevState) / sizeof(double))) p.stw = reinterpret_cast<const double*>(a.st_in)[lane];
+    return p;
+}
+
 // ONE wavefront.  Decision (optimizer_decide, ccal_fused.hpp) on the all-reduced sums, then - when the sums at hand are the
 // system to solve - the K x K camera solve and the candidate intrinsics.
 // red = [A_dir (K1*K1) | Y^T Y (K1*K1) | mc_pose | failed pose blocks]
 // The state is staged in LDS (hs.S0) and stays there for the caller: decided state, camera step hs.x, candidate hs.cand.
 // `writer`: this wavefront also writes them to global memory and tells the host (k_head: always; single-launch groups:
 // workgroup 0 - every workgroup computes the same values from the same sums).
-__device__ __forceinline__ void head_wave(const HeadIO& a, HeadShared& hs, const int lane, const bool writer) {
+__device__ __forceinline__ void head_wave(const HeadIO& a, HeadShared& hs, const int lane, const bool writer, const HeadPre& pre) {
     DevState& S0 = hs.S0;
     double* red = hs.red; double* S = hs.S; double* x = hs.x; int& bad = hs.bad;
     const int K = a.K, K1 = K + 1;
-    // everything the solve needs from global memory is requested up front, next to the state: one memory latency
-    // instead of a chain of three (state -> column info -> intrinsics)
-    ColInfo ci = {};
-    double intr_a = 0.0, intr_b = 0.0;
-    if (lane < K) ci = a.cols[lane];
-    if (lane < CCAL_PMAX) { intr_a = a.intr[0][lane]; intr_b = a.intr[1][lane]; }
+    // everything the solve needs from global memory was requested up front (head_prefetch), next to the state: one memory
+    // latency instead of a chain of three (state -> column info -> intrinsics)
+    const ColInfo ci = pre.ci;
+    const double intr_a = pre.intr_a, intr_b = pre.intr_b;
     {   // stage state + reduced sums
-        const double* src = reinterpret_cast<const double*>(a.st_in);
         double* dst = reinterpret_cast<double*>(&S0);
-        for (int e = lane; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+        if (lane < (int)(sizeof(DevState) / sizeof(double))) dst[lane] = pre.stw;
         if (a.red_g) for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red_g[e];
         if (lane < K) hs.fx[lane] = ci.fixed;
         if (lane == 0) { hs.early_pub = 0; hs.entry_done = 0; }

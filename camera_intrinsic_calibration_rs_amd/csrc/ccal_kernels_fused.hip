@@ -290,6 +290,40 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
 #else
 #define G1V_STAMP(i)
 #endif
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
+    const bool lane_ok = lane < G * LPF;
+    const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
+    const int f = (blockIdx.x * WPB + wave) * G + grp;
+    const bool active = lane_ok && f < a.n_obs;
+    const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
+    // ITER: everything the prologue below reads from global memory is requested in FRONT of the decision - the frame's offsets
+    // and slot before the sum over the previous launch's rows, pose / elimination record / first corner rows (both parameter
+    // sets: the decision picks one) behind that sum's loads and before its workgroup barriers: the prologue's two dependent round
+    // trips run beside the decision instead of behind it (stamps, 625 frames: prologue 3.2 -> 2.1 us)
+    constexpr int PFLEN = 33 + 6 * (D - 6 + 1);                // the slot's elimination record: L (21) | Y (6 x K1) | g_p (6) | diag C (6)
+    constexpr int NPFQ = ITER ? (PFLEN + LPF - 1) / LPF : 1;
+    int64_t start_p = 0; int n_p = 0, slot_p = 0;
+    float pX = 0.f, pY = 0.f, pZ = 0.f, pU = 0.f, pV = 0.f;
+    double pose_p[2][ITER ? 6 : 1], pf_p[2][NPFQ];
+    if constexpr (ITER) {
+        start_p = a.obs_off[fa_];
+        n_p = active ? (int)(a.obs_off[fa_ + 1] - start_p) : 0;
+        slot_p = a.obs_slot[fa_];
+    }
+    auto iter_prefetch2 = [&]() {
+      if constexpr (ITER) {
+        const int64_t g0 = start_p + (gl < n_p ? gl : 0);
+        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { pose_p[0][i] = a.poses[0][(int64_t)slot_p * 6 + i]; pose_p[1][i] = a.poses[1][(int64_t)slot_p * 6 + i]; }
+#pragma unroll
+        for (int q = 0; q < NPFQ; ++q) {
+            const int e = min(gl + LPF * q, PFLEN - 1);
+            pf_p[0][q] = a.pf[0][(int64_t)slot_p * a.PF + e]; pf_p[1][q] = a.pf[1][(int64_t)slot_p * a.PF + e];
+        }
+      }
+    };
     // what the evaluation needs of the optimizer state, in registers (the single-launch form decides in this kernel: LDS; else global)
     struct { int done, redo, cur, first, method; double lambda_solve, lam_schur; } g;
     constexpr int PROW = ITER ? iter_row_len(D - 6) : 1;       // ITER: a workgroup's row of partial sums, symmetric blocks packed
@@ -300,15 +334,20 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
         const IterArgs& it = a.it;
         if (!it.skip_head) {
             // (the rows are summed also for a solve that has finished: asking first would put a memory round trip in front of every group's loads)
-            __shared__ double shr[4][(PROW + 63) / 64][64];
-            iter_reduce_rows<D - 6>(it.partial_in, it.n_part_in, hsh.red, shr);
-            G1V_STAMP(7);                                   // the previous launch's rows are summed
             HeadIO io;
             io.st_in = it.st_in; io.st_out = it.st_out; io.hs = it.hs; io.red_g = nullptr; io.cols = it.cols;
             io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = it.dc_out; io.K = D - 6; io.seq = it.seq;
             io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = it.publish_all;
+            HeadPre hpre = {};
+            if (threadIdx.x < 64) hpre = head_prefetch(io, (int)threadIdx.x);
+            __shared__ double shr[4][(PROW + 63) / 64][64];
+            double vsum[(PROW + 63) / 64][4];
+            iter_reduce_load<D - 6>(it.partial_in, it.n_part_in, vsum);
+            iter_prefetch2();
+            iter_reduce_combine<D - 6>(vsum, hsh.red, shr);
+            G1V_STAMP(7);                                   // the previous launch's rows are summed
             const bool writer = blockIdx.x == 0;
-            if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer);
+            if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer, hpre);
             __syncthreads();
             G1V_STAMP(8);                                   // decided, camera system solved
             head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer);
@@ -318,6 +357,7 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
             g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;
             g.lambda_solve = S.lambda_solve; g.lam_schur = schur_lambda(&S);
         } else {
+            iter_prefetch2();
             // the solve's first launch: the starting state passes through to the buffer the next launch reads
             if (blockIdx.x == 0 && threadIdx.x < 64) {
                 const double* src = reinterpret_cast<const double*>(it.st_in);
@@ -350,13 +390,6 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
     const bool keep_rec = GEN || !fuse || g.method == CCAL_METHOD_LM;
     if (g.done || (g.redo && !fuse)) return;            // finished, or a re-elimination group without fusion (no evaluation)
     G1V_STAMP(1);                                           // the state has arrived
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // LPF need not divide 64 (12 lanes x 5 frames, 6 x 10): the lanes beyond G * LPF idle along with group G - 1
-    const bool lane_ok = lane < G * LPF;
-    const int grp = lane_ok ? lane / LPF : G - 1, gl = lane % LPF;
-    const int f = (blockIdx.x * WPB + wave) * G + grp;
-    const bool active = lane_ok && f < a.n_obs;
-    const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);      // observation frame (GEN: the camera's list)
     const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FC_N0P;
@@ -390,23 +423,37 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
     } else {
         load_theta<MODEL, OF>(a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0), a.rt, th);
     }
-    const int64_t start = a.obs_off[fa_];
-    const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
-    float pX, pY, pZ, pU, pV;
-    {
+    const int64_t start = ITER ? start_p : a.obs_off[fa_];
+    const int n = ITER ? n_p : (active ? (int)(a.obs_off[fa_ + 1] - start) : 0);
+    if constexpr (!ITER) {
         const int64_t g0 = start + (gl < n ? gl : 0);
         pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
     }
     {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants;
         // the 16 lanes of a group compute the same values, the 4 groups work on 4 frames at once
-        const int slot = a.obs_slot[fa_];
+        const int slot = ITER ? slot_p : a.obs_slot[fa_];
         double pose[6];
+        if constexpr (ITER) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pose[i] = a.poses[GEN ? es : cur][(int64_t)slot * 6 + i];     // GEN: k_backsub has formed the candidate
+            for (int i = 0; i < 6; ++i) pose[i] = cur ? pose_p[1][i] : pose_p[0][i];
+            // the accepted set's elimination record of the frame's slot: from the lanes' registers into LDS (the reduction
+            // buffer is free until the corner loop has ended)
+            constexpr int PFS = (PFLEN + 1) & ~1;
+            static_assert(G * PFS <= 64 * LS, "the frames' elimination records fit the reduction buffer");
+            if (lane_ok) {
+#pragma unroll
+                for (int q = 0; q < NPFQ; ++q) if (gl + LPF * q < PFLEN) red[grp * PFS + gl + LPF * q] = cur ? pf_p[1][q] : pf_p[0][q];
+            }
+            wsync();
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pose[i] = a.poses[GEN ? es : cur][(int64_t)slot * 6 + i];     // GEN: k_backsub has formed the candidate
+        }
         double mc = 0.0;
         if (!GEN && !first) {
-            const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
+            const double* pf;
+            if constexpr (ITER) pf = red + grp * ((PFLEN + 1) & ~1); else pf = a.pf[cur] + (int64_t)slot * a.PF;
             double dcr[K];                                  // the camera step
             if constexpr (ITER) {
 #pragma unroll
@@ -1418,7 +1465,7 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
     io.st_in = a.st; io.st_out = a.st; io.hs = a.hs; io.red_g = a.partial ? nullptr : a.red; io.cols = a.cols;
     io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = a.dc; io.K = a.K; io.seq = a.seq;
     io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = a.publish_all;
-    if (threadIdx.x < 64) head_wave(io, hs, (int)threadIdx.x, true);
+    if (threadIdx.x < 64) head_wave(io, hs, (int)threadIdx.x, true, head_prefetch(io, (int)threadIdx.x));
     __syncthreads();
     head_finish(io, hs, a.result_host, a.poses[0], a.poses[1], a.np6, true);
 }

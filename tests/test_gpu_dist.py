@@ -96,9 +96,10 @@ def test_solve_with_rccl_hook_single_rank():
             gp.set_allreduce(counting)
             calls.clear()
             got = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
-            # same device-resident loop with and without the hook: bitwise identical
-            np.testing.assert_array_equal(ref[0], got[0])
-            np.testing.assert_array_equal(ref[1], got[1])
+            # the same decisions with and without the hook; the sums meet in another order (without the hook a session-sized
+            # single-camera problem runs single-launch groups: rows added per workgroup of four wavefronts)
+            np.testing.assert_allclose(ref[0], got[0], rtol=1e-11, atol=1e-13)
+            np.testing.assert_allclose(ref[1], got[1], rtol=1e-11, atol=1e-13)
             assert ref[3].iterations == got[3].iterations
             K = gp.K
             rep = got[3]

@@ -324,6 +324,13 @@ def test_in_process_rccl_communicators_on_one_gpu():
     from camera_intrinsic_calibration_rs_amd import _ffi
     res = _run_child(_child_rccl_one, ())
     assert res["transport"] == _ffi.TRANSPORT_RCCL
-    for ia, pa, ita, ca, ib, pb, itb, cb in res["out"]:
-        assert ita == itb and ca == cb                       # a 1-rank sum is the identity: bit for bit
-        np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(pa, pb)
+    for k, (ia, pa, ita, ca, ib, pb, itb, cb) in enumerate(res["out"]):
+        assert ita == itb
+        if k == 1:                                           # two cameras (general loop): a 1-rank sum is the identity, bit for bit
+            assert ca == cb
+            np.testing.assert_array_equal(ia, ib); np.testing.assert_array_equal(pa, pb)
+        else:
+            # one camera: the unsharded solve of a session-sized problem runs single-launch groups (rows added per workgroup of
+            # four wavefronts), the sharded one Gram -> reduce -> all-reduce -> head: the same sums in another order
+            assert ca == pytest.approx(cb, rel=1e-12)
+            np.testing.assert_allclose(ia, ib, rtol=1e-11, atol=1e-13); np.testing.assert_allclose(pa, pb, rtol=1e-11, atol=1e-13)

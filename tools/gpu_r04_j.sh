@@ -3,7 +3,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out/r04j; mkdir -p $O; rm -f $O/*.json
 CCAL_LIB=$R/camera_intrinsic_calibration_rs_amd/lib/variants/libccal_stamps.so timeout 120 python3 tools/stamps_g1v.py 625 eucm 2>&1 | grep -v amdgpu.ids
-CCAL_LIB=$R/camera_intrinsic_calibration_rs_amd/lib/variants/libccal_stamps.so timeout 120 python3 tools/stamps_g1v.py 625 opencv5 2>&1 | grep -v amdgpu.ids
+
 for rep in 1 2; do
 for v in on off; do
   if [ $v = off ]; then export CCAL_ITER_ROWS=0; else unset CCAL_ITER_ROWS; fi
