@@ -126,7 +126,13 @@ __device__ __forceinline__ void head_wave(const HeadIO& a, HeadShared& hs, const
     const double* Ad = red;
     const double* Yt = red + K1 * K1;
     const bool lm = st->method == CCAL_METHOD_LM;
-    if (lane == 0) hs.solve = optimizer_decide(st, Ad[K * K1 + K], red[2 * K1 * K1], red[2 * K1 * K1 + 1] > 0.0, a.seq) ? 1 : 0;
+    {   // the decision on a register copy of the state (every lane the same wave-uniform work; through the LDS copy each of the
+        // rule's ~40 dependent field accesses was an LDS round trip), written back by lane 0
+        DevState loc = S0;
+        const bool sv = optimizer_decide(&loc, Ad[K * K1 + K], red[2 * K1 * K1], red[2 * K1 * K1 + 1] > 0.0, a.seq);
+        wsync();
+        if (lane == 0) { S0 = loc; hs.solve = sv ? 1 : 0; }
+    }
     wsync();
     // A group that does NOT finish the solve tells the host so as soon as that is certain - after the decision for a group that
     // does not solve (a re-elimination follows), after the camera factorisation otherwise (Gauss-Newton ends the solve there when
