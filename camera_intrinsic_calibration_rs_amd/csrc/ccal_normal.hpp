@@ -37,6 +37,7 @@ struct ColInfo {          // one column of the reduced camera system
 
 struct NormalWs {
     int K = 0, RB = 0, PF = 0, n_pw = 0;
+    bool general_ready = false;                // the general loop's buffers exist (normal_ws_ensure_general); the single-camera loop never asks
     int schur_wpb = 4;                         // wavefronts per workgroup of k_schur: 1 for reduced systems of 64 .. 127 columns
     bool schurq = false;                       // two cameras with equal blocks: elimination with four lanes per slot (k_schurq) instead of k_schur<true>
     int schurq_slots = 16;                     // k_schurq: frame slots per wavefront (16 = four lanes each, 8 = eight lanes each)
@@ -76,6 +77,8 @@ struct NormalWs {
 
 struct FusedWs {
     int PRAW = 0, RB1 = 0, n_pw = 0;
+    char* d_block = nullptr;                   // the ONE device allocation the buffers below are slices of (fcbuf apart)
+    char* h_block = nullptr;                   // the ONE pinned, host-coherent allocation: h_status | h_result | h_stage
     double* pf[2] = { nullptr, nullptr };
     double* praw[2] = { nullptr, nullptr };
     double* partial = nullptr;
@@ -116,7 +119,8 @@ struct SchurArgs {
 
 
 void normal_ws_destroy(ccal_problem* p);
-int normal_ws_ensure(ccal_problem* p);          // allocate on first use
+int normal_ws_ensure(ccal_problem* p);          // sizes, column table, camera step: allocate on first use
+int normal_ws_ensure_general(ccal_problem* p);  // + the general (multi-camera) loop's buffers
 int normal_upload_cols(ccal_problem* p);        // bounds / fixed flags -> device
 
 // launchers (ccal_kernels_normal.hip).  Host-driven form: `cand` / gbuf / lambda select parameter set, G buffer and

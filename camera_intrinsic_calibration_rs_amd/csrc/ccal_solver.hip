@@ -64,12 +64,9 @@ void normal_ws_destroy(ccal_problem* p) {
     if (w->h_gstatus) (void)hipHostFree(w->h_gstatus);
     if (w->h_gstate) (void)hipHostFree(w->h_gstate);
     if (FusedWs* f = w->fws) {
-        void* fp[] = { f->pf[0], f->pf[1], f->praw[0], f->praw[1], f->partial, f->red, f->d_state, f->fcbuf, f->mc_f, f->cost_f };
-        for (void* q : fp) if (q) (void)hipFree(q);
-        if (f->h_status) (void)hipHostFree(f->h_status);
-        if (f->h_stage) (void)hipHostFree(f->h_stage);
-        if (f->h_result) (void)hipHostFree(f->h_result);
-        if (f->d_stage) (void)hipFree(f->d_stage);
+        if (f->d_block) (void)hipFree(f->d_block);          // every device buffer of the workspace is a slice of it
+        if (f->h_block) (void)hipHostFree(f->h_block);      // h_status | h_result | h_stage
+        if (f->fcbuf) (void)hipFree(f->fcbuf);
         if (f->side) (void)hipStreamDestroy(f->side);
         delete f;
     }
@@ -108,34 +105,46 @@ static int fused_ws_ensure(ccal_problem* p) {
     int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 16384);   // 4 workgroups of 4 waves per CU
     f->n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     const size_t ns = (size_t)std::max(p->n_slots, 1), no = (size_t)std::max(p->n_obs, 1);
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(ctx, hipMalloc((void**)&f->pf[i], ns * w->PF * sizeof(double)));
-        HIP_TRY(ctx, hipMemset(f->pf[i], 0, ns * w->PF * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc((void**)&f->praw[i], no * f->PRAW * sizeof(double)));
-        HIP_TRY(ctx, hipMemset(f->praw[i], 0, no * f->PRAW * sizeof(double)));
+    // ONE device allocation and ONE pinned allocation, sliced (a calibration session creates a problem and solves it once or
+    // twice: fifteen hipMalloc / hipHostMalloc calls and five memsets were 0.46 ms of the first solve's 0.58 at 600 frames)
+    { const char* e = std::getenv("CCAL_PREPASS"); f->prepass = e && e[0] == '1'; }
+    const size_t stage_bytes = std::max((ns * 6 + CCAL_PMAX) * sizeof(double) + 64, (size_t)(f->RB1 + 8) * sizeof(double));      // (ccal_build_normal stages the reduced sums here)
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_pf = up(ns * w->PF * sizeof(double)), b_praw = up(no * f->PRAW * sizeof(double)), b_no = up(no * sizeof(double));
+    const size_t b_part = up((size_t)f->RB1 * f->n_pw * sizeof(double)), b_red = up((size_t)(f->RB1 + 7) * sizeof(double));
+    const size_t b_state = up(3 * sizeof(DevState)), b_stage = up(stage_bytes);
+    const size_t zeroed = 2 * b_pf + 2 * b_praw + b_part + b_red;                  // the slices that must start as zeros come first
+    const size_t d_total = zeroed + 2 * b_no + b_state + b_stage;
+    HIP_TRY(ctx, hipMalloc((void**)&f->d_block, d_total));
+    HIP_TRY(ctx, hipMemsetAsync(f->d_block, 0, zeroed, ctx->stream));             // (stream-ordered in front of everything that uses the workspace)
+    {
+        char* q = f->d_block;
+        for (int i = 0; i < 2; ++i) { f->pf[i] = reinterpret_cast<double*>(q); q += b_pf; }
+        for (int i = 0; i < 2; ++i) { f->praw[i] = reinterpret_cast<double*>(q); q += b_praw; }
+        f->partial = reinterpret_cast<double*>(q); q += b_part;
+        f->red = reinterpret_cast<double*>(q); q += b_red;
+        f->mc_f = reinterpret_cast<double*>(q); q += b_no;
+        f->cost_f = reinterpret_cast<double*>(q); q += b_no;
+        f->d_state = reinterpret_cast<DevState*>(q); q += b_state;      // [0] the loops' state; [1], [2]: single-launch groups alternate
+        f->d_stage = reinterpret_cast<double*>(q); q += b_stage;
     }
     // per-frame scratch: the frame constants of the pre-pass experiment (CCAL_PREPASS=1); diagnostic builds park in-kernel
     // timestamps there (tools/stamps_*.py); the product path allocates nothing
-    { const char* e = std::getenv("CCAL_PREPASS"); f->prepass = e && e[0] == '1'; }
 #ifdef CCAL_STAMPS
     const bool want_fcbuf = true;
 #else
     const bool want_fcbuf = f->prepass;
 #endif
     if (want_fcbuf) HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, std::max<size_t>(no * 40, 32768) * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&f->mc_f, no * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&f->cost_f, no * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&f->partial, (size_t)f->RB1 * f->n_pw * sizeof(double)));
-    HIP_TRY(ctx, hipMemset(f->partial, 0, (size_t)f->RB1 * f->n_pw * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&f->red, (size_t)(f->RB1 + 7) * sizeof(double)));
-    HIP_TRY(ctx, hipMemset(f->red, 0, (size_t)(f->RB1 + 7) * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&f->d_state, 3 * sizeof(DevState)));       // [0] the loops' state; [1], [2]: single-launch groups alternate
-    HIP_TRY(ctx, hipHostMalloc((void**)&f->h_status, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
-    const size_t stage_bytes = std::max((ns * 6 + CCAL_PMAX) * sizeof(double) + 64, (size_t)(f->RB1 + 8) * sizeof(double));      // (ccal_build_normal stages the reduced sums here)
-    HIP_TRY(ctx, hipHostMalloc((void**)&f->h_stage, stage_bytes, hipHostMallocDefault));
-    HIP_TRY(ctx, hipMalloc((void**)&f->d_stage, stage_bytes));
-    if (ns * 6 * sizeof(double) <= kZeroCopyBytes)
-        HIP_TRY(ctx, hipHostMalloc((void**)&f->h_result, (ns * 6 + CCAL_PMAX) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
+    {
+        const bool zc = ns * 6 * sizeof(double) <= kZeroCopyBytes;
+        const size_t b_hs = up(sizeof(HostStatus)), b_res = zc ? up((ns * 6 + CCAL_PMAX) * sizeof(double)) : 0;
+        HIP_TRY(ctx, hipHostMalloc((void**)&f->h_block, b_hs + b_res + b_stage, hipHostMallocCoherent | hipHostMallocMapped));
+        char* q = f->h_block;
+        f->h_status = reinterpret_cast<HostStatus*>(q); q += b_hs;
+        f->h_result = zc ? reinterpret_cast<double*>(q) : nullptr; q += b_res;
+        f->h_stage = reinterpret_cast<double*>(q);
+    }
     HIP_TRY(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
     std::memset((void*)f->h_status, 0, sizeof(HostStatus));
     return CCAL_OK;
@@ -148,6 +157,10 @@ static int dev_upload(ccal_ctx* ctx, T** dst, const std::vector<T>& src) {
     return CCAL_OK;
 }
 
+// The part every loop needs: sizes, the column table and the camera step.  The single-camera loop (FusedWs) needs nothing else of
+// NormalWs; the general loop's buffers - per-frame record sets, slot tables, partial sums, a second status block and stream:
+// ~25 allocations, seven synchronous uploads - are made when a general-loop entry first asks (normal_ws_ensure_general): they
+// were 0.4 ms of a single-camera session's first solve.
 int normal_ws_ensure(ccal_problem* p) {
     if (p->nws) return CCAL_OK;
     ccal_ctx* ctx = p->ctx;
@@ -155,6 +168,17 @@ int normal_ws_ensure(ccal_problem* p) {
     NormalWs* w = new NormalWs();
     p->nws = w;
     w->K = p->K; w->RB = red_size(p->K); w->PF = pf_size(p->K);
+    HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
+    return CCAL_OK;
+}
+int normal_ws_ensure_general(ccal_problem* p) {
+    int rc0 = normal_ws_ensure(p);
+    if (rc0 != CCAL_OK) return rc0;
+    NormalWs* w = p->nws;
+    if (w->general_ready) return CCAL_OK;
+    ccal_ctx* ctx = p->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     // persistent Schur waves: at most 2 workgroups per CU worth, never more than slots
     const char* env_sw = std::getenv("CCAL_SCHUR_WAVES");
     // persistent wavefronts of k_schur: 4 per SIMD (measured at 10 000 slots x 2 cameras: 2048 -> 165.7, 4096 -> 158.5, 8192 -> 173 us per build)
@@ -262,7 +286,6 @@ int normal_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMemsetAsync(w->partial, 0, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMalloc((void**)&w->red, (size_t)(w->RB + 8) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->mc_slot, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
     HIP_TRY(ctx, hipMemsetAsync(w->mc_slot, 0, (size_t)std::max(p->n_slots, 1) * sizeof(double), ctx->stream));
     HIP_TRY(ctx, hipMalloc((void**)&w->scal, 8 * sizeof(double)));
@@ -274,8 +297,8 @@ int normal_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstate, sizeof(DevState), hipHostMallocDefault));
     std::memset((void*)w->h_gstatus, 0, sizeof(HostStatus));
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), ctx->stream));
-    HIP_TRY(ctx, hipMalloc((void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_pinned, (size_t)(w->RB + 16) * sizeof(double), hipHostMallocDefault));
+    w->general_ready = true;
     return normal_upload_cols(p);
 }
 
@@ -718,6 +741,7 @@ struct GeneralJob : SolveJob {
     void mark_tail_pending() override { w->tail_pending = true; }
     int begin() override {
         int rc;
+        if ((rc = normal_ws_ensure_general(p)) != CCAL_OK) return rc;
         if (w->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); w->tail_pending = false; }   // a stale k_solve must not publish into this solve
         if (host_io && (rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
         if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
@@ -790,6 +814,7 @@ int ccal_debug_fcbuf(ccal_problem* p, double* out, int64_t n) {
     if (!p || !p->nws || !out) return CCAL_ERR_INVALID_ARG;
     if (!p->nws->fws) {          // general loop: what a -DCCAL_STAMPS build of k_schur4 leaves behind the partial sums
         const NormalWs* w = p->nws;
+        if (!w->general_ready) return CCAL_OK;
         const int64_t room = (int64_t)w->RB * (std::max(w->n_pw, w->n_rows) - w->n_rows), m = std::min(n, room);
         if (m > 0 && hipMemcpy(out, w->partial + (int64_t)w->RB * w->n_rows, m * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return CCAL_ERR_HIP;
         return CCAL_OK;
@@ -828,6 +853,7 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda) {
         w->red_fused = true;
         return CCAL_OK;
     }
+    if ((rc = normal_ws_ensure_general(p)) != CCAL_OK) return rc;
     if (w->tail_pending) { HIP_TRY(p->ctx, hipStreamSynchronize(p->ctx->stream)); w->tail_pending = false; }
     if ((rc = enqueue_gram(p, false, w->cur)) != CCAL_OK) return rc;
     return enqueue_reduce_system(p, w->cur, lambda, 1e-6, 1e32);
