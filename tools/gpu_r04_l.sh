@@ -1,5 +1,6 @@
 #!/bin/bash
-# round-4 GPU pass L: head in front of k_gram2 (CCAL_HEAD_FRONT=0 = off): build + solves at 10 000 frames, tests
+# round-4 GPU pass L: A/B harness for "the decision in front of k_gram2" (CCAL_HEAD_FRONT=0 = off).  The variant was measured with this script and
+# NOT kept: the switch does not exist in the committed library, where both legs run the same code
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=$R/gpurun_out/r04l; mkdir -p $O; rm -f $O/*.json
