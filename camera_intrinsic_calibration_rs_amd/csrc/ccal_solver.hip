@@ -652,6 +652,11 @@ struct FusedJob : SolveJob {
         ha.poses[0] = p->d_poses; ha.poses[1] = p->d_poses_c; ha.np6 = (int64_t)np6;
         max_groups = max_groups_for(o) + (iter_rows ? 1 : 0);          // (single-launch groups: the decision on launch s is taken in launch s + 1)
         depth = groups_in_flight(p, "CCAL_FUSED_DEPTH");
+        // single-launch groups publish their status word from the FRONT of the launch (the decision), ~10 us before the launch
+        // ends: the host has the next launch in the stream in time without one enqueued ahead - and a finished solve leaves
+        // no launches behind that exit early (each of which still sums the rows: four / eight sessions side by side 0.244 / 0.464
+        // -> 0.236 / 0.444 ms per batch, one session 0.108 ms either way).  CCAL_FUSED_DEPTH overrides.
+        if (iter_rows && !std::getenv("CCAL_FUSED_DEPTH")) depth = 1;
         timeout_s = wait_timeout(p, o);
         return fill();
     }
