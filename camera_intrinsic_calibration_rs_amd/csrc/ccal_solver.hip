@@ -701,7 +701,9 @@ struct FusedJob : SolveJob {
         // the result depends on is complete.  A download goes through a side stream so that it does not queue behind
         // the early-exit groups still in the main stream; the next solve drains those before it starts.
         hipStream_t dl = st;
-        if (status_done(hst->word) && !pending.empty()) { dl = f->side; f->tail_pending = true; }
+        // (a finished solve whose result is already on the host - or stays on the device - does not wait for the stream either:
+        // the launch that said `done` has nothing left to write; whatever runs next on this stream is ordered behind it)
+        if (status_done(hst->word) && (!pending.empty() || zero_copy || !host_io)) { dl = f->side; f->tail_pending = true; }
         else HIP_TRY(ctx, hipStreamSynchronize(st));
         struct { int done, iter, cur, acc, rej, hits, misses; double cur_cost, initial_cost; } ds =
             { status_done(hst->word), hst->iter, hst->cur, hst->lm_accepted, hst->lm_rejected, hst->spec_hits, hst->spec_misses, hst->cur_cost, hst->initial_cost };
