@@ -701,6 +701,12 @@ struct SolveArgs {
 };
 // BIG: reduced systems of 64 .. 127 columns - two wavefronts (thread i still owns row i), the matrix in dynamic LDS with a
 // run-time row stride, pivots and finished components travel through LDS instead of wavefront shuffles
+// the value of lane j (wave-uniform j) in every lane: two v_readlane_b32 through scalar registers - a ds_bpermute (what __shfl
+// compiles to) is an LDS-pipe round trip, and the factorisation waits for one per column
+__device__ __forceinline__ double bcast_lane(double v, int j) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
+    return __hiloint2double(hi, lo);
+}
 template <bool BIG>
 __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     constexpr int NTH = BIG ? 128 : 64;
@@ -710,6 +716,38 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
                                        // other, each a global round trip for a single lane otherwise (k_solve 19 -> ~9 us)
     const int lane = threadIdx.x;
     DevState* const gst = a0.st;
+    // Everything the kernel reads from global memory is requested HERE, in one go - the state, the three sums of the decision, the
+    // column table, this lane's entries of the system (up to PRE_S of them: K <= 24 with one wavefront), right-hand side, diagonal
+    // and gradient, and the parameter value of this lane's column in BOTH sets (the decision picks the current one): the kernel
+    // was a chain of three dependent round trips - state and sums, then columns and vectors, then the matrix (session-sized rigs:
+    // k_solve 15.6 us of a 50-us group)
+    constexpr int PRE_S = 9;
+    const int Kp = a.K, K1p = Kp + 1;
+    const bool pre = !BIG && Kp * Kp <= PRE_S * NTH;
+    ColInfo ci = {};
+    if (lane < Kp) ci = a.cols[lane];
+    double sv[PRE_S];
+    if (pre) {
+        const float rk = 1.0f / (float)Kp;
+#pragma unroll
+        for (int q = 0; q < PRE_S; ++q) {
+            const int e = lane + NTH * q;
+            const int ec = e < Kp * Kp ? e : 0;
+            const int i = (int)(((float)ec + 0.5f) * rk), j = ec - i * Kp;
+            sv[q] = a.red[i >= j ? i * K1p + j : j * K1p + i];
+        }
+    }
+    const double rhs = lane < Kp ? a.red[Kp * K1p + lane] : 0.0;          // the system is kept as its lower triangle (row K = b^T)
+    const double hd = lane < Kp ? (a.red + K1p * K1p)[lane] : 0.0, gcl = lane < Kp ? (a.red + K1p * K1p + Kp)[lane] : 0.0;
+    const double xs0 = lane < Kp ? (ci.is_extr ? a0.extr : a0.intr)[ci.dst] : 0.0;
+    const double xs1 = (lane < Kp && a0.st) ? (ci.is_extr ? a0.extr_c : a0.intr_c)[ci.dst] : 0.0;
+    // the candidate set starts as a copy of the current one: both sets' values of this lane's element, requested now as well
+    const bool pre_c = a.n_intr <= NTH && a.n_extr <= NTH;
+    double vi0 = 0.0, vi1 = 0.0, ve0 = 0.0, ve1 = 0.0;
+    if (pre_c) {
+        if (lane < a.n_intr) { vi0 = a0.intr[lane]; if (a0.st) vi1 = a0.intr_c[lane]; }
+        if (lane < a.n_extr) { ve0 = a0.extr[lane]; if (a0.st) ve1 = a0.extr_c[lane]; }
+    }
     if (a.st) {
         // the three sums the decision needs are requested together with the state (one memory latency, not two)
         const double d_cost = a.red[a.RB - 3], d_mc = a.red[a.RB - 2], d_fail = a.red[a.RB - 1];
@@ -721,7 +759,13 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
         __syncthreads();
         a.st = &S0;
         if (S0.done) { if (lane == 0) publish_host_status(a.hs, &S0, a.seq, a.publish_all != 0); return; }
-        if (lane == 0) go = optimizer_decide(&S0, d_cost, d_mc, d_fail > 0.0, a.seq) ? 1 : 0;
+        {   // the decision on a register copy of the state (every lane the same work; through LDS each of its ~40 dependent field
+            // accesses was an LDS round trip), written back by lane 0
+            DevState loc = S0;
+            const bool sv_go = optimizer_decide(&loc, d_cost, d_mc, d_fail > 0.0, a.seq);
+            __syncthreads();
+            if (lane == 0) { S0 = loc; go = sv_go ? 1 : 0; }
+        }
         __syncthreads();
         if (!go) {
             const double* src = reinterpret_cast<const double*>(&S0);
@@ -747,23 +791,40 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     const double* hdiag = a.red + K1 * K1;
     const double* gc = hdiag + K;
     __shared__ int fxs[CCAL_KMAX];
-    ColInfo ci = {};
-    if (lane < K) { ci = a.cols[lane]; fxs[lane] = ci.fixed; }
+    if (lane < K) fxs[lane] = ci.fixed;
     if (lane == 0) bad = 0;
-    for (int e = lane; e < a.n_intr; e += NTH) a.intr_c[e] = a.intr[e];
-    for (int e = lane; e < a.n_extr; e += NTH) a.extr_c[e] = a.extr[e];
-    const double rhs = lane < K ? a.red[K * K1 + lane] : 0.0;          // the system is kept as its lower triangle (row K = b^T)
-    const double hd = lane < K ? hdiag[lane] : 0.0, gcl = lane < K ? gc[lane] : 0.0;
-    const double xsrc = lane < K ? (ci.is_extr ? a.extr : a.intr)[ci.dst] : 0.0;
+    if (pre_c) {
+        const bool c1 = a0.st && S0.cur;
+        if (lane < a.n_intr) a.intr_c[lane] = c1 ? vi1 : vi0;
+        if (lane < a.n_extr) a.extr_c[lane] = c1 ? ve1 : ve0;
+    } else {
+        for (int e = lane; e < a.n_intr; e += NTH) a.intr_c[e] = a.intr[e];
+        for (int e = lane; e < a.n_extr; e += NTH) a.extr_c[e] = a.extr[e];
+    }
+    (void)hdiag; (void)gc;
+    const double xsrc = (a0.st && S0.cur) ? xs1 : xs0;                  // (a.intr / a.extr are the current set: swapped above when cur == 1)
     __syncthreads();
     {
         const float rk = 1.0f / (float)K;
+        if (pre) {
+#pragma unroll
+            for (int q = 0; q < PRE_S; ++q) {
+                const int e = lane + NTH * q;
+                if (e < K * K) {
+                    const int i = (int)(((float)e + 0.5f) * rk), j = e - i * K;
+                    double v = sv[q];
+                    if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
+                    S[i * LD + j] = v;
+                }
+            }
+        } else {
 #pragma unroll 4
-        for (int e = lane; e < K * K; e += NTH) {
-            const int i = (int)(((float)e + 0.5f) * rk), j = e - i * K;
-            double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
-            if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
-            S[i * LD + j] = v;
+            for (int e = lane; e < K * K; e += NTH) {
+                const int i = (int)(((float)e + 0.5f) * rk), j = e - i * K;
+                double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
+                if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
+                S[i * LD + j] = v;
+            }
         }
     }
     __syncthreads();
@@ -784,7 +845,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
         }
         double piv;
         if constexpr (BIG) { if (lane == j) pivs = t; __syncthreads(); piv = pivs; }
-        else piv = __shfl(t, j, 64);
+        else piv = bcast_lane(t, j);
         if (!(piv > 0.0) || !(piv < 1.7e308)) { if (lane == 0) bad = 1; break; }      // uniform
         double sq, inv;
         fast_sqrt_rsqrt(piv, sq, inv);                    // hardware seed + Newton steps (<= 2 ulp), not the IEEE sqrt + division expansions
@@ -820,7 +881,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
             if (lane == j) xi = xi * S[j * LD + j];
             double xj;
             if constexpr (BIG) { if (lane == j) pivs = xi; __syncthreads(); xj = pivs; __syncthreads(); }
-            else xj = __shfl(xi, j, 64);
+            else xj = bcast_lane(xi, j);
             if (lane < j) xi -= S[j * LD + lane] * xj;
         }
         if (lane < K) x[lane] = xi;
