@@ -707,6 +707,36 @@ __device__ __forceinline__ double bcast_lane(double v, int j) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), j), hi = __builtin_amdgcn_readlane(__double2hiint(v), j);
     return __hiloint2double(hi, lo);
 }
+// The factorisation of k_solve for K <= KT with the rows in REGISTERS: lane i holds row i of the lower triangle (lane K: the
+// right-hand side riding along), column j is t = S[i][j] - sum_{k<j} L[i][k] L[j][k] with L[j][k] read from lane j's registers
+// (v_readlane: j and k are compile-time), the same operations in the same order as the LDS loop below - the same bits - without
+// its LDS round trips and its barrier per column (K = 18: ~6 us -> ~1.5).  L goes back to LDS for the back substitution.
+// Returns false when a pivot is not positive (the factor is then incomplete, as in the LDS loop).
+template <int KT>
+__device__ __forceinline__ bool chol_rows_reg(double* S, const int LD, const int K, const int lane) {
+    double r[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) r[k] = (k < K && lane <= K) ? S[lane * LD + k] : 0.0;
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        if (j < K && ok) {                         // wave-uniform
+            double t = r[j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= r[k] * bcast_lane(r[k], j);
+            const double piv = bcast_lane(t, j);
+            if (!(piv > 0.0) || !(piv < 1.7e308)) ok = false;
+            else {
+                double sq, inv;
+                fast_sqrt_rsqrt(piv, sq, inv);
+                r[j] = lane == j ? inv : t * inv;  // (lanes above the diagonal: never written back)
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) if (k < K && lane <= K && (k <= lane)) S[lane * LD + k] = r[k];
+    return ok;
+}
 template <bool BIG>
 __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     constexpr int NTH = BIG ? 128 : 64;
@@ -836,7 +866,15 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     // left-looking Cholesky, lane i owns row i: t = S[i][j] - sum_{k<j} L[i][k] L[j][k] (no stores inside the sum,
     // so the LDS reads pipeline), the pivot travels by shuffle; one barrier per column.  Same operation order as
     // the right-looking form.
-    for (int j = 0; j < K; ++j) {
+    constexpr int KT_REG = 24;
+    bool in_regs = false;
+    if constexpr (!BIG) {
+        if (K <= KT_REG) {
+            in_regs = true;
+            if (!chol_rows_reg<KT_REG>(S, LD, K, lane) && lane == 0) bad = 1;
+        }
+    }
+    for (int j = 0; j < (in_regs ? 0 : K); ++j) {
         double t = 0.0;
         if (lane >= j && lane <= K) {
             t = S[lane * LD + j];
