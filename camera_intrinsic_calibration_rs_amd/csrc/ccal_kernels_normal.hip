@@ -721,9 +721,14 @@ __device__ __forceinline__ bool chol_rows_reg(double* S, const int LD, const int
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         if (j < K && ok) {                         // wave-uniform
+            // lane j's row first, every entry into scalar registers of its own (one pair reused for all of them makes each FMA wait
+            // for "its" v_readlane: ~65 cycles per entry measured), then the dependent chain
+            double lj[KT];
+#pragma unroll
+            for (int k = 0; k < j; ++k) lj[k] = bcast_lane(r[k], j);
             double t = r[j];
 #pragma unroll
-            for (int k = 0; k < j; ++k) t -= r[k] * bcast_lane(r[k], j);
+            for (int k = 0; k < j; ++k) t -= r[k] * lj[k];
             const double piv = bcast_lane(t, j);
             if (!(piv > 0.0) || !(piv < 1.7e308)) ok = false;
             else {
@@ -866,7 +871,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     // left-looking Cholesky, lane i owns row i: t = S[i][j] - sum_{k<j} L[i][k] L[j][k] (no stores inside the sum,
     // so the LDS reads pipeline), the pivot travels by shuffle; one barrier per column.  Same operation order as
     // the right-looking form.
-    constexpr int KT_REG = 24;
+    constexpr int KT_REG = 32;
     bool in_regs = false;
     if constexpr (!BIG) {
         if (K <= KT_REG) {
