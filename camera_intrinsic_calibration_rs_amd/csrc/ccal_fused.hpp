@@ -297,6 +297,12 @@ struct FusedArgs {
     // fcbuf [n_obs][FC_N0P]; the Gram kernel's prologue is then one coalesced read per frame
     int32_t prepass;
     IterArgs it;
+    // general (multi-camera) loop, GEN kernels: the candidate pose of the frame's slot is formed HERE, in the prologue - k_backsub's
+    // work (dp = -L^-T (y_r + Y dc), model decrease of the pose block) with the slot's elimination record of the general loop and
+    // the reduced system's camera step - instead of by a launch of its own behind k_solve (gen_backsub_pose, ccal_gram_common.hpp);
+    // the slot's first observation frame (g_owner) writes the candidate pose and the model decrease
+    int32_t gen_backsub, g_K, g_PF;
+    const double* g_pf; const double* g_dc; double* g_mc_slot; const int8_t* g_owner;
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:

@@ -153,6 +153,72 @@ __device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const double
 }
 
 
+// General loop, GEN kernels with FusedArgs::gen_backsub: the candidate pose of slot `slot` from the accepted pose, the slot's
+// elimination record pf = L (21, inverted diagonal) | Y (6 x K1) | g_p (6) | diag C (6) and the camera step dc (K = columns of the
+// reduced system, run time) - what k_backsub did per slot in a launch of its own (ccal_kernels_normal.hip).  The frame's LPF lanes
+// stage the record and the camera step in LDS together (`buf`: the wavefront's reduction buffer, REGION doubles, free until the
+// corner loop has ended; G frames side by side), six of them take one row of Y dc each, then every lane finishes the 6 x 6 solve
+// for itself: walking the record from global memory lane by lane cost the prologue 5.4 us (K = 18: 126 dependent-latency loads).
+// Records too long for the buffer (many cameras) take that slow way.  Returns the pose block's model decrease; a slot whose
+// record is empty (failed factorisation) keeps its pose.  Called by all lanes of the wavefront (wave-level hand-offs inside).
+template <int LPF, int G, int REGION>
+__device__ __forceinline__ double gen_backsub_pose(const FusedArgs& a, const int slot, const double lambda, double* pose, double* buf,
+                                                   const int grp, const int gl, const bool lane_ok) {
+    const int K = a.g_K, K1 = K + 1, PF = a.g_PF;
+    const int RS = (PF + K + 6 + 1) & ~1;
+    const double* pfg = a.g_pf + (int64_t)slot * PF;
+    double dp[6];
+    const double* pf;
+    if (G * RS <= REGION) {                    // wave-uniform
+        double* R = buf + grp * RS;
+        if (lane_ok) {
+            for (int e = gl; e < PF; e += LPF) R[e] = pfg[e];
+            for (int e = gl; e < K; e += LPF) R[PF + e] = a.g_dc[e];
+        }
+        wsync();
+        if (lane_ok && gl < 6) {
+            const double* yr = R + 21 + gl * K1;
+            const double* dc = R + PF;
+            double t = yr[K];
+#pragma unroll 6
+            for (int j = 0; j < K; ++j) t += yr[j] * dc[j];       // (same order as k_backsub's sum; unrolled: the LDS reads of six steps travel together)
+            R[PF + K + gl] = -t;
+        }
+        wsync();
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dp[i] = R[PF + K + i];
+        pf = R;
+    } else {
+        const double* y0 = pfg + 21;
+        double t0 = y0[K], t1 = y0[K1 + K], t2 = y0[2 * K1 + K], t3 = y0[3 * K1 + K], t4 = y0[4 * K1 + K], t5 = y0[5 * K1 + K];
+        for (int j = 0; j < K; ++j) {
+            const double d = a.g_dc[j];
+            t0 += y0[j] * d; t1 += y0[K1 + j] * d; t2 += y0[2 * K1 + j] * d; t3 += y0[3 * K1 + j] * d; t4 += y0[4 * K1 + j] * d; t5 += y0[5 * K1 + j] * d;
+        }
+        dp[0] = -t0; dp[1] = -t1; dp[2] = -t2; dp[3] = -t3; dp[4] = -t4; dp[5] = -t5;
+        pf = pfg;
+    }
+    double mc = 0.0;
+    if (pf[0] != 0.0) {
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {     // L^T x = rhs, diagonal stored inverted
+            double t = dp[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+            dp[i] = t * pf[i * (i + 1) / 2 + i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double gp = pf[21 + 6 * K1 + i], dC = pf[21 + 6 * K1 + 6 + i];
+            const double Dii = lambda > 0.0 ? lambda * clampd1(dC, a.min_diag, a.max_diag) : 0.0;
+            mc += dp[i] * (Dii * dp[i] - gp);
+            pose[i] += dp[i];
+        }
+    }
+    wsync();                                   // (the buffer is the caller's again)
+    return mc;
+}
+
 #ifndef CCAL_GRAMV_WPB
 #define CCAL_GRAMV_WPB 2          // wavefronts per workgroup of the register Gram kernels
 #endif

@@ -266,8 +266,20 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
         // a group compute the same values, the G groups work on G frames at once
         const int slot = a.obs_slot[fa_];
         double pose[6];
+        // GEN: k_backsub has formed the candidate - or, FusedArgs::gen_backsub, it is formed here from the accepted pose
+        const bool gbs = GEN && a.gen_backsub != 0 && !first;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pose[i] = a.poses[GEN ? es : cur][(int64_t)slot * 6 + i];     // GEN: k_backsub has formed the candidate
+        for (int i = 0; i < 6; ++i) pose[i] = a.poses[(GEN && !gbs) ? es : cur][(int64_t)slot * 6 + i];
+        if constexpr (GEN) {
+            if (gbs) {
+                const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, st->lambda_solve, pose, red, grp, gl, lane_ok);
+                if (active && a.g_owner[fa_]) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+                    if (gl == 0) a.g_mc_slot[slot] = mcg;
+                }
+            }
+        }
         double mc = 0.0;
         if (!GEN && !first) {
             const double* pf = a.pf[cur] + (int64_t)slot * a.PF;

@@ -283,6 +283,10 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
         fa.extr[0] = p->d_extr; fa.extr[1] = p->d_extr_c; fa.cam = 0;
         fa.praw[0] = w->G[w->cur]; fa.praw[1] = w->G[w->cur ^ 1];
         fa.st = st;
+        if (st && w->gen_backsub) {          // device-resident loop: the candidate poses are formed in the kernel's prologue
+            fa.gen_backsub = 1; fa.g_K = w->K; fa.g_PF = w->PF; fa.g_pf = w->pf; fa.g_dc = w->dc; fa.g_mc_slot = w->mc_slot;
+            fa.g_owner = w->d_obs_owner; fa.min_diag = w->lm_min_diag; fa.max_diag = w->lm_max_diag;
+        }
         fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
         return launch_gram1v_general(p->cams[0].model, p->one_focal, fa, s);
     }
@@ -300,6 +304,10 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
         fa.extr[0] = p->d_extr; fa.extr[1] = p->d_extr_c; fa.cam = cam;
         fa.praw[0] = w->G[w->cur]; fa.praw[1] = w->G[w->cur ^ 1];
         fa.st = st;
+        if (st && w->gen_backsub) {          // device-resident loop: the candidate poses are formed in the kernel's prologue
+            fa.gen_backsub = 1; fa.g_K = w->K; fa.g_PF = w->PF; fa.g_pf = w->pf; fa.g_dc = w->dc; fa.g_mc_slot = w->mc_slot;
+            fa.g_owner = w->d_obs_owner; fa.min_diag = w->lm_min_diag; fa.max_diag = w->lm_max_diag;
+        }
         fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
         return launch_gram1v_general(p->cams[cam].model, p->one_focal, fa, s);
     }

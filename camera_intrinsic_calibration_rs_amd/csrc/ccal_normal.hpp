@@ -37,6 +37,12 @@ struct ColInfo {          // one column of the reduced camera system
 
 struct NormalWs {
     int K = 0, RB = 0, PF = 0, n_pw = 0;
+    // the candidate poses are formed in the GEN Gram kernels' prologue (FusedArgs::gen_backsub) instead of by k_backsub: set by the
+    // device-resident general loop for its launches (CCAL_GEN_BACKSUB=0: the separate launch); d_obs_owner[o] = 1 for the first
+    // observation frame of its slot (the one that writes the candidate pose and the model decrease)
+    bool gen_backsub = false; double lm_min_diag = 1e-6, lm_max_diag = 1e32;
+    int8_t* d_obs_owner = nullptr;
+    bool all_slots_observed = false;           // no slot without an observation frame: the two pose sets need not start equal
     bool general_ready = false;                // the general loop's buffers exist (normal_ws_ensure_general); the single-camera loop never asks
     int schur_wpb = 4;                         // wavefronts per workgroup of k_schur: 1 for reduced systems of 64 .. 127 columns
     bool schurq = false;                       // two cameras with equal blocks: elimination with four lanes per slot (k_schurq) instead of k_schur<true>

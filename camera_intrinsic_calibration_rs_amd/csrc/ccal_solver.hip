@@ -56,7 +56,7 @@ void normal_ws_destroy(ccal_problem* p) {
         (void)hipDeviceSynchronize();
     }
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
-                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc, w->d_slot_rec, w->d_all_obs };
+                     w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc, w->d_slot_rec, w->d_all_obs, w->d_obs_owner };
     for (void* q : ptrs) if (q) (void)hipFree(q);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
     if (w->d_gstate) (void)hipFree(w->d_gstate);
@@ -255,6 +255,15 @@ int normal_ws_ensure_general(ccal_problem* p) {
     for (int i = 0; i < p->n_obs; ++i) slot_desc[i] = goff[slot_obs[i]] * 8 + p->h_obs_cam[slot_obs[i]];
     int rc;
     if ((rc = dev_upload(ctx, &w->d_slot_desc, slot_desc))) return rc;
+    {
+        std::vector<int8_t> owner(std::max(p->n_obs, 1), 0);
+        w->all_slots_observed = true;
+        for (int sl = 0; sl < p->n_slots; ++sl) {
+            if (slot_off[sl + 1] > slot_off[sl]) owner[slot_obs[slot_off[sl]]] = 1;
+            else w->all_slots_observed = false;
+        }
+        if ((rc = dev_upload(ctx, &w->d_obs_owner, owner))) return rc;
+    }
     if (w->merged_gram) {
         std::vector<int32_t> all;
         all.reserve(p->n_obs);
@@ -752,6 +761,15 @@ struct GeneralJob : SolveJob {
         if (w->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); w->tail_pending = false; }   // a stale k_solve must not publish into this solve
         if (host_io && (rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
         if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
+        // the candidate poses are formed in the Gram kernels' prologue (one launch less per group: k_backsub).  Slots that no
+        // frame observes are then never written: both parameter sets start from the same poses
+        static const bool gbs_off = [] { const char* e = std::getenv("CCAL_GEN_BACKSUB"); return e && e[0] == '0'; }();
+        // (session-sized rigs: 600 slots x 2 / 3 cameras GN 0.229 / 0.277 -> 0.221 / 0.268 ms; at 2 x 10 000 frames the prologue's
+        // extra work in 4 000 wavefronts costs more than the launch it saves - 0.459 against 0.440 ms - so: up to 4 000 frames)
+        w->gen_backsub = w->register_gram && !gbs_off && p->n_obs <= 4000;
+        w->lm_min_diag = o->lm_min_diagonal; w->lm_max_diag = o->lm_max_diagonal;
+        if (w->gen_backsub && p->n_slots && !w->all_slots_observed)
+            HIP_TRY(ctx, hipMemcpyAsync(p->d_poses_c, p->d_poses, sizeof(double) * p->n_slots * 6, hipMemcpyDeviceToDevice, st));
         t0 = std::chrono::steady_clock::now();
         w->gstate_is_eval = false;
         init_state(w->h_gstate, o);
@@ -775,7 +793,7 @@ struct GeneralJob : SolveJob {
         HIP_TRYN(ctx, launch_reduce(p, st, ds));
         if (int e = allreduce(p, w->red, (size_t)w->RB); e != CCAL_OK) return -e;
         HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds, w->h_gstatus, ++seq, o->verbose != 0));
-        HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
+        if (!w->gen_backsub) HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
         return seq;
     }
     int end(ccal_report* rep) override {

@@ -11,8 +11,14 @@ import csv,glob
 f=glob.glob('$O/trace/**/*kernel_trace.csv',recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
+import statistics, collections
+by=collections.defaultdict(list)
+for r in rows: by[r['Kernel_Name'][:60]].append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+for k,v in by.items():
+    big=[x for x in v if x>5.5] or v
+    print(f"   median {statistics.median(big):6.2f} us  (n {len(big):3d} of {len(v)})  {k}")
 t0=None
-for r in rows[-34:]:
+for r in rows[-34:-12]:
     s=int(r['Start_Timestamp']); e=int(r['End_Timestamp'])
     if t0 is None: t0=s; pe=s
     print(f"{(s-t0)/1e3:9.2f} us  dur {(e-s)/1e3:7.2f}  gap {(s-pe)/1e3:7.2f}  {r['Kernel_Name'][:80]}")
