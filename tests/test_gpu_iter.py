@@ -138,3 +138,83 @@ def test_single_launch_groups_against_the_oracle(both_forms, oracle):
                 np.testing.assert_allclose(i1[0, :P], io[0, :P], rtol=1e-6)
                 np.testing.assert_allclose(p1, po, rtol=0, atol=1e-6)
                 assert c1 == pytest.approx(ro.final_cost, rel=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# General (multi-camera) loop at session size: the GEN Gram kernels form the candidate poses in their prologue
+# (FusedArgs::gen_backsub) - against the form with k_backsub as a launch of its own (CCAL_GEN_BACKSUB=0), fresh child each
+# ---------------------------------------------------------------------------------------------------------------------------
+def _rigs():
+    from camera_intrinsic_calibration_rs_amd import synth
+    ext2 = np.zeros((2, 6)); ext2[1] = [0.05, -0.2, 0.1, 0.1, -0.02, 0.03]
+    ext3 = np.zeros((3, 6)); ext3[1] = [0.05, -0.2, 0.1, 0.1, -0.02, 0.03]; ext3[2] = [-0.1, 0.15, -0.05, -0.08, 0.04, 0.02]
+    return [synth.make_problem(40, "eucm", n_cams=2, seed=13, outlier_frac=0.02),
+            synth.make_rig(60, ["eucm", "kb4"], ext2, seed=21, drop_frac=0.45),                # slots that no camera observes
+            synth.make_rig(50, ["ucm", "eucm", "kb4"], ext3, seed=22, drop_frac=0.3, xy_same_focal=True),
+            synth.make_problem(12, "eucm", n_cams=2, outlier_frac=0.05, ragged=True, init_perturb=0.8, seed=0xBEEF)]      # LM rejections
+
+
+def _child_rig(q, separate_backsub):
+    sys.path.insert(0, ROOT)
+    if separate_backsub:
+        os.environ["CCAL_GEN_BACKSUB"] = "0"
+    else:
+        os.environ.pop("CCAL_GEN_BACKSUB", None)
+    from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
+    ctx = Context(0)
+    out = []
+    for sp in _rigs():
+        gp = Problem.from_synth(ctx, sp)
+        row = []
+        for method in (0, 1):
+            for _ in range(2):
+                i, p, e, r = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method), raise_on_error=False)
+            gp.upload_params(sp.intr0, sp.poses0, sp.extr0)
+            rd = gp.solve_dev(default_opts(method), raise_on_error=False)
+            i_d, p_d, e_d = gp.download_params()
+            row.append((i, p, e, (r.status, r.iterations, r.lm_accepted, r.lm_rejected, r.lm_spec_misses), r.final_cost, i_d, p_d, e_d, (rd.status, rd.iterations)))
+        gp.close()
+        out.append(row)
+    q.put(out)
+
+
+def _run_rig(separate_backsub, timeout=300):
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    p = ctxm.Process(target=_child_rig, args=(q, separate_backsub))
+    p.start()
+    try:
+        res = q.get(timeout=timeout)
+    except Exception:
+        if p.is_alive():
+            p.kill()
+        p.join(10)
+        raise AssertionError(f"solve hung or crashed (exit code {p.exitcode})")
+    p.join(60)
+    assert p.exitcode == 0
+    return res
+
+
+def test_candidate_poses_formed_in_the_gram_prologue_equal_k_backsub(oracle):
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    fused, separate = _run_rig(False), _run_rig(True)
+    assert any(len(np.unique(sp.obs_slot)) < sp.n_slots for sp in _rigs())          # a rig with slots that no camera observes is among them
+    for sp, rf, rs in zip(_rigs(), fused, separate):
+        unobserved = np.setdiff1d(np.arange(sp.n_slots), np.unique(sp.obs_slot))
+        op = oracle.OracleProblem.from_synth(sp)
+        for m, (a, b) in enumerate(zip(rf, rs)):
+            i1, p1, e1, v1, c1, id1, pd1, ed1, vd1 = a
+            i2, p2, e2, v2, c2, id2, pd2, ed2, vd2 = b
+            assert v1 == v2 and vd1 == vd2 == v1[:2], (m, v1, v2)
+            if v1[0] in (0, 5):
+                np.testing.assert_allclose(i1, i2, rtol=1e-10, atol=1e-13); np.testing.assert_allclose(p1, p2, rtol=0, atol=1e-10)
+                np.testing.assert_allclose(e1, e2, rtol=0, atol=1e-10)
+                assert c1 == pytest.approx(c2, rel=1e-11)
+                np.testing.assert_array_equal(i1, id1); np.testing.assert_array_equal(p1, pd1); np.testing.assert_array_equal(e1, ed1)
+                # a slot that no camera observes keeps the pose it came with, whichever parameter set ends up the accepted one
+                np.testing.assert_array_equal(p1[unobserved], sp.poses0[unobserved])
+                np.testing.assert_array_equal(pd1[unobserved], sp.poses0[unobserved])
+            io, po, eo, ro = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(m))
+            assert (v1[0], v1[1]) == (ro.status, ro.iterations)
+            if ro.status == 0:
+                np.testing.assert_allclose(p1, po, rtol=0, atol=1e-6); np.testing.assert_allclose(e1, eo, rtol=0, atol=1e-6)
