@@ -189,6 +189,7 @@ __device__ __forceinline__ double schur_lambda(const DevState* st) {
 // instead of Gram + reduce + head: two kernel boundaries (~3 us each) less per step.  What a launch reads and what the same
 // launch's workgroup 0 writes must not alias - another workgroup may start later: the state and the rows alternate between
 // two buffers by launch number.
+constexpr int kFusedMaxK = 9;     // the single-camera loop: at most 9 camera columns (OPENCV5, two focal lengths)
 struct IterArgs {
     int32_t on;                    // this launch is of the single-launch form
     int32_t skip_head;             // the solve's first launch: no sums to decide on yet, the state passes through
@@ -197,6 +198,13 @@ struct IterArgs {
     const double* partial_in; int32_t n_part_in;       // the previous launch's rows (this launch's go to FusedArgs::partial)
     HostStatus* hs; const ColInfo* cols; double* dc_out;
     double* result_host; int64_t np6;                  // see HeadArgs
+    // The solve's FIRST launch as its own k_unpack1 (`fold`; every slot has an observation frame): the starting state, the column
+    // table and the intrinsics ride in THIS argument block, every frame's lanes read their slot's starting pose where the caller
+    // left it (pinned host memory, or parameter set 0 for device-resident solves) and write it to the parameter sets; workgroup 0
+    // writes state, columns and intrinsics.  One launch (~5 us) and the host's gap behind it (~5 us) less per solve.
+    int32_t fold, n_cols, poses_on_device;
+    const double* poses_src; ColInfo* cols_out;
+    DevState st0; ColInfo col0[kFusedMaxK]; double intr_h[CCAL_PMAX];
 };
 
 // A workgroup's row of partial sums in the single-launch form: the two symmetric blocks as their upper triangles (the mirrored
@@ -363,7 +371,6 @@ struct HeadArgs {
     int32_t publish_all;           // verbose solves: the whole report after every group
 };
 
-constexpr int kFusedMaxK = 9;     // the single-camera loop: at most 9 camera columns (OPENCV5, two focal lengths)
 struct UnpackArgs {               // the starting point of a single-camera solve
     // the small part travels in the kernel-argument block itself (~600 bytes: no staging copy, no dependent load)
     DevState st0; ColInfo col0[kFusedMaxK]; double intr_h[CCAL_PMAX]; int32_t n_cols;

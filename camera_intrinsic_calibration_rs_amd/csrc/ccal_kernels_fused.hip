@@ -311,12 +311,17 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
         n_p = active ? (int)(a.obs_off[fa_ + 1] - start_p) : 0;
         slot_p = a.obs_slot[fa_];
     }
+    bool fold_first = false;                        // ITER: this launch is also the solve's k_unpack1 (IterArgs::fold)
+    if constexpr (ITER) fold_first = a.it.skip_head != 0 && a.it.fold != 0;
     auto iter_prefetch2 = [&]() {
       if constexpr (ITER) {
         const int64_t g0 = start_p + (gl < n_p ? gl : 0);
         pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+        // (fold: the starting pose from where the caller left it - pinned host memory, or set 0 for device-resident solves)
+        const double* ps0 = fold_first ? (a.it.poses_on_device ? a.poses[0] : a.it.poses_src) : a.poses[0];
+        const double* ps1 = fold_first ? ps0 : a.poses[1];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { pose_p[0][i] = a.poses[0][(int64_t)slot_p * 6 + i]; pose_p[1][i] = a.poses[1][(int64_t)slot_p * 6 + i]; }
+        for (int i = 0; i < 6; ++i) { pose_p[0][i] = ps0[(int64_t)slot_p * 6 + i]; pose_p[1][i] = ps1[(int64_t)slot_p * 6 + i]; }
 #pragma unroll
         for (int q = 0; q < NPFQ; ++q) {
             const int e = min(gl + LPF * q, PFLEN - 1);
@@ -354,6 +359,26 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
             G1V_STAMP(9);
             from_lds = true;
             const DevState& S = hsh.S0;
+            g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;
+            g.lambda_solve = S.lambda_solve; g.lam_schur = schur_lambda(&S);
+        } else if (fold_first) {
+            iter_prefetch2();
+            // the solve's first launch AND its k_unpack1: state, columns and intrinsics from the argument block
+            constexpr int NS = (int)(sizeof(DevState) / sizeof(double)), NC1 = (int)(sizeof(ColInfo) / sizeof(double));
+            if (threadIdx.x < CCAL_PMAX) hsh.cand[threadIdx.x] = it.poses_on_device ? a.intr[0][threadIdx.x] : reinterpret_cast<const double*>(it.intr_h)[threadIdx.x];
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                for (int e = threadIdx.x; e < NS; e += 64) reinterpret_cast<double*>(it.st_out)[e] = reinterpret_cast<const double*>(&it.st0)[e];
+                for (int e = threadIdx.x; e < it.n_cols * NC1; e += 64) reinterpret_cast<double*>(it.cols_out)[e] = reinterpret_cast<const double*>(it.col0)[e];
+                if (threadIdx.x < CCAL_PMAX) {
+                    const double v = it.poses_on_device ? a.intr[0][threadIdx.x] : reinterpret_cast<const double*>(it.intr_h)[threadIdx.x];
+                    if (!it.poses_on_device) a.intr[0][threadIdx.x] = v;
+                    a.intr[1][threadIdx.x] = v;
+                }
+                if (threadIdx.x == 0) it.hs->word = status_word(it.seq, 0, 0);
+            }
+            __syncthreads();
+            from_lds = true;                       // (the intrinsics: hsh.cand; the camera step is not read in a first evaluation)
+            const DevState& S = it.st0;
             g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;
             g.lambda_solve = S.lambda_solve; g.lam_schur = schur_lambda(&S);
         } else {
@@ -503,6 +528,12 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
             if (active) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+            }
+        }
+        if constexpr (ITER) {
+            if (fold_first && active) {            // k_unpack1's part of this frame: the starting pose into the parameter sets
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (gl == i) { if (!a.it.poses_on_device) a.poses[0][(int64_t)slot * 6 + i] = pose[i]; a.poses[1][(int64_t)slot * 6 + i] = pose[i]; }
             }
         }
         if (!GEN && active && gl == 0) a.mc_f[f] = mc;

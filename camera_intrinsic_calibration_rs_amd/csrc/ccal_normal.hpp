@@ -102,6 +102,7 @@ struct FusedWs {
     double* h_result = nullptr;                // pinned, host-coherent: [intr | poses] written by the k_head that finishes a session-sized solve
     hipStream_t side = nullptr;                // result download: does not queue behind the early-exit groups
     bool tail_pending = false;                 // early-exit groups of the previous solve may still be in flight
+    int all_slots_observed = -1;               // every frame slot has an observation frame (-1: not looked yet): the first single-launch group may unpack for itself
 };
 
 struct DevState;

@@ -595,6 +595,8 @@ struct FusedJob : SolveJob {
     // single-launch groups (k_gram1v<.., ITER>, IterArgs): launch s reads state buffer s & 1 and the rows of launch s - 1,
     // writes state buffer (s + 1) & 1 and its own rows into the other half of the partial-sum buffer
     int iter_rows = 0;
+    bool fold = false;                // the first single-launch group is also the solve's k_unpack1 (IterArgs::fold)
+    UnpackArgs ua0;                   // its payload
     DevState* iter_state(int s) const { return f->d_state + 1 + (s & 1); }
     double* iter_partial(int s) const { return f->partial + (size_t)(s & 1) * iter_rows * f->RB1; }
     double* h_poses = nullptr;
@@ -647,7 +649,18 @@ struct FusedJob : SolveJob {
                 }
             }
             f->state_is_eval = false;
-            HIP_TRY(ctx, launch_unpack1(ua, st));
+            // every slot observed (single camera: one frame per slot): the first single-launch group unpacks for itself - one launch
+            // and the host's gap behind it less per solve.  CCAL_ITER_FOLD=0: k_unpack1.
+            static const bool fold_off = [] { const char* e = std::getenv("CCAL_ITER_FOLD"); return e && e[0] == '0'; }();
+            if (f->all_slots_observed < 0) {
+                std::vector<char> seen((size_t)std::max(p->n_slots, 1), 0);
+                int n_seen = 0;
+                for (int sl : p->h_obs_slot) if (sl >= 0 && sl < p->n_slots && !seen[(size_t)sl]) { seen[(size_t)sl] = 1; ++n_seen; }
+                f->all_slots_observed = n_seen == p->n_slots ? 1 : 0;
+            }
+            fold = iter_rows > 0 && !fold_off && f->all_slots_observed == 1;
+            if (fold) ua0 = ua;
+            else HIP_TRY(ctx, launch_unpack1(ua, st));
         }
         enqueued_any = true;          // from here on an error exit leaves kernels in flight: the next solve / the destructor drains
         f->h_status->word = 0;
@@ -682,6 +695,13 @@ struct FusedJob : SolveJob {
             it.partial_in = iter_partial(sq - 1); it.n_part_in = iter_rows; fa.partial = iter_partial(sq);
             it.hs = f->h_status; it.cols = w->cols; it.dc_out = w->dc;
             it.result_host = zero_copy ? f->h_result : nullptr; it.np6 = (int64_t)np6;
+            it.fold = (fold && sq == 1) ? 1 : 0;
+            if (it.fold) {
+                it.n_cols = ua0.n_cols; it.poses_on_device = ua0.poses_on_device; it.poses_src = ua0.poses_src; it.cols_out = ua0.cols;
+                it.st0 = ua0.st0;
+                for (int i = 0; i < kFusedMaxK; ++i) it.col0[i] = ua0.col0[i];
+                std::memcpy(it.intr_h, ua0.intr_h, sizeof it.intr_h);
+            }
             HIP_TRYN(ctx, launch_gram_iter(p->cams[0].model, p->one_focal, fa, st));
             if (fa.n_part != iter_rows) { ctx->err = "single-launch group: row count changed"; return -CCAL_ERR_INVALID_ARG; }
             return sq;
