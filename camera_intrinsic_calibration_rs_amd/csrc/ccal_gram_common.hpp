@@ -164,6 +164,10 @@ __device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const double
 template <int LPF, int G, int REGION>
 __device__ __forceinline__ double gen_backsub_pose(const FusedArgs& a, const int slot, const double lambda, double* pose, double* buf,
                                                    const int grp, const int gl, const bool lane_ok) {
+    // every fused multiply-add is spelled out, here and in k_backsub, and the products that must NOT be fused into the pose update
+    // pass an optimisation barrier: the two forms of the general loop give the same bits - the back end (-ffp-contract=fast) had
+    // turned pose + t * L_ii into one FMA here and not there (1 ulp in a few poses per step, enough to move a verdict on a system
+    // that is singular to rounding)
     const int K = a.g_K, K1 = K + 1, PF = a.g_PF;
     const int RS = (PF + K + 6 + 1) & ~1;
     const double* pfg = a.g_pf + (int64_t)slot * PF;
@@ -181,7 +185,7 @@ __device__ __forceinline__ double gen_backsub_pose(const FusedArgs& a, const int
             const double* dc = R + PF;
             double t = yr[K];
 #pragma unroll 6
-            for (int j = 0; j < K; ++j) t += yr[j] * dc[j];       // (same order as k_backsub's sum; unrolled: the LDS reads of six steps travel together)
+            for (int j = 0; j < K; ++j) t = __builtin_fma(yr[j], dc[j], t);       // (k_backsub's sum; unrolled: the LDS reads of six steps travel together)
             R[PF + K + gl] = -t;
         }
         wsync();
@@ -193,7 +197,8 @@ __device__ __forceinline__ double gen_backsub_pose(const FusedArgs& a, const int
         double t0 = y0[K], t1 = y0[K1 + K], t2 = y0[2 * K1 + K], t3 = y0[3 * K1 + K], t4 = y0[4 * K1 + K], t5 = y0[5 * K1 + K];
         for (int j = 0; j < K; ++j) {
             const double d = a.g_dc[j];
-            t0 += y0[j] * d; t1 += y0[K1 + j] * d; t2 += y0[2 * K1 + j] * d; t3 += y0[3 * K1 + j] * d; t4 += y0[4 * K1 + j] * d; t5 += y0[5 * K1 + j] * d;
+            t0 = __builtin_fma(y0[j], d, t0); t1 = __builtin_fma(y0[K1 + j], d, t1); t2 = __builtin_fma(y0[2 * K1 + j], d, t2);
+            t3 = __builtin_fma(y0[3 * K1 + j], d, t3); t4 = __builtin_fma(y0[4 * K1 + j], d, t4); t5 = __builtin_fma(y0[5 * K1 + j], d, t5);
         }
         dp[0] = -t0; dp[1] = -t1; dp[2] = -t2; dp[3] = -t3; dp[4] = -t4; dp[5] = -t5;
         pf = pfg;
@@ -204,15 +209,16 @@ __device__ __forceinline__ double gen_backsub_pose(const FusedArgs& a, const int
         for (int i = 5; i >= 0; --i) {     // L^T x = rhs, diagonal stored inverted
             double t = dp[i];
 #pragma unroll
-            for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
+            for (int k = i + 1; k < 6; ++k) t = __builtin_fma(-pf[k * (k + 1) / 2 + i], dp[k], t);
             dp[i] = t * pf[i * (i + 1) / 2 + i];
+            asm volatile("" : "+v"(dp[i]));        // the product is a value of its own
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const double gp = pf[21 + 6 * K1 + i], dC = pf[21 + 6 * K1 + 6 + i];
             const double Dii = lambda > 0.0 ? lambda * clampd1(dC, a.min_diag, a.max_diag) : 0.0;
-            mc += dp[i] * (Dii * dp[i] - gp);
-            pose[i] += dp[i];
+            mc = __builtin_fma(dp[i], __builtin_fma(Dii, dp[i], -gp), mc);
+            pose[i] = pose[i] + dp[i];
         }
     }
     wsync();                                   // (the buffer is the caller's again)

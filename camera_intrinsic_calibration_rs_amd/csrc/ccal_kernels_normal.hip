@@ -1006,6 +1006,9 @@ struct BacksubArgs {
     const DevState* st;
 };
 __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
+    // every fused multiply-add spelled out and the step kept out of the pose update's addition by an optimisation barrier, here and
+    // in gen_backsub_pose (ccal_gram_common.hpp: the same work in the GEN Gram kernels' prologue for session-sized rigs): the two
+    // forms give the same bits
     __shared__ double dcs[CCAL_KMAX];
     extern __shared__ double smem[];                       // [16][PF + 6]
     BacksubArgs a = a0;
@@ -1030,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     if (active && gl < 6) {
         const double* yr = R + 21 + gl * K1;
         double t = yr[a.K];
-        for (int j = 0; j < a.K; ++j) t += yr[j] * dcs[j];
+        for (int j = 0; j < a.K; ++j) t = __builtin_fma(yr[j], dcs[j], t);
         R[a.PF + gl] = -t;
     }
     __syncthreads();
@@ -1050,15 +1053,16 @@ __global__ __launch_bounds__(256) void k_backsub(const BacksubArgs a0) {
     for (int i = 5; i >= 0; --i) {     // L^T x = rhs, diagonal stored inverted
         double t = dp[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) t -= L[k * (k + 1) / 2 + i] * dp[k];
+        for (int k = i + 1; k < 6; ++k) t = __builtin_fma(-L[k * (k + 1) / 2 + i], dp[k], t);
         dp[i] = t * L[i * (i + 1) / 2 + i];
+        asm volatile("" : "+v"(dp[i]));            // the product is a value of its own
     }
     double mc = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const double gp = R[21 + 6 * K1 + i], dC = R[21 + 6 * K1 + 6 + i];
         const double Dii = a.lambda > 0.0 ? a.lambda * clampd(dC, a.min_diag, a.max_diag) : 0.0;
-        mc += dp[i] * (Dii * dp[i] - gp);
+        mc = __builtin_fma(dp[i], __builtin_fma(Dii, dp[i], -gp), mc);
         poses_c[(int64_t)s * 6 + i] = poses[(int64_t)s * 6 + i] + dp[i];
     }
     a.mc_slot[s] = mc;
