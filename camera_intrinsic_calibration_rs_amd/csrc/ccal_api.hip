@@ -178,22 +178,34 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     p->n_corners = p->h_obs_off[d->n_obs];
     const size_t nc = (size_t)p->n_corners;
     if (nc && (!d->p3d_x || !d->p3d_y || !d->p3d_z || !d->p2d_u || !d->p2d_v)) return fail(ctx, CCAL_ERR_INVALID_ARG, "null corner arrays");
-    int rc;
-#define UP(dst, src, n) if ((rc = upload(ctx, &p->dst, src, n)) != CCAL_OK) return rc;
-    UP(d_x, d->p3d_x, nc) UP(d_y, d->p3d_y, nc) UP(d_z, d->p3d_z, nc) UP(d_u, d->p2d_u, nc) UP(d_v, d->p2d_v, nc)
-    UP(d_obs_off, p->h_obs_off.data(), p->h_obs_off.size())
-    UP(d_joff, p->h_joff.data(), p->h_joff.size())
-    UP(d_obs_cam, p->h_obs_cam.data(), p->h_obs_cam.size())
-    UP(d_obs_slot, p->h_obs_slot.data(), p->h_obs_slot.size())
-    for (int c = 0; c < d->n_cams; ++c) { UP(cams[c].d_obs, p->cams[c].obs.data(), p->cams[c].obs.size()) }
-#undef UP
+    // ONE device allocation, cleared once, sliced (a calibration session creates its problem once: sixteen hipMalloc + memset pairs
+    // were a third of ccal_problem_create's 0.25 ms at 600 frames).  One element of slack behind every uploaded array, as upload().
     const size_t ni = (size_t)d->n_cams * CCAL_PMAX, np6 = (size_t)std::max(d->n_slots, 1) * 6, ne = (size_t)d->n_cams * 6;
-    double** bufs[6] = { &p->d_intr, &p->d_poses, &p->d_extr, &p->d_intr_c, &p->d_poses_c, &p->d_extr_c };
-    const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
-    for (int i = 0; i < 6; ++i) {
-        if (hipMalloc((void**)bufs[i], sz[i] * sizeof(double)) != hipSuccess ||
-            hipMemsetAsync(*bufs[i], 0, sz[i] * sizeof(double), ctx->stream) != hipSuccess)
-            return fail(ctx, CCAL_ERR_HIP, "hipMalloc(params) failed");
+    auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t total = 5 * up256((nc + 1) * sizeof(float)) + 2 * up256((p->h_obs_off.size() + 1) * sizeof(int64_t)) +
+                   2 * up256((p->h_obs_cam.size() + 1) * sizeof(int32_t)) + 2 * (up256(ni * 8) + up256(np6 * 8) + up256(ne * 8));
+    for (int c = 0; c < d->n_cams; ++c) total += up256((p->cams[c].obs.size() + 1) * sizeof(int32_t));
+    HIP_TRY(ctx, hipMalloc((void**)&p->d_block, total));
+    HIP_TRY(ctx, hipMemsetAsync(p->d_block, 0, total, ctx->stream));
+    {
+        char* q = p->d_block;
+        auto put = [&](auto** dst, const auto* src, size_t n) -> hipError_t {
+            using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
+            *dst = reinterpret_cast<T*>(q);
+            q += up256((n + 1) * sizeof(T));
+            return (n && src) ? hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        };
+        HIP_TRY(ctx, put(&p->d_x, d->p3d_x, nc)); HIP_TRY(ctx, put(&p->d_y, d->p3d_y, nc)); HIP_TRY(ctx, put(&p->d_z, d->p3d_z, nc));
+        HIP_TRY(ctx, put(&p->d_u, d->p2d_u, nc)); HIP_TRY(ctx, put(&p->d_v, d->p2d_v, nc));
+        HIP_TRY(ctx, put(&p->d_obs_off, (const int64_t*)p->h_obs_off.data(), p->h_obs_off.size()));
+        HIP_TRY(ctx, put(&p->d_joff, (const int64_t*)p->h_joff.data(), p->h_joff.size()));
+        HIP_TRY(ctx, put(&p->d_obs_cam, (const int32_t*)p->h_obs_cam.data(), p->h_obs_cam.size()));
+        HIP_TRY(ctx, put(&p->d_obs_slot, (const int32_t*)p->h_obs_slot.data(), p->h_obs_slot.size()));
+        for (int c = 0; c < d->n_cams; ++c) HIP_TRY(ctx, put(&p->cams[c].d_obs, (const int32_t*)p->cams[c].obs.data(), p->cams[c].obs.size()));
+        double** bufs[6] = { &p->d_intr, &p->d_poses, &p->d_extr, &p->d_intr_c, &p->d_poses_c, &p->d_extr_c };
+        const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
+        for (int i = 0; i < 6; ++i) { *bufs[i] = reinterpret_cast<double*>(q); q += up256(sz[i] * 8); }
+        if ((size_t)(q - p->d_block) > total) return fail(ctx, CCAL_ERR_HIP, "problem block layout");
     }
     p->lo.assign(ni, 0.0); p->hi.assign(ni, 0.0); p->has_bound.assign(ni, 0); p->fixed.assign(ni, 0);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, CCAL_ERR_HIP, "upload failed");
@@ -214,10 +226,8 @@ void ccal_problem_destroy(ccal_problem* p) {
         p->nws->tail_pending = false;
         if (p->nws->fws) p->nws->fws->tail_pending = false;
     }
-    void* ptrs[] = { p->d_x, p->d_y, p->d_z, p->d_u, p->d_v, p->d_obs_off, p->d_joff, p->d_obs_cam, p->d_obs_slot,
-                     p->d_intr, p->d_poses, p->d_extr, p->d_intr_c, p->d_poses_c, p->d_extr_c, p->d_r, p->d_J, p->d_err };
+    void* ptrs[] = { p->d_block, p->d_r, p->d_J, p->d_err };          // (corner arrays, frame tables, parameter arrays: slices of d_block)
     for (void* q : ptrs) if (q) (void)hipFree(q);
-    for (auto& c : p->cams) if (c.d_obs) (void)hipFree(c.d_obs);
     normal_ws_destroy(p);
     ccal_ctx* ctx = p->ctx;
     const bool counted = p->counted;

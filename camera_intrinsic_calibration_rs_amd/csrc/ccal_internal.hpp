@@ -87,6 +87,7 @@ struct ccal_problem {
     std::vector<int64_t> h_obs_off, h_joff;
     std::vector<int32_t> h_obs_cam, h_obs_slot;
     // device-resident inputs
+    char* d_block = nullptr;       // ONE device allocation: the corner arrays, the frame tables and the six parameter arrays are slices of it
     float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_u = nullptr, *d_v = nullptr;
     int64_t *d_obs_off = nullptr, *d_joff = nullptr;
     int32_t *d_obs_cam = nullptr, *d_obs_slot = nullptr;
