@@ -226,7 +226,7 @@ void ccal_problem_destroy(ccal_problem* p) {
         p->nws->tail_pending = false;
         if (p->nws->fws) p->nws->fws->tail_pending = false;
     }
-    void* ptrs[] = { p->d_block, p->d_r, p->d_J, p->d_err };          // (corner arrays, frame tables, parameter arrays: slices of d_block)
+    void* ptrs[] = { p->d_block, p->d_r, p->d_J, p->d_err, p->d_scratch };          // (corner arrays, frame tables, parameter arrays: slices of d_block)
     for (void* q : ptrs) if (q) (void)hipFree(q);
     normal_ws_destroy(p);
     ccal_ctx* ctx = p->ctx;

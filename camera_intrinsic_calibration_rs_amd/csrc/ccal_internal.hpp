@@ -87,6 +87,7 @@ struct ccal_problem {
     std::vector<int64_t> h_obs_off, h_joff;
     std::vector<int32_t> h_obs_cam, h_obs_slot;
     // device-resident inputs
+    char* d_scratch = nullptr; size_t scratch_bytes = 0;      // validation()'s temporaries (grown on demand, kept between calls)
     char* d_block = nullptr;       // ONE device allocation: the corner arrays, the frame tables and the six parameter arrays are slices of it
     float *d_x = nullptr, *d_y = nullptr, *d_z = nullptr, *d_u = nullptr, *d_v = nullptr;
     int64_t *d_obs_off = nullptr, *d_joff = nullptr;
@@ -133,7 +134,7 @@ int rccl_allreduce_sum(ccal_ctx* ctx, void* comm, double* buf, size_t count, hip
 // ccal_solver.hip: wait for the early-exit groups a finished solve left in the stream (no-op if there are none)
 int drain_pending_groups(ccal_problem* p);
 // ccal_kernels_stats.hip
-hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
+hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
 hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s);
 hipError_t sorted_stats_device(double* d_vals, int64_t n, double* avg_99, double* median, hipStream_t s);
 // ccal_api.hip: reprojection errors of every corner at the given parameters into p->d_err (device); ccal_multi.hip uses it per shard

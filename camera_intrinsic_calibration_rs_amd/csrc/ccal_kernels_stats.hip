@@ -41,15 +41,56 @@ hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_
     return hipSuccess;
 }
 
-// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`.
-hipError_t validation_stats_device(const ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
-    double* d_a = nullptr; int64_t n = 0;
-    hipError_t e = camera_errors_device(p, cam, d_err, &d_a, &n, s);
-    if (e != hipSuccess) return e;
+// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`.  The same kernels in the
+// same order as camera_errors_device + sorted_stats_device (the multi-GPU form's pieces: the same bits), with every temporary a
+// slice of the problem's scratch block (kept for the next call): five hipMalloc / hipFree pairs - a hipFree waits for the device -
+// were half of validation()'s 0.18 ms at 600 frames.
+hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
+    const CamLayout& cl = p->cams[cam];
+    const int n_list = (int)cl.obs.size();
+    std::vector<int64_t> dst(n_list + 1, 0);
+    for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
+    const int64_t n = dst[n_list];
     if (n <= 0) return hipErrorInvalidValue;
-    e = sorted_stats_device(d_a, n, avg_99, median, s);
-    (void)hipFree(d_a);
-    return e;
+    const int64_t n99 = n * 99 / 100;
+    size_t tmp_sort = 0, tmp_red = 0;
+    hipError_t e;
+#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (const double*)nullptr, (double*)nullptr, (int)n, 0, 64, s));
+    TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_red, (const double*)nullptr, (double*)nullptr, (int)std::max<int64_t>(n99, 1), s));
+    const size_t tmp_bytes = std::max<size_t>(std::max(tmp_sort, tmp_red), 16);
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_off = up((size_t)(n_list + 1) * sizeof(int64_t)), b_val = up((size_t)n * sizeof(double)), b_sum = 256, b_tmp = up(tmp_bytes);
+    const size_t total = b_off + 2 * b_val + b_sum + b_tmp;
+    if (p->scratch_bytes < total) {
+        if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
+        TRY(hipMalloc((void**)&p->d_scratch, total));
+        p->scratch_bytes = total;
+    }
+    char* q = p->d_scratch;
+    int64_t* d_dst = reinterpret_cast<int64_t*>(q); q += b_off;
+    double* d_a = reinterpret_cast<double*>(q); q += b_val;
+    double* d_b = reinterpret_cast<double*>(q); q += b_val;
+    double* d_sum = reinterpret_cast<double*>(q); q += b_sum;
+    void* d_tmp = q;
+    double h[2] = { 0.0, 0.0 };
+    size_t tb = tmp_bytes;
+    TRY(hipMemcpyAsync(d_dst, dst.data(), (size_t)(n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a);
+    TRY(hipGetLastError());
+    TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_a, d_b, (int)n, 0, 64, s));       // errors are >= 0: bit order == value order
+    TRY(hipMemcpyAsync(&h[0], d_b + n / 2, sizeof(double), hipMemcpyDeviceToHost, s));          // median = e[len / 2]
+    if (n99 > 0) {
+        hipLaunchKernelGGL(k_scale, dim3((unsigned)((n99 + 255) / 256)), dim3(256), 0, s, d_b, n99, 1.0 / (double)n99);   // e_i / len_99, then sum
+        TRY(hipGetLastError());
+        tb = tmp_bytes;
+        TRY(hipcub::DeviceReduce::Sum(d_tmp, tb, d_b, d_sum, (int)n99, s));
+        TRY(hipMemcpyAsync(&h[1], d_sum, sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    TRY(hipStreamSynchronize(s));          // (dst and h are host objects of this frame)
+#undef TRY
+    *median = h[0]; *avg_99 = h[1];
+    return hipSuccess;
 }
 
 // median = e[len / 2] and avg_99 = sum_{i < len * 99 / 100} e_i / (len * 99 / 100) of n non-negative values on the device (d_a is
