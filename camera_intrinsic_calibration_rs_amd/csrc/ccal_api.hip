@@ -402,9 +402,16 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
     int rc = ccal_upload_params(p, intr, nullptr, nullptr);
     if (rc != CCAL_OK) return rc;
     const size_t no = (size_t)std::max(p->n_obs, 1);
-    double* d_po = nullptr; int32_t* d_va = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**)&d_po, no * 6 * sizeof(double)));
-    if (hipMalloc((void**)&d_va, no * sizeof(int32_t)) != hipSuccess) { (void)hipFree(d_po); return fail(ctx, CCAL_ERR_HIP, "hipMalloc failed"); }
+    // the two temporaries are slices of the problem's scratch block (kept for the next call: no hipMalloc / hipFree pair per call)
+    const size_t b_po = (no * 6 * sizeof(double) + 255) & ~(size_t)255, b_va = (no * sizeof(int32_t) + 255) & ~(size_t)255;
+    if (p->scratch_bytes < b_po + b_va) {
+        if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
+        const size_t want = std::max(b_po + b_va, problem_scratch_hint(p));       // (room for validation()'s temporaries too: growing the block later costs a hipFree)
+        HIP_TRY(ctx, hipMalloc((void**)&p->d_scratch, want));
+        p->scratch_bytes = want;
+    }
+    double* d_po = reinterpret_cast<double*>(p->d_scratch);
+    int32_t* d_va = reinterpret_cast<int32_t*>(p->d_scratch + b_po);
     hipError_t e = hipMemsetAsync(d_va, 0, no * sizeof(int32_t), ctx->stream);
     for (int c = 0; c < p->n_cams && e == hipSuccess; ++c) e = launch_pose_init(p, c, p->d_intr, d_po, d_va, min_points, ctx->stream);
     if (e == hipSuccess && p->n_obs) {
@@ -412,7 +419,6 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
         if (e == hipSuccess) e = hipMemcpyAsync(n_used, d_va, (size_t)p->n_obs * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d_po); (void)hipFree(d_va);
     if (e != hipSuccess) { ctx->err = std::string("ccal_init_poses: ") + hipGetErrorString(e); return CCAL_ERR_HIP; }
     return CCAL_OK;
 }

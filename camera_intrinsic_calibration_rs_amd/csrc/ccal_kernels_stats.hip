@@ -64,8 +64,9 @@ hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err
     const size_t total = b_off + 2 * b_val + b_sum + b_tmp;
     if (p->scratch_bytes < total) {
         if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
-        TRY(hipMalloc((void**)&p->d_scratch, total));
-        p->scratch_bytes = total;
+        const size_t want = std::max(total, problem_scratch_hint(p));
+        TRY(hipMalloc((void**)&p->d_scratch, want));
+        p->scratch_bytes = want;
     }
     char* q = p->d_scratch;
     int64_t* d_dst = reinterpret_cast<int64_t*>(q); q += b_off;
