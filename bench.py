@@ -3,7 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W [--frames F | --frames-total F] [--model eucm]
 
-One process per GPU (torch.distributed.run sets RANK/LOCAL_RANK/WORLD_SIZE).  A "step" is one pass
+One process per GPU.  Under torch.distributed.run the launcher sets RANK/LOCAL_RANK/WORLD_SIZE; started plainly with
+`--gpus N` (N > 1, WORLD_SIZE unset) this file is its own launcher: the parent - which never touches the GPU - starts N fresh
+worker processes of itself, relays rank 0's line and exits non-zero when a worker fails or fewer than N GPUs are visible.
+A "step" is one pass
 of the hot path over one batch: every rank evaluates r[2] + J[2 x D] for all corners of its frame
 shard (F frames x 144 corners per GPU -- weak scaling; mode E needs no collective).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
@@ -86,6 +89,129 @@ def _under_rocprofiler() -> bool:
         return False
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _launch_workers(n, argv):
+    """`python bench.py --gpus N` without a launcher: be the launcher.  This process never initialises the GPU (counting devices
+    does not, on this image); it starts N fresh children of this file (one rank per GPU, rendezvous on 127.0.0.1), relays rank 0's
+    JSON line - with a `launcher` block saying what was started - and returns non-zero when any worker failed, when fewer than N
+    GPUs are visible, or when no line came back."""
+    import subprocess
+    backend = os.environ.get("CCAL_BENCH_BACKEND", "nccl")
+    dry = os.environ.get("CCAL_BENCH_DRYRUN") == "1"
+    if backend == "nccl" and not dry:
+        try:
+            import torch
+            have = torch.cuda.device_count()
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] cannot count GPUs: {e!r}", file=sys.stderr, flush=True)
+            return 4
+        if have < n:
+            print(f"[bench] --gpus {n} asked for, {have} GPU(s) visible: refusing to run on fewer (no silent fallback)", file=sys.stderr, flush=True)
+            return 4
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   CCAL_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
+    line = b""
+    try:
+        line, _ = procs[0].communicate(timeout=float(os.environ.get("CCAL_BENCH_LAUNCH_TIMEOUT", "3600")))     # rank 0 prints its one line at the very end
+    except subprocess.TimeoutExpired:
+        print("[bench] rank 0 did not finish in time: stopping the workers", file=sys.stderr, flush=True)
+        for pr in procs:
+            pr.kill()                            # exactly the children started here
+    except Exception:  # noqa: BLE001
+        pass
+    codes = []
+    deadline = time.time() + 120.0               # the other ranks leave their last barrier together with rank 0
+    for pr in procs:
+        try:
+            codes.append(pr.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            pr.kill()                            # exactly the child started here
+            codes.append(pr.wait())
+    out = None
+    for ln in line.decode(errors="replace").splitlines():
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                out = json.loads(ln)
+            except ValueError:
+                pass
+    bad = next((c for c in codes if c != 0), 0)
+    if out is None:
+        print(f"[bench] no JSON line from rank 0 (worker exit codes {codes})", file=sys.stderr, flush=True)
+        return bad or 5
+    out["launcher"] = {"kind": "bench.py parent process (WORLD_SIZE was unset)", "workers_spawned": n, "worker_exit_codes": codes,
+                       "master": f"127.0.0.1:{port}"}
+    _emit(out)
+    return bad
+
+
+def _dry_run(args, rank, world):
+    """CCAL_BENCH_DRYRUN=1 (tests/test_bench_cpu.py; no GPU needed): everything of a multi-rank run that is NOT the GPU - the
+    launcher, the gloo rendezvous, the product's own partition of the problem (ccal_partition_slots: host code of libccal_hip.so),
+    the barrier / max-over-ranks timing protocol and the one line - with a step that does nothing.  The line says so
+    (`dry_run`, value 0): it is not a measurement."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_intrinsic_calibration_rs_amd import engine, synth
+    strong = args.frames_total > 0
+    total_frames = args.frames_total if strong else args.frames * world
+    if strong:
+        sp = synth.make_problem(args.frames_total, args.model, seed=0xC0FFEE, ragged=True)
+        d, _keep = engine.desc_from_synth(sp)
+        first = engine.partition_slots(d, world)
+        mine = sp.slot_slice(first[rank], first[rank + 1])
+    else:
+        first = None
+        mine = synth.make_problem(args.frames, args.model, seed=0xC0FFEE + 1000003 * rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pass
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed, float(mine.n_corners), float(mine.n_slots)], dtype=torch.float64)
+    mx = t.clone()
+    if world > 1:
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        _emit({"metric": "corner residual+Jacobian evals/sec; LM iters/sec to converge (EUCM, TUM-VI cam0)", "value": 0.0,
+               "unit": "corner residual+Jacobian evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": float(mx[0]) / max(args.steps, 1) * 1e3, "higher_is_better": True,
+               "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "dry_run": "CCAL_BENCH_DRYRUN=1: launcher, rendezvous (gloo), partition and timing protocol only - no GPU work, not a measurement",
+               "config": {"workload": f"dry run, {total_frames} frames, {args.model.upper()}", "frames_total": total_frames,
+                          "slots_all_ranks": int(t[2]), "corners_all_ranks": int(t[1]),
+                          "partition": first, "partition_by": "ccal_partition_slots (libccal_hip.so, host code)" if strong else None}})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     _stdout_for_the_line_only()
     ap = argparse.ArgumentParser()
@@ -101,19 +227,29 @@ def main():
     ap.add_argument("--no-rig", action="store_true", help="skip the two-camera leg of the secondary measurements")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this process: be one (N fresh workers; this parent never touches the GPU)
+        sys.exit(_launch_workers(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if os.environ.get("CCAL_BENCH_DRYRUN") == "1":
+        return _dry_run(args, rank, world)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     # CCAL_BENCH_BACKEND=gloo (developer switch): exercise the multi-rank code path on a box with fewer GPUs than
     # ranks - ranks then share devices, the collective goes through the callback; the numbers mean nothing there
     backend = os.environ.get("CCAL_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    n_visible = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= n_visible:
+        print(f"[bench] rank {rank}: local rank {local_rank} but only {n_visible} GPU(s) visible", file=sys.stderr, flush=True)
+        sys.exit(4)
+    dev_index = local_rank if backend == "nccl" else local_rank % max(n_visible, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -132,7 +268,10 @@ def main():
         # ONE problem, generated identically on every rank (positional PRNG), of which the rank keeps its slot range
         sp = synth.make_problem(args.frames_total, args.model, seed=0xC0FFEE)
         if world > 1:
-            sp = sp.shard(rank, world)
+            # the library's own cut (ccal_partition_slots: contiguous slot ranges balanced by corner count - what
+            # ccal_multi_problem_create does in the single-process form)
+            first = engine.partition_slots(engine.desc_from_synth(sp)[0], world)
+            sp = sp.slot_slice(first[rank], first[rank + 1])
         args.frames = sp.n_slots
     else:
         sp = synth.make_problem(args.frames, args.model, seed=0xC0FFEE + 1000003 * rank)
@@ -457,30 +596,78 @@ def main():
                     except Exception as e:  # noqa: BLE001
                         cfg2[m2] = {"error": repr(e)}
                 extra["config2"] = cfg2
-            # ONE process, several shards (ccal_multi_*: the reference's single-process shape of a multi-GPU solve): the headline
-            # problem split over two contexts of THIS GPU by the library, in-process transport - what the sharding machinery costs
-            # next to the unsharded solve above (on one GPU it can only cost; the multi-GPU run is `extra.sharded_solve`)
-            try:
-                from camera_intrinsic_calibration_rs_amd.engine import MultiContext, MultiProblem
-                mc = MultiContext([dev_index, dev_index])
-                mpb = MultiProblem.from_synth(mc, sp)
-                sps = {}
-                for name, method in (("gn", 0), ("lm", 1)):
-                    best = None
-                    for _ in range(3):
-                        i_m, p_m, _, rep_m = mpb.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
-                        if best is None or rep_m.solve_ms < best[0].solve_ms:
-                            best = (rep_m, i_m)
-                    i_1 = prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))[0]
-                    sps[name] = {"iterations": best[0].iterations, "solve_ms": best[0].solve_ms, "status": best[0].status,
-                                 "unsharded_solve_ms": extra.get(f"{name}_solve_ms"),
-                                 "max_rel_intrinsics_diff_vs_unsharded": float(np.abs(best[1][0, :6] / i_1[0, :6] - 1).max())}
-                sps["shards"] = [mpb.slot_range(i) for i in range(mpb.n_shards)]
-                sps["transport"] = {0: "none", 1: "rccl", 2: "in-process (HIP events + device-side sum in shard order)"}[mc.transport]
-                extra["single_process_sharded"] = sps
-                mpb.close(); mc.close()
-            except Exception as e:  # noqa: BLE001
-                extra["single_process_sharded"] = {"error": repr(e)}
+            # ONE process, several GPUs (ccal_multi_*: the reference's single-process shape of a multi-GPU solve; SURVEY 8(b)'s
+            # `ccal_create(device_ids, n_dev)`): the headline problem cut by the library over EVERY visible GPU - range(device_count);
+            # on a 1-GPU box two shards of the one GPU, where sharding can only cost - with both transports side by side (in-process:
+            # HIP events + the deciding kernel adds the ranks' sums itself; RCCL: one ncclAllReduce per step on communicators made by
+            # ncclCommInitAll), the slot ranges, what RCCL itself counts as ranks, and mode E through ccal_multi_eval_dev
+            if world == 1:
+                try:
+                    from camera_intrinsic_calibration_rs_amd import _ffi as _f
+                    from camera_intrinsic_calibration_rs_amd.engine import MultiContext, MultiProblem
+                    devs_all = list(range(n_visible)) if n_visible > 1 else [dev_index, dev_index]
+                    legs = [("in_process", _f.TRANSPORT_INPROC, devs_all),
+                            ("rccl", _f.TRANSPORT_RCCL, devs_all if n_visible > 1 else [dev_index])]      # RCCL takes every device once: one rank on a 1-GPU box
+                    sps = {"devices": devs_all, "devices_visible": n_visible}
+                    i_ref = {m: prob.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(m))[0] for m in (0, 1)}
+                    for leg, tr, devs in legs:
+                        try:
+                            mc = MultiContext(devs, transport=tr)
+                            mpb = MultiProblem.from_synth(mc, sp)
+                            row = {"devices": devs, "shards": [mpb.slot_range(i) for i in range(mpb.n_shards)],
+                                   "transport": {0: "none (one device)", 1: "rccl (ncclCommInitAll, one ncclAllReduce per step issued by the library)",
+                                                 2: "in-process (HIP events; k_head / k_solve add the ranks' sums in rank order)"}[mc.transport],
+                                   "rccl_ranks": mc.rccl_ranks}
+                            for name, method in (("gn", 0), ("lm", 1)):
+                                best = None
+                                for _ in range(3):
+                                    i_m, p_m, _, rep_m = mpb.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+                                    if best is None or rep_m.solve_ms < best[0].solve_ms:
+                                        best = (rep_m, i_m)
+                                row[name] = {"iterations": best[0].iterations, "solve_ms": best[0].solve_ms, "status": best[0].status,
+                                             "unsharded_solve_ms": extra.get(f"{name}_solve_ms"),
+                                             "max_rel_intrinsics_diff_vs_unsharded": float(np.abs(best[1][0, :6] / i_ref[method][0, :6] - 1).max())}
+                            sps[leg] = row
+                            mpb.close(); mc.close()
+                        except Exception as e:  # noqa: BLE001
+                            sps[leg] = {"error": repr(e)}
+                    extra["single_process_sharded"] = sps
+                except Exception as e:  # noqa: BLE001
+                    extra["single_process_sharded"] = {"error": repr(e)}
+                try:
+                    # mode E through ccal_multi_eval_dev: one process, every visible GPU, no collective - each shard's launches on its
+                    # own context's stream; wall clock around K passes over the whole problem (the per-GPU roofline is the headline's)
+                    from camera_intrinsic_calibration_rs_amd.engine import MultiContext, MultiProblem
+                    devs = list(range(n_visible)) if n_visible > 1 else [dev_index, dev_index]
+                    mc = MultiContext(devs)
+                    mpb = MultiProblem.from_synth(mc, sp)
+                    mpb.upload_params(sp.intr0, sp.poses0, sp.extr0)
+                    bufs = []
+                    for i, d in enumerate(devs):
+                        nc_i, jl_i = mpb.shard_sizes(i)
+                        bufs.append((torch.empty(max(nc_i * 2, 1), dtype=torch.float64, device=f"cuda:{d}"),
+                                     torch.empty(max(jl_i, 1), dtype=torch.float64, device=f"cuda:{d}")))
+                    rp = [b[0].data_ptr() for b in bufs]; jp = [b[1].data_ptr() for b in bufs]
+                    t_r = time.perf_counter()
+                    while time.perf_counter() - t_r < CLOCK_RAMP_S:
+                        for _ in range(20):
+                            mpb.eval_dev(rp, jp)
+                        mc.sync()
+                    ne = 200
+                    t_e = time.perf_counter()
+                    for _ in range(ne):
+                        mpb.eval_dev(rp, jp)
+                    mc.sync()
+                    dt = (time.perf_counter() - t_e) / ne
+                    ab = n_corners * (20 + 16 + 16 * D) + sp.n_slots * 48
+                    extra["multi_eval"] = {"devices": devs, "shards": [mpb.slot_range(i) for i in range(mpb.n_shards)],
+                                           "ms_per_pass": dt * 1e3, "evals_per_s": n_corners / dt, "achieved_GBps_all_devices": ab / dt / 1e9,
+                                           "frac_hbm_per_device": ab / dt / 1e9 / HBM_PEAK_GBPS / len(set(devs)),
+                                           "how": "ccal_multi_eval_dev, wall clock around 200 passes (host enqueue of n launches per pass included)"}
+                    del bufs
+                    mpb.close(); mc.close()
+                except Exception as e:  # noqa: BLE001
+                    extra["multi_eval"] = {"error": repr(e)}
         except Exception as e:  # noqa: BLE001
             extra["error"] = repr(e)
         out["extra"] = extra
@@ -517,7 +704,8 @@ def main():
             split_total = int(os.environ.get("CCAL_BENCH_CONFIG3_FRAMES", "50000"))
             split_sp = synth.make_problem(split_total, args.model, seed=0xC0FFEE)
             if world > 1:
-                split_sp = split_sp.shard(rank, world)
+                first3 = engine.partition_slots(engine.desc_from_synth(split_sp)[0], world)
+                split_sp = split_sp.slot_slice(first3[rank], first3[rank + 1])
             split = Problem.from_synth(ctx, split_sp)
 
         def attach(pr):
@@ -537,6 +725,7 @@ def main():
             res["collective"] = ("ncclAllReduce issued by libccal_hip.so (ccal_set_rccl_comm), one per optimizer step"
                                  if native else "callback (torch.distributed, developer switch)")
             res["rccl_version"] = engine._ffi.load().ccal_rccl_version() if native else None
+            res["rccl_ranks"] = engine.rccl_comm_count(comm) if (native and comm) else None      # what RCCL itself counts (ncclCommCount)
 
         def sharded():
             nonlocal comm
@@ -566,18 +755,20 @@ def main():
             result = {"error": "timeout (180 s) in the sharded solve"}
         if rank == 0:
             out.setdefault("extra", {})["sharded_solve"] = result
+            out["rccl_ranks"] = result.get("rccl_ranks")          # did RCCL see all N ranks: ncclCommCount of the communicator the solves used
             if split is not None:
                 out["extra"]["config3_split"] = result3 or {"error": "not reached"}
         if th.is_alive():
             # the headline (mode E, no collective) was measured before this leg: the line goes out with the failure of the
             # SECONDARY leg spelled out in it (extra.sharded_solve.error, top-level "secondary_leg_failed") and on stderr.  The
-            # process cannot be unwound (a thread sits inside a collective with no partner): it ends here, without a re-exec.
-            # Exit code 0: the metric the line reports is valid; 3 with CCAL_BENCH_STRICT=1 (a developer's run)
+            # process cannot be unwound (a thread sits inside a collective with no partner): it ends here, without a re-exec,
+            # with a NON-ZERO exit code on every rank that hangs - a hung collective is never reported as success.  Rank 0's line
+            # (the headline is valid) is on stdout first; bench.py's own launcher relays it and passes the exit code on.
             if rank == 0:
                 out["secondary_leg_failed"] = "sharded_solve: timeout (180 s) inside the frame-sharded solve"
                 _emit(out)
             print("[bench] sharded solve timed out after 180 s on rank %d" % rank, file=sys.stderr, flush=True)
-            os._exit(3 if os.environ.get("CCAL_BENCH_STRICT") == "1" else 0)
+            os._exit(3)
         if comm:
             engine.rccl_comm_destroy(comm)
 

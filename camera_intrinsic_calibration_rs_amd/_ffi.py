@@ -84,6 +84,7 @@ SYMBOLS = [
     ("ccal_rccl_unique_id", C.c_int, [_vp]),
     ("ccal_rccl_comm_create", C.c_int, [_vp, C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     ("ccal_rccl_comm_destroy", C.c_int, [_vp]),
+    ("ccal_rccl_comm_count", C.c_int, [_vp]),
     ("ccal_get_model_conventions", C.c_int, [_vp, C.POINTER(ModelConventions)]),
     ("ccal_set_model_conventions", C.c_int, [_vp, C.POINTER(ModelConventions)]),
     ("ccal_num_corners", C.c_int64, [_vp]),
@@ -108,6 +109,10 @@ SYMBOLS = [
     # one process, several GPUs
     ("ccal_solve_sharded", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(SolverOpts), _dp, C.POINTER(_dp), _dp, C.POINTER(Report)]),
     ("ccal_multi_create", C.c_int, [_ip, C.c_int, C.POINTER(_vp)]),
+    ("ccal_multi_create_transport", C.c_int, [_ip, C.c_int, C.c_int, C.POINTER(_vp)]),
+    ("ccal_multi_rccl_ranks", C.c_int, [_vp]),
+    ("ccal_create_last_error", C.c_char_p, []),
+    ("ccal_partition_slots", C.c_int, [C.POINTER(ProblemDesc), C.c_int, _ip]),
     ("ccal_multi_destroy", None, [_vp]),
     ("ccal_multi_num_devices", C.c_int, [_vp]),
     ("ccal_multi_transport", C.c_int, [_vp]),

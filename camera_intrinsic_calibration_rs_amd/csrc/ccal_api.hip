@@ -82,15 +82,16 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
     if (!out) return CCAL_ERR_INVALID_ARG;
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n) return CCAL_ERR_HIP;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); note_create_error("ccal_ctx_create: no HIP device"); return CCAL_ERR_HIP; }
+    if (device_id < 0 || device_id >= n) { note_create_error("ccal_ctx_create: device " + std::to_string(device_id) + " of " + std::to_string(n)); return CCAL_ERR_HIP; }
     ccal_ctx* c = new (std::nothrow) ccal_ctx();
     if (!c) return CCAL_ERR_NO_MEMORY;
     default_conventions(&c->conv);
     c->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess) { delete c; return CCAL_ERR_HIP; }
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; note_create_error("ccal_ctx_create: hipSetDevice failed"); return CCAL_ERR_HIP; }
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
-        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CCAL_ERR_HIP; }
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; note_create_error("ccal_ctx_create: hipStreamCreate failed"); return CCAL_ERR_HIP; }
         c->own_stream = true;
     }
     *out = c;

@@ -369,7 +369,19 @@ struct HeadArgs {
     // partial == NULL: `red` holds the (all-)reduced sums
     const double* partial; int32_t n_part;
     int32_t publish_all;           // verbose solves: the whole report after every group
+    // single-process sharded solves over the in-process transport (ccal_multi.hip): every rank's reduced sums of this step, rank
+    // order; the head adds them itself (the same order - the same bits - on every rank).  peers.n == 0: `red` / `partial` as above
+    PeerView peers;
 };
+
+// one element of a peer rank's buffer: a system-scope load that bypasses this GPU's caches (the buffer lives on another device
+// when the shards sit on different GPUs; what an earlier step left of the same address in L2 must not be served again)
+__device__ __forceinline__ double ld_peer(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double peer_sum(const PeerView& pv, const int e) {
+    double v = ld_peer(pv.src[0] + e);
+    for (int q = 1; q < pv.n; ++q) v += ld_peer(pv.src[q] + e);
+    return v;
+}
 
 struct UnpackArgs {               // the starting point of a single-camera solve
     // the small part travels in the kernel-argument block itself (~600 bytes: no staging copy, no dependent load)

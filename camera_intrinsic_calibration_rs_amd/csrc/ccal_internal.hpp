@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdint>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <string>
@@ -105,10 +106,10 @@ struct ccal_problem {
     ccal_allreduce_fn allreduce = nullptr;     // callback form of the step's collective (tests over gloo)
     void* allreduce_user = nullptr;
     void* rccl_comm = nullptr;                 // ncclComm_t: the library issues ncclAllReduce itself (ccal_set_rccl_comm)
-    bool allreduce_stream_ordered = false;     // the callback only enqueues on the stream (the library's in-process transport,
-                                               // ccal_multi.hip): groups are enqueued ahead of the host like with RCCL
+    void* peer = nullptr;                      // the library's in-process transport (ccal_multi.hip, an InprocRank): the deciding kernel
+                                               // adds the ranks' buffers itself; stream-ordered, groups are enqueued ahead like with RCCL
     bool counted = false;                      // registered in ctx->n_problems (creation succeeded)
-    bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr; }
+    bool sharded() const { return allreduce != nullptr || rccl_comm != nullptr || peer != nullptr; }
 };
 
 // No exception crosses the C ABI (include/ccal.h:9): every extern "C" body that can allocate host memory (operator new,
@@ -139,8 +140,9 @@ inline size_t problem_scratch_hint(const ccal_problem* p) {
     return (size_t)std::max<int64_t>(p->n_corners, 1) * 32 + (size_t)(std::max(p->n_obs, 1) + 1) * 64 + (size_t)256 * 1024;
 }
 hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
-hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s);
-hipError_t sorted_stats_device(double* d_vals, int64_t n, double* avg_99, double* median, hipStream_t s);
+hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s);     // *d_out: a slice of p->d_scratch
+size_t sorted_stats_scratch_bytes(int64_t n, hipStream_t s);      // block size sorted_stats_device needs for n values (0: sizing failed)
+hipError_t sorted_stats_device(char* block /* values in front */, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s);
 // ccal_api.hip: reprojection errors of every corner at the given parameters into p->d_err (device); ccal_multi.hip uses it per shard
 int reprojection_errors_dev(ccal_problem* p, const double* intr, const double* poses, const double* extr);
 // ccal_kernels_init.hip
@@ -169,16 +171,25 @@ inline hipError_t ensure_dyn_lds(const void* fn, size_t lds, DynLdsGuard& g) {
 }
 
 // ccal_multi.hip: the in-process transport of single-process sharded solves (shards on one GPU, or on GPUs with peer
-// access when RCCL is not there) - events order the ranks' streams, a kernel adds the ranks' buffers in rank order.
+// access when RCCL is not there) - events order the ranks' streams, the deciding kernel (k_head / k_solve) adds the ranks'
+// buffers in rank order itself: PeerView = every rank's buffer of the step's sums, in its argument block.
+constexpr int kMaxPeers = CCAL_MULTI_MAX_DEVICES;
+struct PeerView { const double* src[kMaxPeers]; int32_t n; };
 struct InprocComm;
 InprocComm* inproc_create(int n, const int* devices, std::string* err);
 void inproc_destroy(InprocComm* c);
-void inproc_abort(InprocComm* c);                       // a rank failed: release the ranks waiting in the host barrier
+void inproc_abort(InprocComm* c);                       // a rank failed: release the ranks waiting in the host rendezvous
 bool inproc_aborted(const InprocComm* c);
-int inproc_recover(InprocComm* c);                      // after an abort, no rank inside: drain the devices, reset the barrier
-void inproc_set_timeout(InprocComm* c, double seconds); // host barrier: how long a rank waits for its peers (<= 0: 600 s)
-void* inproc_rank_handle(InprocComm* c, int rank);      // `user` of inproc_allreduce for that rank
-int inproc_allreduce(void* user, double* device_buf, size_t count, void* hip_stream);      // a ccal_allreduce_fn
+int inproc_recover(InprocComm* c);                      // after an abort, no rank inside: drain the devices, reset the rendezvous
+void inproc_set_timeout(InprocComm* c, double seconds); // host rendezvous: how long a rank waits for its peers (<= 0: 600 s)
+void* inproc_rank_handle(InprocComm* c, int rank);      // ccal_problem::peer of that rank
+int inproc_parity(const void* rank_handle);             // which of its two sum buffers the rank's next collective uses
+int inproc_post(void* rank_handle, const double* device_buf, size_t count, void* hip_stream, PeerView* out);   // 0 = ok
+// a context's persistent helper thread (ccal_solver.hip; created on first use): run fn on it / wait until it has finished
+void ctx_worker_submit(ccal_ctx* ctx, std::function<void()> fn);
+void ctx_worker_wait(ccal_ctx* ctx);
+// why the last ccal_ctx_create / ccal_multi_create* on this thread failed (ccal_create_last_error)
+void note_create_error(const std::string& msg) noexcept;
 // ccal_rccl.hip: communicators of one process, one per device (ncclCommInitAll); abort = ncclCommAbort
 int rccl_comm_init_all(const int* devices, int n, void** comms_out, std::string* err);
 void rccl_comm_abort(void* comm);

@@ -1515,9 +1515,15 @@ __global__ __launch_bounds__(256) void k_head(const HeadArgs a) {
             if (threadIdx.x < 64 && e < rb) hs.red[e] = t;
         }
         __syncthreads();
+    } else if (a.peers.n > 0) {
+        // in-process transport: this step's sums of every rank, added here in rank order (no launch, no buffer in between)
+        if (a.st->done) { if (threadIdx.x == 0) publish_host_status(a.hs, a.st, a.seq, a.publish_all != 0); return; }
+        const int rb = fused_red_size(a.K);
+        for (int e = threadIdx.x; e < rb; e += 256) hs.red[e] = peer_sum(a.peers, e);
+        __syncthreads();
     }
     HeadIO io;
-    io.st_in = a.st; io.st_out = a.st; io.hs = a.hs; io.red_g = a.partial ? nullptr : a.red; io.cols = a.cols;
+    io.st_in = a.st; io.st_out = a.st; io.hs = a.hs; io.red_g = (a.partial || a.peers.n > 0) ? nullptr : a.red; io.cols = a.cols;
     io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = a.dc; io.K = a.K; io.seq = a.seq;
     io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = a.publish_all;
     if (threadIdx.x < 64) head_wave(io, hs, (int)threadIdx.x, true, head_prefetch(io, (int)threadIdx.x));

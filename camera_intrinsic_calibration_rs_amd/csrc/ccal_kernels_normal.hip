@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256) void k_reduce(const double* partial, int n_pw,
 }
 hipError_t launch_reduce(const ccal_problem* p, hipStream_t s, const DevState* st) {
     const NormalWs* w = p->nws;
-    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_rows, w->red, st);
+    hipLaunchKernelGGL(k_reduce, dim3(w->RB), dim3(256), 0, s, w->partial, w->n_rows, w->red_out ? w->red_out : w->red, st);
     return hipGetLastError();
 }
 
@@ -706,6 +706,7 @@ struct SolveArgs {
     double* dc; double* scal; int32_t* flags;
     DevState* st;                  // device-resident loop: current set = st->cur (0: intr/extr, 1: intr_c/extr_c), lambda from the state
     HostStatus* hs; int32_t seq, publish_all;
+    PeerView peers;                // in-process transport: every rank's sums of this step (rank order), added here; n == 0: `red`
 };
 // BIG: reduced systems of 64 .. 127 columns - two wavefronts (thread i still owns row i), the matrix in dynamic LDS with a
 // run-time row stride, pivots and finished components travel through LDS instead of wavefront shuffles
@@ -766,6 +767,8 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     // k_solve 15.6 us of a 50-us group)
     constexpr int PRE_S = 9;
     const int Kp = a.K, K1p = Kp + 1;
+    // entry idx of the (all-)reduced sums: the all-reduce buffer, or - in-process transport - the ranks' buffers added in rank order
+    auto R = [&a0](const int idx) -> double { return a0.peers.n > 0 ? peer_sum(a0.peers, idx) : a0.red[idx]; };
     const bool pre = !BIG && Kp * Kp <= PRE_S * NTH;
     ColInfo ci = {};
     if (lane < Kp) ci = a.cols[lane];
@@ -777,11 +780,11 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
             const int e = lane + NTH * q;
             const int ec = e < Kp * Kp ? e : 0;
             const int i = (int)(((float)ec + 0.5f) * rk), j = ec - i * Kp;
-            sv[q] = a.red[i >= j ? i * K1p + j : j * K1p + i];
+            sv[q] = R(i >= j ? i * K1p + j : j * K1p + i);
         }
     }
-    const double rhs = lane < Kp ? a.red[Kp * K1p + lane] : 0.0;          // the system is kept as its lower triangle (row K = b^T)
-    const double hd = lane < Kp ? (a.red + K1p * K1p)[lane] : 0.0, gcl = lane < Kp ? (a.red + K1p * K1p + Kp)[lane] : 0.0;
+    const double rhs = lane < Kp ? R(Kp * K1p + lane) : 0.0;          // the system is kept as its lower triangle (row K = b^T)
+    const double hd = lane < Kp ? R(K1p * K1p + lane) : 0.0, gcl = lane < Kp ? R(K1p * K1p + Kp + lane) : 0.0;
     const double xs0 = lane < Kp ? (ci.is_extr ? a0.extr : a0.intr)[ci.dst] : 0.0;
     const double xs1 = (lane < Kp && a0.st) ? (ci.is_extr ? a0.extr_c : a0.intr_c)[ci.dst] : 0.0;
     // the candidate set starts as a copy of the current one: both sets' values of this lane's element, requested now as well
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     }
     if (a.st) {
         // the three sums the decision needs are requested together with the state (one memory latency, not two)
-        const double d_cost = a.red[a.RB - 3], d_mc = a.red[a.RB - 2], d_fail = a.red[a.RB - 1];
+        const double d_cost = R(a.RB - 3), d_mc = R(a.RB - 2), d_fail = R(a.RB - 1);
         {
             const double* src = reinterpret_cast<const double*>(gst);
             double* dst = reinterpret_cast<double*>(&S0);
@@ -831,8 +834,6 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
     const int K = a.K, K1 = K + 1;
     double* const S = BIG ? S_big : S_small;
     const int LD = BIG ? (K1 | 1) : KS + 1;                          // odd row stride: a column walk touches every bank
-    const double* hdiag = a.red + K1 * K1;
-    const double* gc = hdiag + K;
     __shared__ int fxs[CCAL_KMAX];
     if (lane < K) fxs[lane] = ci.fixed;
     if (lane == 0) bad = 0;
@@ -844,7 +845,6 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
         for (int e = lane; e < a.n_intr; e += NTH) a.intr_c[e] = a.intr[e];
         for (int e = lane; e < a.n_extr; e += NTH) a.extr_c[e] = a.extr[e];
     }
-    (void)hdiag; (void)gc;
     const double xsrc = (a0.st && S0.cur) ? xs1 : xs0;                  // (a.intr / a.extr are the current set: swapped above when cur == 1)
     __syncthreads();
     {
@@ -864,7 +864,7 @@ __global__ __launch_bounds__(BIG ? 128 : 64) void k_solve(const SolveArgs a0) {
 #pragma unroll 4
             for (int e = lane; e < K * K; e += NTH) {
                 const int i = (int)(((float)e + 0.5f) * rk), j = e - i * K;
-                double v = a.red[i >= j ? i * K1 + j : j * K1 + i];
+                double v = R(i >= j ? i * K1 + j : j * K1 + i);
                 if (fxs[i] || fxs[j]) v = (i == j) ? 1.0 : 0.0;
                 S[i * LD + j] = v;
             }
@@ -978,6 +978,7 @@ hipError_t launch_solve(const ccal_problem* p, double lambda, double min_diag, d
     SolveArgs a = {};
     a.st = st; a.hs = hs; a.seq = seq; a.publish_all = publish_all ? 1 : 0;
     a.red = w->red; a.cols = w->cols; a.K = w->K; a.RB = w->RB; a.lambda = lambda; a.min_diag = min_diag; a.max_diag = max_diag;
+    a.peers = w->peers;
     a.intr = p->d_intr; a.extr = p->d_extr; a.intr_c = p->d_intr_c; a.extr_c = p->d_extr_c;
     a.n_intr = p->n_cams * CCAL_PMAX; a.n_extr = p->n_cams * 6;
     a.dc = w->dc; a.scal = w->scal; a.flags = w->flags;

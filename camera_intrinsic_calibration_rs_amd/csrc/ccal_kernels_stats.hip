@@ -19,9 +19,20 @@ __global__ __launch_bounds__(256) void k_scale(double* v, int64_t n, double inv)
     if (i < n) v[i] *= inv;
 }
 
-// One camera's errors out of the per-corner errors of the whole problem (device), packed in observation-frame order into a fresh
-// device buffer (*d_out, *n_out doubles; the caller frees it).  A camera without corners: *d_out = NULL, *n_out = 0.
-hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s) {
+static hipError_t ensure_scratch(ccal_problem* p, size_t total) {
+    if (p->scratch_bytes >= total) return hipSuccess;
+    if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
+    const size_t want = std::max(total, problem_scratch_hint(p));
+    const hipError_t e = hipMalloc((void**)&p->d_scratch, want);
+    if (e == hipSuccess) p->scratch_bytes = want;
+    return e;
+}
+static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// One camera's errors out of the per-corner errors of the whole problem (device), packed in observation-frame order into the
+// problem's scratch block (*d_out: a slice of it, valid until the next call that uses the scratch; *n_out doubles; complete when
+// the function returns).  A camera without corners: *d_out = NULL, *n_out = 0.
+hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s) {
     *d_out = nullptr; *n_out = 0;
     const CamLayout& cl = p->cams[cam];
     const int n_list = (int)cl.obs.size();
@@ -29,14 +40,15 @@ hipError_t camera_errors_device(const ccal_problem* p, int cam, const double* d_
     for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
     const int64_t n = dst[n_list];
     if (n <= 0) return hipSuccess;
-    int64_t* d_dst = nullptr; double* d_a = nullptr;
-    hipError_t e = hipMalloc((void**)&d_dst, (n_list + 1) * sizeof(int64_t));
-    if (e == hipSuccess) e = hipMalloc((void**)&d_a, n * sizeof(double));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_dst, dst.data(), (n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
+    const size_t b_off = up256((size_t)(n_list + 1) * sizeof(int64_t));
+    hipError_t e = ensure_scratch(p, b_off + up256((size_t)n * sizeof(double)));
+    if (e != hipSuccess) return e;
+    int64_t* d_dst = reinterpret_cast<int64_t*>(p->d_scratch);
+    double* d_a = reinterpret_cast<double*>(p->d_scratch + b_off);
+    e = hipMemcpyAsync(d_dst, dst.data(), (size_t)(n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);       // (dst is a host vector of this frame)
-    if (d_dst) (void)hipFree(d_dst);
-    if (e != hipSuccess) { if (d_a) (void)hipFree(d_a); return e; }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);       // (dst is a host vector of this frame; the caller copies d_a across devices next)
+    if (e != hipSuccess) return e;
     *d_out = d_a; *n_out = n;
     return hipSuccess;
 }
@@ -62,12 +74,7 @@ hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_off = up((size_t)(n_list + 1) * sizeof(int64_t)), b_val = up((size_t)n * sizeof(double)), b_sum = 256, b_tmp = up(tmp_bytes);
     const size_t total = b_off + 2 * b_val + b_sum + b_tmp;
-    if (p->scratch_bytes < total) {
-        if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
-        const size_t want = std::max(total, problem_scratch_hint(p));
-        TRY(hipMalloc((void**)&p->d_scratch, want));
-        p->scratch_bytes = want;
-    }
+    TRY(ensure_scratch(p, total));
     char* q = p->d_scratch;
     int64_t* d_dst = reinterpret_cast<int64_t*>(q); q += b_off;
     double* d_a = reinterpret_cast<double*>(q); q += b_val;
@@ -94,39 +101,50 @@ hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err
     return hipSuccess;
 }
 
-// median = e[len / 2] and avg_99 = sum_{i < len * 99 / 100} e_i / (len * 99 / 100) of n non-negative values on the device (d_a is
-// used as the sort's input buffer).  The multi-GPU form gathers the shards' values into one buffer and calls this: same values,
-// same sorted order, same reduction - the same bits as on one GPU.
-hipError_t sorted_stats_device(double* d_a, int64_t n, double* avg_99, double* median, hipStream_t s) {
-    if (n <= 0) return hipErrorInvalidValue;
-    double *d_b = nullptr, *d_sum = nullptr; void* d_tmp = nullptr;
+// median = e[len / 2] and avg_99 = sum_{i < len * 99 / 100} e_i / (len * 99 / 100) of n non-negative values on the device.  The
+// multi-GPU form gathers the shards' values into the front of one block and calls this: same values, same sorted order, same
+// reduction - the same bits as on one GPU.  block = [values (n) | sort buffer (n) | sum | hipCUB's temporary], sized by
+// sorted_stats_scratch_bytes and kept by the caller between calls (no allocation here).
+static hipError_t sorted_stats_sizes(int64_t n, hipStream_t s, size_t* b_val, size_t* tmp_bytes) {
+    size_t tmp_sort = 0, tmp_red = 0;
+    const int64_t n99 = n * 99 / 100;
+    hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (const double*)nullptr, (double*)nullptr, (int)n, 0, 64, s);
+    if (e == hipSuccess) e = hipcub::DeviceReduce::Sum(nullptr, tmp_red, (const double*)nullptr, (double*)nullptr, (int)std::max<int64_t>(n99, 1), s);
+    *b_val = up256((size_t)n * sizeof(double)); *tmp_bytes = std::max<size_t>(std::max(tmp_sort, tmp_red), 16);
+    return e;
+}
+size_t sorted_stats_scratch_bytes(int64_t n, hipStream_t s) {
+    size_t b_val = 0, tmp = 0;
+    if (n <= 0 || sorted_stats_sizes(n, s, &b_val, &tmp) != hipSuccess) return 0;
+    return 2 * b_val + 256 + up256(tmp);
+}
+hipError_t sorted_stats_device(char* block, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s) {
+    if (n <= 0 || !block) return hipErrorInvalidValue;
+    size_t b_val = 0, tmp_bytes = 0;
     hipError_t e;
-#define TRY(x) do { e = (x); if (e != hipSuccess) goto done; } while (0)
-    size_t tmp_sort = 0, tmp_red = 0, tmp_bytes = 0;
+#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    TRY(sorted_stats_sizes(n, s, &b_val, &tmp_bytes));
+    if (2 * b_val + 256 + up256(tmp_bytes) > block_bytes) return hipErrorInvalidValue;
+    double* d_a = reinterpret_cast<double*>(block);
+    double* d_b = reinterpret_cast<double*>(block + b_val);
+    double* d_sum = reinterpret_cast<double*>(block + 2 * b_val);
+    void* d_tmp = block + 2 * b_val + 256;
     const int64_t n99 = n * 99 / 100;
     double h[2] = { 0.0, 0.0 };
-    TRY(hipMalloc((void**)&d_b, n * sizeof(double)));
-    TRY(hipMalloc((void**)&d_sum, sizeof(double)));
-    TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, d_a, d_b, (int)n, 0, 64, s));
-    TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_red, d_b, d_sum, (int)std::max<int64_t>(n99, 1), s));
-    tmp_bytes = std::max(tmp_sort, tmp_red);
-    TRY(hipMalloc(&d_tmp, std::max<size_t>(tmp_bytes, 16)));
-    TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_a, d_b, (int)n, 0, 64, s));       // errors are >= 0: bit order == value order
+    size_t tb = tmp_bytes;
+    TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_a, d_b, (int)n, 0, 64, s));       // errors are >= 0: bit order == value order
     TRY(hipMemcpyAsync(&h[0], d_b + n / 2, sizeof(double), hipMemcpyDeviceToHost, s));          // median = e[len / 2]
     if (n99 > 0) {
         hipLaunchKernelGGL(k_scale, dim3((unsigned)((n99 + 255) / 256)), dim3(256), 0, s, d_b, n99, 1.0 / (double)n99);   // e_i / len_99, then sum
         TRY(hipGetLastError());
-        TRY(hipcub::DeviceReduce::Sum(d_tmp, tmp_bytes, d_b, d_sum, (int)n99, s));
+        tb = tmp_bytes;
+        TRY(hipcub::DeviceReduce::Sum(d_tmp, tb, d_b, d_sum, (int)n99, s));
         TRY(hipMemcpyAsync(&h[1], d_sum, sizeof(double), hipMemcpyDeviceToHost, s));
     }
     TRY(hipStreamSynchronize(s));
-    *median = h[0]; *avg_99 = h[1];
-done:
 #undef TRY
-    if (d_b) (void)hipFree(d_b);
-    if (d_sum) (void)hipFree(d_sum);
-    if (d_tmp) (void)hipFree(d_tmp);
-    return e;
+    *median = h[0]; *avg_99 = h[1];
+    return hipSuccess;
 }
 
 }  // namespace ccal

@@ -11,8 +11,10 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "ccal_fused.hpp"
@@ -20,43 +22,37 @@
 using namespace ccal;
 
 // ---------------------------------------------------------------------------------------------------------------------
-// In-process transport.  Per collective and rank r (the rank's host thread, its stream):
-//     record ready[r]            | host barrier A (every rank has recorded, every buffer address is published)
-//     wait ready[q], q != r      | k_sum_ranks: sum[r] = buf[0] + buf[1] + ... + buf[n-1]  (rank order: the same bits on every rank)
-//     record summed[r]           | host barrier B
-//     wait summed[q], q != r     | buf[r] = sum[r]          (in place only once every peer has read buf[r])
-// The host barriers order the event records against the waits (a wait captures the record made before it); they never wait
-// for the device.  A rank that fails sets `abort`, which releases the peers spinning in a barrier with an error.
+// In-process transport (v2, round 5): the sum over the ranks is taken by the DECIDING kernel itself.  Every rank's reduce
+// kernel leaves its packed sums in one of two buffers of its own (alternating by collective); the rank then POSTS the
+// buffer - records an event behind the reduce on its stream and publishes pointer + sequence number - and makes its
+// stream wait for the peers' events of the same collective; its k_head / k_solve receives all ranks' buffer addresses
+// in its argument block and adds them in rank order (the same bits on every rank).  Per collective and rank: ONE event
+// record, ONE host rendezvous (per-rank posted counters, no central barrier), n - 1 stream waits - and no launch at all
+// (v1: k_sum_ranks + k_copy_sum as launches of their own, two host barriers, 2 (n - 1) waits).
+// Why two buffers are enough: rank q overwrites buffer b at collective c + 2; that reduce sits behind q's deciding kernel
+// of collective c + 1 in q's stream, which waited for the event rank r recorded BEHIND its reduce of c + 1 - and that
+// is behind r's deciding kernel of collective c, the last reader of q's buffer b.
+// The host side only orders event records against waits (a wait captures the record made before it) and never waits for
+// the device, so groups are enqueued ahead exactly as with RCCL.  A rank that fails sets `abort`: peers spinning in the
+// rendezvous come back with an error instead of hanging; the rendezvous has a timeout of its own.
 // ---------------------------------------------------------------------------------------------------------------------
 namespace ccal {
 
 constexpr int kInprocMaxRanks = CCAL_MULTI_MAX_DEVICES;
-struct SumArgs { const double* src[kInprocMaxRanks]; int32_t n; };
-
-__global__ void __launch_bounds__(256) k_sum_ranks(const SumArgs a, const size_t count, double* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    double s = a.src[0][i];
-    for (int r = 1; r < a.n; ++r) s += a.src[r][i];
-    out[i] = s;
-}
-__global__ void __launch_bounds__(256) k_copy_sum(const double* __restrict__ src, const size_t count, double* __restrict__ dst) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < count) dst[i] = src[i];
-}
+static_assert(kInprocMaxRanks == kMaxPeers, "PeerView holds one pointer per rank");
 
 struct InprocRank { InprocComm* c; int rank; };
 struct InprocComm {
     int n = 0;
-    size_t cap = 0;
     std::vector<int> device;
-    std::vector<double*> sum;
-    std::vector<hipEvent_t> ready, summed;           // [parity][rank]
-    std::vector<const double*> src;
-    std::vector<size_t> cnt;
-    std::vector<uint64_t> calls;
+    std::vector<hipEvent_t> ready;                   // [parity][rank]
+    std::vector<const double*> src;                  // [parity][rank]: what the rank posted for the collective of that parity
+    std::vector<size_t> cnt;                         // [parity][rank]
+    std::vector<uint64_t> calls;                     // [rank]: collectives this rank has begun (its thread only)
+    std::unique_ptr<std::atomic<uint64_t>[]> posted; // [rank]: collectives whose event record + pointer are published
     std::vector<InprocRank> handles;
-    std::atomic<int> arrived{0}, gen{0}, abort{0};
+    std::atomic<int> abort{0}, sleepers{0};
+    std::mutex m; std::condition_variable cv;        // back-off of a rank that has spun for ~50 us (a peer is uploading, or slow)
     double timeout_s = 600.0;
 };
 
@@ -67,24 +63,22 @@ static inline void relax() {
     std::this_thread::yield();
 #endif
 }
-// false: aborted (by a peer, or by this rank after `timeout_s` without the peers arriving)
-static bool inproc_barrier(InprocComm* c) {
-    if (c->abort.load(std::memory_order_acquire)) return false;
-    const int g = c->gen.load(std::memory_order_acquire);
-    if (c->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == c->n) {
-        c->arrived.store(0, std::memory_order_relaxed);
-        c->gen.fetch_add(1, std::memory_order_release);
-        return !c->abort.load(std::memory_order_acquire);
-    }
+// wait until rank q has posted collective number `call`.  Spins ~50 us (the peers of a step arrive within microseconds of each
+// other), then sleeps on the condition variable in 200-us slices.  false: aborted (by a peer, or by this rank after `timeout_s`).
+static bool inproc_wait_posted(InprocComm* c, int q, uint64_t call) {
+    std::atomic<uint64_t>& pq = c->posted[(size_t)q];
     const auto t0 = std::chrono::steady_clock::now();
     for (long spins = 1;; ++spins) {
-        if (c->gen.load(std::memory_order_acquire) != g) return !c->abort.load(std::memory_order_acquire);
+        if (pq.load(std::memory_order_acquire) >= call) return !c->abort.load(std::memory_order_acquire);
         if (c->abort.load(std::memory_order_acquire)) return false;
-        if ((spins & 0x3FF) == 0) std::this_thread::yield(); else relax();
-        if ((spins & 0xFFFF) == 0 && c->timeout_s > 0 &&
-            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > c->timeout_s) {
-            c->abort.store(1, std::memory_order_release);
-            return false;
+        if (spins & 0xFF) { relax(); continue; }
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (c->timeout_s > 0 && el > c->timeout_s) { inproc_abort(c); return false; }
+        if (el > 50e-6) {
+            std::unique_lock<std::mutex> lk(c->m);
+            c->sleepers.fetch_add(1, std::memory_order_acq_rel);
+            c->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return pq.load(std::memory_order_acquire) >= call || c->abort.load(std::memory_order_acquire) != 0; });
+            c->sleepers.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
 }
@@ -98,7 +92,7 @@ InprocComm* inproc_create(int n, const int* devices, std::string* err) {
             if (devices[i] == devices[k]) continue;
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, devices[i], devices[k]) != hipSuccess || !can)
-                return fail("in-process transport: no peer access between device " + std::to_string(devices[i]) + " and " + std::to_string(devices[k]) + " (and no RCCL)");
+                return fail("in-process transport: no peer access between device " + std::to_string(devices[i]) + " and " + std::to_string(devices[k]));
             if (hipSetDevice(devices[i]) != hipSuccess) return fail("hipSetDevice failed");
             const hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
@@ -106,19 +100,17 @@ InprocComm* inproc_create(int n, const int* devices, std::string* err) {
         }
     std::unique_ptr<InprocComm> c(new InprocComm());
     c->n = n;
-    c->cap = (size_t)fused_red_size(CCAL_KMAX);              // the largest all-reduce buffer of any problem (~266 KB)
     c->device.assign(devices, devices + n);
-    c->sum.assign((size_t)n, nullptr);
-    c->ready.assign((size_t)2 * n, nullptr); c->summed.assign((size_t)2 * n, nullptr);
-    c->src.assign((size_t)n, nullptr); c->cnt.assign((size_t)n, 0); c->calls.assign((size_t)n, 0);
+    c->ready.assign((size_t)2 * n, nullptr);
+    c->src.assign((size_t)2 * n, nullptr); c->cnt.assign((size_t)2 * n, 0); c->calls.assign((size_t)n, 0);
+    c->posted.reset(new std::atomic<uint64_t>[(size_t)n]);
+    for (int r = 0; r < n; ++r) c->posted[(size_t)r].store(0);
     c->handles.resize((size_t)n);
     for (int r = 0; r < n; ++r) {
         c->handles[r] = InprocRank{ c.get(), r };
-        bool ok = hipSetDevice(devices[r]) == hipSuccess && hipMalloc((void**)&c->sum[r], c->cap * sizeof(double)) == hipSuccess;
-        for (int par = 0; par < 2 && ok; ++par)
-            ok = hipEventCreateWithFlags(&c->ready[par * n + r], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&c->summed[par * n + r], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { InprocComm* raw = c.release(); inproc_destroy(raw); return fail("in-process transport: device allocation failed"); }
+        bool ok = hipSetDevice(devices[r]) == hipSuccess;
+        for (int par = 0; par < 2 && ok; ++par) ok = hipEventCreateWithFlags(&c->ready[par * n + r], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { InprocComm* raw = c.release(); inproc_destroy(raw); return fail("in-process transport: event creation failed"); }
     }
     return c.release();
 }
@@ -126,55 +118,59 @@ void inproc_destroy(InprocComm* c) {
     if (!c) return;
     for (int r = 0; r < c->n; ++r) {
         (void)hipSetDevice(c->device[r]);
-        if (c->sum[r]) (void)hipFree(c->sum[r]);
-        for (int par = 0; par < 2; ++par) {
-            if (c->ready[par * c->n + r]) (void)hipEventDestroy(c->ready[par * c->n + r]);
-            if (c->summed[par * c->n + r]) (void)hipEventDestroy(c->summed[par * c->n + r]);
-        }
+        for (int par = 0; par < 2; ++par) if (c->ready[par * c->n + r]) (void)hipEventDestroy(c->ready[par * c->n + r]);
     }
     delete c;
 }
-void inproc_abort(InprocComm* c) { if (c) c->abort.store(1, std::memory_order_release); }
+void inproc_abort(InprocComm* c) {
+    if (!c) return;
+    c->abort.store(1, std::memory_order_release);
+    if (c->sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(c->m); c->cv.notify_all(); }
+}
 bool inproc_aborted(const InprocComm* c) { return c && c->abort.load(std::memory_order_acquire) != 0; }
 void inproc_set_timeout(InprocComm* c, double seconds) { if (c) c->timeout_s = seconds > 0 ? seconds : 600.0; }
 void* inproc_rank_handle(InprocComm* c, int rank) { return &c->handles[(size_t)rank]; }
 int inproc_recover(InprocComm* c) {
     if (!c) return CCAL_OK;
     // no rank is inside a collective any more (their threads have returned): whatever they enqueued runs to its end - a
-    // wait on an event that was never recorded is no wait - then the barrier and the call counters start over
+    // wait on an event that was never recorded is no wait - then the rendezvous counters start over
     for (int r = 0; r < c->n; ++r)
         if (hipSetDevice(c->device[r]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return CCAL_ERR_HIP;
-    c->arrived.store(0); c->gen.store(0); c->abort.store(0);
+    c->abort.store(0);
     std::fill(c->calls.begin(), c->calls.end(), 0);
+    for (int r = 0; r < c->n; ++r) c->posted[(size_t)r].store(0);
     return CCAL_OK;
 }
 
-int inproc_allreduce(void* user, double* buf, size_t count, void* hip_stream) {
+// which of its two buffers the rank's NEXT collective uses (the reduce kernel in front of inproc_post writes there)
+int inproc_parity(const void* user) {
+    const InprocRank* h = static_cast<const InprocRank*>(user);
+    return (int)(h->c->calls[(size_t)h->rank] & 1);
+}
+// Post `buf` (count doubles, complete once everything enqueued on `hip_stream` so far has run) as this rank's contribution to
+// its next collective, make the stream wait for every peer's contribution, and hand back all ranks' buffers in rank order.
+// Returns 0, or 1 after an abort / timeout / HIP error (the transport is aborted then).
+int inproc_post(void* user, const double* buf, size_t count, void* hip_stream, PeerView* out) {
     InprocRank* h = static_cast<InprocRank*>(user);
     InprocComm* c = h->c;
     const int r = h->rank, n = c->n;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    if (count > c->cap) { inproc_abort(c); return 1; }
-    const int par = (int)(c->calls[r]++ & 1);
-    c->src[r] = buf; c->cnt[r] = count;
-    bool ok = hipEventRecord(c->ready[par * n + r], st) == hipSuccess;
-    if (!ok) inproc_abort(c);
-    if (!inproc_barrier(c)) return 1;
-    SumArgs a = {};
-    a.n = n;
+    if (c->abort.load(std::memory_order_acquire)) return 1;
+    const int par = (int)(c->calls[(size_t)r] & 1);
+    const uint64_t call = ++c->calls[(size_t)r];
+    c->src[(size_t)(par * n + r)] = buf; c->cnt[(size_t)(par * n + r)] = count;
+    if (hipEventRecord(c->ready[(size_t)(par * n + r)], st) != hipSuccess) { inproc_abort(c); return 1; }
+    c->posted[(size_t)r].store(call, std::memory_order_release);
+    if (c->sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(c->m); c->cv.notify_all(); }
+    out->n = n;
     for (int q = 0; q < n; ++q) {
-        a.src[q] = c->src[q];
-        ok = ok && c->cnt[q] == count;                     // every rank sums the same buffer of the same step
-        if (q != r) ok = ok && hipStreamWaitEvent(st, c->ready[par * n + q], 0) == hipSuccess;
+        if (q == r) { out->src[q] = buf; continue; }
+        if (!inproc_wait_posted(c, q, call)) return 1;
+        // every rank posts the same buffer of the same step; the peer's record precedes this wait (acquire above)
+        if (c->cnt[(size_t)(par * n + q)] != count || hipStreamWaitEvent(st, c->ready[(size_t)(par * n + q)], 0) != hipSuccess) { inproc_abort(c); return 1; }
+        out->src[q] = c->src[(size_t)(par * n + q)];
     }
-    const unsigned blocks = (unsigned)((count + 255) / 256);
-    if (ok && count) { hipLaunchKernelGGL(k_sum_ranks, dim3(blocks), dim3(256), 0, st, a, count, c->sum[r]); ok = hipGetLastError() == hipSuccess; }
-    ok = ok && hipEventRecord(c->summed[par * n + r], st) == hipSuccess;
-    if (!ok) inproc_abort(c);
-    if (!inproc_barrier(c)) return 1;
-    for (int q = 0; q < n; ++q) if (q != r) ok = ok && hipStreamWaitEvent(st, c->summed[par * n + q], 0) == hipSuccess;
-    if (ok && count) { hipLaunchKernelGGL(k_copy_sum, dim3(blocks), dim3(256), 0, st, c->sum[r], count, buf); ok = hipGetLastError() == hipSuccess; }
-    if (!ok) { inproc_abort(c); return 1; }
+    for (int q = n; q < kMaxPeers; ++q) out->src[q] = nullptr;
     return 0;
 }
 
@@ -200,6 +196,9 @@ struct ccal_multi_problem {
     std::vector<ccal_problem*> shard;
     std::vector<int32_t> first;                // [n + 1] slot range of every shard
     std::vector<std::vector<int32_t>> obs_of;  // shard -> its observation frames (indices into the caller's description)
+    // ccal_multi_validation: where the shards' errors of one camera meet on the first shard's GPU - [values | sort buffer | sum |
+    // hipCUB's temporary], grown on demand and kept between calls (like ccal_problem::d_scratch for the single-GPU validation())
+    char* d_gather = nullptr; size_t gather_bytes = 0;
 };
 
 static void multi_free(ccal_multi* m) {
@@ -209,58 +208,83 @@ static void multi_free(ccal_multi* m) {
     delete m;
 }
 static int mfail(ccal_multi* m, int code, const std::string& msg) { if (m) { try { m->err = msg; } catch (...) { } } return code; }
-// run fn(i) for every shard: shard 0 on the caller's thread, the others on short-lived threads (one-shot entry points: pose
-// initialisation, uploads; the solver's own threads are the contexts' persistent helpers, ccal_solver.hip)
+// run fn(i) for every shard: shard 0 on the caller's thread, the others on their contexts' persistent helper threads (the ones
+// ccal_multi_solve / ccal_solve_batch use: created on first use, asleep on a condition variable in between)
 template <class F>
-static void for_each_shard(int n, F&& fn) {
-    std::vector<std::thread> th;
-    th.reserve((size_t)n);
-    try { for (int i = 1; i < n; ++i) th.emplace_back([&fn, i] { fn(i); }); }
-    catch (...) { for (auto& t : th) t.join(); throw; }
+static void for_each_shard(ccal_multi* m, int n, F&& fn) {
+    int started = 0;
+    try { for (int i = 1; i < n; ++i) { ctx_worker_submit(m->ctx[(size_t)i], [&fn, i] { fn(i); }); started = i; } }
+    catch (...) { for (int i = 1; i <= started; ++i) ctx_worker_wait(m->ctx[(size_t)i]); throw; }
     fn(0);
-    for (auto& t : th) t.join();
+    for (int i = 1; i < n; ++i) ctx_worker_wait(m->ctx[(size_t)i]);
 }
+// why the last ccal_ctx_create / ccal_multi_create* of this thread failed (there is no handle to ask)
+static thread_local std::string t_create_err;
+namespace ccal { void note_create_error(const std::string& msg) noexcept { try { t_create_err = msg; } catch (...) { } } }
 
 extern "C" {
 
-int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out) {
+const char* ccal_create_last_error(void) { return t_create_err.c_str(); }
+
+// transport: -1 = automatic (RCCL when the devices are all different and RCCL can be resolved, else the in-process transport;
+// the environment variable CCAL_MULTI_TRANSPORT=inproc|rccl overrides the automatic choice), CCAL_TRANSPORT_RCCL = communicators
+// even for ONE device (how a 1-GPU box runs ncclCommInitAll and the library-issued collective), CCAL_TRANSPORT_INPROC = the
+// in-process transport even when RCCL is there.  A transport asked for by name is not replaced by another one when it fails.
+int ccal_multi_create_transport(const int* device_ids, int n_dev, int transport, ccal_multi** out) {
     if (!out) return CCAL_ERR_INVALID_ARG;
     *out = nullptr;
-    if (!device_ids || n_dev < 1 || n_dev > CCAL_MULTI_MAX_DEVICES) return CCAL_ERR_INVALID_ARG;
+    note_create_error("");
+    if (!device_ids || n_dev < 1 || n_dev > CCAL_MULTI_MAX_DEVICES || transport < -1 || transport > CCAL_TRANSPORT_INPROC) { note_create_error("ccal_multi_create: bad arguments"); return CCAL_ERR_INVALID_ARG; }
     CCAL_API_TRY
     std::unique_ptr<ccal_multi> m(new ccal_multi());
     m->n = n_dev;
     m->device.assign(device_ids, device_ids + n_dev);
     m->ctx.assign((size_t)n_dev, nullptr);
-    auto bail = [&](int rc) { ccal_multi* raw = m.release(); multi_free(raw); return rc; };
+    auto bail = [&](int rc, const std::string& why) { note_create_error(why); ccal_multi* raw = m.release(); multi_free(raw); return rc; };
     for (int i = 0; i < n_dev; ++i) {
         const int rc = ccal_ctx_create(device_ids[i], nullptr, &m->ctx[i]);
-        if (rc != CCAL_OK) return bail(rc);
+        if (rc != CCAL_OK) return bail(rc, "ccal_multi_create: no context on device " + std::to_string(device_ids[i]) + " (" + t_create_err + ")");
     }
-    const char* force = std::getenv("CCAL_MULTI_TRANSPORT");              // developer switch: "inproc" keeps RCCL out of it; "rccl" asks
-                                                                          // for communicators even for ONE device (the 1-GPU test box
-                                                                          // runs ncclCommInitAll and the library-issued collective so)
-    if (n_dev > 1 || (force && force[0] == 'r')) {
+    if (transport < 0) {
+        const char* force = std::getenv("CCAL_MULTI_TRANSPORT");
+        if (force && force[0] == 'r') transport = CCAL_TRANSPORT_RCCL;
+        else if (force && force[0] == 'i') transport = CCAL_TRANSPORT_INPROC;
+    }
+    if (n_dev > 1 || transport == CCAL_TRANSPORT_RCCL) {
         bool distinct = true;
         for (int i = 0; i < n_dev; ++i) for (int k = 0; k < i; ++k) distinct = distinct && device_ids[i] != device_ids[k];
-        const bool want_rccl = distinct && ccal_rccl_available() && !(force && force[0] == 'i');
+        std::string err_rccl, err_inproc;
+        const bool want_rccl = transport == CCAL_TRANSPORT_RCCL || (transport < 0 && distinct && ccal_rccl_available());
         if (want_rccl) {
-            m->comms.assign((size_t)n_dev, nullptr);
-            std::string err;
-            const int rc = rccl_comm_init_all(device_ids, n_dev, m->comms.data(), &err);
-            if (rc == CCAL_OK) m->transport = CCAL_TRANSPORT_RCCL;
-            else m->comms.clear();                         // (falls through to the in-process transport: peer access may still do)
+            if (!distinct) err_rccl = "RCCL needs every device listed once";
+            else {
+                m->comms.assign((size_t)n_dev, nullptr);
+                const int rc = rccl_comm_init_all(device_ids, n_dev, m->comms.data(), &err_rccl);
+                if (rc == CCAL_OK) m->transport = CCAL_TRANSPORT_RCCL;
+                else {                                       // whatever communicators the failed call did make must not leak
+                    for (void*& c : m->comms) if (c) { rccl_comm_abort(c); c = nullptr; }
+                    m->comms.clear();
+                }
+            }
+            if (m->transport != CCAL_TRANSPORT_RCCL && transport == CCAL_TRANSPORT_RCCL) return bail(CCAL_ERR_UNSUPPORTED, "ccal_multi_create: RCCL transport: " + err_rccl);
         }
-        if (m->transport == CCAL_TRANSPORT_NONE && n_dev > 1) {
-            std::string err;
-            m->inproc = inproc_create(n_dev, device_ids, &err);
-            if (!m->inproc) return bail(CCAL_ERR_UNSUPPORTED);
+        if (m->transport == CCAL_TRANSPORT_NONE && n_dev > 1) {      // (automatic: peer access may still do where RCCL did not)
+            m->inproc = inproc_create(n_dev, device_ids, &err_inproc);
+            if (!m->inproc) return bail(CCAL_ERR_UNSUPPORTED, "ccal_multi_create: " + err_inproc + (err_rccl.empty() ? std::string("; RCCL not tried") : "; RCCL: " + err_rccl));
             m->transport = CCAL_TRANSPORT_INPROC;
+            if (!err_rccl.empty()) m->err = "RCCL transport not used: " + err_rccl;       // readable through ccal_multi_last_error
         }
     }
     *out = m.release();
     return CCAL_OK;
     CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out) { return ccal_multi_create_transport(device_ids, n_dev, -1, out); }
+// ranks of the device set's communicators as RCCL counts them (ncclCommCount of the first one); 0: the transport is not RCCL
+int ccal_multi_rccl_ranks(const ccal_multi* m) {
+    if (!m) return -1;
+    if (m->transport != CCAL_TRANSPORT_RCCL || m->comms.empty() || !m->comms[0]) return 0;
+    return ccal_rccl_comm_count(m->comms[0]);
 }
 void ccal_multi_destroy(ccal_multi* m) {
     if (!m) return;
@@ -290,8 +314,48 @@ void ccal_multi_problem_destroy(ccal_multi_problem* mp) {
         ccal_problem_destroy(p);
     }
     ccal_multi* m = mp->m;
+    if (mp->d_gather && m) { (void)hipSetDevice(m->ctx[0]->device); (void)hipFree(mp->d_gather); }
     delete mp;
     if (m && --m->n_problems == 0 && m->destroy_requested) multi_free(m);
+}
+
+// Where a description is cut: contiguous slot ranges balanced by corner count - boundary r = the first slot at which the corners
+// of the slots before it reach r / n of all corners ("balanced by corner count (CSR offsets)"); all cameras'
+// observations of a slot stay on one shard.  Pure host code (ccal_partition_slots: the same cut for one process per GPU).
+static int partition_slots(const ccal_problem_desc* d, int n, std::vector<int32_t>& first, int64_t* total_out, const char** why) {
+    if (d->n_slots < 0 || d->n_obs < 0 || (d->n_obs > 0 && (!d->obs_slot || !d->obs_offsets))) { *why = "bad problem description"; return CCAL_ERR_INVALID_ARG; }
+    std::vector<int64_t> before((size_t)d->n_slots + 1, 0);
+    for (int o = 0; o < d->n_obs; ++o) {
+        const int s = d->obs_slot[o];
+        const int64_t c = d->obs_offsets[o + 1] - d->obs_offsets[o];
+        if (s < 0 || s >= d->n_slots || c < 0) { *why = "bad observation frame table"; return CCAL_ERR_INVALID_ARG; }
+        before[(size_t)s + 1] += c;
+    }
+    for (int s = 0; s < d->n_slots; ++s) before[(size_t)s + 1] += before[(size_t)s];
+    const int64_t total = before[(size_t)d->n_slots];
+    first.assign((size_t)n + 1, 0);
+    first[(size_t)n] = d->n_slots;
+    for (int r = 1; r < n; ++r) {
+        int s;
+        if (total > 0) {
+            const int64_t target = (int64_t)(((__int128)total * r) / n);
+            s = (int)(std::lower_bound(before.begin(), before.end(), target) - before.begin());
+        } else s = (int)((int64_t)d->n_slots * r / n);
+        first[(size_t)r] = std::min(std::max(s, first[(size_t)r - 1]), d->n_slots);
+    }
+    if (total_out) *total_out = total;
+    return CCAL_OK;
+}
+int ccal_partition_slots(const ccal_problem_desc* d, int n_shards, int32_t* first_out) {
+    if (!d || !first_out || n_shards < 1) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    std::vector<int32_t> first;
+    const char* why = "";
+    const int rc = partition_slots(d, n_shards, first, nullptr, &why);
+    if (rc != CCAL_OK) return rc;
+    std::memcpy(first_out, first.data(), ((size_t)n_shards + 1) * sizeof(int32_t));
+    return CCAL_OK;
+    CCAL_API_CATCH((ccal_ctx*)nullptr)
 }
 
 int ccal_multi_problem_create(ccal_multi* m, const ccal_problem_desc* d, ccal_multi_problem** out) {
@@ -302,29 +366,10 @@ int ccal_multi_problem_create(ccal_multi* m, const ccal_problem_desc* d, ccal_mu
         (d->n_obs > 0 && (!d->obs_cam || !d->obs_slot || !d->obs_offsets)))
         return mfail(m, CCAL_ERR_INVALID_ARG, "bad problem description");
     const int n = m->n;
-    // contiguous slot ranges, balanced by corner count: boundary r = the first slot at which the corners of the slots
-    // before it reach r / n of all corners ("balanced by corner count (CSR offsets)")
-    std::vector<int64_t> before((size_t)d->n_slots + 1, 0);
-    for (int o = 0; o < d->n_obs; ++o) {
-        const int s = d->obs_slot[o];
-        const int64_t c = d->obs_offsets[o + 1] - d->obs_offsets[o];
-        if (s < 0 || s >= d->n_slots || c < 0) return mfail(m, CCAL_ERR_INVALID_ARG, "bad observation frame table");
-        before[(size_t)s + 1] += c;
-    }
-    for (int s = 0; s < d->n_slots; ++s) before[(size_t)s + 1] += before[(size_t)s];
-    const int64_t total = before[(size_t)d->n_slots];
     std::unique_ptr<ccal_multi_problem> mp(new ccal_multi_problem());
+    int64_t total = 0;
+    { const char* why = ""; const int rc = partition_slots(d, n, mp->first, &total, &why); if (rc != CCAL_OK) return mfail(m, rc, why); }
     mp->m = m; mp->n_slots = d->n_slots; mp->n_obs = d->n_obs; mp->n_cams = d->n_cams; mp->n_corners = total;
-    mp->first.assign((size_t)n + 1, 0);
-    mp->first[(size_t)n] = d->n_slots;
-    for (int r = 1; r < n; ++r) {
-        int s;
-        if (total > 0) {
-            const int64_t target = (int64_t)(((__int128)total * r) / n);
-            s = (int)(std::lower_bound(before.begin(), before.end(), target) - before.begin());
-        } else s = (int)((int64_t)d->n_slots * r / n);
-        mp->first[(size_t)r] = std::min(std::max(s, mp->first[(size_t)r - 1]), d->n_slots);
-    }
     mp->obs_of.assign((size_t)n, {});
     std::vector<int> shard_of_slot((size_t)std::max(d->n_slots, 1), 0);
     for (int r = 0; r < n; ++r) for (int s = mp->first[(size_t)r]; s < mp->first[(size_t)r + 1]; ++s) shard_of_slot[(size_t)s] = r;
@@ -360,9 +405,7 @@ int ccal_multi_problem_create(ccal_multi* m, const ccal_problem_desc* d, ccal_mu
         if (rc != CCAL_OK) return bail(rc, std::string("shard ") + std::to_string(r) + ": " + ccal_last_error(m->ctx[(size_t)r]));
         ccal_problem* p = mp->shard[(size_t)r];
         if (m->transport == CCAL_TRANSPORT_RCCL) p->rccl_comm = m->comms[(size_t)r];
-        else if (m->transport == CCAL_TRANSPORT_INPROC) {
-            p->allreduce = inproc_allreduce; p->allreduce_user = inproc_rank_handle(m->inproc, r); p->allreduce_stream_ordered = true;
-        }
+        else if (m->transport == CCAL_TRANSPORT_INPROC) p->peer = inproc_rank_handle(m->inproc, r);
     }
     *out = mp.release();
     return CCAL_OK;
@@ -418,7 +461,7 @@ int ccal_multi_init_poses(ccal_multi_problem* mp, const double* intr, int min_po
     std::vector<std::vector<double>> po((size_t)n);
     std::vector<std::vector<int32_t>> nu((size_t)n);
     for (int r = 0; r < n; ++r) { po[(size_t)r].assign(std::max<size_t>(mp->obs_of[(size_t)r].size(), 1) * 6, 0.0); nu[(size_t)r].assign(std::max<size_t>(mp->obs_of[(size_t)r].size(), 1), 0); }
-    for_each_shard(n, [&](int r) { rc[(size_t)r] = ccal_init_poses(mp->shard[(size_t)r], intr, min_points, po[(size_t)r].data(), nu[(size_t)r].data()); });
+    for_each_shard(mp->m, n, [&](int r) { rc[(size_t)r] = ccal_init_poses(mp->shard[(size_t)r], intr, min_points, po[(size_t)r].data(), nu[(size_t)r].data()); });
     for (int r = 0; r < n; ++r) {
         if (rc[(size_t)r] != CCAL_OK) return mfail(mp->m, rc[(size_t)r], ccal_last_error(mp->m->ctx[(size_t)r]));
         const std::vector<int32_t>& obs = mp->obs_of[(size_t)r];
@@ -440,34 +483,43 @@ int ccal_multi_validation(ccal_multi_problem* mp, int cam, const double* intr, c
     ccal_multi* m = mp->m;
     CCAL_API_TRY
     const int n = (int)mp->shard.size();
-    std::vector<double*> d_part((size_t)n, nullptr);
+    std::vector<double*> d_part((size_t)n, nullptr);       // slices of the shards' own scratch blocks (nothing to free)
     std::vector<int64_t> cnt((size_t)n, 0);
     std::vector<int> rc((size_t)n, CCAL_OK);
-    for_each_shard(n, [&](int r) {
+    for_each_shard(m, n, [&](int r) {
         ccal_problem* p = mp->shard[(size_t)r];
         rc[(size_t)r] = reprojection_errors_dev(p, intr, poses ? poses + 6 * (size_t)mp->first[(size_t)r] : nullptr, extr);
-        if (rc[(size_t)r] == CCAL_OK && camera_errors_device(p, cam, p->d_err, &d_part[(size_t)r], &cnt[(size_t)r], p->ctx->stream) != hipSuccess) rc[(size_t)r] = CCAL_ERR_HIP;
+        if (rc[(size_t)r] == CCAL_OK && camera_errors_device(p, cam, p->d_err, &d_part[(size_t)r], &cnt[(size_t)r], p->ctx->stream) != hipSuccess) {
+            rc[(size_t)r] = CCAL_ERR_HIP; note_error(p->ctx, "ccal_multi_validation: gathering the camera's errors failed");
+        }
     });
     int64_t total = 0;
-    int bad = CCAL_OK;
-    for (int r = 0; r < n; ++r) { total += cnt[(size_t)r]; if (rc[(size_t)r] != CCAL_OK && bad == CCAL_OK) bad = rc[(size_t)r]; }
-    double* d_all = nullptr;
-    ccal_ctx* c0 = m->ctx[0];
-    if (bad == CCAL_OK && total <= 0) { bad = CCAL_ERR_INVALID_ARG; m->err = "camera has no observations"; }
-    if (bad == CCAL_OK && (hipSetDevice(c0->device) != hipSuccess || hipMalloc((void**)&d_all, (size_t)total * sizeof(double)) != hipSuccess)) bad = CCAL_ERR_HIP;
-    if (bad == CCAL_OK) {
-        int64_t at = 0;
-        for (int r = 0; r < n && bad == CCAL_OK; ++r) {          // shard order = slot order: the single-GPU gather's order
-            if (!cnt[(size_t)r]) continue;
-            if (hipMemcpy(d_all + at, d_part[(size_t)r], (size_t)cnt[(size_t)r] * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) bad = CCAL_ERR_HIP;
-            at += cnt[(size_t)r];
-        }
+    for (int r = 0; r < n; ++r) {
+        if (rc[(size_t)r] != CCAL_OK) return mfail(m, rc[(size_t)r], std::string("shard ") + std::to_string(r) + ": " + ccal_last_error(m->ctx[(size_t)r]));
+        total += cnt[(size_t)r];
     }
-    if (bad == CCAL_OK && sorted_stats_device(d_all, total, avg_99_percent, median, c0->stream) != hipSuccess) bad = CCAL_ERR_HIP;
-    for (int r = 0; r < n; ++r) if (d_part[(size_t)r]) { (void)hipSetDevice(mp->shard[(size_t)r]->ctx->device); (void)hipFree(d_part[(size_t)r]); }
-    if (d_all) { (void)hipSetDevice(c0->device); (void)hipFree(d_all); }
-    if (bad == CCAL_ERR_HIP) m->err = "ccal_multi_validation: a HIP call failed";
-    return bad;
+    if (total <= 0) return mfail(m, CCAL_ERR_INVALID_ARG, "camera has no observations");
+    ccal_ctx* c0 = m->ctx[0];
+    if (hipSetDevice(c0->device) != hipSuccess) return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: hipSetDevice failed");
+    const size_t need = sorted_stats_scratch_bytes(total, c0->stream);
+    if (need == 0) return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: sizing the sort failed");
+    if (mp->gather_bytes < need) {
+        if (mp->d_gather) { (void)hipFree(mp->d_gather); mp->d_gather = nullptr; mp->gather_bytes = 0; }
+        const size_t want = std::max(need, sorted_stats_scratch_bytes(std::max<int64_t>(mp->n_corners, 1), c0->stream));     // every camera of the problem fits
+        if (hipMalloc((void**)&mp->d_gather, want) != hipSuccess) { (void)hipGetLastError(); return mfail(m, CCAL_ERR_NO_MEMORY, "ccal_multi_validation: out of device memory"); }
+        mp->gather_bytes = want;
+    }
+    double* d_all = reinterpret_cast<double*>(mp->d_gather);
+    int64_t at = 0;
+    for (int r = 0; r < n; ++r) {                            // shard order = slot order: the single-GPU gather's order
+        if (!cnt[(size_t)r]) continue;                       // (the shards' gathers have completed: camera_errors_device waits for its stream)
+        if (hipMemcpyAsync(d_all + at, d_part[(size_t)r], (size_t)cnt[(size_t)r] * sizeof(double), hipMemcpyDeviceToDevice, c0->stream) != hipSuccess)
+            return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: gathering the shards' errors failed");
+        at += cnt[(size_t)r];
+    }
+    if (sorted_stats_device(mp->d_gather, mp->gather_bytes, total, avg_99_percent, median, c0->stream) != hipSuccess)
+        return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: the statistics kernels failed");
+    return CCAL_OK;
     CCAL_API_CATCH((ccal_ctx*)nullptr)
 }
 
@@ -480,7 +532,7 @@ int ccal_multi_reprojection_errors(ccal_multi_problem* mp, const double* intr, c
     std::vector<int> rc((size_t)n, CCAL_OK);
     std::vector<std::vector<double>> part((size_t)n);
     for (int r = 0; r < n; ++r) part[(size_t)r].assign((size_t)std::max<int64_t>(ccal_num_corners(mp->shard[(size_t)r]), 1), 0.0);
-    for_each_shard(n, [&](int r) {
+    for_each_shard(mp->m, n, [&](int r) {
         rc[(size_t)r] = ccal_reprojection_errors(mp->shard[(size_t)r], intr, poses ? poses + 6 * (size_t)mp->first[(size_t)r] : nullptr, extr, part[(size_t)r].data());
     });
     for (int r = 0; r < n; ++r) {

@@ -60,7 +60,9 @@ struct NormalWs {
     int32_t* d_obs_cam = nullptr;
     int32_t* d_caminfo = nullptr;              // [n_cams][4]: Peff, col_theta, col_extr, NCP
     double* partial = nullptr;                 // [RB][n_pw]
-    double* red = nullptr;                     // [RB]
+    double* red = nullptr;                     // [2][RB + 8]: the reduced sums; the in-process transport alternates between the two
+    double* red_out = nullptr;                 // where this group's k_reduce writes (NULL: red)
+    PeerView peers = {};                       // this group's k_solve: every rank's sums (in-process transport), n == 0: red
     double* pf = nullptr;                      // [n_slots][PF]
     double* dc = nullptr;                      // [K]
     double* mc_slot = nullptr;                 // [n_slots]
@@ -88,7 +90,8 @@ struct FusedWs {
     double* pf[2] = { nullptr, nullptr };
     double* praw[2] = { nullptr, nullptr };
     double* partial = nullptr;
-    double* red = nullptr;
+    double* red = nullptr;                     // [2][RB1 + 7 rounded]: the in-process transport alternates between the two (red_stride apart)
+    size_t red_stride = 0;
     double* fcbuf = nullptr;                   // -DCCAL_STAMPS builds only: in-kernel timestamps (NULL in the product build)
     double* mc_f = nullptr;                    // [n_obs] model decrease of each pose block
     double* cost_f = nullptr;                  // [n_obs] cost of each frame

@@ -142,6 +142,13 @@ int ccal_rccl_comm_destroy(void* comm) {
     return r->CommDestroy(static_cast<ncclComm_t>(comm)) == ncclSuccess ? CCAL_OK : CCAL_ERR_HIP;
 }
 
+int ccal_rccl_comm_count(void* comm) {
+    const RcclApi* r = rccl();
+    int n = 0;
+    if (!comm || !r || !r->CommCount || r->CommCount(static_cast<ncclComm_t>(comm), &n) != ncclSuccess) return -1;
+    return n;
+}
+
 int ccal_set_rccl_comm(ccal_problem* p, void* nccl_comm) {
     if (!p) return CCAL_ERR_INVALID_ARG;
     if (nccl_comm && !rccl()) { note_error(p->ctx, "RCCL is not available (librccl.so.1 not found)"); return CCAL_ERR_UNSUPPORTED; }

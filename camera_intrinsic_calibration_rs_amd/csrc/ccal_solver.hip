@@ -113,7 +113,8 @@ static int fused_ws_ensure(ccal_problem* p) {
     const size_t b_pf = up(ns * w->PF * sizeof(double)), b_praw = up(no * f->PRAW * sizeof(double)), b_no = up(no * sizeof(double));
     const size_t b_part = up((size_t)f->RB1 * f->n_pw * sizeof(double)), b_red = up((size_t)(f->RB1 + 7) * sizeof(double));
     const size_t b_state = up(3 * sizeof(DevState)), b_stage = up(stage_bytes);
-    const size_t zeroed = 2 * b_pf + 2 * b_praw + b_part + b_red;                  // the slices that must start as zeros come first
+    const size_t zeroed = 2 * b_pf + 2 * b_praw + b_part + 2 * b_red;              // the slices that must start as zeros come first (red: two buffers,
+                                                                                  // the in-process transport alternates between them)
     const size_t d_total = zeroed + 2 * b_no + b_state + b_stage;
     HIP_TRY(ctx, hipMalloc((void**)&f->d_block, d_total));
     HIP_TRY(ctx, hipMemsetAsync(f->d_block, 0, zeroed, ctx->stream));             // (stream-ordered in front of everything that uses the workspace)
@@ -122,7 +123,7 @@ static int fused_ws_ensure(ccal_problem* p) {
         for (int i = 0; i < 2; ++i) { f->pf[i] = reinterpret_cast<double*>(q); q += b_pf; }
         for (int i = 0; i < 2; ++i) { f->praw[i] = reinterpret_cast<double*>(q); q += b_praw; }
         f->partial = reinterpret_cast<double*>(q); q += b_part;
-        f->red = reinterpret_cast<double*>(q); q += b_red;
+        f->red = reinterpret_cast<double*>(q); q += 2 * b_red; f->red_stride = b_red / sizeof(double);
         f->mc_f = reinterpret_cast<double*>(q); q += b_no;
         f->cost_f = reinterpret_cast<double*>(q); q += b_no;
         f->d_state = reinterpret_cast<DevState*>(q); q += b_state;      // [0] the loops' state; [1], [2]: single-launch groups alternate
@@ -293,7 +294,7 @@ int normal_ws_ensure_general(ccal_problem* p) {
     // stream: it does not synchronise with the null stream, a plain hipMemset could still be running when the first
     // elimination writes the buffer
     HIP_TRY(ctx, hipMemsetAsync(w->partial, 0, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMalloc((void**)&w->red, (size_t)(w->RB + 8) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc((void**)&w->red, 2 * (size_t)(w->RB + 8) * sizeof(double)));      // two buffers: the in-process transport alternates
     HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
     HIP_TRY(ctx, hipMalloc((void**)&w->mc_slot, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
     HIP_TRY(ctx, hipMemsetAsync(w->mc_slot, 0, (size_t)std::max(p->n_slots, 1) * sizeof(double), ctx->stream));
@@ -381,6 +382,7 @@ static int enqueue_gram(ccal_problem* p, bool cand, int gbuf) {
 // when a communicator is set (ccal_rccl.hip), else the callback, else nothing (single GPU).
 static int allreduce(ccal_problem* p, double* buf, size_t n) {
     ccal_ctx* ctx = p->ctx;
+    if (p->peer) { ctx->err = "this entry point does not run on a shard of an in-process device set (its sums are added by the solver's deciding kernel)"; return CCAL_ERR_UNSUPPORTED; }
     if (p->rccl_comm) return rccl_allreduce_sum(ctx, p->rccl_comm, buf, n, ctx->stream);
     if (p->allreduce && p->allreduce(p->allreduce_user, buf, n, (void*)ctx->stream) != 0) { ctx->err = "all-reduce callback failed"; return CCAL_ERR_HIP; }
     return CCAL_OK;
@@ -505,7 +507,7 @@ static int max_groups_for(const ccal_solver_opts* o) {
 // another stream operation, so sharded solves run ahead like single-GPU ones; a callback is host code - the loop waits
 // for every group before the next one (no collective is ever issued for a solve that has finished).
 static int groups_in_flight(const ccal_problem* p, const char* env_name) {
-    if (p->allreduce && !p->rccl_comm && !p->allreduce_stream_ordered) {
+    if (p->allreduce && !p->rccl_comm && !p->peer) {
         static const int hook_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH_HOOK"); return e ? std::max(1, std::atoi(e)) : 1; }();
         return hook_depth;
     }
@@ -708,8 +710,15 @@ struct FusedJob : SolveJob {
         }
         if (sharded) {
             // Gram -> elimination -> reduce -> all-reduce of the packed sums -> head
-            HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));
-            if (int e = allreduce(p, f->red, (size_t)f->RB1); e != CCAL_OK) return -e;
+            if (p->peer) {
+                // in-process transport: the reduce leaves this rank's sums in one of two buffers, the head adds all ranks' (rank order)
+                fa.red = f->red + (size_t)inproc_parity(p->peer) * f->red_stride;
+                HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));
+                if (inproc_post(p->peer, fa.red, (size_t)f->RB1, (void*)st, &ha.peers) != 0) { ctx->err = "in-process transport: a peer shard failed or did not arrive"; return -CCAL_ERR_HIP; }
+            } else {
+                HIP_TRYN(ctx, enqueue_fused_system(p, fa, schur_m, st));
+                if (int e = allreduce(p, f->red, (size_t)f->RB1); e != CCAL_OK) return -e;
+            }
             ha.partial = nullptr; ha.n_part = 0;
         } else {
             // single GPU: for session-sized problems (<= 40 rows of partial sums = 1 280 frames) the head adds them up itself,
@@ -781,6 +790,7 @@ struct GeneralJob : SolveJob {
         if (w->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); w->tail_pending = false; }   // a stale k_solve must not publish into this solve
         if (host_io && (rc = ccal_upload_params(p, intr_io, poses_io, extr_io)) != CCAL_OK) return rc;
         if ((rc = normal_upload_cols(p)) != CCAL_OK) return rc;
+        w->peers.n = 0; w->red_out = nullptr;
         // the candidate poses are formed in the Gram kernels' prologue (one launch less per group: k_backsub).  Slots that no
         // frame observes are then never written: both parameter sets start from the same poses
         static const bool gbs_off = [] { const char* e = std::getenv("CCAL_GEN_BACKSUB"); return e && e[0] == '0'; }();
@@ -810,9 +820,18 @@ struct GeneralJob : SolveJob {
         DevState* ds = w->d_gstate;
         HIP_TRYN(ctx, launch_gram_dev_all(p, ds, st));
         HIP_TRYN(ctx, launch_schur(p, w->cur, 0.0, min_d, max_d, st, ds));
-        HIP_TRYN(ctx, launch_reduce(p, st, ds));
-        if (int e = allreduce(p, w->red, (size_t)w->RB); e != CCAL_OK) return -e;
+        if (p->peer) {
+            w->red_out = w->red + (size_t)inproc_parity(p->peer) * (size_t)(w->RB + 8);
+            HIP_TRYN(ctx, launch_reduce(p, st, ds));
+            const int bad = inproc_post(p->peer, w->red_out, (size_t)w->RB, (void*)st, &w->peers);
+            w->red_out = nullptr;
+            if (bad) { w->peers.n = 0; ctx->err = "in-process transport: a peer shard failed or did not arrive"; return -CCAL_ERR_HIP; }
+        } else {
+            HIP_TRYN(ctx, launch_reduce(p, st, ds));
+            if (int e = allreduce(p, w->red, (size_t)w->RB); e != CCAL_OK) return -e;
+        }
         HIP_TRYN(ctx, launch_solve(p, 0.0, min_d, max_d, st, ds, w->h_gstatus, ++seq, o->verbose != 0));
+        w->peers.n = 0;
         if (!w->gen_backsub) HIP_TRYN(ctx, launch_backsub(p, 0.0, min_d, max_d, st, ds));
         return seq;
     }
@@ -991,11 +1010,19 @@ struct ccal_ctx_worker {
     std::condition_variable cv, cv_done;
     std::function<void()> task;
     std::atomic<int> has_task{0}, done{0}, stop{0};
+    // how long a helper spins for its next task / the caller for a helper's result before either sleeps on its condition variable:
+    // the next batch of session-sized solves usually follows within this window, a 50 000-frame upload does not - and must not
+    // burn a core while it lasts
+    static constexpr double kSpinSeconds = 100e-6;
+    static bool spun_out(std::chrono::steady_clock::time_point t0, int spins) {
+        return (spins & 0x3F) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > kSpinSeconds;
+    }
     void loop() {
         for (;;) {
             int spins = 0;
+            const auto t0 = std::chrono::steady_clock::now();
             while (!has_task.load(std::memory_order_acquire) && !stop.load(std::memory_order_acquire)) {
-                if (++spins < 200000) { cpu_relax(); continue; }
+                if (!spun_out(t0, ++spins)) { cpu_relax(); continue; }
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return has_task.load() || stop.load(); });
             }
@@ -1010,9 +1037,10 @@ struct ccal_ctx_worker {
         { std::lock_guard<std::mutex> lk(m); task = std::move(fn); done.store(0); has_task.store(1, std::memory_order_release); }
         cv.notify_one();
     }
-    // spin briefly (a session-sized solve is ~0.1 ms), then sleep on the condition variable
+    // spin briefly (the helpers of a batch finish within microseconds of the caller's own solve), then sleep on the condition variable
     void wait() {
-        for (int spins = 0; spins < 400000; ++spins) { if (done.load(std::memory_order_acquire)) return; cpu_relax(); }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int spins = 1;; ++spins) { if (done.load(std::memory_order_acquire)) return; if (spun_out(t0, spins)) break; cpu_relax(); }
         std::unique_lock<std::mutex> lk(m);
         cv_done.wait(lk, [&] { return done.load(std::memory_order_acquire) != 0; });
     }
@@ -1040,6 +1068,11 @@ static ccal_ctx_worker* ctx_worker(ccal_ctx* ctx) {
     }
     return ctx->worker;
 }
+
+namespace ccal {
+void ctx_worker_submit(ccal_ctx* ctx, std::function<void()> fn) { ctx_worker(ctx)->submit(std::move(fn)); }
+void ctx_worker_wait(ccal_ctx* ctx) { if (ctx->worker) ctx->worker->wait(); }
+}  // namespace ccal
 
 extern "C" {
 
@@ -1116,13 +1149,18 @@ int solve_sharded_run(ccal_problem** ps, int n, const ccal_solver_opts* o, doubl
     }
     std::vector<int> rc((size_t)n, CCAL_ERR_HIP);
     std::vector<ccal_report> reps((size_t)n);
-    // test hook (tests/test_gpu_multi.py): CCAL_TEST_FAIL_SHARD=r makes shard r fail before it enqueues anything - its peers are
-    // then inside the step's collective with no partner, which is what the transport's abort / timeout path is for
+    // fault injection for tests/test_gpu_multi.py - in builds with -DCCAL_TEST_HOOKS only (libccal_hip_legacy.so, which the product
+    // never loads): CCAL_TEST_FAIL_SHARD=r makes shard r fail before it enqueues anything - its peers are then inside the step's
+    // collective with no partner, which is what the transport's abort / timeout path is for
+#ifdef CCAL_TEST_HOOKS
     const int fail_shard = [] { const char* e = std::getenv("CCAL_TEST_FAIL_SHARD"); return e ? std::atoi(e) : -1; }();
+#else
+    constexpr int fail_shard = -1;
+#endif
     std::atomic<int> cancel{0}, first_failed{-1};        // first_failed: the shard that raised `cancel` (its peers fail BECAUSE of it)
     auto run = [&](int i) noexcept {
         try {
-            if (i == fail_shard) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "injected failure (CCAL_TEST_FAIL_SHARD)"); }
+            if (i == fail_shard) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "injected failure (test hook)"); }
             else rc[i] = solve_entry(ps[i], o, true, &intr[i * ni], poses_io ? poses_io[i] : nullptr, &extr[i * ne], &reps[i], &cancel);
         } catch (const std::bad_alloc&) { rc[i] = CCAL_ERR_NO_MEMORY; note_error(ps[i]->ctx, "out of host memory");
         } catch (...) { rc[i] = CCAL_ERR_HIP; note_error(ps[i]->ctx, "C++ exception in ccal_solve_sharded"); }
@@ -1184,7 +1222,7 @@ int ccal_solve_sharded(ccal_problem** ps, int n, const ccal_solver_opts* o, doub
     for (int i = 0; i < n; ++i) if (!ps[i]) return CCAL_ERR_INVALID_ARG;
     ccal_ctx* c0 = ps[0]->ctx;
     CCAL_API_TRY
-    int n_native = 0, n_cb = 0;
+    int n_native = 0, n_cb = 0, n_peer = 0;
     for (int i = 0; i < n; ++i) {
         const ccal_problem* p = ps[i];
         if ((p->n_slots && !(poses_io && poses_io[i])) || (p->n_cams > 1 && !extr_io)) { c0->err = "ccal_solve_sharded: null parameter array"; return CCAL_ERR_INVALID_ARG; }
@@ -1193,10 +1231,11 @@ int ccal_solve_sharded(ccal_problem** ps, int n, const ccal_solver_opts* o, doub
         for (int c = 0; c < p->n_cams; ++c) if (p->cams[c].model != ps[0]->cams[c].model) { c0->err = "ccal_solve_sharded: the shards describe different cameras"; return CCAL_ERR_INVALID_ARG; }
         if (std::memcmp(p->lo.data(), ps[0]->lo.data(), p->lo.size() * sizeof(double)) || std::memcmp(p->hi.data(), ps[0]->hi.data(), p->hi.size() * sizeof(double)) ||
             p->has_bound != ps[0]->has_bound || p->fixed != ps[0]->fixed) { c0->err = "ccal_solve_sharded: the shards carry different bounds / fixed parameters"; return CCAL_ERR_INVALID_ARG; }
-        n_native += p->rccl_comm ? 1 : 0; n_cb += (!p->rccl_comm && p->allreduce) ? 1 : 0;
+        n_native += p->rccl_comm ? 1 : 0; n_cb += (!p->rccl_comm && p->allreduce) ? 1 : 0; n_peer += p->peer ? 1 : 0;
     }
     if (n == 1 && !ps[0]->sharded()) return solve_entry(ps[0], o, true, intr_io, poses_io ? poses_io[0] : nullptr, extr_io, rep);
-    if ((n_native && n_native != n) || (n_cb && n_cb != n) || (n_native && n_cb)) { c0->err = "ccal_solve_sharded: a transport on some shards only"; return CCAL_ERR_INVALID_ARG; }
+    if ((n_native && n_native != n) || (n_cb && n_cb != n) || (n_peer && n_peer != n) || (n_native > 0) + (n_cb > 0) + (n_peer > 0) > 1) { c0->err = "ccal_solve_sharded: a transport on some shards only"; return CCAL_ERR_INVALID_ARG; }
+    if (n_peer) { c0->err = "ccal_solve_sharded: the shards of a ccal_multi_problem are solved by ccal_multi_solve"; return CCAL_ERR_INVALID_ARG; }
     if (n_native || n_cb) return solve_sharded_run(ps, n, o, intr_io, poses_io, extr_io, rep, nullptr);
     // no transport set: the library's own in-process one for the duration of the call (shards on one GPU, or on GPUs with
     // peer access); ccal_multi_* keeps a transport - RCCL when the devices differ - for the lifetime of the device set
@@ -1205,7 +1244,7 @@ int ccal_solve_sharded(ccal_problem** ps, int n, const ccal_solver_opts* o, doub
     std::string err;
     InprocComm* ic = inproc_create(n, devs.data(), &err);
     if (!ic) { c0->err = "ccal_solve_sharded: " + err; return CCAL_ERR_UNSUPPORTED; }
-    for (int i = 0; i < n; ++i) { ps[i]->allreduce = inproc_allreduce; ps[i]->allreduce_user = inproc_rank_handle(ic, i); ps[i]->allreduce_stream_ordered = true; }
+    for (int i = 0; i < n; ++i) ps[i]->peer = inproc_rank_handle(ic, i);
     inproc_set_timeout(ic, wait_timeout(ps[0], o));
     int rc = CCAL_ERR_HIP;
     try { rc = solve_sharded_run(ps, n, o, intr_io, poses_io, extr_io, rep, ic); } catch (...) { rc = CCAL_ERR_NO_MEMORY; }
@@ -1214,7 +1253,7 @@ int ccal_solve_sharded(ccal_problem** ps, int n, const ccal_solver_opts* o, doub
         (void)hipSetDevice(ps[i]->ctx->device);
         (void)hipStreamSynchronize(ps[i]->ctx->stream);
         if (ps[i]->nws) { ps[i]->nws->tail_pending = false; if (ps[i]->nws->fws) ps[i]->nws->fws->tail_pending = false; }
-        ps[i]->allreduce = nullptr; ps[i]->allreduce_user = nullptr; ps[i]->allreduce_stream_ordered = false;
+        ps[i]->peer = nullptr;
     }
     inproc_destroy(ic);
     return rc;

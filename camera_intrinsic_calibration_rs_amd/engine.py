@@ -108,6 +108,21 @@ def rccl_comm_destroy(comm: int) -> None:
     _ffi.load().ccal_rccl_comm_destroy(C.c_void_p(comm))
 
 
+def rccl_comm_count(comm: int) -> int:
+    """ncclCommCount of a communicator made by Context.rccl_comm_create (-1 on error)."""
+    return int(_ffi.load().ccal_rccl_comm_count(C.c_void_p(comm)))
+
+
+def partition_slots(desc: "_ffi.ProblemDesc", n_shards: int, lib=None) -> list:
+    """ccal_partition_slots (host only, no GPU): the n_shards + 1 slot boundaries ccal_multi_problem_create cuts `desc` at -
+    contiguous frame-slot ranges balanced by corner count."""
+    first = np.zeros(n_shards + 1, dtype=np.int32)
+    rc = (lib or _ffi.load()).ccal_partition_slots(C.byref(desc), int(n_shards), first.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != _ffi.OK:
+        raise CcalError(rc, "ccal_partition_slots")
+    return [int(x) for x in first]
+
+
 def make_desc(n_cams, model, width, height, xy_same_focal, n_slots, obs_cam, obs_slot, obs_offsets,
               x, y, z, u, v, huber_delta):
     """Build a ccal_problem_desc and return (desc, keepalive-list-of-arrays)."""
@@ -152,13 +167,16 @@ class MultiContext:
     """A set of GPUs driven from THIS process (ccal_multi): one context per listed device plus the transport of the step's
     all-reduce - RCCL when the devices differ, the library's in-process transport when a device is listed more than once."""
 
-    def __init__(self, devices):
-        self.lib = _ffi.load()
+    def __init__(self, devices, transport: int | None = None, lib=None):
+        """transport: None = automatic, _ffi.TRANSPORT_RCCL / TRANSPORT_INPROC = that one or an error (ccal_multi_create_transport).
+        lib: another build of the library (tests: _ffi.load_legacy(), which carries the fault-injection hook)."""
+        self.lib = lib if lib is not None else _ffi.load()
         devs = np.ascontiguousarray(devices, dtype=np.int32)
         h = C.c_void_p()
-        rc = self.lib.ccal_multi_create(devs.ctypes.data_as(C.POINTER(C.c_int32)), len(devs), C.byref(h))
+        rc = self.lib.ccal_multi_create_transport(devs.ctypes.data_as(C.POINTER(C.c_int32)), len(devs),
+                                                  -1 if transport is None else int(transport), C.byref(h))
         if rc != _ffi.OK:
-            raise CcalError(rc, "ccal_multi_create")
+            raise CcalError(rc, "ccal_multi_create", (self.lib.ccal_create_last_error() or b"").decode())
         self.handle = h
         self.devices = [int(d) for d in devs]
         self._problems = weakref.WeakSet()
@@ -166,6 +184,11 @@ class MultiContext:
     @property
     def transport(self) -> int:
         return int(self.lib.ccal_multi_transport(self.handle))
+
+    @property
+    def rccl_ranks(self) -> int:
+        """Ranks RCCL itself counts in this set's communicators (ncclCommCount); 0 when the transport is not RCCL."""
+        return int(self.lib.ccal_multi_rccl_ranks(self.handle))
 
     def last_error(self) -> str:
         return (self.lib.ccal_multi_last_error(self.handle) or b"").decode()
@@ -249,6 +272,21 @@ class MultiProblem:
         poses = _f64(poses, (self.n_slots, 6))
         extr = _f64(np.zeros((self.n_cams, 6)) if extr is None else extr, (self.n_cams, 6))
         return intr, poses, extr
+
+    def upload_params(self, intr, poses, extr=None):
+        intr, poses, extr = self._params(intr, poses, extr)
+        self._check(self.lib.ccal_multi_upload_params(self.handle, _dp(intr), _dp(poses), _dp(extr)), "ccal_multi_upload_params")
+
+    def shard_sizes(self, i: int):
+        """(corners, doubles of J_out) of shard i: the sizes of its mode-E output buffers."""
+        h = self.shard_handle(i)
+        return int(self.lib.ccal_num_corners(h)), int(self.lib.ccal_jacobian_len(h))
+
+    def eval_dev(self, r_dev_ptrs, J_dev_ptrs, apply_loss=False):
+        """ccal_multi_eval_dev: mode E on every shard (device buffers on the shard's own GPU); enqueues only - MultiContext.sync()."""
+        n = self.n_shards
+        ra = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in r_dev_ptrs]); ja = (C.c_void_p * n)(*[C.c_void_p(int(x)) for x in J_dev_ptrs])
+        self._check(self.lib.ccal_multi_eval_dev(self.handle, 1 if apply_loss else 0, ra, ja), "ccal_multi_eval_dev")
 
     def init_poses(self, intr, min_points: int = 10):
         intr = _f64(intr, (self.n_cams, PMAX))

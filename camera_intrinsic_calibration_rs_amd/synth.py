@@ -183,8 +183,11 @@ class SynthProblem:
     def shard(self, rank: int, world: int) -> "SynthProblem":
         """Contiguous frame-slot range of this problem for one rank: every camera's
         observations of a slot stay together; slots are renumbered from 0."""
-        lo = self.n_slots * rank // world
-        hi = self.n_slots * (rank + 1) // world
+        return self.slot_slice(self.n_slots * rank // world, self.n_slots * (rank + 1) // world)
+
+    def slot_slice(self, lo: int, hi: int) -> "SynthProblem":
+        """The frame slots lo .. hi - 1 as a problem of their own (every camera's observations of them; slots renumbered from 0):
+        one shard of a cut made elsewhere, e.g. by the library's ccal_partition_slots (balanced by corner count)."""
         keep = np.nonzero((self.obs_slot >= lo) & (self.obs_slot < hi))[0]
         counts = (self.obs_offsets[1:] - self.obs_offsets[:-1])[keep]
         offs = np.zeros(len(keep) + 1, dtype=np.int64)

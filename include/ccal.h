@@ -216,6 +216,7 @@ int ccal_rccl_version(void);                                      /* ncclGetVers
 int ccal_rccl_unique_id(void* id_out /* CCAL_RCCL_UNIQUE_ID_BYTES */);
 int ccal_rccl_comm_create(ccal_ctx* ctx, int world, int rank, const void* id /* 128 bytes */, void** comm_out);
 int ccal_rccl_comm_destroy(void* comm);
+int ccal_rccl_comm_count(void* comm);                             /* ncclCommCount: ranks of the communicator, -1 on error */
 
 int64_t ccal_num_corners(const ccal_problem* p);
 int ccal_reduced_dim(const ccal_problem* p);                      /* K */
@@ -293,6 +294,17 @@ int ccal_solve_sharded(ccal_problem** shards, int n, const ccal_solver_opts* opt
                        double* intr_io, double** poses_io, double* extr_io, ccal_report* report);
 
 int ccal_multi_create(const int* device_ids, int n_dev, ccal_multi** out);
+/* the same with the transport named: -1 = automatic (ccal_multi_create), CCAL_TRANSPORT_RCCL = communicators even for ONE listed
+ * device, CCAL_TRANSPORT_INPROC = the in-process transport even where RCCL is there.  A transport asked for by name is not
+ * replaced by another one when it cannot be set up (CCAL_ERR_UNSUPPORTED, reason in ccal_create_last_error). */
+int ccal_multi_create_transport(const int* device_ids, int n_dev, int transport, ccal_multi** out);
+int ccal_multi_rccl_ranks(const ccal_multi* m);        /* ranks RCCL counts in the set's communicators (ncclCommCount); 0: not RCCL */
+/* why the last ccal_ctx_create / ccal_multi_create* ON THIS THREAD failed (no handle exists to ask); "" after a success */
+const char* ccal_create_last_error(void);
+/* Host-only (no GPU touched): where ccal_multi_problem_create cuts a description into n_shards contiguous frame-slot ranges
+ * balanced by corner count - first_out[i] .. first_out[i + 1] are shard i's slots (first_out has n_shards + 1 entries).  A host
+ * that runs one process per GPU cuts its problem with the same function (bench.py --frames-total does). */
+int ccal_partition_slots(const ccal_problem_desc* desc, int n_shards, int32_t* first_out);
 void ccal_multi_destroy(ccal_multi* m);                /* deferred to the last ccal_multi_problem_destroy if problems are alive */
 int ccal_multi_num_devices(const ccal_multi* m);
 int ccal_multi_transport(const ccal_multi* m);         /* ccal_transport */

@@ -42,6 +42,14 @@ def test_library_exports_nothing_beyond_the_header():
     assert not extra, f"exported but not declared in include/ccal.h: {extra}"
 
 
+def test_no_test_hooks_in_the_product_library():
+    """Fault injection (CCAL_TEST_FAIL_SHARD) is compiled only into the second library the tests load (-DCCAL_TEST_HOOKS);
+    the product .so does not even contain the string."""
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    assert b"CCAL_TEST_" not in blob
+    assert b"CCAL_TEST_FAIL_SHARD" in open(_ffi.LEGACY_LIB_PATH, "rb").read()
+
+
 def test_host_only_entry_points():
     lib = _ffi.load()
     assert lib.ccal_version().startswith(b"ccal-mi355x")

@@ -70,6 +70,92 @@ def test_two_rank_sharded_solve_equals_single_process(oracle, model, n_cams, met
     assert abs(c0 - rep1.final_cost) <= 1e-10 * rep1.final_cost
 
 
+def _py_partition(sp, n):
+    """SURVEY 8(e) / ccal_multi.hip::partition_slots restated: boundary r = the first slot at which the corners of the slots
+    before it reach r / n of all corners."""
+    per_slot = np.zeros(sp.n_slots, dtype=np.int64)
+    np.add.at(per_slot, sp.obs_slot, sp.obs_offsets[1:] - sp.obs_offsets[:-1])
+    before = np.concatenate([[0], np.cumsum(per_slot)])
+    total = int(before[-1])
+    first = [0]
+    for r in range(1, n):
+        s_ = int(np.searchsorted(before, total * r // n, side="left")) if total else sp.n_slots * r // n
+        first.append(min(max(s_, first[-1]), sp.n_slots))
+    return first + [sp.n_slots]
+
+
+@pytest.mark.parametrize("n_frames,n_cams,ragged,n_shards", [(13, 2, True, 4), (100, 1, True, 8), (7, 1, False, 3), (2, 1, False, 5), (0, 1, False, 2), (64, 3, True, 16)])
+def test_product_partition_function(n_frames, n_cams, ragged, n_shards):
+    """The PRODUCT's cut (ccal_partition_slots: the host code ccal_multi_problem_create shards with, called here without a GPU):
+    contiguous, in order, every slot exactly once, balanced by corner count to within one slot's corners, and equal to the
+    restatement above; the shards it yields hold every observation once with all cameras' observations of a slot together."""
+    from camera_intrinsic_calibration_rs_amd import engine, synth
+    if n_frames:
+        sp = synth.make_problem(n_frames, "eucm", n_cams=n_cams, ragged=ragged)
+    else:
+        sp = synth.make_problem(3, "eucm").slot_slice(0, 0)          # a description without a single slot
+    d, _keep = engine.desc_from_synth(sp)
+    first = engine.partition_slots(d, n_shards)
+    assert first == _py_partition(sp, n_shards)
+    assert first[0] == 0 and first[-1] == sp.n_slots and all(a <= b for a, b in zip(first[:-1], first[1:]))
+    corners = [sp.slot_slice(a, b).n_corners for a, b in zip(first[:-1], first[1:])]
+    assert sum(corners) == sp.n_corners
+    if sp.n_corners and sp.n_slots >= n_shards:
+        per_slot_max = int((sp.obs_offsets[1:] - sp.obs_offsets[:-1]).max()) * n_cams
+        assert max(corners) - sp.n_corners / n_shards <= per_slot_max + 1        # balanced by corner count (CSR offsets)
+    for a, b in zip(first[:-1], first[1:]):
+        sh = sp.slot_slice(a, b)
+        assert sh.poses0.shape[0] == sh.n_slots == b - a
+        assert len(sh.obs_slot) == 0 or (sh.obs_slot.min() >= 0 and sh.obs_slot.max() < sh.n_slots)
+
+
+def test_two_rank_solve_over_the_products_cut(oracle):
+    """world_size 2, gloo: the ranks' shards come from the PRODUCT's partition function (uneven, corner-balanced), the per-shard
+    arithmetic is the oracle's, the collective goes through the product's hook - and the result equals the one-process solve."""
+    from camera_intrinsic_calibration_rs_amd import engine, synth
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    sp = synth.make_problem(23, "eucm", outlier_frac=0.01, ragged=True, seed=4242)
+    first = engine.partition_slots(engine.desc_from_synth(sp)[0], 2)
+    assert 0 < first[1] < 23
+    op = oracle.OracleProblem.from_synth(sp)
+    op.apply_reference_bounds()
+    intr1, poses1, extr1, rep1 = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(0))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cut, args=(r, 2, port, first, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, i0, p0, it0), (_, i1, p1, it1) = res
+    np.testing.assert_array_equal(i0, i1)
+    assert it0 == it1 == rep1.iterations
+    np.testing.assert_allclose(i0, intr1, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.concatenate([p0, p1]), poses1, rtol=0, atol=1e-9)
+
+
+def _worker_cut(rank, world, port, first, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    from oracle import binding as ob
+    sp = synth.make_problem(23, "eucm", outlier_frac=0.01, ragged=True, seed=4242)
+    shard = sp.slot_slice(first[rank], first[rank + 1])
+    op = ob.OracleProblem.from_synth(shard)
+    op.apply_reference_bounds()
+    intr, poses, extr, rep = op.solve(shard.intr0, shard.poses0, shard.extr0, opts=default_opts(0), allreduce=make_allreduce_hook(device=None))
+    q.put((rank, intr, poses, rep.iterations))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_shard_partitions_every_observation_once():
     from camera_intrinsic_calibration_rs_amd import synth
     sp = synth.make_problem(13, "eucm", n_cams=2, ragged=True)

@@ -269,10 +269,11 @@ def _child_abort(q, devices):
     """A shard that fails must not hang its peers: the in-process transport's abort releases them, the call returns an error, and
     the SAME device set solves again afterwards (ccal_multi_solve drains the devices and resets the transport)."""
     sys.path.insert(0, ROOT)
-    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd import _ffi, synth
     from camera_intrinsic_calibration_rs_amd.engine import CcalError, MultiContext, MultiProblem, default_opts
     sp = synth.make_problem(30, "eucm", seed=3)
-    mc = MultiContext(devices)
+    # the fault-injection hook (CCAL_TEST_FAIL_SHARD) exists only in the second build of the library (-DCCAL_TEST_HOOKS)
+    mc = MultiContext(devices, lib=_ffi.load_legacy())
     mpb = MultiProblem.from_synth(mc, sp)
     ok0 = mpb.solve(sp.intr0, sp.poses0, opts=default_opts(0))
     codes = []
@@ -297,6 +298,50 @@ def test_a_failing_shard_does_not_hang_the_others():
     for k in range(3):
         assert res["codes"][2 * k] == _ffi.ERR_HIP                       # the call comes back with an error, promptly
         assert res["codes"][2 * k + 1] == (0, True)                      # and the device set still solves, bit for bit as before
+
+
+def _child_create_errors(q):
+    """A transport asked for by name is that one or an error with a reason; a bad device list says which device."""
+    sys.path.insert(0, ROOT)
+    from camera_intrinsic_calibration_rs_amd import _ffi, synth
+    from camera_intrinsic_calibration_rs_amd.engine import CcalError, MultiContext, MultiProblem, default_opts
+    out = {}
+    try:
+        MultiContext([0, 0], transport=_ffi.TRANSPORT_RCCL)
+        out["rccl_dup"] = "created"
+    except CcalError as e:
+        out["rccl_dup"] = (e.code, str(e))
+    try:
+        MultiContext([0, 97])
+        out["bad_dev"] = "created"
+    except CcalError as e:
+        out["bad_dev"] = (e.code, str(e))
+    mc = MultiContext([0], transport=_ffi.TRANSPORT_RCCL)
+    out["one_rank"] = (mc.transport, mc.rccl_ranks)
+    mc.close()
+    mc = MultiContext([0, 0], transport=_ffi.TRANSPORT_INPROC)
+    sp = synth.make_problem(20, "eucm", seed=8)
+    mpb = MultiProblem.from_synth(mc, sp)
+    rep = mpb.solve(sp.intr0, sp.poses0, opts=default_opts(0))[3]
+    out["inproc"] = (mc.transport, mc.rccl_ranks, rep.status)
+    # the product library carries no fault-injection hook: the variable is inert here
+    os.environ["CCAL_TEST_FAIL_SHARD"] = "0"
+    try:
+        out["hook_inert"] = mpb.solve(sp.intr0, sp.poses0, opts=default_opts(0))[3].status
+    finally:
+        del os.environ["CCAL_TEST_FAIL_SHARD"]
+    mpb.close(); mc.close()
+    q.put(out)
+
+
+def test_named_transports_and_create_errors():
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    res = _run_child(_child_create_errors, ())
+    assert res["rccl_dup"][0] == _ffi.ERR_UNSUPPORTED and "RCCL" in res["rccl_dup"][1]
+    assert res["bad_dev"][0] == _ffi.ERR_HIP and "97" in res["bad_dev"][1]
+    assert res["one_rank"] == (_ffi.TRANSPORT_RCCL, 1)
+    assert res["inproc"] == (_ffi.TRANSPORT_INPROC, 0, _ffi.OK)
+    assert res["hook_inert"] == _ffi.OK
 
 
 def _child_rccl_one(q):
