@@ -174,6 +174,14 @@ def load():
     return _lib
 
 
+def load_for_switches():
+    """TEST / A-B INFRASTRUCTURE: the second build when a developer switch (any CCAL_* variable the product ignores) is set in the
+    environment, else the product library.  Child processes of the tests call this after setting their switch."""
+    keep = {"CCAL_LIB", "CCAL_RCCL_LIB", "CCAL_MULTI_TRANSPORT"}
+    dev = any(k.startswith("CCAL_") and k not in keep and not k.startswith("CCAL_BENCH") for k in os.environ)
+    return load_legacy() if dev else load()
+
+
 def load_legacy():
     """TEST INFRASTRUCTURE: the second build of the library that still carries the superseded matrix-core kernels
     (-DCCAL_LEGACY_KERNELS: k_gram1, k_gram, k_schur<false>; CCAL_GRAM=mfma / CCAL_GENERAL_GRAM=mfma select them there) - the

@@ -300,10 +300,7 @@ struct FusedArgs {
     // GEN, all cameras of a rig in ONE launch (same model and focal mode): the camera of every observation frame; `list` then
     // holds every camera's frames, `intr` / `extr` point at camera 0.  NULL: one camera per launch (`cam`)
     const int32_t* obs_cam;
-    // single-camera loop, experiment of round 4 (CCAL_PREPASS=1, off by default - it loses): a per-frame
-    // launch in front of the Gram kernel does the pose update and the exponential map and leaves the frame constants in
-    // fcbuf [n_obs][FC_N0P]; the Gram kernel's prologue is then one coalesced read per frame
-    int32_t prepass;
+    int32_t lpf_force;             // lanes per frame forced by a developer switch of the second library (0: the launchers' cost model)
     IterArgs it;
     // general (multi-camera) loop, GEN kernels: the candidate pose of the frame's slot is formed HERE, in the prologue - k_backsub's
     // work (dp = -L^-T (y_r + Y dc), model decrease of the pose block) with the slot's elimination record of the general loop and
@@ -402,8 +399,7 @@ hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, 
 // ccal_kernels_gram2.hip: a corner's two rows on two lanes (row-local columns), same records, same fused tail
 hipError_t launch_gram2(int model, bool one_focal, FusedArgs& a, hipStream_t s);
 hipError_t launch_gram2_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);
-hipError_t launch_schur1(FusedArgs& a, hipStream_t s);    // one frame per wavefront, persistent (any size); sets a.n_part
-hipError_t launch_schur1m(FusedArgs& a, hipStream_t s);   // four frames per wavefront, 32 per workgroup, one pass; sets a.n_part
+hipError_t launch_schur1m(FusedArgs& a, hipStream_t s);   // second library only (-DCCAL_LEGACY_KERNELS): the separate elimination launch; sets a.n_part
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s);
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 hipError_t launch_state_eval(DevState* st, double lambda, hipStream_t s);     // state := "first evaluation of set 0 with this lambda"

@@ -137,7 +137,7 @@ int drain_pending_groups(ccal_problem* p);
 // ccal_kernels_stats.hip
 // first size of ccal_problem::d_scratch: what ccal_init_poses and validation() of every camera need (gather + sort buffers + hipCUB's temporary)
 inline size_t problem_scratch_hint(const ccal_problem* p) {
-    return (size_t)std::max<int64_t>(p->n_corners, 1) * 32 + (size_t)(std::max(p->n_obs, 1) + 1) * 64 + (size_t)256 * 1024;
+    return (size_t)std::max<int64_t>(p->n_corners, 1) * 32 + (size_t)(std::max(p->n_obs, 1) + 1) * 64 + (size_t)384 * 1024;
 }
 hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
 hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s);     // *d_out: a slice of p->d_scratch

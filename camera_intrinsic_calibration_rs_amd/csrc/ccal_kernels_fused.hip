@@ -22,6 +22,7 @@
 #include "ccal_fused.hpp"
 #include "ccal_gram_common.hpp"
 #include "ccal_head.hpp"
+#include "ccal_devopt.hpp"
 
 namespace ccal {
 
@@ -1048,23 +1049,25 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
 //     EUCM us per build, best in brackets: 5 000 frames 37.4 40.2 33.7 [31.2] 37.2 50.7; 10 000: 52.9 45.8 [40.8] 45.7 58.3 82.4;
 //     20 000: 85.2 [67.6] 72.1 74.6 98.0 117; 50 000: 159 [138] 151 154 191 267;  KB4 (k_gram1v) 10 000: [54.6] 78.1 63.4 74.3
 //     88.4 138; 20 000: [99.4] 115 116 120 168 214).  c0 = 6 passes' worth of prologue + epilogue (6 lanes: 8).
-// CCAL_GRAMV_LPF overrides.
-static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots) {
+// The second library's CCAL_GRAMV_LPF overrides.  Mappings whose wavefronts would not fit the rows of the partial-sum buffer
+// (`max_waves`: the single-camera loop's fused elimination writes one row per wavefront) are left out; six lanes per frame
+// (the fewest wavefronts) always fit (fused_ws_ensure sizes the buffer for them).
+static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots, int64_t max_waves = (int64_t)1 << 40) {
     static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
     // developer override: only the instantiated mappings (anything else would make the launcher's wavefront count and the
     // kernel it falls back to disagree)
     static const int lpf_env = [] {
-        const char* e = std::getenv("CCAL_GRAMV_LPF");
-        const int v = e ? std::atoi(e) : 0;
+        const int v = dev_env_int("CCAL_GRAMV_LPF", 0);
         for (int c : cand) if (v == c) return v;
         return 0;
     }();
     if (lpf_env) return lpf_env;
-    int best = 64;
+    int best = 6;
     double best_cost = 1e300;
     for (int i = 0; i < 6; ++i) {
         const int lpf = cand[i], g = 64 / lpf;
         const int64_t waves = ((int64_t)n_obs + g - 1) / g;
+        if (((waves + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB) * CCAL_GRAMV_WPB > max_waves && lpf != 6) continue;
         const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
         const double c0 = lpf == 6 ? 8.0 : 6.0;
         double occ;
@@ -1084,20 +1087,25 @@ static hipError_t launch_gram1v_t(FusedArgs& a, hipStream_t s) {
     // More wavefronts than SIMDs (>= 2000 frames): k_gram1w, two wavefronts per SIMD (10 000 frames: 40 vs 53 us).
     // Below that every wavefront has a SIMD to itself and k_gram1v's all-register accumulators are a little faster.
     // CCAL_GRAMV_LDSACC=0|1 forces one or the other.
-    static const int force = [] { const char* e = std::getenv("CCAL_GRAMV_LDSACC"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static const int force = [] { const char* e = dev_env("CCAL_GRAMV_LDSACC"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     constexpr int NCt = block_dim(MODEL, OF, false) + 1;
     // larger triangles (KB4: 105 / 120 entries, OPENCV5: 120 / 136) do not fit two wavefronts per SIMD without scratch
     // (one-focal KB4 through k_gram1w: 124 us instead of 64 at 10 000 frames): k_gram1v there
     // (k_gram1w is not even instantiated for them: CCAL_GRAMV_LDSACC=1 has no effect there)
+    // The PRODUCT launchers never reach k_gram1w (UCM / EUCM from 2 000 frames go to k_gram2, use_gram2) nor any OPENCV5
+    // instantiation of k_gram1v (k_gram2 for every size): they are compiled into the second library only (CCAL_GRAM2=0 there)
+#ifdef CCAL_DEV_SWITCHES
     constexpr bool W_OK = NCt * (NCt + 1) / 2 <= 91;
+#else
+    constexpr bool W_OK = false; (void)NCt;
+#endif
     const bool w = W_OK && (force >= 0 ? force == 1 : a.n_obs >= 2000);
-    const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024);
-    // fused elimination (single-camera loop, k_gram1w only): one row of partial sums per wavefront
+    const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap);
+    // fused elimination (single-camera loop): one row of partial sums per wavefront
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
-    // (every size: 300 / 625 / 1 000 / 1 280 frames GN 0.135-0.155 ms fused against 0.145-0.172 with k_schur1m and the head's own
-    // reduction of its <= 40 rows; CCAL_FUSE_MIN = fewest frames that fuse, CCAL_FUSE_ELIM=0 never)
-    static const int fuse_min = [] { const char* e = std::getenv("CCAL_FUSE_MIN"); return e ? std::atoi(e) : 1; }();
-    const bool fuse = !GEN && a.n_obs >= fuse_min && a.fuse_elim != 0 && waves <= a.part_cap;
+    // (every size: 300 / 625 / 1 000 / 1 280 frames GN 0.135-0.155 ms fused against 0.145-0.172 with a separate elimination launch and
+    // the head's own reduction of its <= 40 rows; the second library's CCAL_FUSE_ELIM=0 still takes the separate launch)
+    const bool fuse = !GEN && a.fuse_elim != 0 && waves <= a.part_cap;
     a.fuse_elim = fuse ? 1 : 0;
     a.elim_fused = fuse ? 1 : 0;
     if (fuse) a.n_part = waves;
@@ -1117,8 +1125,12 @@ static hipError_t launch_gram1v_m(int model, bool one_focal, FusedArgs& a, hipSt
         case 3: return launch_gram1v_t<kEUCM, true, GEN>(a, s);
         case 4: return launch_gram1v_t<kKB4, false, GEN>(a, s);
         case 5: return launch_gram1v_t<kKB4, true, GEN>(a, s);
+#ifdef CCAL_DEV_SWITCHES
         case 6: return launch_gram1v_t<kOCV5, false, GEN>(a, s);
         case 7: return launch_gram1v_t<kOCV5, true, GEN>(a, s);
+#else
+        case 6: case 7: return hipErrorNotSupported;          // (OPENCV5: k_gram2 for every size)
+#endif
         default: return hipErrorInvalidValue;
     }
 }
@@ -1151,7 +1163,7 @@ template <int MODEL, bool OF>
 static int iter_rows_t(int n_obs, int avg_corners, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
     // CCAL_ITER_ROWS: most rows (= workgroups, each of which reads every row of the launch before) for which a group is one
     // launch; 0 = never.  One wavefront per SIMD, every workgroup resident at once: <= 256 workgroups.
-    static const int max_rows = [] { const char* e = std::getenv("CCAL_ITER_ROWS"); return e ? std::min(std::atoi(e), 256) : 256; }();
+    static const int max_rows = std::min(dev_env_int("CCAL_ITER_ROWS", 256), 256);
     if (n_obs <= 0 || max_rows <= 0) return 0;
     const int lpf = gram_lanes_per_frame(n_obs, avg_corners, 1024);
     const int g = 64 / lpf, rows = (n_obs + g * kIterWpb - 1) / (g * kIterWpb);
@@ -1174,8 +1186,10 @@ static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, bo
         case 3: return iter_rows_t<kEUCM, true>(n_obs, avg_corners, launch, a, s, err);
         case 4: return iter_rows_t<kKB4, false>(n_obs, avg_corners, launch, a, s, err);
         case 5: return iter_rows_t<kKB4, true>(n_obs, avg_corners, launch, a, s, err);
+#ifdef CCAL_DEV_SWITCHES
         case 6: return iter_rows_t<kOCV5, false>(n_obs, avg_corners, launch, a, s, err);
         case 7: return iter_rows_t<kOCV5, true>(n_obs, avg_corners, launch, a, s, err);
+#endif
         default: return 0;
     }
 }
@@ -1183,7 +1197,7 @@ int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K
     if (K != block_dim(model, one_focal, false) - 6) return 0;      // (the kernel's compile-time column count is the problem's)
     // OPENCV5: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch
     // form (112-double rows: two chunks per lane to sum, 4.9 us).  CCAL_ITER_OCV5=1 forces the single-launch form.
-    static const bool ocv5 = [] { const char* e = std::getenv("CCAL_ITER_OCV5"); return e && e[0] == '1'; }();
+    static const bool ocv5 = dev_env_int("CCAL_ITER_OCV5", 0) == 1;
     if (model == kOCV5 && !ocv5) return 0;
     return iter_rows_m(model, one_focal, n_obs, avg_corners, false, nullptr, nullptr, nullptr);
 }
@@ -1199,19 +1213,21 @@ hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t
 // 21.1 vs 36.9 / 22.2 (from 2 000 frames: two wavefronts per SIMD, no LDS accumulators; 625 frames 15.9 vs 14.2 with k_gram1v),
 // KB4 49.3 vs 49.7 two-focal but 48.2 vs 46.5 one-focal: KB4 stays on k_gram1v.  CCAL_GRAM2=0|1 forces.
 static bool use_gram2(int model, int n_obs) {
-    static const int force = [] { const char* e = std::getenv("CCAL_GRAM2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static const int force = [] { const char* e = dev_env("CCAL_GRAM2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     if (force >= 0) return force == 1;
     if (model == kOCV5) return true;
     return (model == kUCM || model == kEUCM) && n_obs >= 2000;
 }
+static int gram2_lpf_force() { static const int v = dev_env_int("CCAL_GRAM2_LPF", 0); return v; }
 hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
-    if (use_gram2(model, a.n_obs)) return launch_gram2(model, one_focal, a, s);
+    if (use_gram2(model, a.n_obs)) { a.lpf_force = gram2_lpf_force(); return launch_gram2(model, one_focal, a, s); }
     return launch_gram1v_m<false>(model, one_focal, a, s);
 }
 // one camera's blocks of a multi-camera problem: a.list / a.rec_off / a.n_obs = that camera's observation frames
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a0, hipStream_t s) {
-    if (use_gram2(model, a0.n_obs)) return launch_gram2_general(model, one_focal, a0, s);
-    FusedArgs a = a0; a.fuse_elim = 0; return launch_gram1v_m<true>(model, one_focal, a, s);
+    FusedArgs a = a0; a.fuse_elim = 0;
+    if (use_gram2(model, a0.n_obs)) { a.lpf_force = gram2_lpf_force(); return launch_gram2_general(model, one_focal, a, s); }
+    return launch_gram1v_m<true>(model, one_focal, a, s);
 }
 #ifdef CCAL_LEGACY_KERNELS
 template <int MODEL, bool OF>
@@ -1242,142 +1258,13 @@ hipError_t launch_gram1(int, bool, const FusedArgs&, hipStream_t) { return hipEr
 #endif
 
 // ---------------------------------------------------------------------------------------------
-// k_schur1: persistent wavefronts over frames (problems too large for one pass of k_schur1m).  Works on the set and
-// with the damping the state prescribes (schur_set / schur_lambda in ccal_fused.hpp): the set just evaluated, or - in a
-// re-elimination group - the accepted set, whose records an LM rejection left untouched.
-// Per workgroup partial sums: [A_dir | Y^T Y | model decrease of the pose blocks | pose blocks that failed].
+// The separate elimination launch - superseded by the Gram kernels' fused tail (gram_fused_tail) for every model and size; kept
+// in the SECOND library only (-DCCAL_LEGACY_KERNELS), where the matrix-core Gram k_gram1 and CCAL_FUSE_ELIM=0 still use it and
+// tools/count_flops.py reads the elimination's operation count off its ISA.
 // ---------------------------------------------------------------------------------------------
-
-template <int K>
-__global__ __launch_bounds__(256) void k_schur1(const FusedArgs a) {
-    constexpr int K1 = K + 1, NA = K1 * K1;
-    constexpr int NQ = (NA + 63) / 64;
-    constexpr int WSL = ((36 + 12 * K1) + 1) & ~1;      // C[36] | [B|g][6][K1] | Y[6][K1]
-    __shared__ double smem[WAVES_PER_BLOCK * WSL];
-    const DevState* st = a.st;
-    if (st->done) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * WAVES_PER_BLOCK + wave;
-    double* Cm = smem + wave * WSL;
-    double* Bm = Cm + 36;
-    double* Ym = Bm + 6 * K1;
-    const int set = schur_set(st);
-    const double lambda = schur_lambda(st);
-    double accA[NQ], accY[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
-    double acc_mc = 0.0, acc_fail = 0.0;             // wave-uniform
-    // packed-lower index of this lane (lanes 0..20)
-    int li = 0, lr = lane;
-    while (lr > li && li < 6) { lr -= li + 1; ++li; }
-
-    for (int f = gw; f < a.n_obs; f += a.n_pw) {
-        const int slot = a.obs_slot[f];
-        const double* rec = a.praw[set] + (int64_t)f * a.PRAW;
-        if (lane < 21) Cm[lane] = rec[lane];                                   // packed lower triangle, phi basis
-        if (lane >= 32 && lane < 41) Cm[21 + lane - 32] = rec[praw_jl_off(K) + lane - 32];   // the frame's left Jacobian
-        for (int e = lane; e < 6 * K1; e += 64) Bm[e] = rec[21 + e];
-        double adir[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) { const int e = lane + 64 * q; adir[q] = e < NA ? rec[21 + 6 * K1 + e] : 0.0; }
-        acc_mc += a.mc_f[f];
-        wsync();
-        // phi -> rvec, then the 6x6 Cholesky of C + lambda clamp(diag C): every lane runs the same factorisation (diag inverted)
-        double Cr[21], jl[9];
-#pragma unroll
-        for (int i = 0; i < 21; ++i) Cr[i] = Cm[i];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) jl[i] = Cm[21 + i];
-        phi_to_rvec_C(Cr, jl);
-        double L[21], dC[6];
-        bool ok = true;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            dC[i] = Cr[i * (i + 1) / 2 + i];
-#pragma unroll
-            for (int j = 0; j <= i; ++j) {
-                double t = Cr[i * (i + 1) / 2 + j];
-                if (i == j && lambda > 0.0) t += lambda * clampd1(dC[i], a.min_diag, a.max_diag);
-#pragma unroll
-                for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
-                if (i == j) {
-                    ok = ok && (t > 0.0) && (t < 1.7e308);
-                    double sq, rsq;
-                    fast_sqrt_rsqrt(ok ? t : 1.0, sq, rsq);
-                    L[i * (i + 1) / 2 + i] = ok ? rsq : 0.0;
-                } else {
-                    L[i * (i + 1) / 2 + j] = t * L[j * (j + 1) / 2 + j];
-                }
-            }
-        }
-        double* pf = a.pf[set] + (int64_t)slot * a.PF;
-        if (!ok) {
-            acc_fail += 1.0;
-            for (int e = lane; e < a.PF; e += 64) pf[e] = 0.0;
-            for (int e = lane; e < 6 * K1; e += 64) Ym[e] = 0.0;
-        } else {
-            if (lane < K1) {
-                double bc[6], y[6];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + lane];
-                phi_to_rvec_col(bc, jl);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    double t = bc[i];
-#pragma unroll
-                    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
-                    y[i] = t * L[i * (i + 1) / 2 + i];
-                    Ym[i * K1 + lane] = y[i];
-                    pf[21 + i * K1 + lane] = y[i];
-                }
-                if (lane == K) {                   // g_p in the rvec basis
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
-                }
-            }
-            {   // lane i stores L[i], lane i the damping diagonal dC[i]: a select chain over static register indices (no
-                // scratch) and ONE coalesced store each, instead of 27 single-lane predicated stores
-                double lv = L[0], dv = dC[0];
-#pragma unroll
-                for (int i = 1; i < 21; ++i) lv = lane == i ? L[i] : lv;
-#pragma unroll
-                for (int i = 1; i < 6; ++i) dv = lane == i ? dC[i] : dv;
-                if (lane < 21) pf[lane] = lv;
-                if (lane < 6) pf[21 + 6 * K1 + 6 + lane] = dv;
-            }
-        }
-        wsync();
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = lane + 64 * q;
-            if (e < NA) {
-                const int i = e / K1, j = e - i * K1;
-                double t = 0.0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
-                accY[q] += t;
-                accA[q] += adir[q];
-            }
-        }
-        wsync();
-    }
-    // the four waves of the workgroup combine in LDS (fixed order), one flush per workgroup
-    __shared__ double blk[WAVES_PER_BLOCK][2 * NA + 2];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int e = lane + 64 * q;
-        if (e < NA) { blk[wave][e] = accA[q]; blk[wave][NA + e] = accY[q]; }
-    }
-    if (lane == 0) { blk[wave][2 * NA] = acc_mc; blk[wave][2 * NA + 1] = acc_fail; }
-    __syncthreads();
-    // [workgroup][entry]: k_reduce1 / k_head sum the rows (reduce_partial_rows)
-    for (int e = threadIdx.x; e < 2 * NA + 2; e += 256)
-        a.partial[(int64_t)blockIdx.x * (2 * NA + 2) + e] = (blk[0][e] + blk[1][e]) + (blk[2][e] + blk[3][e]);
-}
-// k_schur1m: the same elimination with FOUR frames per wavefront (16 lanes each) - k_schur1 keeps 64 lanes busy with
-// one frame's 7 columns and 49 sums, so a 10 000-frame problem is 10 000 latency-bound wavefronts (381 vector + 520
-// scalar instructions each, 46 % of the time waiting); here the same instruction stream serves four frames.
-// One pass per wavefront: the grid covers all frames (n_pw = 4 ceil(n_obs / 16)).
+#ifdef CCAL_LEGACY_KERNELS
+// k_schur1m: the elimination with FOUR frames per wavefront (16 lanes each), one pass per wavefront: the grid covers all frames
+// (n_pw = 4 ceil(n_obs / 16)).
 constexpr int SCHUR1M_WAVES = 8;          // 32 frames per workgroup: a quarter of the partial sums k_head / k_reduce1 have to add up
 template <int K>
 __global__ __launch_bounds__(64 * SCHUR1M_WAVES) void k_schur1m(const FusedArgs a) {
@@ -1443,21 +1330,9 @@ hipError_t launch_schur1m(FusedArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_schur1(FusedArgs& a, hipStream_t s) {
-    const dim3 grid(a.n_pw / WAVES_PER_BLOCK), blk(256);
-    a.n_part = (int32_t)grid.x;
-    if (grid.x == 0) return hipSuccess;
-    switch (a.K) {
-        case 4: hipLaunchKernelGGL(k_schur1<4>, grid, blk, 0, s, a); break;
-        case 5: hipLaunchKernelGGL(k_schur1<5>, grid, blk, 0, s, a); break;
-        case 6: hipLaunchKernelGGL(k_schur1<6>, grid, blk, 0, s, a); break;
-        case 7: hipLaunchKernelGGL(k_schur1<7>, grid, blk, 0, s, a); break;
-        case 8: hipLaunchKernelGGL(k_schur1<8>, grid, blk, 0, s, a); break;
-        case 9: hipLaunchKernelGGL(k_schur1<9>, grid, blk, 0, s, a); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
+#else
+hipError_t launch_schur1m(FusedArgs&, hipStream_t) { return hipErrorNotSupported; }       // not in the product build
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // k_reduce1: red[e] = sum over workgroups of partial[w][e], fixed order (no atomics: bitwise reproducible)

@@ -20,7 +20,6 @@
 // are those of k_gram1w.
 //   KB4: 91 accumulators + two rows of 13 = 234 registers' worth: no AGPR copies, two wavefronts per SIMD.
 #include <algorithm>
-#include <cstdlib>
 
 #include "ccal_gram_common.hpp"
 
@@ -55,37 +54,22 @@ __host__ __device__ constexpr uint32_t g2_rec_dst(int i, int j) {
     return a | (b << 16);
 }
 // One ITEM per entry of the full triangle, in the order of the accumulator t it is summed from:
-//   src = t | h << 8 | mask << 12   (mask bit 0: the u lanes contribute, bit 1: the v lanes; 0: a structural zero of the block;
-//                                    h: QUAD only - which half of the row-local triangle, i.e. which 16-lane row of the half)
+//   src = t | mask << 12   (mask bit 0: the u lanes contribute, bit 1: the v lanes; 0: a structural zero of the block)
 //   rec = where it goes in the record
 // NS = number of slices the accumulators are reduced in (LDS per wavefront = 64 x slice); first[s] = first item of slice s.
-//
-// QUAD (KB4, OPENCV5: 91 / 105 row-local entries are too many for two wavefronts per SIMD): the row-local columns split into
-// a = columns 0..6 and b = columns 7..NCR-1 (NB = 6 or 7), and the triangle = tri(a) + a (x) b + tri(b) goes to TWO lane roles:
-//   h = 0:  tri(a)  +  a[0..3] (x) b          h = 1:  tri(b)  +  a[4..6] (x) b
-// With the row staged in LDS as  S = [a0..a6, 0, b0..b(NB-1), 0...]  both roles run the SAME code on different addresses:
-//   X = S[8 h + i], i < 7;   W = S[4 h + i], i < 4;   V = S[8 + i], i < NB;     accumulators: tri(X) (28) then W (x) V (4 NB)
-// - 52 / 56 accumulators per lane instead of 91 / 105.
-constexpr int G4_NA = 7, G4_NW = 4;
-__host__ __device__ constexpr int g4_tri7(int i, int j) { return i * G4_NA - i * (i - 1) / 2 + (j - i); }     // i <= j < 7
-template <int MODEL, bool OF, bool GEN, int NS, bool QUAD>
+// (The four-role form of round 3 - the row-local triangle split between two lane roles, rows staged in LDS - was measured slower
+//  for every model and is gone: EXPERIMENTS.md.)
+template <int MODEL, bool OF, bool GEN, int NS>
 struct RowMap {
     static constexpr int P = model_np(MODEL), ND = P - 4, K = P - (OF ? 1 : 0), D = K + 6, NCF = D + 1, NEF = NCF * (NCF + 1) / 2;
-    static constexpr int NCR = ND + 9, NB = NCR - G4_NA;
-    static constexpr int NER = QUAD ? G4_NA * (G4_NA + 1) / 2 + G4_NW * NB : NCR * (NCR + 1) / 2;      // accumulators per lane
+    static constexpr int NCR = ND + 9;
+    static constexpr int NER = NCR * (NCR + 1) / 2;      // accumulators per lane
     static constexpr int CH = (NER + NS - 1) / NS;
-    static_assert(!QUAD || (NB >= 1 && NB <= 7), "QUAD: 8 .. 14 row-local columns");
     uint32_t rec[NEF];
     uint16_t src[NEF];
     int first[NS + 1];
-    // (h, t) of the row-local pair p <= q
-    static constexpr int where(int p, int q) {
-        if (!QUAD) { int t = 0; for (int a = 0; a < p; ++a) t += NCR - a; return t + (q - p); }
-        if (q < G4_NA) return g4_tri7(p, q);                                             // both in a: h = 0
-        if (p >= G4_NA) return (1 << 8) | g4_tri7(p - G4_NA, q - G4_NA);                   // both in b: h = 1
-        const int hh = p < G4_NW ? 0 : 1, pi = p - G4_NW * hh;
-        return (hh << 8) | (G4_NA * (G4_NA + 1) / 2 + pi * NB + (q - G4_NA));
-    }
+    // accumulator t of the row-local pair p <= q
+    static constexpr int where(int p, int q) { int t = 0; for (int a = 0; a < p; ++a) t += NCR - a; return t + (q - p); }
     constexpr RowMap() : rec{}, src{}, first{} {
         bool seen[NCF][NCF] = {};
         int n = 0;
@@ -121,19 +105,11 @@ struct RowMap {
         return mx;
     }
 };
-template <int MODEL, bool OF, bool GEN, int NS, bool QUAD> __device__ const RowMap<MODEL, OF, GEN, NS, QUAD> g_rowmap = RowMap<MODEL, OF, GEN, NS, QUAD>();
+template <int MODEL, bool OF, bool GEN, int NS> __device__ const RowMap<MODEL, OF, GEN, NS> g_rowmap = RowMap<MODEL, OF, GEN, NS>();
 
 // slices of the reduction: the LDS a wavefront needs is 64 lanes x (slice | 1) doubles; two wavefronts per SIMD = 8 per CU
 // have to share 160 KB with the frames' constants
-template <int MODEL, bool QUAD> __host__ __device__ constexpr int g2_slices() { return (!QUAD && (MODEL == kKB4 || MODEL == kOCV5)) ? 3 : 2; }
-// QUAD: which models take the four-role form.  It does what it was built for - KB4: 52 accumulators, 256 VGPRs, no AGPR copy,
-// no scratch, two wavefronts per SIMD - and is NOT faster: 10 000 frames, build, KB4 51.6 us / OPENCV5 53.1 us against 49.3 /
-// 47.1 for the two-role form at one wavefront per SIMD (and 49.8 / 51.2 for k_gram1v): 574 / 504 instructions per pass instead of
-// 500 / 478, 52 LDS accesses of 16 bytes per pass (with 8-byte accesses, 45 % of the LDS cycles were bank conflicts: 60 us), and
-// the pair of wavefronts issues at 9.6 cycles per instruction where the lone one manages 6.5.  Compile-time opt-in only.
-#ifndef CCAL_G2_QUAD
-#define CCAL_G2_QUAD(MODEL) 0
-#endif
+template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MODEL == kKB4 || MODEL == kOCV5) ? 3 : 2; }
 
 // diagnostic build (-DCCAL_STAMPS, tools/stamps_g2.py): the 100 MHz clock at the phase boundaries of every wavefront, parked
 // in the per-frame scratch (8 stamps per wavefront)
@@ -150,20 +126,11 @@ template <int MODEL, bool QUAD> __host__ __device__ constexpr int g2_slices() { 
 // KB4 / OPENCV5 (182 / 210 + 52 / 56) do not without scratch or LDS accumulators, both of which cost more than they buy
 // (measured, 10 000 frames, build: scratch 99 / 98 us, 16 / 32 LDS accumulators 68 / 60 us, one wavefront per SIMD 52 / 50 us)
 #ifndef CCAL_G2_MINW
-#define CCAL_G2_MINW(MODEL, QUAD) ((!(QUAD) && ((MODEL) == kKB4 || (MODEL) == kOCV5)) ? 1 : 2)
+#define CCAL_G2_MINW(MODEL) (((MODEL) == kKB4 || (MODEL) == kOCV5) ? 1 : 2)
 #endif
 // R and t of the lane's frame in registers (24 of them) instead of twelve LDS reads per corner: only where they fit
 #ifndef CCAL_G2_HOIST
 #define CCAL_G2_HOIST(MODEL) ((MODEL) == kUCM)
-#endif
-// software pipeline of the corner loop (products of corner i beside the projection of corner i + 1 in one basic block).
-// Measured and left off: the scheduler does interleave them, but the longer live ranges cost 139 / 205 v_accvgpr copies per
-// pass instead of 41 / 81 (KB4 / OPENCV5, 10 000 frames: build 54.1 / 53.8 us against 49.3 / 47.1)
-#ifndef CCAL_G2_PRIO
-#define CCAL_G2_PRIO 0
-#endif
-#ifndef CCAL_G2_PIPE
-#define CCAL_G2_PIPE(MODEL) 0
 #endif
 // accumulators kept in LDS ([entry][lane], stride 65: lane-private ds_add_f64, fire and forget) instead of registers: the
 // first NLA entries of the row-local triangle, as many as keeps the kernel inside 256 registers without scratch
@@ -173,24 +140,21 @@ template <int MODEL, bool QUAD> __host__ __device__ constexpr int g2_slices() { 
 
 // LPF = lanes per frame, EVEN: LPF / 2 corners of a frame per pass.  The frame's lanes are contiguous (grp = lane / LPF), so
 // the prologue and the fused tail are those of k_gram1w.
-template <int MODEL, bool OF, int LPF, bool GEN, bool QUAD>
-__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) void k_gram2(const FusedArgs a) {
-    static_assert(LPF % (QUAD ? 4 : 2) == 0, "a frame's lanes: LPF / 2 in each half of the wavefront (QUAD: LPF / 4 in each 16-lane row)");
-    constexpr int NS = g2_slices<MODEL, QUAD>();
-    using Map = RowMap<MODEL, OF, GEN, NS, QUAD>;
+template <int MODEL, bool OF, int LPF, bool GEN>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2(const FusedArgs a) {
+    static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 in each half of the wavefront");
+    constexpr int NS = g2_slices<MODEL>();
+    using Map = RowMap<MODEL, OF, GEN, NS>;
     constexpr int L2 = LPF / 2;                     // lanes of a frame in each half of the wavefront
-    constexpr int L4 = LPF / 4;                     // QUAD: lanes of a frame in each 16-lane row
-    constexpr int G = QUAD ? 16 / (L4 > 0 ? L4 : 1) : 32 / L2;      // frames per wavefront
-    constexpr int SST = 34;                         // QUAD: doubles of a lane's two staged rows (2 x 16 + 2: conflict-free ds_write_b128)
+    constexpr int G = 32 / L2;                      // frames per wavefront
     constexpr int P = model_np(MODEL), ND = P - 4;
     constexpr int D = block_dim(MODEL, OF, false);
     constexpr int K = D - 6, K1 = K + 1;
     constexpr int NCR = Map::NCR, NER = Map::NER, CH = Map::CH, NEF = Map::NEF;
     constexpr int LS = CH | 1;                      // odd row stride (doubles): conflict-free column sums
     constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
-    constexpr int RED0 = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
-    constexpr int RED = (QUAD && 64 * SST > RED0) ? 64 * SST : RED0;
-    constexpr int WSL = (G * FC_N0P + RED + NEF + 1) & ~1;     // per wave: G frames' constants | reduction buffer / records / staged rows | item table
+    constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
+    constexpr int WSL = (G * FC_N0P + RED + NEF + 1) & ~1;     // per wave: G frames' constants | reduction buffer / records | item table
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevState* st = a.st;
     const bool fuse = !GEN && a.fuse_elim != 0;
@@ -198,14 +162,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
     if (st->done || (st->redo && !fuse)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // frame g: lanes [g L2, (g + 1) L2) of BOTH halves; gl = the lane's index within its frame (u half first)
-    // QUAD: lanes [g L4, (g + 1) L4) of all four 16-lane rows; row r: rho = r & 1 (u / v: rows traded with v_permlane16_swap),
-    // h = r >> 1 (which part of the triangle) - every LDS access group lies in one half of the wavefront, i.e. has ONE h: the
-    // role offsets are uniform within a group and the staged rows stay conflict-free (h = r & 1: 45 % of the LDS cycles were
-    // bank conflicts)
-    const int half = lane >> 5, l31 = lane & 31, row16 = lane >> 4, l15 = lane & 15;
-    const bool lane_ok = QUAD ? l15 < G * L4 : l31 < G * L2;
-    const int grp = lane_ok ? (QUAD ? l15 / L4 : l31 / L2) : G - 1;
-    const int gl = QUAD ? l15 % L4 + row16 * L4 : l31 % L2 + half * L2;
+    const int half = lane >> 5, l31 = lane & 31;
+    const bool lane_ok = l31 < G * L2;
+    const int grp = lane_ok ? l31 / L2 : G - 1;
+    const int gl = l31 % L2 + half * L2;
     G2_STAMPS_DECL;
     G2_STAMP(0);
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
@@ -221,7 +181,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
     constexpr int NTQ = (NEF + 63) / 64;
     unsigned long long tabv[NTQ];
     {
-        const Map& gmap = g_rowmap<MODEL, OF, GEN, NS, QUAD>;
+        const Map& gmap = g_rowmap<MODEL, OF, GEN, NS>;
 #pragma unroll
         for (int q = 0; q < NTQ; ++q) {
             const int it = lane + 64 * q;
@@ -258,10 +218,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
         const int64_t g0 = start + (cl < n ? cl : 0);
         pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
     }
-    if (!GEN && a.prepass) {
-        // k_prepass has updated the pose, written the pose block's model decrease and left R, t, J_l of this frame in fcbuf
-        if (lane_ok) for (int e = gl; e < FC_N0; e += LPF) fc[e] = a.fcbuf[(int64_t)fa_ * FC_N0P + e];
-    } else {
+    {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants; the lanes of
         // a group compute the same values, the G groups work on G frames at once
         const int slot = a.obs_slot[fa_];
@@ -399,63 +356,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
 #pragma unroll
         for (int i = 0; i < NCR; ++i) {
             typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-            u2 lo, hi;
-            if constexpr (QUAD) {       // partner = the lane 16 away: even 16-lane rows end up with two u rows, odd ones with two v rows
-                lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(su[i]), (unsigned)__double2loint(sv[i]), false, false);
-                hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(su[i]), (unsigned)__double2hiint(sv[i]), false, false);
-            } else {
-                lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(su[i]), (unsigned)__double2loint(sv[i]), false, false);
-                hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(su[i]), (unsigned)__double2hiint(sv[i]), false, false);
-            }
+            const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(su[i]), (unsigned)__double2loint(sv[i]), false, false);
+            const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(su[i]), (unsigned)__double2hiint(sv[i]), false, false);
             su[i] = __hiloint2double((int)hi[0], (int)lo[0]); sv[i] = __hiloint2double((int)hi[1], (int)lo[1]);
         }
     };
-    // QUAD: the two rows a lane holds after the trade go to its slot of the staging area as S = [a0..a6, 0, b0.., 0..]; then
-    // every lane reads the FOUR rows of its type that its 16-lane row and the neighbouring one (h = 0 / 1) hold for the same
-    // corners - own slot and the slot 16 lanes away - at the addresses of its role, and adds tri(X) and W (x) V
-    constexpr int NB = Map::NB;
-    double* stage = red;                                    // the reduction buffer is free during the loop
-    const int slot_a = (lane & ~32) * SST, slot_b = (lane | 32) * SST;       // the h = 0 and the h = 1 lane of this lane's pair
-    const int hx = QUAD ? (lane >> 5) : 0;
-    // every access of the staged rows is a 16-byte one (ds_write_b128 / ds_read_b128): with the slot stride of 34 doubles the
-    // 8 lanes of a write group and the 16 lanes of a read group (all of one h) fall on different banks
-    auto gram_quad = [&](const double* su, const double* sv) {
-        double2* mine = reinterpret_cast<double2*>(__builtin_assume_aligned(stage + lane * SST, 16));
-#pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2) {
-            const double* row = r2 ? sv : su;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mine[8 * r2 + i] = make_double2(row[2 * i], 2 * i + 1 < G4_NA ? row[2 * i + 1] : 0.0);      // a0..a6, 0
-#pragma unroll
-            for (int i = 0; i < (NB + 1) / 2; ++i) mine[8 * r2 + 4 + i] = make_double2(row[G4_NA + 2 * i], 2 * i + 1 < NB ? row[G4_NA + 2 * i + 1] : 0.0);
-        }
-        wsync();
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const double2* S = reinterpret_cast<const double2*>(__builtin_assume_aligned(stage + ((r4 & 2) ? slot_b : slot_a) + 16 * (r4 & 1), 16));
-            double X[8], W[G4_NW], V[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { const double2 t = S[4 * hx + i]; X[2 * i] = t.x; X[2 * i + 1] = t.y; }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) { const double2 t = S[2 * hx + i]; W[2 * i] = t.x; W[2 * i + 1] = t.y; }
-#pragma unroll
-            for (int i = 0; i < (NB + 1) / 2; ++i) { const double2 t = S[4 + i]; V[2 * i] = t.x; V[2 * i + 1] = t.y; }
-            int e = 0;
-#pragma unroll
-            for (int i = 0; i < G4_NA; ++i) {
-#pragma unroll
-                for (int j = i; j < G4_NA; ++j) { acc[e] = __builtin_fma(X[i], X[j], acc[e]); ++e; }
-            }
-#pragma unroll
-            for (int i = 0; i < G4_NW; ++i) {
-#pragma unroll
-                for (int j = 0; j < NB; ++j) { acc[e] = __builtin_fma(W[i], V[j], acc[e]); ++e; }
-            }
-        }
-        wsync();                                            // the next pass overwrites the slots
-    };
     auto gram = [&](const double* su, const double* sv) {
-        if constexpr (QUAD) { gram_quad(su, sv); return; }
         int e = 0;
 #pragma unroll
         for (int i = 0; i < NCR; ++i) {
@@ -471,58 +377,21 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
             }
         }
     };
-    constexpr bool PIPE = CCAL_G2_PIPE(MODEL);
-#if CCAL_G2_PRIO > 0
-    // Two wavefronts share a SIMD; instruction arbitration is oldest-first, so the wavefront dispatched second (the second
-    // 1 024 of the launch) runs its loop at ~0.57 of the first one's speed and finishes its epilogue alone on an idle SIMD.
-    // Raising its priority for the loop evens the two out: both reach their (latency-bound) epilogues together.
-    const bool younger = (blockIdx.x * CCAL_GRAMV_WPB + wave) >= 1024;
-    if (younger) __builtin_amdgcn_s_setprio(CCAL_G2_PRIO);
-#endif
-    if constexpr (!PIPE) {
-        for (int base = 0; base < nmax; base += LPF) {
-            const bool valid = base + cl < n;
-            const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
-            if (base + LPF < nmax) {
-                const int cn = base + LPF + cl;
-                const int64_t gn = start + (cn < n ? cn : 0);
-                pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
-            }
-            Proj p;
-            double su[NCR], sv[NCR];
-            step_a(X, Y, Z, uo, vo, p);
-            step_b(p, valid, su, sv);
-            gram(su, sv);
-        }
-    } else {
-        // Software pipeline (one wavefront per SIMD: nothing else hides the projection's dependent chain): the products of
-        // corner i and step A of corner i + 1 are independent and sit in ONE basic block, so the scheduler interleaves them.
-        double su[NCR], sv[NCR];
-        {
-            Proj p;
-            step_a(pX, pY, pZ, pU, pV, p);
-            step_b(p, cl < n, su, sv);
-            const int cn = LPF + cl;
+    for (int base = 0; base < nmax; base += LPF) {
+        const bool valid = base + cl < n;
+        const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
+        if (base + LPF < nmax) {
+            const int cn = base + LPF + cl;
             const int64_t gn = start + (cn < n ? cn : 0);
             pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
         }
-        for (int base = 0; base < nmax; base += LPF) {
-            const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;          // corner base + LPF (clamped past the frame's end: weight 0)
-            if (base + 2 * LPF < nmax) {
-                const int cn = base + 2 * LPF + cl;
-                const int64_t gn = start + (cn < n ? cn : 0);
-                pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
-            }
-            Proj p;
-            step_a(X, Y, Z, uo, vo, p);
-            gram(su, sv);
-            step_b(p, base + LPF + cl < n, su, sv);
-        }
+        Proj p;
+        double su[NCR], sv[NCR];
+        step_a(X, Y, Z, uo, vo, p);
+        step_b(p, valid, su, sv);
+        gram(su, sv);
     }
 
-#if CCAL_G2_PRIO > 0
-    if (younger) __builtin_amdgcn_s_setprio(0);
-#endif
     G2_STAMP(2);
     if constexpr (NLA > 0) {              // the LDS accumulators join the others (the rows are dead: registers to spare)
         wsync();
@@ -561,16 +430,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
                 recm[s][q] = (uint32_t)(tv >> 32);
                 const int t = (int)(sc & 0xff) - s * CH;
                 double s_u = 0.0, s_v = 0.0;
-                if constexpr (QUAD) {
-                    // the frame's lanes of role (u | v, h): L4 in the 16-lane row 2 h + rho
-                    const double* src = red + (32 * (int)((sc >> 8) & 1) + g * L4) * LS + t;
+                const double* src = red + (g * L2) * LS + t;      // the frame's u lanes; its v lanes are 32 lanes on
 #pragma unroll
-                    for (int l = 0; l < L4; ++l) { s_u += src[l * LS]; s_v += src[(16 + l) * LS]; }
-                } else {
-                    const double* src = red + (g * L2) * LS + t;      // the frame's u lanes; its v lanes are 32 lanes on
-#pragma unroll
-                    for (int l = 0; l < L2; ++l) { s_u += src[l * LS]; s_v += src[(32 + l) * LS]; }
-                }
+                for (int l = 0; l < L2; ++l) { s_u += src[l * LS]; s_v += src[(32 + l) * LS]; }
                 sum = ((sc >> 12) & 1 ? s_u : 0.0) + ((sc >> 13) & 1 ? s_v : 0.0);
             }
             res[s][q] = sum;
@@ -624,105 +486,44 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL, QUAD)) voi
     G2_STAMPS_FLUSH;
 }
 
-// The per-frame pre-pass (experiment, FusedArgs::prepass): what k_gram2's prologue does per LANE GROUP, once per frame by one
-// thread - candidate pose from the stored elimination record and the camera step, its model decrease, exponential map and
-// left Jacobian - into fcbuf.
-__global__ __launch_bounds__(256) void k_prepass(const FusedArgs a) {
-    const DevState* st = a.st;
-    if (st->done || st->redo) return;
-    const int f = blockIdx.x * 256 + threadIdx.x;
-    if (f >= a.n_obs) return;
-    const int K = a.K, K1 = K + 1;
-    const int cur = st->cur, first = st->first;
-    const int es = first ? cur : (cur ^ 1);
-    const int slot = a.obs_slot[f];
-    double pose[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pose[i] = a.poses[cur][(int64_t)slot * 6 + i];
-    double mc = 0.0;
-    if (!first) {
-        const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
-        if (pf[0] != 0.0) {
-            double dp[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double* yr = pf + 21 + i * K1;
-                double t = yr[K];
-                for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
-                dp[i] = -t;
-            }
-#pragma unroll
-            for (int i = 5; i >= 0; --i) {
-                double t = dp[i];
-#pragma unroll
-                for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
-                dp[i] = t * pf[i * (i + 1) / 2 + i];
-            }
-            const double lam = st->lambda_solve;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
-                const double Dii = lam > 0.0 ? lam * clampd1(dCi, a.min_diag, a.max_diag) : 0.0;
-                mc += dp[i] * (Dii * dp[i] - gp);
-                pose[i] += dp[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
-    }
-    a.mc_f[f] = mc;
-    double fcr[FC_N0];
-    frame_setup<false>(pose, nullptr, fcr);
-    double* dst = a.fcbuf + (int64_t)f * FC_N0P;
-#pragma unroll
-    for (int i = 0; i < FC_N0; ++i) dst[i] = fcr[i];
-}
-
 #ifdef CCAL_G2_PROBE      // register-allocation probes (developer): a few instantiations, no launchers
-template __global__ void k_gram2<kEUCM, false, 12, false, false>(const FusedArgs);
-template __global__ void k_gram2<kKB4, false, 12, false, CCAL_G2_QUAD(kKB4)>(const FusedArgs);
-template __global__ void k_gram2<kOCV5, false, 12, false, CCAL_G2_QUAD(kOCV5)>(const FusedArgs);
-template __global__ void k_gram2<kOCV5, true, 12, true, CCAL_G2_QUAD(kOCV5)>(const FusedArgs);
+template __global__ void k_gram2<kEUCM, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2<kKB4, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2<kOCV5, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2<kOCV5, true, 12, true>(const FusedArgs);
 }  // namespace ccal
 #else
 template <int MODEL, bool OF, int LPF, bool GEN>
 static hipError_t launch_gram2_l(const FusedArgs& a, hipStream_t s) {
-    constexpr bool QUAD = CCAL_G2_QUAD(MODEL);
-    constexpr int NS = g2_slices<MODEL, QUAD>();
-    using Map = RowMap<MODEL, OF, GEN, NS, QUAD>;
+    constexpr int NS = g2_slices<MODEL>();
+    using Map = RowMap<MODEL, OF, GEN, NS>;
     constexpr int G = 64 / LPF, K = block_dim(MODEL, OF, false) - 6, K1 = K + 1;
     constexpr int LS = Map::CH | 1;
     constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
-    constexpr int RED0 = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
-    constexpr int RED = (QUAD && 64 * 34 > RED0) ? 64 * 34 : RED0;
+    constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
     constexpr int WSL = (G * FC_N0P + RED + Map::NEF + 1) & ~1;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
-    void (*kern)(const FusedArgs) = k_gram2<MODEL, OF, LPF, GEN, QUAD>;
+    void (*kern)(const FusedArgs) = k_gram2<MODEL, OF, LPF, GEN>;
     static DynLdsGuard lds_guard;
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
     const int fpb = G * CCAL_GRAMV_WPB;
     if (a.n_obs <= 0) return hipSuccess;
-    if (!GEN && a.prepass) hipLaunchKernelGGL(k_prepass, dim3((a.n_obs + 255) / 256), dim3(256), 0, s, a);
     hipLaunchKernelGGL(kern, dim3((a.n_obs + fpb - 1) / fpb), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
 
 // Lanes per frame (even: 64, 32, 16, 12, 8, 6): the cost model of gram_lanes_per_frame (ccal_kernels_fused.hip).
-// CCAL_GRAM2_LPF overrides.
-static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, bool quad, bool gen) {
+// `force` (FusedArgs::lpf_force: a developer switch of the second library) overrides; mappings whose wavefronts would not fit
+// the rows of the partial-sum buffer (`max_waves`, single-camera loop: one row per wavefront) are left out.
+static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, bool gen, int force, int64_t max_waves) {
     static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
-    static const int lpf_env = [] {
-        const char* e = std::getenv("CCAL_GRAM2_LPF");
-        const int v = e ? std::atoi(e) : 0;
-        for (int c : cand) if (v == c) return v;
-        return 0;
-    }();
-    if (lpf_env && !(quad && lpf_env == 6)) return lpf_env;
-    int best = 64;
+    for (int c : cand) if (force == c) return c;
+    int best = 6;
     double best_cost = 1e300;
-    for (int i = 0; i < (quad ? 5 : 6); ++i) {               // the four-role form needs a multiple of four lanes per frame
+    for (int i = 0; i < 6; ++i) {
         const int lpf = cand[i], g = 64 / lpf;
         const int64_t waves = ((int64_t)n_obs + g - 1) / g;
+        if (((waves + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB) * CCAL_GRAMV_WPB > max_waves && lpf != 6) continue;
         const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
         // prologue + reductions + elimination, in passes; the general loop's launches (GEN) have no elimination in their tail
         // (two EUCM cameras x 10 000 frames in one launch, whole build: 6 lanes 77.0 us, 8: 81.5, 12: 83.1, 16: 85.0)
@@ -742,16 +543,14 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
 
 template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
-    constexpr bool QUAD = CCAL_G2_QUAD(MODEL);
-    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL, QUAD) >= 2, QUAD, GEN);
+    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL) >= 2, GEN, a.lpf_force, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap);
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
-    static const int fuse_min = [] { const char* e = std::getenv("CCAL_FUSE_MIN"); return e ? std::atoi(e) : 1; }();
-    const bool fuse = !GEN && a.n_obs >= fuse_min && a.fuse_elim != 0 && waves <= a.part_cap;
+    const bool fuse = !GEN && a.fuse_elim != 0 && waves <= a.part_cap;
     a.fuse_elim = fuse ? 1 : 0;
     a.elim_fused = fuse ? 1 : 0;
     if (fuse) a.n_part = waves;
     switch (lpf) {
-        case 6: if constexpr (!QUAD) return launch_gram2_l<MODEL, OF, 6, GEN>(a, s); else return hipErrorInvalidValue;
+        case 6: return launch_gram2_l<MODEL, OF, 6, GEN>(a, s);
         case 8: return launch_gram2_l<MODEL, OF, 8, GEN>(a, s);
         case 12: return launch_gram2_l<MODEL, OF, 12, GEN>(a, s);
         case 16: return launch_gram2_l<MODEL, OF, 16, GEN>(a, s);

@@ -510,13 +510,8 @@ bool schurq_fits(int n_cams, const int* peff, const int* col_theta, const int* c
 // Measured (two EUCM cameras, whole build, us; eight | four lanes | generic k_schur): 1 000 slots 27.5 | 30.6 | 28.2; 3 000: 37.6 |
 // 40.0 | 42.6; 6 000: 56.1 | 57.3 | 63.8; 10 000: 71.6 | 71.8; 20 000: 134.5 | 135.9; two one-focal UCM cameras x 10 000: 64.4 | 62.9 -
 // the eight-lane form's shorter chain wins while its wavefronts (twice as many) still get a SIMD to themselves.
-// CCAL_SCHURQ_SLOTS=8|16 overrides
-int schurq_slots_per_wave(int n_slots) {
-    const char* e = std::getenv("CCAL_SCHURQ_SLOTS");
-    const int n = e ? std::atoi(e) : 0;
-    if (n == 8 || n == 16) return n;
-    return n_slots <= 8192 ? 8 : 16;
-}
+// (the second library's CCAL_SCHURQ_SLOTS=8|16 overrides it where the workspace is made, ccal_solver.hip)
+int schurq_slots_per_wave(int n_slots) { return n_slots <= 8192 ? 8 : 16; }
 int schurq_rows(int n_slots, int slots_per_wave) { return (std::max(n_slots, 1) + slots_per_wave - 1) / slots_per_wave; }
 
 template <int PE, int SLOTS>

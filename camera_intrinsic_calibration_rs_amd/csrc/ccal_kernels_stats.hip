@@ -1,8 +1,11 @@
-// validation() statistics on the device (src/util.rs:778-795): gather one camera's reprojection errors,
-// radix-sort them (hipCUB/rocPRIM header-only device primitives), median = e[len/2],
-// avg_99 = sum_{i < len*99/100} e_i / (len*99/100).
-#include <hipcub/hipcub.hpp>
-
+// validation() statistics on the device (src/util.rs:778-795): gather one camera's reprojection errors, then
+//     median = e_sorted[len / 2],   avg_99 = sum_{i < len * 99 / 100} e_sorted[i] / (len * 99 / 100).
+// Neither needs the sorted array: both are ORDER STATISTICS.  An MSB-first radix select over the values' bit patterns (errors are
+// >= 0: bit order == value order; six digits of 11 bits) finds, for both ranks at once, the exact value K at the rank and how many
+// copies of it lie at or below the rank; the 99 % mean is then  sum_{e < K} e / len_99  +  copies x K / len_99,  accumulated in
+// 128-bit FIXED POINT (2^-80 px): integer addition is associative, so the result does not depend on the order of the values at all
+// (what the sort used to guarantee) - the same bits on one GPU and over the shards of several, whatever the frame order.  Hand-written: the
+// header-only library sort this replaced (hipCUB radix sort) was 5 MB of the 13 MB library for this one small step.
 #include "ccal_internal.hpp"
 
 namespace ccal {
@@ -14,9 +17,159 @@ __global__ __launch_bounds__(256) void k_gather_err(const double* err, const int
     const int64_t s = obs_off[o], n = obs_off[o + 1] - s, d = dst_off[blockIdx.x];
     for (int64_t i = threadIdx.x; i < n; i += 256) out[d + i] = err[s + i];
 }
-__global__ __launch_bounds__(256) void k_scale(double* v, int64_t n, double inv) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] *= inv;
+
+// ---- radix select ------------------------------------------------------------------------------------------------------
+constexpr int kSelBits = 11, kSelBins = 1 << kSelBits, kSelPasses = 6;        // 5 x 11 + 9 bits
+constexpr int kSelBlocks = 256;                                              // workgroups of the histogram / sum kernels
+__host__ __device__ constexpr int sel_shift(int pass) { return pass < 5 ? 64 - kSelBits * (pass + 1) : 0; }
+__host__ __device__ constexpr int sel_bins(int pass) { return pass < 5 ? kSelBins : 1 << 9; }
+struct SelState { unsigned long long prefix[2]; long long rank[2]; };        // per target: the digits found so far (right-aligned), rank among the keys that share them
+typedef unsigned __int128 u128;
+struct SelWork {                                                              // the work area (device): zeroed in front of every use
+    uint32_t hist[kSelPasses][2][kSelBins];
+    SelState state[kSelPasses + 1];
+    unsigned long long part_lo[kSelBlocks], part_hi[kSelBlocks];              // per-workgroup sums, fixed point
+    uint32_t part_bad[kSelBlocks];                                            // a value that is not finite (or beyond 2^40 px)
+    double out[2];
+};
+constexpr int kFixFrac = 80;                                                  // fractional bits of the fixed-point sums
+// v >= 0 as an integer multiple of 2^-80 (bits below are dropped: < 2^-80 px per term); *bad: NaN, infinity or >= 2^40
+__device__ __forceinline__ u128 to_fixed(const double v, bool* bad) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int ex = (int)((b >> 52) & 0x7ff);
+    const unsigned long long man = (b & 0xfffffffffffffull) | (ex ? (1ull << 52) : 0ull);
+    const int sh = (ex ? ex : 1) - 1075 + kFixFrac;                            // value = man x 2^(ex - 1075)
+    if ((b >> 63) || ex >= 1023 + 40) { *bad = true; return 0; }
+    if (sh <= -64) return 0;
+    return sh >= 0 ? ((u128)man << sh) : (u128)(man >> (-sh));
+}
+__device__ __forceinline__ double from_fixed(const u128 f) {
+    const double hi = (double)(unsigned long long)(f >> 64), lo = (double)(unsigned long long)f;
+    return (hi * 18446744073709551616.0 + lo) * 8.271806125530277e-25;          // x 2^-80
+}
+size_t order_stats_work_bytes() { return (sizeof(SelWork) + 255) & ~(size_t)255; }
+
+// What the histogram of pass p - 1 says about both targets: every workgroup derives it for itself (the same numbers in the same
+// order: the same answer), workgroup 0 leaves it for the next launch.  state[p] = state at the ENTRY of pass p.
+__device__ __forceinline__ SelState sel_advance(SelWork* w, const int pass, uint32_t* sh_scan /* [2][256] */, SelState* sh_state) {
+    if (pass == 0) return w->state[0];
+    const int pp = pass - 1, nb = sel_bins(pp), per = nb / 256 > 0 ? nb / 256 : 1;
+    const SelState prev = w->state[pp];
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t* h = w->hist[pp][t];
+        uint32_t loc = 0;
+        for (int i = 0; i < per; ++i) { const int b = threadIdx.x * per + i; if (b < nb) loc += h[b]; }
+        sh_scan[t * 256 + threadIdx.x] = loc;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int t = threadIdx.x;
+        const uint32_t* h = w->hist[pp][t];
+        long long r = prev.rank[t], cum = 0;
+        int chunk = 0;
+        while (chunk < 255 && cum + (long long)sh_scan[t * 256 + chunk] <= r) { cum += sh_scan[t * 256 + chunk]; ++chunk; }
+        int b = chunk * per;
+        const int bend = b + per < nb ? b + per : nb;
+        while (b < bend - 1 && cum + (long long)h[b] <= r) { cum += h[b]; ++b; }
+        sh_state->prefix[t] = (prev.prefix[t] << (pp < 5 ? kSelBits : 9)) | (unsigned long long)b;
+        sh_state->rank[t] = r - cum;
+    }
+    __syncthreads();
+    const SelState st = *sh_state;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w->state[pass] = st;
+    return st;
+}
+__global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ vals, const long long n, SelWork* w, const int pass,
+                                                  const long long rank0, const long long rank1) {
+    __shared__ uint32_t hist[2][kSelBins];
+    __shared__ uint32_t scan[2 * 256];
+    __shared__ SelState shs;
+    SelState st;
+    if (pass == 0) {                        // the two ranks arrive in the argument block
+        st.prefix[0] = 0; st.prefix[1] = 0; st.rank[0] = rank0; st.rank[1] = rank1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) w->state[0] = st;
+    } else st = sel_advance(w, pass, scan, &shs);
+    const int nb = sel_bins(pass), shift = sel_shift(pass);
+    const int hi_shift = pass == 0 ? 0 : (pass < 5 ? 64 - kSelBits * pass : 9);      // bits above this pass's digit: key >> hi_shift == prefix
+    for (int b = threadIdx.x; b < 2 * kSelBins; b += 256) (&hist[0][0])[b] = 0;
+    __syncthreads();
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(vals);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const unsigned long long k = keys[i];
+        const uint32_t d = (uint32_t)(k >> shift) & (uint32_t)(nb - 1);
+        const unsigned long long hi = pass == 0 ? 0ull : (k >> hi_shift);
+        if (pass == 0 || hi == st.prefix[0]) atomicAdd(&hist[0][d], 1u);
+        if (pass == 0 || hi == st.prefix[1]) atomicAdd(&hist[1][d], 1u);
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < 2 * kSelBins; b += 256) {
+        const uint32_t c = (&hist[0][0])[b];
+        if (c) atomicAdd(&w->hist[pass][0][0] + b, c);         // integer counts: the order of the additions does not matter
+    }
+}
+// sum over the values below the 99 % key, each scaled (e x 1 / len_99, one rounding per value) and added as a 128-bit integer:
+// per thread, then per workgroup (thread 0 adds its 256 threads' sums), one partial per workgroup; k_sel_finish adds the partials
+__global__ __launch_bounds__(256) void k_sel_sum(const double* __restrict__ vals, const long long n, SelWork* w, const double inv) {
+    __shared__ uint32_t scan[2 * 256];
+    __shared__ SelState shs;
+    __shared__ unsigned long long s_lo[256], s_hi[256];
+    __shared__ uint32_t s_bad[256];
+    const SelState st = sel_advance(w, kSelPasses, scan, &shs);
+    const unsigned long long K99 = st.prefix[1];
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(vals);
+    u128 acc = 0;
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        if (keys[i] < K99) acc += to_fixed(vals[i] * inv, &bad);
+    s_lo[threadIdx.x] = (unsigned long long)acc; s_hi[threadIdx.x] = (unsigned long long)(acc >> 64); s_bad[threadIdx.x] = bad ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u128 t = 0;
+        uint32_t anyb = 0;
+        for (int i = 0; i < 256; ++i) { t += ((u128)s_hi[i] << 64) | (u128)s_lo[i]; anyb |= s_bad[i]; }
+        w->part_lo[blockIdx.x] = (unsigned long long)t; w->part_hi[blockIdx.x] = (unsigned long long)(t >> 64); w->part_bad[blockIdx.x] = anyb;
+    }
+}
+__global__ __launch_bounds__(64) void k_sel_finish(SelWork* w, const int n_part, const double inv, const int have99) {
+    if (threadIdx.x != 0) return;
+    const SelState st = w->state[kSelPasses];
+    const double k99 = __longlong_as_double((long long)st.prefix[1]);
+    w->out[0] = __longlong_as_double((long long)st.prefix[0]);                        // median = e_sorted[len / 2]
+    double avg = 0.0;
+    if (have99) {
+        u128 t = 0;
+        bool bad = false;
+        for (int i = 0; i < n_part; ++i) { t += ((u128)w->part_hi[i] << 64) | (u128)w->part_lo[i]; bad = bad || w->part_bad[i] != 0; }
+        t += to_fixed(k99 * inv, &bad) * (u128)(unsigned long long)(st.rank[1] + 1);   // + the copies of the key at or below the rank
+        avg = bad ? (k99 != k99 ? k99 : __longlong_as_double(0x7ff0000000000000ll)) : from_fixed(t);
+    }
+    w->out[1] = avg;
+}
+
+// median and 99 % mean of n non-negative values on the device; `work`: order_stats_work_bytes() of device memory
+hipError_t order_stats_device(const double* d_vals, int64_t n, char* work, double* avg_99, double* median, hipStream_t s) {
+    if (n <= 0 || !work) return hipErrorInvalidValue;
+    SelWork* w = reinterpret_cast<SelWork*>(work);
+    const int64_t n99 = n * 99 / 100;
+    hipError_t e;
+#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    TRY(hipMemsetAsync(w, 0, sizeof(SelWork), s));
+    const int blocks = (int)std::min<int64_t>(kSelBlocks, (n + 256 * 8 - 1) / (256 * 8));
+    for (int pass = 0; pass < kSelPasses; ++pass) {
+        hipLaunchKernelGGL(k_sel_hist, dim3(blocks), dim3(256), 0, s, d_vals, (long long)n, w, pass, (long long)(n / 2), (long long)(n99 > 0 ? n99 - 1 : 0));
+        TRY(hipGetLastError());
+    }
+    const double inv = n99 > 0 ? 1.0 / (double)n99 : 0.0;
+    hipLaunchKernelGGL(k_sel_sum, dim3(blocks), dim3(256), 0, s, d_vals, (long long)n, w, inv);
+    TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, s, w, blocks, inv, n99 > 0 ? 1 : 0);
+    TRY(hipGetLastError());
+    double h[2] = { 0.0, 0.0 };
+    TRY(hipMemcpyAsync(h, w->out, sizeof h, hipMemcpyDeviceToHost, s));
+    TRY(hipStreamSynchronize(s));
+#undef TRY
+    *median = h[0]; *avg_99 = h[1];
+    return hipSuccess;
 }
 
 static hipError_t ensure_scratch(ccal_problem* p, size_t total) {
@@ -30,8 +183,8 @@ static hipError_t ensure_scratch(ccal_problem* p, size_t total) {
 static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // One camera's errors out of the per-corner errors of the whole problem (device), packed in observation-frame order into the
-// problem's scratch block (*d_out: a slice of it, valid until the next call that uses the scratch; *n_out doubles; complete when
-// the function returns).  A camera without corners: *d_out = NULL, *n_out = 0.
+// problem's scratch block [offsets | values | room for the statistics' work area] (*d_out: the values, valid until the next call
+// that uses the scratch; *n_out doubles; complete when the function returns).  A camera without corners: *d_out = NULL, *n_out = 0.
 hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s) {
     *d_out = nullptr; *n_out = 0;
     const CamLayout& cl = p->cams[cam];
@@ -40,111 +193,37 @@ hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, d
     for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
     const int64_t n = dst[n_list];
     if (n <= 0) return hipSuccess;
-    const size_t b_off = up256((size_t)(n_list + 1) * sizeof(int64_t));
-    hipError_t e = ensure_scratch(p, b_off + up256((size_t)n * sizeof(double)));
+    const size_t b_off = up256((size_t)(n_list + 1) * sizeof(int64_t)), b_val = up256((size_t)n * sizeof(double));
+    hipError_t e = ensure_scratch(p, b_off + b_val + order_stats_work_bytes());
     if (e != hipSuccess) return e;
     int64_t* d_dst = reinterpret_cast<int64_t*>(p->d_scratch);
     double* d_a = reinterpret_cast<double*>(p->d_scratch + b_off);
     e = hipMemcpyAsync(d_dst, dst.data(), (size_t)(n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);       // (dst is a host vector of this frame; the caller copies d_a across devices next)
+    if (e == hipSuccess) e = hipStreamSynchronize(s);       // (dst is a host vector of this frame; the multi-GPU form copies d_a across devices next)
     if (e != hipSuccess) return e;
     *d_out = d_a; *n_out = n;
     return hipSuccess;
 }
 
-// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`.  The same kernels in the
-// same order as camera_errors_device + sorted_stats_device (the multi-GPU form's pieces: the same bits), with every temporary a
-// slice of the problem's scratch block (kept for the next call): five hipMalloc / hipFree pairs - a hipFree waits for the device -
-// were half of validation()'s 0.18 ms at 600 frames.
+// d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`: the gather above, then the
+// selection on the gathered values (the multi-GPU form runs the same selection on the shards' values side by side: the same values
+// in the same order, the same kernels - the same bits).  Every temporary is a slice of the problem's scratch block.
 hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
-    const CamLayout& cl = p->cams[cam];
-    const int n_list = (int)cl.obs.size();
-    std::vector<int64_t> dst(n_list + 1, 0);
-    for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
-    const int64_t n = dst[n_list];
+    double* d_a = nullptr;
+    int64_t n = 0;
+    hipError_t e = camera_errors_device(p, cam, d_err, &d_a, &n, s);
+    if (e != hipSuccess) return e;
     if (n <= 0) return hipErrorInvalidValue;
-    const int64_t n99 = n * 99 / 100;
-    size_t tmp_sort = 0, tmp_red = 0;
-    hipError_t e;
-#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-    TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (const double*)nullptr, (double*)nullptr, (int)n, 0, 64, s));
-    TRY(hipcub::DeviceReduce::Sum(nullptr, tmp_red, (const double*)nullptr, (double*)nullptr, (int)std::max<int64_t>(n99, 1), s));
-    const size_t tmp_bytes = std::max<size_t>(std::max(tmp_sort, tmp_red), 16);
-    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_off = up((size_t)(n_list + 1) * sizeof(int64_t)), b_val = up((size_t)n * sizeof(double)), b_sum = 256, b_tmp = up(tmp_bytes);
-    const size_t total = b_off + 2 * b_val + b_sum + b_tmp;
-    TRY(ensure_scratch(p, total));
-    char* q = p->d_scratch;
-    int64_t* d_dst = reinterpret_cast<int64_t*>(q); q += b_off;
-    double* d_a = reinterpret_cast<double*>(q); q += b_val;
-    double* d_b = reinterpret_cast<double*>(q); q += b_val;
-    double* d_sum = reinterpret_cast<double*>(q); q += b_sum;
-    void* d_tmp = q;
-    double h[2] = { 0.0, 0.0 };
-    size_t tb = tmp_bytes;
-    TRY(hipMemcpyAsync(d_dst, dst.data(), (size_t)(n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a);
-    TRY(hipGetLastError());
-    TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_a, d_b, (int)n, 0, 64, s));       // errors are >= 0: bit order == value order
-    TRY(hipMemcpyAsync(&h[0], d_b + n / 2, sizeof(double), hipMemcpyDeviceToHost, s));          // median = e[len / 2]
-    if (n99 > 0) {
-        hipLaunchKernelGGL(k_scale, dim3((unsigned)((n99 + 255) / 256)), dim3(256), 0, s, d_b, n99, 1.0 / (double)n99);   // e_i / len_99, then sum
-        TRY(hipGetLastError());
-        tb = tmp_bytes;
-        TRY(hipcub::DeviceReduce::Sum(d_tmp, tb, d_b, d_sum, (int)n99, s));
-        TRY(hipMemcpyAsync(&h[1], d_sum, sizeof(double), hipMemcpyDeviceToHost, s));
-    }
-    TRY(hipStreamSynchronize(s));          // (dst and h are host objects of this frame)
-#undef TRY
-    *median = h[0]; *avg_99 = h[1];
-    return hipSuccess;
+    char* work = reinterpret_cast<char*>(d_a) + up256((size_t)n * sizeof(double));
+    return order_stats_device(d_a, n, work, avg_99, median, s);
 }
 
-// median = e[len / 2] and avg_99 = sum_{i < len * 99 / 100} e_i / (len * 99 / 100) of n non-negative values on the device.  The
-// multi-GPU form gathers the shards' values into the front of one block and calls this: same values, same sorted order, same
-// reduction - the same bits as on one GPU.  block = [values (n) | sort buffer (n) | sum | hipCUB's temporary], sized by
-// sorted_stats_scratch_bytes and kept by the caller between calls (no allocation here).
-static hipError_t sorted_stats_sizes(int64_t n, hipStream_t s, size_t* b_val, size_t* tmp_bytes) {
-    size_t tmp_sort = 0, tmp_red = 0;
-    const int64_t n99 = n * 99 / 100;
-    hipError_t e = hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, (const double*)nullptr, (double*)nullptr, (int)n, 0, 64, s);
-    if (e == hipSuccess) e = hipcub::DeviceReduce::Sum(nullptr, tmp_red, (const double*)nullptr, (double*)nullptr, (int)std::max<int64_t>(n99, 1), s);
-    *b_val = up256((size_t)n * sizeof(double)); *tmp_bytes = std::max<size_t>(std::max(tmp_sort, tmp_red), 16);
-    return e;
-}
-size_t sorted_stats_scratch_bytes(int64_t n, hipStream_t s) {
-    size_t b_val = 0, tmp = 0;
-    if (n <= 0 || sorted_stats_sizes(n, s, &b_val, &tmp) != hipSuccess) return 0;
-    return 2 * b_val + 256 + up256(tmp);
-}
+// the multi-GPU form: block = [values (n) | work area], sized by sorted_stats_scratch_bytes and kept by the caller between calls
+size_t sorted_stats_scratch_bytes(int64_t n, hipStream_t) { return n <= 0 ? 0 : up256((size_t)n * sizeof(double)) + order_stats_work_bytes(); }
 hipError_t sorted_stats_device(char* block, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s) {
-    if (n <= 0 || !block) return hipErrorInvalidValue;
-    size_t b_val = 0, tmp_bytes = 0;
-    hipError_t e;
-#define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-    TRY(sorted_stats_sizes(n, s, &b_val, &tmp_bytes));
-    if (2 * b_val + 256 + up256(tmp_bytes) > block_bytes) return hipErrorInvalidValue;
-    double* d_a = reinterpret_cast<double*>(block);
-    double* d_b = reinterpret_cast<double*>(block + b_val);
-    double* d_sum = reinterpret_cast<double*>(block + 2 * b_val);
-    void* d_tmp = block + 2 * b_val + 256;
-    const int64_t n99 = n * 99 / 100;
-    double h[2] = { 0.0, 0.0 };
-    size_t tb = tmp_bytes;
-    TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tb, d_a, d_b, (int)n, 0, 64, s));       // errors are >= 0: bit order == value order
-    TRY(hipMemcpyAsync(&h[0], d_b + n / 2, sizeof(double), hipMemcpyDeviceToHost, s));          // median = e[len / 2]
-    if (n99 > 0) {
-        hipLaunchKernelGGL(k_scale, dim3((unsigned)((n99 + 255) / 256)), dim3(256), 0, s, d_b, n99, 1.0 / (double)n99);   // e_i / len_99, then sum
-        TRY(hipGetLastError());
-        tb = tmp_bytes;
-        TRY(hipcub::DeviceReduce::Sum(d_tmp, tb, d_b, d_sum, (int)n99, s));
-        TRY(hipMemcpyAsync(&h[1], d_sum, sizeof(double), hipMemcpyDeviceToHost, s));
-    }
-    TRY(hipStreamSynchronize(s));
-#undef TRY
-    *median = h[0]; *avg_99 = h[1];
-    return hipSuccess;
+    if (n <= 0 || !block || sorted_stats_scratch_bytes(n, s) > block_bytes) return hipErrorInvalidValue;
+    return order_stats_device(reinterpret_cast<const double*>(block), n, block + up256((size_t)n * sizeof(double)), avg_99, median, s);
 }
 
 }  // namespace ccal

@@ -97,8 +97,7 @@ struct FusedWs {
     double* cost_f = nullptr;                  // [n_obs] cost of each frame
     struct DevState* d_state = nullptr;
     bool state_is_eval = false; double state_eval_lambda = 0.0;     // d_state already says "first evaluation of set 0" with this damping
-    bool prepass = false;                      // CCAL_PREPASS=1: per-frame pre-pass launch in front of k_gram2 (experiment, off)
-    bool fuse_elim = true;                     // the Gram kernels eliminate their frames' pose blocks in their tail (CCAL_FUSE_ELIM=0: separate launch)
+    bool fuse_elim = true;                     // the Gram kernels eliminate their frames' pose blocks in their tail (second library, CCAL_FUSE_ELIM=0: separate launch)
     struct HostStatus* h_status = nullptr;     // pinned, host-coherent
     double* h_stage = nullptr;                 // pinned staging of the caller's poses (read by k_unpack1 in place when small)
     double* d_stage = nullptr;                 // their device image (large problems: one copy per solve, k_unpack1 distributes it)

@@ -21,6 +21,7 @@
 #include <thread>
 
 #include "ccal_fused.hpp"
+#include "ccal_devopt.hpp"
 
 using namespace ccal;
 
@@ -99,15 +100,18 @@ static int fused_ws_ensure(ccal_problem* p) {
     FusedWs* f = new FusedWs();
     w->fws = f;
     f->PRAW = praw_size(p->K);
-    { const char* e = std::getenv("CCAL_FUSE_ELIM"); f->fuse_elim = !(e && e[0] == '0'); }
+#ifdef CCAL_LEGACY_KERNELS
+    { const char* e = dev_env("CCAL_FUSE_ELIM"); f->fuse_elim = !(e && e[0] == '0'); }      // second library: the separate elimination launch (k_schur1m)
+#endif
     f->RB1 = fused_red_size(p->K);
-    const char* env_pw = std::getenv("CCAL_FUSED_WAVES");
-    int n_pw = std::min(std::max(p->n_obs, 1), env_pw ? std::atoi(env_pw) : 16384);   // 4 workgroups of 4 waves per CU
+    // rows of the partial-sum buffer = most wavefronts a Gram launch of this problem may have: one row per wavefront (fused
+    // elimination).  Up to 16 384 frames any lanes-per-frame mapping fits; beyond, the launchers keep to mappings that do - six
+    // lanes per frame (ten frames per wavefront) always does
+    int n_pw = std::max(std::min(std::max(p->n_obs, 1), 16384), (std::max(p->n_obs, 1) + 9) / 10 + 8);
     f->n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     const size_t ns = (size_t)std::max(p->n_slots, 1), no = (size_t)std::max(p->n_obs, 1);
     // ONE device allocation and ONE pinned allocation, sliced (a calibration session creates a problem and solves it once or
     // twice: fifteen hipMalloc / hipHostMalloc calls and five memsets were 0.46 ms of the first solve's 0.58 at 600 frames)
-    { const char* e = std::getenv("CCAL_PREPASS"); f->prepass = e && e[0] == '1'; }
     const size_t stage_bytes = std::max((ns * 6 + CCAL_PMAX) * sizeof(double) + 64, (size_t)(f->RB1 + 8) * sizeof(double));      // (ccal_build_normal stages the reduced sums here)
     auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_pf = up(ns * w->PF * sizeof(double)), b_praw = up(no * f->PRAW * sizeof(double)), b_no = up(no * sizeof(double));
@@ -129,14 +133,10 @@ static int fused_ws_ensure(ccal_problem* p) {
         f->d_state = reinterpret_cast<DevState*>(q); q += b_state;      // [0] the loops' state; [1], [2]: single-launch groups alternate
         f->d_stage = reinterpret_cast<double*>(q); q += b_stage;
     }
-    // per-frame scratch: the frame constants of the pre-pass experiment (CCAL_PREPASS=1); diagnostic builds park in-kernel
-    // timestamps there (tools/stamps_*.py); the product path allocates nothing
+    // per-frame scratch of diagnostic builds (-DCCAL_STAMPS: in-kernel timestamps, tools/stamps_*.py); the product allocates nothing
 #ifdef CCAL_STAMPS
-    const bool want_fcbuf = true;
-#else
-    const bool want_fcbuf = f->prepass;
+    HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, std::max<size_t>(no * 40, 32768) * sizeof(double)));
 #endif
-    if (want_fcbuf) HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, std::max<size_t>(no * 40, 32768) * sizeof(double)));
     {
         const bool zc = ns * 6 * sizeof(double) <= kZeroCopyBytes;
         const size_t b_hs = up(sizeof(HostStatus)), b_res = zc ? up((ns * 6 + CCAL_PMAX) * sizeof(double)) : 0;
@@ -181,9 +181,8 @@ int normal_ws_ensure_general(ccal_problem* p) {
     ccal_ctx* ctx = p->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // persistent Schur waves: at most 2 workgroups per CU worth, never more than slots
-    const char* env_sw = std::getenv("CCAL_SCHUR_WAVES");
     // persistent wavefronts of k_schur: 4 per SIMD (measured at 10 000 slots x 2 cameras: 2048 -> 165.7, 4096 -> 158.5, 8192 -> 173 us per build)
-    int n_pw = std::min(std::max(p->n_slots, 1), env_sw ? std::max(4, std::atoi(env_sw)) : 4096);
+    int n_pw = std::min(std::max(p->n_slots, 1), std::max(4, dev_env_int("CCAL_SCHUR_WAVES", 4096)));
     n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
     // 64 .. 127 columns (five and more cameras): the (K + 1)^2 accumulators of a wavefront take up to 131 KB of LDS - one
     // wavefront per workgroup and CU, 512 of them (each writes its own row of partial sums: 512 x RB doubles)
@@ -203,7 +202,7 @@ int normal_ws_ensure_general(ccal_problem* p) {
     // CCAL_GENERAL_GRAM=mfma: the matrix-core kernel k_gram with its 16 x 16 / 32-stride tiles (19-column other-camera
     // blocks), kept as the independent second implementation the tests compare against.
 #ifdef CCAL_LEGACY_KERNELS
-    { const char* e = std::getenv("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || w->schur_wpb == 1; }      // the matrix-core pair: four-wavefront elimination only
+    { const char* e = dev_env("CCAL_GENERAL_GRAM"); w->register_gram = !(e && e[0] == 'm') || w->schur_wpb == 1; }      // the matrix-core pair: four-wavefront elimination only
 #else
     w->register_gram = true;               // (the matrix-core pair lives in libccal_hip_legacy.so only)
 #endif
@@ -214,16 +213,17 @@ int normal_ws_ensure_general(ccal_problem* p) {
     {
         int pe[CCAL_MAX_CAMS], ct[CCAL_MAX_CAMS], ce[CCAL_MAX_CAMS];
         for (int c = 0; c < p->n_cams; ++c) { pe[c] = p->cams[c].Peff; ct[c] = p->cams[c].col_theta; ce[c] = p->cams[c].col_extr; }
-        const char* e = std::getenv("CCAL_SCHURQ");
+        const char* e = dev_env("CCAL_SCHURQ");
         w->schurq = w->register_gram && schurq_fits(p->n_cams, pe, ct, ce) && (e ? e[0] != '0' : p->n_slots >= 1000);
     }
     w->schurq_slots = schurq_slots_per_wave(p->n_slots);
+    { const int v = dev_env_int("CCAL_SCHURQ_SLOTS", 0); if (v == 8 || v == 16) w->schurq_slots = v; }
     w->n_rows = w->schurq ? schurq_rows(p->n_slots, w->schurq_slots) : n_pw / w->schur_wpb;
     // cameras of one model (and the problem's one focal mode): their blocks go through ONE launch (CCAL_MERGE_GRAM=0: one per camera)
     {
         bool same = p->n_cams > 1;
         for (int c = 1; c < p->n_cams; ++c) same = same && p->cams[c].model == p->cams[0].model && p->cams[c].Peff == p->cams[0].Peff;
-        const char* e = std::getenv("CCAL_MERGE_GRAM");
+        const char* e = dev_env("CCAL_MERGE_GRAM");
         w->merged_gram = w->register_gram && same && !(e && e[0] == '0');
     }
     std::vector<int> ncp_of(p->n_cams);
@@ -410,16 +410,14 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.intr[0] = p->d_intr; fa.intr[1] = p->d_intr_c; fa.poses[0] = p->d_poses; fa.poses[1] = p->d_poses_c;
     fa.pf[0] = f->pf[0]; fa.pf[1] = f->pf[1]; fa.praw[0] = f->praw[0]; fa.praw[1] = f->praw[1];
     fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
-    fa.prepass = f->prepass ? 1 : 0;
     fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
     fa.part_cap = f->n_pw;
     return fa;
 }
-// Per-frame elimination with four frames per wavefront (k_schur1m) when one pass covers the problem; sets fa.n_pw.
+// Second library only: the separate elimination launch (k_schur1m, four frames per wavefront) fits the partial-sum buffer; sets fa.n_pw.
 static bool fused_use_schur1m(const ccal_problem* p, FusedArgs& fa) {
-    static const bool off = [] { const char* e = std::getenv("CCAL_SCHUR1M"); return e && e[0] == '0'; }();
     const int n_pw = (p->n_obs + 15) / 16 * 4;
-    if (off || n_pw > p->nws->fws->n_pw) return false;
+    if (n_pw > p->nws->fws->n_pw) return false;
     fa.n_pw = n_pw;
     return true;
 }
@@ -430,7 +428,7 @@ static bool fused_use_schur1m(const ccal_problem* p, FusedArgs& fa) {
 static bool fused_use_valu_gram(const ccal_problem* p) {
     (void)p;
 #ifdef CCAL_LEGACY_KERNELS
-    if (const char* g = std::getenv("CCAL_GRAM")) return g[0] != 'm';
+    if (const char* g = dev_env("CCAL_GRAM")) return g[0] != 'm';
 #endif
     return true;
 }
@@ -443,8 +441,8 @@ static hipError_t enqueue_fused_gram_schur(const ccal_problem* p, FusedArgs& fa,
     fa.fuse_elim = (p->nws->fws->fuse_elim && valu) ? 1 : 0; fa.elim_fused = 0;
     hipError_t e = valu ? launch_gram1v(p->cams[0].model, p->one_focal, fa, st) : launch_gram1(p->cams[0].model, p->one_focal, fa, st);
     if (e != hipSuccess) return e;
-    if (fa.elim_fused) return hipSuccess;      // k_gram1w eliminated its frames' pose blocks itself: fa.n_part rows of partial sums
-    return schur_m ? launch_schur1m(fa, st) : launch_schur1(fa, st);
+    if (fa.elim_fused) return hipSuccess;      // the Gram kernel eliminated its frames' pose blocks itself: fa.n_part rows of partial sums
+    return schur_m ? launch_schur1m(fa, st) : hipErrorNotSupported;      // (second library: matrix-core Gram / CCAL_FUSE_ELIM=0)
 }
 // ... + k_reduce1: the reduced sums in fws->red (the all-reduce buffer of sharded solves; ccal_build_normal_dev)
 static hipError_t enqueue_fused_system(const ccal_problem* p, FusedArgs& fa, bool schur_m, hipStream_t st) {
@@ -508,11 +506,10 @@ static int max_groups_for(const ccal_solver_opts* o) {
 // for every group before the next one (no collective is ever issued for a solve that has finished).
 static int groups_in_flight(const ccal_problem* p, const char* env_name) {
     if (p->allreduce && !p->rccl_comm && !p->peer) {
-        static const int hook_depth = [] { const char* e = std::getenv("CCAL_FUSED_DEPTH_HOOK"); return e ? std::max(1, std::atoi(e)) : 1; }();
+        static const int hook_depth = std::max(1, dev_env_int("CCAL_FUSED_DEPTH_HOOK", 1));
         return hook_depth;
     }
-    const char* e = std::getenv(env_name);
-    return e ? std::max(1, std::atoi(e)) : 2;
+    return std::max(1, dev_env_int(env_name, 2));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -624,7 +621,7 @@ struct FusedJob : SolveJob {
         fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
         sharded = p->sharded();
         iter_rows = 0;
-        if (!sharded && f->fuse_elim && !f->prepass && fused_use_valu_gram(p)) {
+        if (!sharded && f->fuse_elim && fused_use_valu_gram(p)) {
             const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K);
             if (rows > 0 && 2 * rows <= f->n_pw) iter_rows = rows;
         }
@@ -653,7 +650,7 @@ struct FusedJob : SolveJob {
             f->state_is_eval = false;
             // every slot observed (single camera: one frame per slot): the first single-launch group unpacks for itself - one launch
             // and the host's gap behind it less per solve.  CCAL_ITER_FOLD=0: k_unpack1.
-            static const bool fold_off = [] { const char* e = std::getenv("CCAL_ITER_FOLD"); return e && e[0] == '0'; }();
+            static const bool fold_off = dev_env_int("CCAL_ITER_FOLD", 1) == 0;
             if (f->all_slots_observed < 0) {
                 std::vector<char> seen((size_t)std::max(p->n_slots, 1), 0);
                 int n_seen = 0;
@@ -680,13 +677,13 @@ struct FusedJob : SolveJob {
         // ends: the host has the next launch in the stream in time without one enqueued ahead - and a finished solve leaves
         // no launches behind that exit early (each of which still sums the rows: four / eight sessions side by side 0.244 / 0.464
         // -> 0.236 / 0.444 ms per batch, one session 0.108 ms either way).  CCAL_FUSED_DEPTH overrides.
-        if (iter_rows && !std::getenv("CCAL_FUSED_DEPTH")) depth = 1;
+        if (iter_rows && !dev_env("CCAL_FUSED_DEPTH")) depth = 1;
         timeout_s = wait_timeout(p, o);
         return fill();
     }
     int enqueue() override {          // one group: evaluation + elimination + ONE collective + decision/solve
         // CCAL_HEAD_REDUCE_ROWS=0 (developer switch): always the separate reduce launch
-        static const int head_reduce_max_rows = [] { const char* e = std::getenv("CCAL_HEAD_REDUCE_ROWS"); return e ? std::min(std::atoi(e), kHeadReduceRows) : kHeadReduceRows; }();
+        static const int head_reduce_max_rows = std::min(dev_env_int("CCAL_HEAD_REDUCE_ROWS", kHeadReduceRows), kHeadReduceRows);
         if (iter_rows) {
             // session sizes on one GPU: the whole group is ONE launch - the Gram kernel sums the previous launch's rows, decides
             // and solves the camera system in front of its own evaluation (every workgroup the same arithmetic, workgroup 0 writes)
@@ -793,7 +790,7 @@ struct GeneralJob : SolveJob {
         w->peers.n = 0; w->red_out = nullptr;
         // the candidate poses are formed in the Gram kernels' prologue (one launch less per group: k_backsub).  Slots that no
         // frame observes are then never written: both parameter sets start from the same poses
-        static const bool gbs_off = [] { const char* e = std::getenv("CCAL_GEN_BACKSUB"); return e && e[0] == '0'; }();
+        static const bool gbs_off = dev_env_int("CCAL_GEN_BACKSUB", 1) == 0;
         // (session-sized rigs: 600 slots x 2 / 3 cameras GN 0.229 / 0.277 -> 0.221 / 0.268 ms; at 2 x 10 000 frames the prologue's
         // extra work in 4 000 wavefronts costs more than the launch it saves - 0.459 against 0.440 ms - so: up to 4 000 frames)
         w->gen_backsub = w->register_gram && !gbs_off && p->n_obs <= 4000;
@@ -867,7 +864,7 @@ struct GeneralJob : SolveJob {
 
 // single camera: its own device-resident loop (GN and LM, sharded or not, empty shards included); the choice must not
 // depend on anything rank-local, or sharded ranks would issue different collectives
-static bool use_fused_path(const ccal_problem* p) { return p->n_cams == 1 && !std::getenv("CCAL_DISABLE_FUSED"); }
+static bool use_fused_path(const ccal_problem* p) { return p->n_cams == 1 && !dev_env("CCAL_DISABLE_FUSED"); }
 
 extern "C" {
 
@@ -897,7 +894,7 @@ int ccal_build_normal_dev(ccal_problem* p, double lambda) {
     if (rc != CCAL_OK) return rc;
     NormalWs* w = p->nws;
     w->red_fused = false;
-    if (p->n_cams == 1 && p->n_obs > 0 && !p->sharded() && !std::getenv("CCAL_DISABLE_FUSED")) {
+    if (p->n_cams == 1 && p->n_obs > 0 && !p->sharded() && !dev_env("CCAL_DISABLE_FUSED")) {
         // single camera: the device loop's own kernels (register / LDS Gram + per-frame elimination), evaluated at the
         // current parameters with the state set to "first evaluation"; fws->red = [A_dir | Y^T Y | . | failed blocks]
         ccal_ctx* ctx = p->ctx;

@@ -133,7 +133,7 @@ def _gpu_worker(rank, world, port, model, n_cams, method, n_frames, q):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
-    ctx = Context(0, stream=stream.cuda_stream)
+    ctx = Context(0, stream=stream.cuda_stream, lib=engine._ffi.load_for_switches())      # (`fast`: CCAL_SCHURQ=1 - a switch of the second library)
     sp = synth.make_problem(n_frames, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
     shard = sp.shard(rank, world)
     gp = Problem.from_synth(ctx, shard)
@@ -210,7 +210,7 @@ def _ahead_worker(rank, world, port, scenario, method, n_cams, q):
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(device=dev)
-    ctx = Context(0, stream=stream.cuda_stream)
+    ctx = Context(0, stream=stream.cuda_stream, lib=engine._ffi.load_for_switches())      # CCAL_FUSED_DEPTH_HOOK lives in the second library
     if scenario == "lm_rejections":                      # poor starting points on which the (CPU oracle's) LM rejects 7 / 3 steps
         sp = synth.make_problem(12, "eucm", n_cams=n_cams, outlier_frac=0.05, ragged=True, init_perturb=0.8, seed=1 if n_cams == 1 else 0xBEEF)
     else:

@@ -142,6 +142,41 @@ def test_reprojection_errors_and_validation(gpu_ctx, oracle):
         assert abs(a - ao) < 1e-11 and abs(m - mo) < 1e-11
 
 
+def test_validation_statistics_are_order_statistics(gpu_ctx, oracle):
+    """validation()'s median and 99 % mean come from a radix SELECT on the device (no sort): exact order statistics with ties
+    (every corner of several frames duplicated: equal errors at and around both ranks), and a fixed-point sum that does not depend
+    on the order of the values - the same bits for the frames in any order."""
+    import dataclasses
+    sp = synth.make_problem(40, "eucm", ragged=True, outlier_frac=0.02, seed=77)
+    # ties: frames 0-9 twice (same corners, same poses -> identical errors)
+    def with_frames(order):
+        offs = [0]; idx = []
+        for f in order:
+            a, b = sp.obs_offsets[f], sp.obs_offsets[f + 1]
+            idx.append(np.arange(a, b)); offs.append(offs[-1] + (b - a))
+        idx = np.concatenate(idx)
+        n = len(order)
+        return dataclasses.replace(sp, n_slots=n, obs_cam=np.zeros(n, np.int32), obs_slot=np.arange(n, dtype=np.int32),
+                                   obs_offsets=np.array(offs, dtype=np.int64), p3d=sp.p3d[idx].copy(), p2d=sp.p2d[idx].copy(),
+                                   poses_gt=sp.poses_gt[order].copy(), poses0=sp.poses0[order].copy())
+    order = list(range(40)) + list(range(10))
+    rng = np.random.default_rng(3)
+    res = []
+    for perm in (np.arange(50), rng.permutation(50), rng.permutation(50)):
+        q = with_frames([order[i] for i in perm])
+        gp = Problem.from_synth(gpu_ctx, q)
+        res.append(gp.validation(0, q.intr0, q.poses0))
+        if len(res) == 1:
+            e = np.sort(gp.reprojection_errors(q.intr0, q.poses0))
+            n99 = len(e) * 99 // 100
+            assert res[0][1] == e[len(e) // 2]                                   # the median: an element of the array, exactly
+            assert abs(res[0][0] - float(np.sum(e[:n99] / n99))) <= 1e-13
+            ao, mo = oracle.OracleProblem.from_synth(q).validation(0, q.intr0, q.poses0)
+            assert abs(res[0][0] - ao) < 1e-11 and abs(res[0][1] - mo) < 1e-11
+        gp.close()
+    assert res[0] == res[1] == res[2]                                           # bit for bit, whatever the order of the frames
+
+
 def test_full_size_sampled_frames(gpu_ctx, oracle):
     """BASELINE north-star size (10 000 frames x 144 corners): GPU output for sampled frames equals the
     oracle's on those frames, and the whole output is finite."""

@@ -46,8 +46,9 @@ def _child(q, iter_rows):
         os.environ["CCAL_ITER_ROWS"] = str(iter_rows)
     else:
         os.environ.pop("CCAL_ITER_ROWS", None)
+    from camera_intrinsic_calibration_rs_amd import _ffi
     from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
-    ctx = Context(0)
+    ctx = Context(0, lib=_ffi.load_for_switches())       # CCAL_ITER_ROWS is a switch of the second library; without it: the product
     out = []
     for case in CASES:
         sp, bounds = _make(case)
@@ -160,8 +161,9 @@ def _child_rig(q, separate_backsub):
         os.environ["CCAL_GEN_BACKSUB"] = "0"
     else:
         os.environ.pop("CCAL_GEN_BACKSUB", None)
+    from camera_intrinsic_calibration_rs_amd import _ffi
     from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
-    ctx = Context(0)
+    ctx = Context(0, lib=_ffi.load_for_switches())       # CCAL_GEN_BACKSUB=0 is a switch of the second library; without it: the product
     out = []
     for sp in _rigs():
         gp = Problem.from_synth(ctx, sp)

@@ -144,7 +144,7 @@ def test_full_size_solve_recovers_ground_truth(gpu_ctx):
     assert 0.08 < m < 0.16
 
 
-def test_lm_with_rejected_steps_matches_oracle(gpu_ctx, oracle):
+def test_lm_with_rejected_steps_matches_oracle(gpu_ctx, dev_ctx, oracle):
     """A poor starting point (intrinsics off by up to 80 %, 5 % gross outliers): the LM path takes a rejected
     step (radius shrink, re-elimination of the pose blocks from the stored records with the new damping, no
     Jacobian re-evaluation) and must walk the same accept / reject sequence as the oracle -- in the
@@ -152,12 +152,14 @@ def test_lm_with_rejected_steps_matches_oracle(gpu_ctx, oracle):
     import os
     sp = synth.make_problem(8, "eucm", init_perturb=0.8, outlier_frac=0.05, seed=1)
     gp, op = _pair(gpu_ctx, oracle, sp)
-    gp.apply_reference_bounds(); op.apply_reference_bounds()
+    gd = Problem.from_synth(dev_ctx, sp)                # the general loop on a single camera: a switch of the second library
+    gp.apply_reference_bounds(); op.apply_reference_bounds(); gd.apply_reference_bounds()
     intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
     assert rep_o.lm_rejected >= 1 and rep_o.status == 0
     for disable_fused in ("", "1"):
         if disable_fused:
             os.environ["CCAL_DISABLE_FUSED"] = "1"
+            gp = gd
         try:
             intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
         finally:
@@ -236,13 +238,14 @@ def test_lm_speculative_elimination_bookkeeping(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("fused", [True, False])
-def test_one_degenerate_frame_gn_not_pd_lm_recovers(gpu_ctx, fused, monkeypatch):
+def test_one_degenerate_frame_gn_not_pd_lm_recovers(gpu_ctx, dev_ctx, fused, monkeypatch):
     """One frame with a single corner (rank-deficient 6 x 6 pose block) among good frames: Gauss-Newton reports
     CCAL_ERR_NOT_PD on both loops (the failed block also poisons the all-reduced cost, so every rank of a sharded
     solve stops in the same iteration); Levenberg-Marquardt damps the block and converges."""
     from camera_intrinsic_calibration_rs_amd.engine import make_desc
     if not fused:
-        monkeypatch.setenv("CCAL_DISABLE_FUSED", "1")
+        monkeypatch.setenv("CCAL_DISABLE_FUSED", "1")    # (a switch of the second library)
+        gpu_ctx = dev_ctx
     sp = synth.make_problem(12, "eucm")
     offs = sp.obs_offsets.copy()
     keep_idx = np.concatenate([np.arange(offs[0], offs[5]), [offs[5]], np.arange(offs[6], offs[-1])])
@@ -360,7 +363,7 @@ sys.path.insert(0, {root!r})
 from camera_intrinsic_calibration_rs_amd import _ffi, synth
 from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
 from oracle import binding as ob
-ctx = Context(0)
+ctx = Context(0, lib=_ffi.load_for_switches())          # CCAL_GRAMV_LPF: a switch of the second library
 for n_frames, model in ((300, "eucm"), (2600, "eucm"), (2600, "ucm"), (700, "kb4")):
     sp = synth.make_problem(n_frames, model, ragged=True, outlier_frac=0.01)
     gp = Problem.from_synth(ctx, sp); op = ob.OracleProblem.from_synth(sp)
@@ -561,7 +564,7 @@ def test_rig_of_different_cameras(gpu_ctx, oracle, models, one_focal, monkeypatc
 
 @pytest.mark.parametrize("model", ["ucm", "eucm", "kb4", "opencv5"])
 @pytest.mark.parametrize("one_focal", [False, True])
-def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal, monkeypatch):
+def test_two_equal_cameras_elimination_kernels(dev_ctx, oracle, model, one_focal, monkeypatch):
     """A rig of two cameras of one model takes, above 1 000 slots, the compile-time structured elimination k_schurq (four or eight lanes
     per slot; UCM and EUCM: P_eff = 4 .. 6) and ONE launch of the register Gram kernel for both cameras.  Forced here on a small rig - 0.4 rad
     extrinsic rotation, slots seen by one camera only, ragged corner sets - against the oracle and against
@@ -579,7 +582,7 @@ def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal
                       ("merged_only", {"CCAL_SCHURQ": "0", "CCAL_MERGE_GRAM": "1"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        g = Problem.from_synth(gpu_ctx, sp)
+        g = Problem.from_synth(dev_ctx, sp)                             # the forcing switches belong to the second library
         g.build_normal(sp.intr0, sp.poses0, sp.extr0)                   # the workspace (and the choice of kernels) is made here
         probs[name] = g
     monkeypatch.delenv("CCAL_SCHURQ"); monkeypatch.delenv("CCAL_MERGE_GRAM"); monkeypatch.delenv("CCAL_SCHURQ_SLOTS")
@@ -616,14 +619,14 @@ def test_two_equal_cameras_elimination_kernels(gpu_ctx, oracle, model, one_focal
 
 
 @pytest.mark.parametrize("model,frames", [("eucm", 2600), ("kb4", 2100), ("eucm", 300)])
-def test_fused_elimination_equals_separate_launch(gpu_ctx, oracle, model, frames, monkeypatch):
+def test_fused_elimination_equals_separate_launch(gpu_ctx, dev_ctx, oracle, model, frames, monkeypatch):
     """The Gram kernels eliminate their frames' pose blocks in their own tail (k_gram1w from 2 000 frames up for UCM / EUCM,
     k_gram1v otherwise; re-elimination groups of LM run there too).  Against the separate elimination launch
     (CCAL_FUSE_ELIM=0: k_schur1m) and the oracle, from a poor start that makes LM reject steps and miss speculations."""
     sp = synth.make_problem(frames, model, init_perturb=0.6, outlier_frac=0.03, seed=5, ragged=True)
     gp, op = _pair(gpu_ctx, oracle, sp)
     monkeypatch.setenv("CCAL_FUSE_ELIM", "0")
-    gs = Problem.from_synth(gpu_ctx, sp)
+    gs = Problem.from_synth(dev_ctx, sp)                    # the separate launch (k_schur1m) lives in the second library only
     gs.build_normal(sp.intr0, sp.poses0)                    # workspace (and the choice) made under the switch
     monkeypatch.delenv("CCAL_FUSE_ELIM")
     for p_ in (gp, gs, op):

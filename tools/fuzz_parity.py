@@ -17,7 +17,7 @@ args = ap.parse_args()
 mctx = MultiContext([0] * args.shards) if args.shards > 1 else None
 worst_sh = {"intr": 0.0, "poses": 0.0}; n_sh = 0
 rng = np.random.default_rng(args.seed)
-ctx = Context(0)
+ctx = Context(0, lib=_ffi.load_for_switches())      # developer switches (CCAL_SCHURQ=1, ...) live in the second library
 t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []; both_none = []
 while time.time() - t0 < args.seconds:
     model = rng.choice(["ucm", "eucm", "kb4", "opencv5"])
