@@ -294,14 +294,17 @@ def calib_camera(frame_feature_list: Sequence[Optional[FrameFeature]], generic_c
 
 def calib_cameras(cams_frame_feature_lists: Sequence[Sequence[Optional[FrameFeature]]], generic_cameras: Sequence[GenericModel],
                   xy_same_focal: bool, disabled_distortions: int, fixed_focal: bool, device: int = 0,
-                  opts: Optional[_ffi.SolverOpts] = None
+                  opts: Optional[_ffi.SolverOpts] = None, devices: Optional[Sequence[int]] = None
                   ) -> List[Optional[Tuple[GenericModel, Dict[int, RvecTvec]]]]:
     """The per-camera loop of the tool - `for cam in 0..cam_num { calib_camera(...) }` (src/bin/camera_calibration.rs:255-265) -
     as ONE ccal_solve_batch: every camera's single-camera problem on a context of its own, solved side by side (a session-
-    sized problem leaves the GPU almost idle).  Entry i equals calib_camera(cams_frame_feature_lists[i], generic_cameras[i], ...)
-    bit for bit."""
+    sized problem leaves the GPU almost idle).  `devices`: the cameras' contexts are placed round-robin on the listed GPUs
+    (independent sessions are the path's most natural multi-GPU split at session size: no collective at all); default: all on
+    `device`.  Entry i equals calib_camera(cams_frame_feature_lists[i], generic_cameras[i], ...) - same verdict and iteration
+    count, results to the order of summation (ccal_solve_batch sizes every problem's launches for its share of its GPU)."""
     n = len(generic_cameras)
-    ctxs = [Context(device) for _ in range(n)]
+    devs = [int(d) for d in devices] if devices else [int(device)]
+    ctxs = [Context(devs[c % len(devs)]) for c in range(n)]
     out: List[Optional[Tuple[GenericModel, Dict[int, RvecTvec]]]] = [None] * n
     jobs = []                                       # (camera, problem, slots, intr, poses)
     try:

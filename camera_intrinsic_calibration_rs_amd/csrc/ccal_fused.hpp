@@ -301,6 +301,10 @@ struct FusedArgs {
     // holds every camera's frames, `intr` / `extr` point at camera 0.  NULL: one camera per launch (`cam`)
     const int32_t* obs_cam;
     int32_t lpf_force;             // lanes per frame forced by a developer switch of the second library (0: the launchers' cost model)
+    // ccal_solve_batch: how many problems are being solved side by side on this GPU (contexts of the batch; 0 / 1: alone).  The
+    // lanes-per-frame cost model then counts 1 / share of the chip's SIMDs as this problem's: fewer, longer wavefronts per launch
+    // (625 frames alone: one frame per wavefront, 625 wavefronts that each hold a SIMD; eight side by side: five frames each)
+    int32_t share;
     IterArgs it;
     // general (multi-camera) loop, GEN kernels: the candidate pose of the frame's slot is formed HERE, in the prologue - k_backsub's
     // work (dp = -L^-T (y_r + Y dc), model decrease of the pose block) with the slot's elimination record of the general loop and
@@ -393,7 +397,7 @@ hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
 // rows of partial sums (= workgroups) a single-launch group of this problem would have; 0: that form does not apply
-int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K);
+int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share);
 hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s);  // k_gram1v<.., ITER>; a.it filled in
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
 // ccal_kernels_gram2.hip: a corner's two rows on two lanes (row-local columns), same records, same fused tail

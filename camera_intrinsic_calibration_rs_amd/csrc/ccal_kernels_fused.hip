@@ -1052,7 +1052,7 @@ static hipError_t launch_gram1v_l(const FusedArgs& a, hipStream_t s) {
 // The second library's CCAL_GRAMV_LPF overrides.  Mappings whose wavefronts would not fit the rows of the partial-sum buffer
 // (`max_waves`: the single-camera loop's fused elimination writes one row per wavefront) are left out; six lanes per frame
 // (the fewest wavefronts) always fit (fused_ws_ensure sizes the buffer for them).
-static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots, int64_t max_waves = (int64_t)1 << 40) {
+static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots, int64_t max_waves = (int64_t)1 << 40, int share = 1) {
     static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
     // developer override: only the instantiated mappings (anything else would make the launcher's wavefront count and the
     // kernel it falls back to disagree)
@@ -1071,11 +1071,12 @@ static int gram_lanes_per_frame(int n_obs, int avg_corners, int slots, int64_t m
         const int passes = (std::max(avg_corners, 1) + lpf - 1) / lpf;
         const double c0 = lpf == 6 ? 8.0 : 6.0;
         double occ;
+        const int simds = std::max(1024 / std::max(share, 1), 64);      // side-by-side sessions (ccal_solve_batch) share the chip
         if (slots > 1024) {
-            const double n = (double)waves / 1024.0;
+            const double n = (double)waves / (double)simds;
             occ = n <= 1.0 ? 1.0 : (n <= 2.0 ? 1.0 + 0.3 * (n - 1.0) : 0.65 + 0.43 * n);
         } else {
-            occ = (double)((waves + 1023) / 1024);
+            occ = (double)((waves + simds - 1) / simds);
         }
         const double cost = occ * (c0 + passes);
         if (cost < best_cost) { best_cost = cost; best = lpf; }        // ties: the wider mapping (listed first)
@@ -1100,7 +1101,7 @@ static hipError_t launch_gram1v_t(FusedArgs& a, hipStream_t s) {
     constexpr bool W_OK = false; (void)NCt;
 #endif
     const bool w = W_OK && (force >= 0 ? force == 1 : a.n_obs >= 2000);
-    const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap);
+    const int lpf = gram_lanes_per_frame(a.n_obs, a.avg_corners, w ? 2048 : 1024, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap, a.share);
     // fused elimination (single-camera loop): one row of partial sums per wavefront
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
     // (every size: 300 / 625 / 1 000 / 1 280 frames GN 0.135-0.155 ms fused against 0.145-0.172 with a separate elimination launch and
@@ -1160,12 +1161,12 @@ static hipError_t launch_gram_iter_l(FusedArgs& a, hipStream_t s) {
 template <int MODEL, bool OF>
 static constexpr size_t iter_static_lds() { return sizeof(HeadShared) + 4 * 2 * 64 * 8 + 4 * 8 * (size_t)fused_red_size(block_dim(MODEL, OF, false) - 6) + 256; }
 template <int MODEL, bool OF>
-static int iter_rows_t(int n_obs, int avg_corners, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
+static int iter_rows_t(int n_obs, int avg_corners, int share, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
     // CCAL_ITER_ROWS: most rows (= workgroups, each of which reads every row of the launch before) for which a group is one
     // launch; 0 = never.  One wavefront per SIMD, every workgroup resident at once: <= 256 workgroups.
     static const int max_rows = std::min(dev_env_int("CCAL_ITER_ROWS", 256), 256);
     if (n_obs <= 0 || max_rows <= 0) return 0;
-    const int lpf = gram_lanes_per_frame(n_obs, avg_corners, 1024);
+    const int lpf = gram_lanes_per_frame(n_obs, avg_corners, 1024, (int64_t)1 << 40, share);
     const int g = 64 / lpf, rows = (n_obs + g * kIterWpb - 1) / (g * kIterWpb);
     if (rows > max_rows) return 0;
     size_t lds = 0;
@@ -1178,32 +1179,32 @@ static int iter_rows_t(int n_obs, int avg_corners, bool launch, FusedArgs* a, hi
     if (lds + iter_static_lds<MODEL, OF>() > kLdsPerCu) return 0;
     return rows;
 }
-static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
+static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, int share, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
-        case 0: return iter_rows_t<kUCM, false>(n_obs, avg_corners, launch, a, s, err);
-        case 1: return iter_rows_t<kUCM, true>(n_obs, avg_corners, launch, a, s, err);
-        case 2: return iter_rows_t<kEUCM, false>(n_obs, avg_corners, launch, a, s, err);
-        case 3: return iter_rows_t<kEUCM, true>(n_obs, avg_corners, launch, a, s, err);
-        case 4: return iter_rows_t<kKB4, false>(n_obs, avg_corners, launch, a, s, err);
-        case 5: return iter_rows_t<kKB4, true>(n_obs, avg_corners, launch, a, s, err);
+        case 0: return iter_rows_t<kUCM, false>(n_obs, avg_corners, share, launch, a, s, err);
+        case 1: return iter_rows_t<kUCM, true>(n_obs, avg_corners, share, launch, a, s, err);
+        case 2: return iter_rows_t<kEUCM, false>(n_obs, avg_corners, share, launch, a, s, err);
+        case 3: return iter_rows_t<kEUCM, true>(n_obs, avg_corners, share, launch, a, s, err);
+        case 4: return iter_rows_t<kKB4, false>(n_obs, avg_corners, share, launch, a, s, err);
+        case 5: return iter_rows_t<kKB4, true>(n_obs, avg_corners, share, launch, a, s, err);
 #ifdef CCAL_DEV_SWITCHES
-        case 6: return iter_rows_t<kOCV5, false>(n_obs, avg_corners, launch, a, s, err);
-        case 7: return iter_rows_t<kOCV5, true>(n_obs, avg_corners, launch, a, s, err);
+        case 6: return iter_rows_t<kOCV5, false>(n_obs, avg_corners, share, launch, a, s, err);
+        case 7: return iter_rows_t<kOCV5, true>(n_obs, avg_corners, share, launch, a, s, err);
 #endif
         default: return 0;
     }
 }
-int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K) {
+int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share) {
     if (K != block_dim(model, one_focal, false) - 6) return 0;      // (the kernel's compile-time column count is the problem's)
     // OPENCV5: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch
     // form (112-double rows: two chunks per lane to sum, 4.9 us).  CCAL_ITER_OCV5=1 forces the single-launch form.
     static const bool ocv5 = dev_env_int("CCAL_ITER_OCV5", 0) == 1;
     if (model == kOCV5 && !ocv5) return 0;
-    return iter_rows_m(model, one_focal, n_obs, avg_corners, false, nullptr, nullptr, nullptr);
+    return iter_rows_m(model, one_focal, n_obs, avg_corners, share, false, nullptr, nullptr, nullptr);
 }
 hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
     hipError_t err = hipErrorInvalidValue;
-    const int rows = iter_rows_m(model, one_focal, a.n_obs, a.avg_corners, true, &a, s, &err);
+    const int rows = iter_rows_m(model, one_focal, a.n_obs, a.avg_corners, a.share, true, &a, s, &err);
     return rows > 0 ? err : hipErrorInvalidValue;
 }
 

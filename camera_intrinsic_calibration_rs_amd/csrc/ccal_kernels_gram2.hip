@@ -515,7 +515,7 @@ static hipError_t launch_gram2_l(const FusedArgs& a, hipStream_t s) {
 // Lanes per frame (even: 64, 32, 16, 12, 8, 6): the cost model of gram_lanes_per_frame (ccal_kernels_fused.hip).
 // `force` (FusedArgs::lpf_force: a developer switch of the second library) overrides; mappings whose wavefronts would not fit
 // the rows of the partial-sum buffer (`max_waves`, single-camera loop: one row per wavefront) are left out.
-static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, bool gen, int force, int64_t max_waves) {
+static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, bool gen, int force, int64_t max_waves, int share) {
     static const int cand[6] = { 64, 32, 16, 12, 8, 6 };
     for (int c : cand) if (force == c) return c;
     int best = 6;
@@ -532,9 +532,10 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
         // (single camera, 20 000 frames, whole build: 6 lanes 55.1 us, 8: 59.1, 12: 63.8; 50 000 frames: 133.8, 123.5, 136.8)
         const double c0 = gen ? (lpf == 6 ? 8.0 : 7.0) : (lpf == 6 ? 7.0 : 6.0);
         double occ;
-        const double nw = (double)waves / 1024.0;
+        const int simds = std::max(1024 / std::max(share, 1), 64);      // side-by-side sessions (ccal_solve_batch) share the chip
+        const double nw = (double)waves / (double)simds;
         if (two_per_simd) occ = nw <= 1.0 ? 1.0 : (nw <= 2.0 ? 1.0 + 0.3 * (nw - 1.0) : 0.65 + 0.43 * nw);
-        else occ = (double)((waves + 1023) / 1024);
+        else occ = (double)((waves + simds - 1) / simds);
         const double cost = occ * (c0 + passes);
         if (cost < best_cost) { best_cost = cost; best = lpf; }
     }
@@ -543,7 +544,7 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
 
 template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
-    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL) >= 2, GEN, a.lpf_force, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap);
+    const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL) >= 2, GEN, a.lpf_force, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap, a.share);
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
     const bool fuse = !GEN && a.fuse_elim != 0 && waves <= a.part_cap;
     a.fuse_elim = fuse ? 1 : 0;

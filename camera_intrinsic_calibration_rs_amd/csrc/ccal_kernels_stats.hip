@@ -49,30 +49,35 @@ __device__ __forceinline__ double from_fixed(const u128 f) {
 }
 size_t order_stats_work_bytes() { return (sizeof(SelWork) + 255) & ~(size_t)255; }
 
-// What the histogram of pass p - 1 says about both targets: every workgroup derives it for itself (the same numbers in the same
-// order: the same answer), workgroup 0 leaves it for the next launch.  state[p] = state at the ENTRY of pass p.
-__device__ __forceinline__ SelState sel_advance(SelWork* w, const int pass, uint32_t* sh_scan /* [2][256] */, SelState* sh_state) {
-    if (pass == 0) return w->state[0];
-    const int pp = pass - 1, nb = sel_bins(pp), per = nb / 256 > 0 ? nb / 256 : 1;
-    const SelState prev = w->state[pp];
-    for (int t = 0; t < 2; ++t) {
-        const uint32_t* h = w->hist[pp][t];
+// What the histogram of pass p - 1 says about both targets: every workgroup derives it for itself (the same counts: the same
+// answer), workgroup 0 leaves it for the next launch.  state[p] = state at the ENTRY of pass p.  Wavefront t of the workgroup takes
+// target t: lane l owns nb / 64 consecutive bins (requested together), a shuffle scan over the lanes' sums finds the lane whose
+// range holds the rank, that lane walks its own bins in registers.
+__device__ __forceinline__ SelState sel_advance(SelWork* w, const int pass, SelState* sh_state) {
+    const int pp = pass - 1, nb = sel_bins(pp), per = nb / 64;              // 32 or 8 bins per lane
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave < 2) {
+        const int t = wave;
+        const SelState prev = w->state[pp];
+        const uint32_t* h = w->hist[pp][t] + lane * per;
+        uint32_t c[32];
         uint32_t loc = 0;
-        for (int i = 0; i < per; ++i) { const int b = threadIdx.x * per + i; if (b < nb) loc += h[b]; }
-        sh_scan[t * 256 + threadIdx.x] = loc;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const int t = threadIdx.x;
-        const uint32_t* h = w->hist[pp][t];
-        long long r = prev.rank[t], cum = 0;
-        int chunk = 0;
-        while (chunk < 255 && cum + (long long)sh_scan[t * 256 + chunk] <= r) { cum += sh_scan[t * 256 + chunk]; ++chunk; }
-        int b = chunk * per;
-        const int bend = b + per < nb ? b + per : nb;
-        while (b < bend - 1 && cum + (long long)h[b] <= r) { cum += h[b]; ++b; }
-        sh_state->prefix[t] = (prev.prefix[t] << (pp < 5 ? kSelBits : 9)) | (unsigned long long)b;
-        sh_state->rank[t] = r - cum;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { c[i] = i < per ? h[i] : 0u; loc += c[i]; }
+        long long incl = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+        const long long excl = incl - loc, r = prev.rank[t];
+        // the lane whose range holds rank r (the last lane takes whatever lies beyond: cannot happen for a rank < count)
+        const bool mine = (excl <= r && r < incl) || (lane == 63 && r >= incl);
+        if (mine) {
+            long long cum = excl;
+            int b = 0;
+#pragma unroll
+            for (int i = 0; i < 31; ++i) if (b == i && i < per - 1 && cum + (long long)c[i] <= r) { cum += c[i]; ++b; }
+            sh_state->prefix[t] = (prev.prefix[t] << (pp < 5 ? kSelBits : 9)) | (unsigned long long)(lane * per + b);
+            sh_state->rank[t] = r - cum;
+        }
     }
     __syncthreads();
     const SelState st = *sh_state;
@@ -82,13 +87,12 @@ __device__ __forceinline__ SelState sel_advance(SelWork* w, const int pass, uint
 __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ vals, const long long n, SelWork* w, const int pass,
                                                   const long long rank0, const long long rank1) {
     __shared__ uint32_t hist[2][kSelBins];
-    __shared__ uint32_t scan[2 * 256];
     __shared__ SelState shs;
     SelState st;
     if (pass == 0) {                        // the two ranks arrive in the argument block
         st.prefix[0] = 0; st.prefix[1] = 0; st.rank[0] = rank0; st.rank[1] = rank1;
         if (blockIdx.x == 0 && threadIdx.x == 0) w->state[0] = st;
-    } else st = sel_advance(w, pass, scan, &shs);
+    } else st = sel_advance(w, pass, &shs);
     const int nb = sel_bins(pass), shift = sel_shift(pass);
     const int hi_shift = pass == 0 ? 0 : (pass < 5 ? 64 - kSelBits * pass : 9);      // bits above this pass's digit: key >> hi_shift == prefix
     for (int b = threadIdx.x; b < 2 * kSelBins; b += 256) (&hist[0][0])[b] = 0;
@@ -110,11 +114,10 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ val
 // sum over the values below the 99 % key, each scaled (e x 1 / len_99, one rounding per value) and added as a 128-bit integer:
 // per thread, then per workgroup (thread 0 adds its 256 threads' sums), one partial per workgroup; k_sel_finish adds the partials
 __global__ __launch_bounds__(256) void k_sel_sum(const double* __restrict__ vals, const long long n, SelWork* w, const double inv) {
-    __shared__ uint32_t scan[2 * 256];
     __shared__ SelState shs;
     __shared__ unsigned long long s_lo[256], s_hi[256];
     __shared__ uint32_t s_bad[256];
-    const SelState st = sel_advance(w, kSelPasses, scan, &shs);
+    const SelState st = sel_advance(w, kSelPasses, &shs);
     const unsigned long long K99 = st.prefix[1];
     const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(vals);
     u128 acc = 0;
@@ -146,6 +149,88 @@ __global__ __launch_bounds__(64) void k_sel_finish(SelWork* w, const int n_part,
     w->out[1] = avg;
 }
 
+// The whole selection in ONE launch of one workgroup for session-sized arrays (a camera session's ~50 000 errors: nine launches
+// of the general form are ~45 us of launch latency for ~3 us of work).  Same digits, same keys, the same fixed-point sum: the same
+// bits as the general form.
+constexpr int kSelOneMax = 1 << 17;
+__global__ __launch_bounds__(1024) void k_sel_one(const double* __restrict__ vals, const int n, SelWork* w, const double inv,
+                                                  const long long rank0, const long long rank1, const int have99) {
+    __shared__ uint32_t hist[2][kSelBins];
+    __shared__ SelState shs;
+    __shared__ unsigned long long s_lo[16], s_hi[16];
+    __shared__ uint32_t s_bad[16];
+    const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(vals);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    SelState st;
+    st.prefix[0] = 0; st.prefix[1] = 0; st.rank[0] = rank0; st.rank[1] = rank1;
+    for (int pass = 0; pass < kSelPasses; ++pass) {
+        const int nb = sel_bins(pass), shift = sel_shift(pass), per = nb / 64;
+        const int hi_shift = pass == 0 ? 0 : (pass < 5 ? 64 - kSelBits * pass : 9);
+        for (int b = threadIdx.x; b < 2 * kSelBins; b += 1024) (&hist[0][0])[b] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const unsigned long long k = keys[i];
+            const uint32_t d = (uint32_t)(k >> shift) & (uint32_t)(nb - 1);
+            const unsigned long long hi = pass == 0 ? 0ull : (k >> hi_shift);
+            if (pass == 0 || hi == st.prefix[0]) atomicAdd(&hist[0][d], 1u);
+            if (pass == 0 || hi == st.prefix[1]) atomicAdd(&hist[1][d], 1u);
+        }
+        __syncthreads();
+        if (wave < 2) {                                     // sel_advance's search on the workgroup's own histogram
+            const int t = wave;
+            const uint32_t* h = hist[t] + lane * per;
+            uint32_t c[32];
+            uint32_t loc = 0;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { c[i] = i < per ? h[i] : 0u; loc += c[i]; }
+            long long incl = loc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const long long o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
+            const long long excl = incl - loc, r = st.rank[t];
+            if ((excl <= r && r < incl) || (lane == 63 && r >= incl)) {
+                long long cum = excl;
+                int b = 0;
+#pragma unroll
+                for (int i = 0; i < 31; ++i) if (b == i && i < per - 1 && cum + (long long)c[i] <= r) { cum += c[i]; ++b; }
+                shs.prefix[t] = (st.prefix[t] << (pass < 5 ? kSelBits : 9)) | (unsigned long long)(lane * per + b);
+                shs.rank[t] = r - cum;
+            }
+        }
+        __syncthreads();
+        st = shs;
+        __syncthreads();
+    }
+    const unsigned long long K99 = st.prefix[1];
+    u128 acc = 0;
+    bool bad = false;
+    if (have99) for (int i = threadIdx.x; i < n; i += 1024) if (keys[i] < K99) acc += to_fixed(vals[i] * inv, &bad);
+    // 128-bit integer sums: any order gives the same bits - lanes by shuffle, wavefronts through LDS
+    unsigned long long lo = (unsigned long long)acc, hi = (unsigned long long)(acc >> 64);
+    uint32_t bd = bad ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long olo = __shfl_down(lo, off, 64), ohi = __shfl_down(hi, off, 64);
+        const u128 t = (((u128)hi << 64) | lo) + (((u128)ohi << 64) | olo);
+        lo = (unsigned long long)t; hi = (unsigned long long)(t >> 64);
+        bd |= __shfl_down(bd, off, 64);
+    }
+    if (lane == 0) { s_lo[wave] = lo; s_hi[wave] = hi; s_bad[wave] = bd; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u128 t = 0;
+        bool anyb = false;
+        for (int i = 0; i < 16; ++i) { t += ((u128)s_hi[i] << 64) | (u128)s_lo[i]; anyb = anyb || s_bad[i] != 0; }
+        const double k99 = __longlong_as_double((long long)K99);
+        double avg = 0.0;
+        if (have99) {
+            t += to_fixed(k99 * inv, &anyb) * (u128)(unsigned long long)(st.rank[1] + 1);
+            avg = anyb ? (k99 != k99 ? k99 : __longlong_as_double(0x7ff0000000000000ll)) : from_fixed(t);
+        }
+        w->out[0] = __longlong_as_double((long long)st.prefix[0]);
+        w->out[1] = avg;
+    }
+}
+
 // median and 99 % mean of n non-negative values on the device; `work`: order_stats_work_bytes() of device memory
 hipError_t order_stats_device(const double* d_vals, int64_t n, char* work, double* avg_99, double* median, hipStream_t s) {
     if (n <= 0 || !work) return hipErrorInvalidValue;
@@ -153,18 +238,26 @@ hipError_t order_stats_device(const double* d_vals, int64_t n, char* work, doubl
     const int64_t n99 = n * 99 / 100;
     hipError_t e;
 #define TRY(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    const double inv = n99 > 0 ? 1.0 / (double)n99 : 0.0;
+    double h[2] = { 0.0, 0.0 };
+    if (n <= kSelOneMax) {
+        hipLaunchKernelGGL(k_sel_one, dim3(1), dim3(1024), 0, s, d_vals, (int)n, w, inv, (long long)(n / 2), (long long)(n99 > 0 ? n99 - 1 : 0), n99 > 0 ? 1 : 0);
+        TRY(hipGetLastError());
+        TRY(hipMemcpyAsync(h, w->out, sizeof h, hipMemcpyDeviceToHost, s));
+        TRY(hipStreamSynchronize(s));
+        *median = h[0]; *avg_99 = h[1];
+        return hipSuccess;
+    }
     TRY(hipMemsetAsync(w, 0, sizeof(SelWork), s));
     const int blocks = (int)std::min<int64_t>(kSelBlocks, (n + 256 * 8 - 1) / (256 * 8));
     for (int pass = 0; pass < kSelPasses; ++pass) {
         hipLaunchKernelGGL(k_sel_hist, dim3(blocks), dim3(256), 0, s, d_vals, (long long)n, w, pass, (long long)(n / 2), (long long)(n99 > 0 ? n99 - 1 : 0));
         TRY(hipGetLastError());
     }
-    const double inv = n99 > 0 ? 1.0 / (double)n99 : 0.0;
     hipLaunchKernelGGL(k_sel_sum, dim3(blocks), dim3(256), 0, s, d_vals, (long long)n, w, inv);
     TRY(hipGetLastError());
     hipLaunchKernelGGL(k_sel_finish, dim3(1), dim3(64), 0, s, w, blocks, inv, n99 > 0 ? 1 : 0);
     TRY(hipGetLastError());
-    double h[2] = { 0.0, 0.0 };
     TRY(hipMemcpyAsync(h, w->out, sizeof h, hipMemcpyDeviceToHost, s));
     TRY(hipStreamSynchronize(s));
 #undef TRY

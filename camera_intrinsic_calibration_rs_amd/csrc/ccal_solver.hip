@@ -533,6 +533,7 @@ struct SolveJob {
     // single-process sharded solves: raised by the first shard that fails with something other than the solver's verdicts; its
     // peers - whose collectives will never find their partner - stop waiting at their next look instead of at the timeout
     const std::atomic<int>* cancel = nullptr;
+    int share = 1;                    // ccal_solve_batch: problems solved side by side on this GPU (FusedArgs::share)
     SolveJob(ccal_problem* p_, const ccal_solver_opts* o_, bool hio, double* i, double* po, double* e)
         : p(p_), o(o_), host_io(hio), intr_io(i), poses_io(po), extr_io(e), ctx(p_->ctx), w(p_->nws), st(p_->ctx->stream) {}
     virtual ~SolveJob() {}
@@ -620,9 +621,10 @@ struct FusedJob : SolveJob {
         zero_copy = host_io && f->h_result != nullptr;
         fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
         sharded = p->sharded();
+        fa.share = share;
         iter_rows = 0;
         if (!sharded && f->fuse_elim && fused_use_valu_gram(p)) {
-            const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K);
+            const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K, share);
             if (rows > 0 && 2 * rows <= f->n_pw) iter_rows = rows;
         }
         {
@@ -974,13 +976,14 @@ static std::unique_ptr<SolveJob> make_job(ccal_problem* p, const ccal_solver_opt
     return std::unique_ptr<SolveJob>(new GeneralJob(p, o, host_io, intr_io, poses_io, extr_io));
 }
 static int solve_entry(ccal_problem* p, const ccal_solver_opts* o, bool host_io, double* intr_io, double* poses_io, double* extr_io,
-                       ccal_report* rep, const std::atomic<int>* cancel = nullptr) {
+                       ccal_report* rep, const std::atomic<int>* cancel = nullptr, int share = 1) {
     ccal_ctx* ctx = p->ctx;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = normal_ws_ensure(p);
     if (rc != CCAL_OK) return rc;
     auto job = make_job(p, o, host_io, intr_io, poses_io, extr_io);
     job->cancel = cancel;
+    job->share = share;
     if ((rc = job->begin()) != CCAL_OK) return rc;
     bool fin = false;
     while (!fin) if ((rc = job->poll(&fin)) != CCAL_OK) return rc;
@@ -1094,12 +1097,15 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
     std::vector<int> rc(n, CCAL_ERR_HIP);
     std::vector<ccal_ctx*> ctxs;                                  // distinct contexts, in order of first appearance
     for (int i = 0; i < n; ++i) if (std::find(ctxs.begin(), ctxs.end(), ps[i]->ctx) == ctxs.end()) ctxs.push_back(ps[i]->ctx);
+    // how many of the batch's contexts sit on each GPU: a problem's launches are sized for its share of that chip (FusedArgs::share)
+    auto side_by_side = [&](const ccal_ctx* c) { int k = 0; for (ccal_ctx* q : ctxs) k += q->device == c->device ? 1 : 0; return k; };
     auto run_ctx = [&](ccal_ctx* c) noexcept {
+        const int n_side = side_by_side(c);
         for (int i = 0; i < n; ++i) {
             if (ps[i]->ctx != c) continue;
             try {
                 rc[i] = solve_entry(ps[i], o, host_io, host_io ? intr_io[i] : nullptr, host_io && poses_io ? poses_io[i] : nullptr,
-                                    host_io && extr_io ? extr_io[i] : nullptr, reps ? &reps[i] : nullptr);
+                                    host_io && extr_io ? extr_io[i] : nullptr, reps ? &reps[i] : nullptr, nullptr, n_side);
             } catch (const std::bad_alloc&) { rc[i] = CCAL_ERR_NO_MEMORY; note_error(c, "out of host memory");
             } catch (...) { rc[i] = CCAL_ERR_HIP; note_error(c, "C++ exception in ccal_solve_batch"); }
             if (reps && rc[i] != CCAL_OK && rc[i] != reps[i].status) { reps[i] = ccal_report{}; reps[i].status = rc[i]; }

@@ -175,6 +175,17 @@ def test_validation_statistics_are_order_statistics(gpu_ctx, oracle):
             assert abs(res[0][0] - ao) < 1e-11 and abs(res[0][1] - mo) < 1e-11
         gp.close()
     assert res[0] == res[1] == res[2]                                           # bit for bit, whatever the order of the frames
+    # above 2^17 values the selection is the multi-launch form (one histogram launch per digit): same definition, same checks
+    big = synth.make_problem(1000, "kb4", outlier_frac=0.01, seed=78)
+    gp = Problem.from_synth(gpu_ctx, big)
+    a, m = gp.validation(0, big.intr0, big.poses0)
+    e = np.sort(gp.reprojection_errors(big.intr0, big.poses0))
+    assert len(e) > (1 << 17)
+    n99 = len(e) * 99 // 100
+    assert m == e[len(e) // 2] and abs(a - float(np.sum(e[:n99] / n99))) <= 1e-12
+    ao, mo = oracle.OracleProblem.from_synth(big).validation(0, big.intr0, big.poses0)
+    assert abs(a - ao) < 1e-11 and abs(m - mo) < 1e-11
+    gp.close()
 
 
 def test_full_size_sampled_frames(gpu_ctx, oracle):

@@ -2,8 +2,8 @@
 """Developer tool / bench helper: N independent session-sized problems solved concurrently, one host thread + one
 context (own HIP stream) + one problem each - the regime of the reference's real workload (a single camera session of a
 few hundred frames; the per-camera calib_camera calls of a rig, the three retries of src/bin/camera_calibration.rs:205-246).
-Reports aggregate Gauss-Newton iterations/s for N = 1, 2, 4, 8 and checks that every concurrent result is bit-identical to
-the sequential one.
+Reports aggregate Gauss-Newton iterations/s for N = 1, 2, 4, 8 and checks every concurrent result against the sequential one
+(same iteration count; results equal to the order of summation, 1e-11: a batch sizes each problem's launches for its share of the GPU).
     python tools/concurrent_sessions.py [frames] [model] [--lm]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -37,11 +37,11 @@ def measure(frames=625, model="eucm", method=0, reps=200, counts=(1, 2, 4, 8), d
                 rp, res = Problem.solve_batch(probs[:n], opts, starts=starts[:n])
             w = time.perf_counter() - t0
             wall = w if wall is None or w < wall else wall
-        same = all(rp[i].iterations == ref[i][3].iterations and rp[i].final_cost == ref[i][3].final_cost and
-                   np.array_equal(res[i][0], ref[i][0]) and np.array_equal(res[i][1], ref[i][1]) for i in range(n))
+        same = all(rp[i].iterations == ref[i][3].iterations and abs(rp[i].final_cost - ref[i][3].final_cost) <= 1e-11 * abs(ref[i][3].final_cost) and
+                   np.allclose(res[i][0], ref[i][0], rtol=1e-11, atol=1e-13) and np.allclose(res[i][1], ref[i][1], rtol=1e-11, atol=1e-13) for i in range(n))
         out["by_sessions"][str(n)] = {"wall_s": wall, "solves_per_s": n * reps / wall,
                                       "iters_per_s": sum(r.iterations for r in rp) * reps / wall,
-                                      "ms_per_batch": wall / reps * 1e3, "bit_identical_to_sequential": bool(same)}
+                                      "ms_per_batch": wall / reps * 1e3, "equal_to_sequential_1e-11": bool(same)}
     b = out["by_sessions"]
     if "1" in b:
         for k in b: b[k]["speedup_vs_1"] = b[k]["iters_per_s"] / b["1"]["iters_per_s"]
