@@ -99,6 +99,11 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
 }
 static void ctx_free(ccal_ctx* ctx) {
     ctx_worker_destroy(ctx);
+    if (ctx->d_batch_tab || ctx->h_batch_tab) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->d_batch_tab) (void)hipFree(ctx->d_batch_tab);
+        if (ctx->h_batch_tab) (void)hipHostFree(ctx->h_batch_tab);
+    }
     if (ctx->own_stream && ctx->stream) { (void)hipSetDevice(ctx->device); (void)hipStreamDestroy(ctx->stream); }
     delete ctx;
 }

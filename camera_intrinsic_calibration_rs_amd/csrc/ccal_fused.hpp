@@ -399,6 +399,11 @@ hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s)
 // rows of partial sums (= workgroups) a single-launch group of this problem would have; 0: that form does not apply
 int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share);
 hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s);  // k_gram1v<.., ITER>; a.it filled in
+int fused_iter_lpf(int n_obs, int avg_corners, int share);                           // the lane mapping of that launch
+// ccal_solve_batch: launch number s_no of a whole batch of session-sized problems (UCM / EUCM / KB4, one model, focal mode and lane
+// mapping); tab: n argument blocks in DEVICE memory with it.st_in = the first of the two state buffers, partial = the partial-sum
+// buffer's base, n_part = the problem's rows, it.fold = the first launch unpacks; max_rows = the largest n_part
+hipError_t launch_gram_iter_batch(int model, bool one_focal, int lpf, const FusedArgs* tab, int n, int max_rows, int s_no, hipStream_t s);
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
 // ccal_kernels_gram2.hip: a corner's two rows on two lanes (row-local columns), same records, same fused tail
 hipError_t launch_gram2(int model, bool one_focal, FusedArgs& a, hipStream_t s);

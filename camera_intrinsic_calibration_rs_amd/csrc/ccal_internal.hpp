@@ -64,6 +64,9 @@ struct ccal_ctx {
     // ccal_solve_batch: the host thread that drives this context's stream while the caller's thread drives another one
     // (created on first use, joined when the context is freed; ccal_solver.hip)
     struct ccal_ctx_worker* worker = nullptr;
+    // ccal_solve_batch, session sizes: the argument blocks of a batch's problems, one launch per step for all of them
+    // (k_gram1v_batch reads the table on the device; h_: its pinned staging) - grown on demand, freed with the context
+    char* d_batch_tab = nullptr; char* h_batch_tab = nullptr; size_t batch_tab_bytes = 0;
 };
 namespace ccal {
 void ctx_worker_destroy(ccal_ctx* ctx);

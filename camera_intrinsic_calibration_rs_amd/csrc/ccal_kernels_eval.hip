@@ -11,6 +11,7 @@
 #include "ccal_internal.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ccal {
 
@@ -47,7 +48,13 @@ template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : FC_N
 // and their latency, not bandwidth, sets the pace (tools/eval_cliff.py: 40 000 frames run at 6.4 TB/s with warm inputs
 // and at 5.0 TB/s when the inputs are evicted between launches) - there PF hides one memory latency per pass:
 // 50 000 frames 5.4 -> 6.0 TB/s.
-template <int MODEL, bool OF, bool OTHER, bool PF>
+// AL: the Huber corrector applied to r and J (a compile-time fact: as a run-time flag the compiler multiplied every entry by a
+// weight of 1.0 when it was off - 2 D + 2 FP64 multiplies per corner on the benchmark's path).
+// The J tile of a FULL pass (64 corners) leaves with a compile-time number of stores (TW / 2 per lane, unrolled): with a run-time
+// trip count the compiler cannot count the stores in flight and drains them all (s_waitcnt vmcnt(0)) before the next pass may
+// use its - long since arrived - corner rows; counted, the next pass computes under the stores of this one (what holds the wide
+// blocks back is wavefront-level concurrency).
+template <int MODEL, bool OF, bool OTHER, bool PF, bool AL>
 __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int TW = 2 * D;            // doubles per block Jacobian
@@ -99,9 +106,14 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     wave_lds_sync();
 
     const int64_t jbase = a.joff[o];
-    for (int base = 0; base < n; base += 64) {
+    // One pass = 64 corners.  FULL passes (all 64 lanes hold a corner) run in a loop of their own whose every memory operation is
+    // unconditional and counted at compile time - r as one 16-byte store, the J tile as TW / 2 stores per lane - so that the
+    // compiler's wait for the NEXT pass's corner rows (PF: requested before this pass's stores) is s_waitcnt vmcnt(<stores since>)
+    // and not vmcnt(0): the next pass computes under this pass's stores.  The frame's last, partial pass follows the loop.
+    auto pass = [&](auto full_tag, const int base) {
+        constexpr bool FULL = decltype(full_tag)::value;
         const int c = base + lane;
-        const bool valid = c < n;
+        const bool valid = FULL || c < n;
         const int64_t g = start + (valid ? c : 0);
         double X, Y, Z, uo, vo;
         if constexpr (PF) {
@@ -118,7 +130,7 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         double* Ju = J;
         double* Jv = J + D;
         corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, Ju, Jv);
-        if (a.apply_loss) {
+        if constexpr (AL) {
             const double sw = huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta);
             ru *= sw; rv *= sw;
 #pragma unroll
@@ -147,10 +159,8 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         }
         wave_lds_sync();
         // contiguous tile of J_out: 16 B per lane, 1 KiB per wave-instruction
-        const int nv = min(64, n - base);
-        const int tot = nv * TW;
         double* dst = a.J_out + jbase + (int64_t)base * TW;
-        for (int e = lane * 2; e < tot; e += 128) {
+        auto put = [&](const int e) {
             const int cr = e / TW;
             const int k = e - cr * TW;
             const double2 val = *reinterpret_cast<const double2*>(tile + cr * TS + k);
@@ -160,9 +170,19 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
 #else
             *reinterpret_cast<double2*>(dst + e) = val;
 #endif
+        };
+        if constexpr (FULL) {
+#pragma unroll
+            for (int it = 0; it < TW / 2; ++it) put(lane * 2 + 128 * it);
+        } else {
+            const int tot = (n - base) * TW;
+            for (int e = lane * 2; e < tot; e += 128) put(e);
         }
         wave_lds_sync();
-    }
+    };
+    const int n_full = n & ~63;
+    for (int base = 0; base < n_full; base += 64) pass(std::true_type{}, base);
+    if (n_full < n) pass(std::false_type{}, n_full);
     }
 }
 
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
     }
 }
 
-template <int MODEL, bool OF, bool OTHER, bool PF>
+template <int MODEL, bool OF, bool OTHER, bool PF, bool AL>
 static hipError_t launch_eval_pf(const KArgs& a, hipStream_t s) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int WS = fc_doubles<OTHER>() + 64 * eval_tile_stride(D);
@@ -217,14 +237,20 @@ static hipError_t launch_eval_pf(const KArgs& a, hipStream_t s) {
     if (blocks == 0) return hipSuccess;
     if (CCAL_EVAL_PERSIST > 0) blocks = std::min(blocks, 256 * CCAL_EVAL_PERSIST);
     static DynLdsGuard lds_guard;
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER, PF>), lds, lds_guard); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER, PF>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER, PF, AL>), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER, PF, AL>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
     return hipGetLastError();
 }
+// blocks for which the prefetching form wins whatever the input size (measured; 0 = none yet: CCAL_EVAL_PF_MIN_D)
+#ifndef CCAL_EVAL_PF_MIN_D
+#define CCAL_EVAL_PF_MIN_D 99
+#endif
+template <int MODEL, bool OF, bool OTHER> constexpr bool eval_prefetch_always() { return block_dim(MODEL, OF, OTHER) >= CCAL_EVAL_PF_MIN_D; }
 template <int MODEL, bool OF, bool OTHER>
 static hipError_t launch_eval_t(const KArgs& a, bool big_inputs, hipStream_t s) {
-    const bool pf = CCAL_EVAL_PREFETCH < 0 ? big_inputs : CCAL_EVAL_PREFETCH != 0;
-    return pf ? launch_eval_pf<MODEL, OF, OTHER, true>(a, s) : launch_eval_pf<MODEL, OF, OTHER, false>(a, s);
+    const bool pf = CCAL_EVAL_PREFETCH < 0 ? (big_inputs || eval_prefetch_always<MODEL, OF, OTHER>()) : CCAL_EVAL_PREFETCH != 0;
+    if (a.apply_loss) return pf ? launch_eval_pf<MODEL, OF, OTHER, true, true>(a, s) : launch_eval_pf<MODEL, OF, OTHER, false, true>(a, s);
+    return pf ? launch_eval_pf<MODEL, OF, OTHER, true, false>(a, s) : launch_eval_pf<MODEL, OF, OTHER, false, false>(a, s);
 }
 template <int MODEL, bool OF, bool OTHER>
 static hipError_t launch_err_t(const KArgs& a, hipStream_t s) {

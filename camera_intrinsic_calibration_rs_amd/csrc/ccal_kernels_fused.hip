@@ -270,8 +270,11 @@ template <bool OF> __device__ constexpr bool nz_v(int i) { return OF ? (i != 1) 
 // in front of the evaluation every workgroup sums the previous launch's rows (reduce_partial_rows: k_head's order), its first
 // wavefront decides and solves the camera system (head_wave), and the evaluation takes state, camera step and candidate
 // intrinsics from LDS; behind it the four wavefronts' rows of partial sums are added in LDS: one row per workgroup.
-template <int MODEL, bool OF, int LPF, bool GEN, bool ITER = false>
-__global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(const FusedArgs a) {
+// What changes from one single-launch group of a solve to the next - in the argument block (IterArgs) when a launch serves ONE
+// problem, derived from the launch number when it serves a whole batch (k_gram1v_batch: the table of argument blocks is written once).
+struct IterDyn { int32_t seq, skip_head, fold; const DevState* st_in; DevState* st_out; const double* partial_in; double* partial_out; };
+template <int MODEL, bool OF, int LPF, bool GEN, bool ITER>
+__device__ __forceinline__ void gram1v_body(const FusedArgs& a, const IterDyn& dy) {
     static_assert(!(ITER && GEN), "single-launch groups: single-camera loop only");
     constexpr int WPB = ITER ? 4 : CCAL_GRAMV_WPB;
     constexpr int G = 64 / LPF;                     // frames per wavefront
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
         slot_p = a.obs_slot[fa_];
     }
     bool fold_first = false;                        // ITER: this launch is also the solve's k_unpack1 (IterArgs::fold)
-    if constexpr (ITER) fold_first = a.it.skip_head != 0 && a.it.fold != 0;
+    if constexpr (ITER) fold_first = dy.skip_head != 0 && dy.fold != 0;
     auto iter_prefetch2 = [&]() {
       if constexpr (ITER) {
         const int64_t g0 = start_p + (gl < n_p ? gl : 0);
@@ -338,17 +341,17 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
     bool from_lds = false;                          // ITER, not the first launch: state, camera step and candidate are in hsh
     if constexpr (ITER) {
         const IterArgs& it = a.it;
-        if (!it.skip_head) {
+        if (!dy.skip_head) {
             // (the rows are summed also for a solve that has finished: asking first would put a memory round trip in front of every group's loads)
             HeadIO io;
-            io.st_in = it.st_in; io.st_out = it.st_out; io.hs = it.hs; io.red_g = nullptr; io.cols = it.cols;
-            io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = it.dc_out; io.K = D - 6; io.seq = it.seq;
+            io.st_in = dy.st_in; io.st_out = dy.st_out; io.hs = it.hs; io.red_g = nullptr; io.cols = it.cols;
+            io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = it.dc_out; io.K = D - 6; io.seq = dy.seq;
             io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = it.publish_all;
             HeadPre hpre = {};
             if (threadIdx.x < 64) hpre = head_prefetch(io, (int)threadIdx.x);
             __shared__ double shr[4][(PROW + 63) / 64][64];
             double vsum[(PROW + 63) / 64][4];
-            iter_reduce_load<D - 6>(it.partial_in, it.n_part_in, vsum);
+            iter_reduce_load<D - 6>(dy.partial_in, it.n_part_in, vsum);
             iter_prefetch2();
             iter_reduce_combine<D - 6>(vsum, hsh.red, shr);
             G1V_STAMP(7);                                   // the previous launch's rows are summed
@@ -368,14 +371,14 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
             constexpr int NS = (int)(sizeof(DevState) / sizeof(double)), NC1 = (int)(sizeof(ColInfo) / sizeof(double));
             if (threadIdx.x < CCAL_PMAX) hsh.cand[threadIdx.x] = it.poses_on_device ? a.intr[0][threadIdx.x] : reinterpret_cast<const double*>(it.intr_h)[threadIdx.x];
             if (blockIdx.x == 0 && threadIdx.x < 64) {
-                for (int e = threadIdx.x; e < NS; e += 64) reinterpret_cast<double*>(it.st_out)[e] = reinterpret_cast<const double*>(&it.st0)[e];
+                for (int e = threadIdx.x; e < NS; e += 64) reinterpret_cast<double*>(dy.st_out)[e] = reinterpret_cast<const double*>(&it.st0)[e];
                 for (int e = threadIdx.x; e < it.n_cols * NC1; e += 64) reinterpret_cast<double*>(it.cols_out)[e] = reinterpret_cast<const double*>(it.col0)[e];
                 if (threadIdx.x < CCAL_PMAX) {
                     const double v = it.poses_on_device ? a.intr[0][threadIdx.x] : reinterpret_cast<const double*>(it.intr_h)[threadIdx.x];
                     if (!it.poses_on_device) a.intr[0][threadIdx.x] = v;
                     a.intr[1][threadIdx.x] = v;
                 }
-                if (threadIdx.x == 0) it.hs->word = status_word(it.seq, 0, 0);
+                if (threadIdx.x == 0) it.hs->word = status_word(dy.seq, 0, 0);
             }
             __syncthreads();
             from_lds = true;                       // (the intrinsics: hsh.cand; the camera step is not read in a first evaluation)
@@ -386,12 +389,12 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
             iter_prefetch2();
             // the solve's first launch: the starting state passes through to the buffer the next launch reads
             if (blockIdx.x == 0 && threadIdx.x < 64) {
-                const double* src = reinterpret_cast<const double*>(it.st_in);
-                double* dst = reinterpret_cast<double*>(it.st_out);
+                const double* src = reinterpret_cast<const double*>(dy.st_in);
+                double* dst = reinterpret_cast<double*>(dy.st_out);
                 for (int e = threadIdx.x; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
-                if (threadIdx.x == 0) it.hs->word = status_word(it.seq, 0, 0);
+                if (threadIdx.x == 0) it.hs->word = status_word(dy.seq, 0, 0);
             }
-            const DevState* st = it.st_in;
+            const DevState* st = dy.st_in;
             g.done = st->done; g.redo = st->redo; g.cur = st->cur; g.first = st->first; g.method = st->method;
             g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
         }
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
             __syncthreads();
             if (threadIdx.x < 64) for (int pe = threadIdx.x; pe < PROW; pe += 64) {
                 const int e = iter_row_src(D - 6, pe);
-                a.partial[(int64_t)blockIdx.x * PROW + pe] = ((it_rows[0][e] + it_rows[1][e]) + it_rows[2][e]) + it_rows[3][e];
+                dy.partial_out[(int64_t)blockIdx.x * PROW + pe] = ((it_rows[0][e] + it_rows[1][e]) + it_rows[2][e]) + it_rows[3][e];
             }
         }
     };
@@ -680,6 +683,39 @@ __global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(
     if (!GEN && lane == 0) { ts[6] = wall_clock64(); const int wg = blockIdx.x * WPB + wave; for (int i = 0; i < 10; ++i) a.fcbuf[16 * wg + i] = (double)ts[i]; }
 #endif
 #undef G1V_STAMP
+}
+template <int MODEL, bool OF, int LPF, bool GEN, bool ITER = false>
+__global__ __launch_bounds__(64 * (ITER ? 4 : CCAL_GRAMV_WPB), 1) void k_gram1v(const FusedArgs) {
+    // The argument block is read where it lies - the kernarg segment, offset 0 - through a pointer: handing the by-value parameter
+    // to the (inlined) body by reference made the compiler copy all 1 088 bytes of it into scratch, because the body indexes its
+    // pointer arrays (a.intr[set], a.poses[set], ...) at run time; a pointer into constant memory keeps those scalar loads at a
+    // computed offset, which is also exactly what the batched kernel below does with its table.
+    const FusedArgs& a = *(const FusedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    IterDyn dy = {};
+    if constexpr (ITER) {
+        dy.seq = a.it.seq; dy.skip_head = a.it.skip_head; dy.fold = a.it.fold;
+        dy.st_in = a.it.st_in; dy.st_out = a.it.st_out; dy.partial_in = a.it.partial_in; dy.partial_out = a.partial;
+    }
+    gram1v_body<MODEL, OF, LPF, GEN, ITER>(a, dy);
+}
+// ccal_solve_batch: ONE launch per optimizer step for a whole batch of session-sized problems (same model, focal mode and lane
+// mapping): blockIdx.y = the problem, `tab` = the problems' argument blocks in device memory, written once per batch; what a
+// single-problem launch finds in IterArgs per step follows from the launch number s here - the two state buffers and the two
+// halves of the partial-sum buffer alternate by s (tab[.].it.st_in / tab[.].partial: their bases), the first launch has nothing to
+// decide and (it.fold) unpacks the starting point.  n problems x 4 launches per solve from n host threads were serialised by the
+// runtime's launch path (eight 625-frame sessions: 0.48 ms per batch for ~0.1 ms of device work); this is 4-5 launches per BATCH.
+template <int MODEL, bool OF, int LPF>
+__global__ __launch_bounds__(256, 1) void k_gram1v_batch(const FusedArgs* __restrict__ tab, const int s) {
+    const FusedArgs& a = tab[blockIdx.y];
+    if ((int)blockIdx.x >= a.n_part) return;                   // (problems of a batch differ in size: the grid is the largest one's)
+    constexpr int RB1 = fused_red_size(block_dim(MODEL, OF, false) - 6);
+    IterDyn dy;
+    dy.seq = s; dy.skip_head = s == 1 ? 1 : 0; dy.fold = (s == 1 && a.it.fold != 0) ? 1 : 0;
+    DevState* const sb = const_cast<DevState*>(a.it.st_in);
+    dy.st_in = sb + (s & 1); dy.st_out = sb + ((s + 1) & 1);
+    const size_t half = (size_t)a.n_part * RB1;
+    dy.partial_in = a.partial + (size_t)((s - 1) & 1) * half; dy.partial_out = a.partial + (size_t)(s & 1) * half;
+    gram1v_body<MODEL, OF, LPF, false, true>(a, dy);
 }
 
 // k_gram1w: k_gram1v with two wavefronts per SIMD.  k_gram1v needs 256 VGPRs + 66 AGPRs (91 accumulators and the
@@ -1194,6 +1230,44 @@ static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, in
         default: return 0;
     }
 }
+// ---- the batched form (k_gram1v_batch) ----
+template <int MODEL, bool OF, int LPF>
+static hipError_t launch_iter_batch_l(const FusedArgs* tab, int n, int max_rows, int s_no, hipStream_t s) {
+    const size_t lds = iter_lds_bytes<MODEL, OF, LPF>();
+    if (lds + iter_static_lds<MODEL, OF>() > kLdsPerCu) return hipErrorInvalidValue;
+    void (*kern)(const FusedArgs*, int) = k_gram1v_batch<MODEL, OF, LPF>;
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(max_rows, n), dim3(64 * kIterWpb), lds, s, tab, s_no);
+    return hipGetLastError();
+}
+template <int MODEL, bool OF>
+static hipError_t launch_iter_batch_t(int lpf, const FusedArgs* tab, int n, int max_rows, int s_no, hipStream_t s) {
+    switch (lpf) {
+        case 6: return launch_iter_batch_l<MODEL, OF, 6>(tab, n, max_rows, s_no, s);
+        case 8: return launch_iter_batch_l<MODEL, OF, 8>(tab, n, max_rows, s_no, s);
+        case 12: return launch_iter_batch_l<MODEL, OF, 12>(tab, n, max_rows, s_no, s);
+        case 16: return launch_iter_batch_l<MODEL, OF, 16>(tab, n, max_rows, s_no, s);
+        case 32: return launch_iter_batch_l<MODEL, OF, 32>(tab, n, max_rows, s_no, s);
+        case 64: return launch_iter_batch_l<MODEL, OF, 64>(tab, n, max_rows, s_no, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+// one launch for n problems of one model / focal mode / lane mapping; tab: device memory, n FusedArgs (bases, see the kernel)
+hipError_t launch_gram_iter_batch(int model, bool one_focal, int lpf, const FusedArgs* tab, int n, int max_rows, int s_no, hipStream_t s) {
+    switch (model * 2 + (one_focal ? 1 : 0)) {
+        case 0: return launch_iter_batch_t<kUCM, false>(lpf, tab, n, max_rows, s_no, s);
+        case 1: return launch_iter_batch_t<kUCM, true>(lpf, tab, n, max_rows, s_no, s);
+        case 2: return launch_iter_batch_t<kEUCM, false>(lpf, tab, n, max_rows, s_no, s);
+        case 3: return launch_iter_batch_t<kEUCM, true>(lpf, tab, n, max_rows, s_no, s);
+        case 4: return launch_iter_batch_t<kKB4, false>(lpf, tab, n, max_rows, s_no, s);
+        case 5: return launch_iter_batch_t<kKB4, true>(lpf, tab, n, max_rows, s_no, s);
+        default: return hipErrorNotSupported;
+    }
+}
+// the lane mapping a single-launch group of this problem takes (what launch_gram_iter dispatches on)
+int fused_iter_lpf(int n_obs, int avg_corners, int share) { return gram_lanes_per_frame(n_obs, avg_corners, 1024, (int64_t)1 << 40, share); }
+
 int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share) {
     if (K != block_dim(model, one_focal, false) - 6) return 0;      // (the kernel's compile-time column count is the problem's)
     // OPENCV5: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch

@@ -92,6 +92,11 @@ int drain_pending_groups(ccal_problem* p) {
 // cost more than the DMA it saves).
 constexpr size_t kZeroCopyBytes = 96 * 1024;
 
+// rows of the single-camera loop's partial-sum buffer (fused_ws_ensure)
+static int fused_partial_rows(int n_obs) {
+    const int n_pw = std::max(std::min(std::max(n_obs, 1), 16384), (std::max(n_obs, 1) + 9) / 10 + 8);
+    return (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+}
 static int fused_ws_ensure(ccal_problem* p) {
     NormalWs* w = p->nws;
     if (w->fws) return CCAL_OK;
@@ -107,8 +112,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     // rows of the partial-sum buffer = most wavefronts a Gram launch of this problem may have: one row per wavefront (fused
     // elimination).  Up to 16 384 frames any lanes-per-frame mapping fits; beyond, the launchers keep to mappings that do - six
     // lanes per frame (ten frames per wavefront) always does
-    int n_pw = std::max(std::min(std::max(p->n_obs, 1), 16384), (std::max(p->n_obs, 1) + 9) / 10 + 8);
-    f->n_pw = (n_pw + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK * WAVES_PER_BLOCK;
+    f->n_pw = fused_partial_rows(p->n_obs);
     const size_t ns = (size_t)std::max(p->n_slots, 1), no = (size_t)std::max(p->n_obs, 1);
     // ONE device allocation and ONE pinned allocation, sliced (a calibration session creates a problem and solves it once or
     // twice: fifteen hipMalloc / hipHostMalloc calls and five memsets were 0.46 ms of the first solve's 0.58 at 600 frames)
@@ -595,6 +599,7 @@ struct FusedJob : SolveJob {
     // single-launch groups (k_gram1v<.., ITER>, IterArgs): launch s reads state buffer s & 1 and the rows of launch s - 1,
     // writes state buffer (s + 1) & 1 and its own rows into the other half of the partial-sum buffer
     int iter_rows = 0;
+    bool batch_member = false;        // ccal_solve_batch drives this job's launches together with other problems' (run_iter_group): begin() enqueues nothing
     bool fold = false;                // the first single-launch group is also the solve's k_unpack1 (IterArgs::fold)
     UnpackArgs ua0;                   // its payload
     DevState* iter_state(int s) const { return f->d_state + 1 + (s & 1); }
@@ -660,8 +665,8 @@ struct FusedJob : SolveJob {
                 f->all_slots_observed = n_seen == p->n_slots ? 1 : 0;
             }
             fold = iter_rows > 0 && !fold_off && f->all_slots_observed == 1;
-            if (fold) ua0 = ua;
-            else HIP_TRY(ctx, launch_unpack1(ua, st));
+            ua0 = ua;                  // (fold: the first single-launch group's payload)
+            if (!fold) HIP_TRY(ctx, launch_unpack1(ua, st));
         }
         enqueued_any = true;          // from here on an error exit leaves kernels in flight: the next solve / the destructor drains
         f->h_status->word = 0;
@@ -681,7 +686,27 @@ struct FusedJob : SolveJob {
         // -> 0.236 / 0.444 ms per batch, one session 0.108 ms either way).  CCAL_FUSED_DEPTH overrides.
         if (iter_rows && !dev_env("CCAL_FUSED_DEPTH")) depth = 1;
         timeout_s = wait_timeout(p, o);
-        return fill();
+        return batch_member ? CCAL_OK : fill();
+    }
+    // what every single-launch group of this solve finds in IterArgs (the per-launch fields are set by enqueue() / derived from the
+    // launch number by k_gram1v_batch)
+    void iter_args_common(IterArgs& it) const {
+        it.on = 1; it.publish_all = o->verbose ? 1 : 0; it.n_part_in = iter_rows;
+        it.hs = f->h_status; it.cols = w->cols; it.dc_out = w->dc;
+        it.result_host = zero_copy ? f->h_result : nullptr; it.np6 = (int64_t)np6;
+        it.n_cols = ua0.n_cols; it.poses_on_device = ua0.poses_on_device; it.poses_src = ua0.poses_src; it.cols_out = ua0.cols;
+        it.st0 = ua0.st0;
+        for (int i = 0; i < kFusedMaxK; ++i) it.col0[i] = ua0.col0[i];
+        std::memcpy(it.intr_h, ua0.intr_h, sizeof it.intr_h);
+    }
+    // this problem's entry of a batch's table (k_gram1v_batch): bases instead of per-launch pointers
+    FusedArgs batch_entry() const {
+        FusedArgs e = fa;
+        iter_args_common(e.it);
+        e.it.fold = fold ? 1 : 0; e.it.skip_head = 0; e.it.seq = 0;
+        e.it.st_in = iter_state(0); e.it.st_out = nullptr; e.it.partial_in = nullptr;
+        e.partial = f->partial; e.n_part = iter_rows; e.fuse_elim = 1; e.elim_fused = 1;
+        return e;
     }
     int enqueue() override {          // one group: evaluation + elimination + ONE collective + decision/solve
         // CCAL_HEAD_REDUCE_ROWS=0 (developer switch): always the separate reduce launch
@@ -1069,6 +1094,106 @@ static ccal_ctx_worker* ctx_worker(ccal_ctx* ctx) {
     return ctx->worker;
 }
 
+// ---- ccal_solve_batch at session size: ONE launch per optimizer step for a whole group of problems ---------------------------
+// A session-sized single-camera problem solved through single-launch groups costs the host four launches and their polls; n of
+// them driven by n host threads were serialised by the runtime's launch path - eight 625-frame sessions took 0.48 ms per batch for
+// ~0.1 ms of device work, whatever the kernels did.  Problems of one device, model, focal mode and lane mapping therefore advance in
+// LOCKSTEP through k_gram1v_batch: launch s serves all of them (blockIdx.y = the problem; its argument block is an entry of a table
+// written once per batch), the host waits for every member's word of launch s and enqueues launch s + 1 while any member is
+// still running; a member that has finished leaves its later workgroups at their first look at the state.  Same arithmetic per
+// problem as its own single-launch groups with this lane mapping: same verdicts, iteration counts, bits.
+struct IterGroupKey { int device, model, one_focal, lpf; bool operator==(const IterGroupKey& o) const { return device == o.device && model == o.model && one_focal == o.one_focal && lpf == o.lpf; } };
+// the lane mapping of the problem's single-launch groups when it is one of `share` problems side by side (0: that form does not apply)
+static int batch_iter_lpf(const ccal_problem* p, int share) {
+    if (p->n_cams != 1 || p->sharded() || p->n_obs <= 0 || p->K > kFusedMaxK || dev_env("CCAL_DISABLE_FUSED") || dev_env("CCAL_BATCH_LOCKSTEP_OFF")) return 0;
+    if (p->cams[0].model == kOCV5) return 0;                                   // (k_gram2 + reduce + head there)
+    const int avg = (int)(p->n_corners / std::max(p->n_obs, 1));
+    const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, avg, p->K, share);
+    if (rows <= 0 || 2 * rows > fused_partial_rows(p->n_obs)) return 0;
+    return fused_iter_lpf(p->n_obs, avg, share);
+}
+// solve the members of one group; rc / reps per member.  Runs on the caller's thread.
+static void run_iter_group(const IterGroupKey& key, const std::vector<int>& members, ccal_problem** ps, const ccal_solver_opts* o, bool host_io,
+                           double** intr_io, double** poses_io, int share, std::vector<int>& rc, ccal_report* reps) {
+    const int n = (int)members.size();
+    ccal_ctx* c0 = ps[members[0]]->ctx;
+    hipStream_t st = c0->stream;
+    auto fail_all = [&](int code, const char* why) { for (int i : members) { rc[i] = code; note_error(ps[i]->ctx, why); } };
+    if (hipSetDevice(c0->device) != hipSuccess) { fail_all(CCAL_ERR_HIP, "hipSetDevice failed"); return; }
+    std::vector<std::unique_ptr<FusedJob>> jobs;
+    jobs.reserve((size_t)n);
+    int max_rows = 0, max_groups = 0;
+    for (int i : members) {
+        ccal_problem* p = ps[i];
+        int r = normal_ws_ensure(p);
+        std::unique_ptr<FusedJob> j;
+        if (r == CCAL_OK) {
+            // a stale launch of this problem's last solve may still sit in ITS OWN stream: the group's launches run elsewhere
+            if (p->nws->fws && p->nws->fws->tail_pending && p->ctx->stream != st) { (void)hipStreamSynchronize(p->ctx->stream); p->nws->fws->tail_pending = false; }
+            const bool fresh = !p->nws->fws;                     // begin() makes the workspace: its clears are ordered on the problem's own stream
+            j.reset(new FusedJob(p, o, host_io, host_io ? intr_io[i] : nullptr, host_io && poses_io ? poses_io[i] : nullptr, nullptr));
+            j->w = p->nws; j->st = st; j->share = share; j->batch_member = true;
+            r = j->begin();
+            if (r == CCAL_OK && fresh && p->ctx->stream != st && hipStreamSynchronize(p->ctx->stream) != hipSuccess) { r = CCAL_ERR_HIP; note_error(p->ctx, "hipStreamSynchronize failed"); }
+            if (r == CCAL_OK && (j->iter_rows <= 0 || fused_iter_lpf(p->n_obs, j->fa.avg_corners, share) != key.lpf)) { r = CCAL_ERR_INVALID_ARG; note_error(p->ctx, "ccal_solve_batch: lockstep group mismatch"); }
+        }
+        if (r != CCAL_OK) { fail_all(r, ccal_last_error(p->ctx)); (void)hipStreamSynchronize(st); return; }
+        max_rows = std::max(max_rows, j->iter_rows); max_groups = std::max(max_groups, j->max_groups);
+        jobs.push_back(std::move(j));
+    }
+    // the table: grown on demand, kept by the group's first context
+    const size_t bytes = (size_t)n * sizeof(FusedArgs);
+    if (c0->batch_tab_bytes < bytes) {
+        if (c0->d_batch_tab) (void)hipFree(c0->d_batch_tab);
+        if (c0->h_batch_tab) (void)hipHostFree(c0->h_batch_tab);
+        c0->d_batch_tab = nullptr; c0->h_batch_tab = nullptr; c0->batch_tab_bytes = 0;
+        const size_t want = std::max(bytes, (size_t)16 * sizeof(FusedArgs));
+        if (hipMalloc((void**)&c0->d_batch_tab, want) != hipSuccess || hipHostMalloc((void**)&c0->h_batch_tab, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); fail_all(CCAL_ERR_NO_MEMORY, "ccal_solve_batch: out of memory for the batch table"); (void)hipStreamSynchronize(st); return;
+        }
+        c0->batch_tab_bytes = want;
+    }
+    FusedArgs* h_tab = reinterpret_cast<FusedArgs*>(c0->h_batch_tab);
+    for (int k = 0; k < n; ++k) h_tab[k] = jobs[(size_t)k]->batch_entry();
+    bool ok = hipMemcpyAsync(c0->d_batch_tab, h_tab, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    std::vector<char> fin((size_t)n, 0);
+    int n_fin = 0, err = CCAL_OK;
+    for (int s = 1; ok && n_fin < n && s <= max_groups; ++s) {
+        if (launch_gram_iter_batch(key.model, key.one_focal != 0, key.lpf, reinterpret_cast<const FusedArgs*>(c0->d_batch_tab), n, max_rows, s, st) != hipSuccess) { ok = false; break; }
+        const auto t_wait = std::chrono::steady_clock::now();
+        std::vector<long> spins((size_t)n, 0);
+        int arrived_n = n_fin;
+        std::vector<char> got(fin);
+        while (arrived_n < n) {
+            for (int k = 0; k < n; ++k) {
+                if (got[(size_t)k]) continue;
+                FusedJob* j = jobs[(size_t)k].get();
+                j->seq = s;
+                bool arrived = false;
+                const int r = check_status(j->ctx, st, j->f->h_status, j->dev_state(), s, j->timeout_s, t_wait, &spins[(size_t)k], &arrived);
+                if (r != CCAL_OK) { err = r; ok = false; break; }
+                if (!arrived) continue;
+                got[(size_t)k] = 1; ++arrived_n;
+                const uint64_t wd = j->f->h_status->word;
+                if (status_done(wd) && status_done_seq(wd) <= s) { fin[(size_t)k] = 1; ++n_fin; }
+                else if (o->verbose) std::printf("[ccal %s] problem %d iter %d cost %.12g\n", o->method == CCAL_METHOD_LM ? "LM" : "GN", members[(size_t)k], j->f->h_status->iter, j->f->h_status->cur_cost);
+            }
+            if (!ok) break;
+        }
+    }
+    // nothing of the group may still run when the members' buffers change hands (end() swaps parameter sets; the next solve of a
+    // member may use its own stream)
+    if (hipStreamSynchronize(st) != hipSuccess) ok = false;
+    for (int k = 0; k < n; ++k) {
+        FusedJob* j = jobs[(size_t)k].get();
+        const int i = members[(size_t)k];
+        if (!ok) { rc[i] = err != CCAL_OK ? err : CCAL_ERR_HIP; if (err == CCAL_OK) note_error(j->ctx, "ccal_solve_batch: a launch of the lockstep group failed"); j->f->tail_pending = false; continue; }
+        j->finished = true;
+        rc[i] = j->end(reps ? &reps[i] : nullptr);
+        j->f->tail_pending = false;
+    }
+}
+
 namespace ccal {
 void ctx_worker_submit(ccal_ctx* ctx, std::function<void()> fn) { ctx_worker(ctx)->submit(std::move(fn)); }
 void ctx_worker_wait(ccal_ctx* ctx) { if (ctx->worker) ctx->worker->wait(); }
@@ -1097,12 +1222,30 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
     std::vector<int> rc(n, CCAL_ERR_HIP);
     std::vector<ccal_ctx*> ctxs;                                  // distinct contexts, in order of first appearance
     for (int i = 0; i < n; ++i) if (std::find(ctxs.begin(), ctxs.end(), ps[i]->ctx) == ctxs.end()) ctxs.push_back(ps[i]->ctx);
-    // how many of the batch's contexts sit on each GPU: a problem's launches are sized for its share of that chip (FusedArgs::share)
-    auto side_by_side = [&](const ccal_ctx* c) { int k = 0; for (ccal_ctx* q : ctxs) k += q->device == c->device ? 1 : 0; return k; };
+    // how many of the batch's problems sit on each GPU: a problem's launches are sized for its share of that chip (FusedArgs::share)
+    auto side_by_side = [&](const ccal_ctx* c) { int k = 0; for (int i = 0; i < n; ++i) k += ps[i]->ctx->device == c->device ? 1 : 0; return k; };
+    // session-sized single-camera problems of one device, model, focal mode and lane mapping advance in lockstep, one launch per
+    // step for the whole group (run_iter_group); everything else is driven per context as before
+    std::vector<IterGroupKey> gkeys;
+    std::vector<std::vector<int>> gmembers;
+    std::vector<char> grouped((size_t)n, 0);
+    for (int i = 0; i < n; ++i) {
+        const int share = side_by_side(ps[i]->ctx);
+        const int lpf = share >= 2 ? batch_iter_lpf(ps[i], share) : 0;
+        if (!lpf) continue;
+        const IterGroupKey key = { ps[i]->ctx->device, ps[i]->cams[0].model, ps[i]->one_focal ? 1 : 0, lpf };
+        size_t g = 0;
+        while (g < gkeys.size() && !(gkeys[g] == key)) ++g;
+        if (g == gkeys.size()) { gkeys.push_back(key); gmembers.emplace_back(); }
+        gmembers[g].push_back(i);
+    }
+    for (size_t g = 0; g < gkeys.size(); ++g) if (gmembers[g].size() >= 2) for (int i : gmembers[g]) grouped[(size_t)i] = 1;
+    ctxs.clear();                                                  // contexts that still have problems of their own to drive
+    for (int i = 0; i < n; ++i) if (!grouped[(size_t)i] && std::find(ctxs.begin(), ctxs.end(), ps[i]->ctx) == ctxs.end()) ctxs.push_back(ps[i]->ctx);
     auto run_ctx = [&](ccal_ctx* c) noexcept {
         const int n_side = side_by_side(c);
         for (int i = 0; i < n; ++i) {
-            if (ps[i]->ctx != c) continue;
+            if (ps[i]->ctx != c || grouped[(size_t)i]) continue;
             try {
                 rc[i] = solve_entry(ps[i], o, host_io, host_io ? intr_io[i] : nullptr, host_io && poses_io ? poses_io[i] : nullptr,
                                     host_io && extr_io ? extr_io[i] : nullptr, reps ? &reps[i] : nullptr, nullptr, n_side);
@@ -1111,10 +1254,13 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
             if (reps && rc[i] != CCAL_OK && rc[i] != reps[i].status) { reps[i] = ccal_report{}; reps[i].status = rc[i]; }
         }
     };
+    bool any_group = false;
+    for (size_t g = 0; g < gkeys.size(); ++g) any_group = any_group || gmembers[g].size() >= 2;
     std::vector<ccal_ctx_worker*> busy;
     busy.reserve(ctxs.size());
     try {
-        for (size_t k = 1; k < ctxs.size(); ++k) {
+        // (the caller's thread drives the lockstep groups when there are any, else the first context)
+        for (size_t k = any_group ? 0 : 1; k < ctxs.size(); ++k) {
             ccal_ctx_worker* wk = ctx_worker(ctxs[k]);
             ccal_ctx* c = ctxs[k];
             wk->submit([&run_ctx, c] { run_ctx(c); });
@@ -1124,7 +1270,16 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
         for (ccal_ctx_worker* wk : busy) wk->wait();
         throw;
     }
-    if (!ctxs.empty()) run_ctx(ctxs[0]);
+    if (any_group) {
+        for (size_t g = 0; g < gkeys.size(); ++g) {
+            if (gmembers[g].size() < 2) continue;
+            try {
+                run_iter_group(gkeys[g], gmembers[g], ps, o, host_io, intr_io, poses_io, side_by_side(ps[gmembers[g][0]]->ctx), rc, reps);
+            } catch (const std::bad_alloc&) { for (int i : gmembers[g]) rc[i] = CCAL_ERR_NO_MEMORY;
+            } catch (...) { for (int i : gmembers[g]) rc[i] = CCAL_ERR_HIP; }
+            for (int i : gmembers[g]) if (reps && rc[i] != CCAL_OK && rc[i] != reps[i].status) { reps[i] = ccal_report{}; reps[i].status = rc[i]; }
+        }
+    } else if (!ctxs.empty()) run_ctx(ctxs[0]);
     for (ccal_ctx_worker* wk : busy) wk->wait();
     for (int i = 0; i < n; ++i)
         if (rc[i] == CCAL_ERR_HIP || rc[i] == CCAL_ERR_INVALID_ARG || rc[i] == CCAL_ERR_NO_MEMORY || rc[i] == CCAL_ERR_UNSUPPORTED) return rc[i];

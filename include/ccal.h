@@ -252,13 +252,13 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
 int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* opts, ccal_report* report);
 /* n INDEPENDENT problems solved side by side in ONE call (the per-camera calib_camera calls of a rig, the retries of
  * src/bin/camera_calibration.rs:205-246, many sessions of a service): a session-sized problem (a few hundred frames) leaves
- * the GPU almost idle - its iteration is three dependent, latency-bound launches - so every context's problems are driven by
- * a host thread of their own (the caller's thread takes the first context) and the contexts' streams overlap on the device.
- * Create the problems on contexts of their own (ccal_ctx_create with stream NULL) to make them overlap; problems that share a
- * context are solved one after the other.  A problem's launches are sized for its share of the GPU (the batch's contexts on that device):
- * fewer, longer wavefronts than a lone ccal_solve takes, so that the sessions really run side by side - same verdicts and iteration
- * counts as n ccal_solve calls, results equal to them up to the order of summation (<= 1e-11 relative; bit-identical when all
- * problems share one context).  intr_io == NULL: device-resident like ccal_solve_dev (poses_io / extr_io ignored);
+ * the GPU almost idle - one latency-bound launch per optimizer step.  Session-sized single-camera problems (UCM / EUCM / KB4) of one
+ * GPU, model and focal mode advance in LOCKSTEP: ONE launch per step serves all of them (the problems' workgroups side by side), so
+ * a batch of eight costs the host what one solve costs.  Everything else (rigs, large problems, OPENCV5) is driven per context by a
+ * host thread of its own (create such problems on contexts of their own - ccal_ctx_create with stream NULL - to make them overlap;
+ * those that share a context are solved one after the other).  A problem's launches are sized for its share of the GPU (the batch's
+ * problems on that device): fewer, longer wavefronts than a lone ccal_solve takes - same verdicts and iteration counts as n
+ * ccal_solve calls, results equal to them up to the order of summation (<= 1e-11 relative).  intr_io == NULL: device-resident like ccal_solve_dev (poses_io / extr_io ignored);
  * else intr_io[i] / poses_io[i] / extr_io[i] as in ccal_solve.  Every problem's verdict goes to reports[i].status; the return
  * value is CCAL_OK unless a call failed for another reason (then the first such code).  Sharded problems are refused. */
 int ccal_solve_batch(ccal_problem** problems, int n, const ccal_solver_opts* opts,

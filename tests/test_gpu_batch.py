@@ -1,7 +1,7 @@
 """ccal_solve_batch: independent problems solved side by side from one host thread (the per-camera calib_camera calls of a
 rig, the retries of src/bin/camera_calibration.rs:205-246) - the same verdicts, iteration counts and accept / reject sequences as
-solving them one after the other; results bit-identical when the problems share a context, equal up to the order of summation
-(1e-11) when every problem has a context of its own (its launches are then sized for its share of the GPU: other lane mappings)."""
+solving them one after the other; results equal up to the order of summation (1e-11): a problem's launches are sized for its share
+of the GPU (other lane mappings), and session-sized single-camera problems of one model advance in lockstep, one launch per step."""
 import numpy as np
 import pytest
 
@@ -30,10 +30,7 @@ def test_batch_equals_sequential(method, own_context):
     seq = [p.solve(s.intr0, s.poses0, s.extr0, opts=opts) for p, s in zip(probs, sps)]
     reps, res = Problem.solve_batch(probs, opts, starts=[(s.intr0, s.poses0, s.extr0) for s in sps])
     def same(a, b):
-        if own_context:
-            np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13)
-        else:
-            np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, b, rtol=1e-11, atol=1e-13)
     for (i0, p0, e0, r0), rep, (i1, p1, e1) in zip(seq, reps, res):
         assert (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected) == (r0.status, r0.iterations, r0.lm_accepted, r0.lm_rejected)
         same(rep.final_cost, r0.final_cost); same(rep.initial_cost, r0.initial_cost)
@@ -47,6 +44,53 @@ def test_batch_equals_sequential(method, own_context):
         i1, p1, e1 = p.download_params()
         assert rep.iterations == r0.iterations
         same(rep.final_cost, r0.final_cost); same(i1, i0); same(p1, p0)
+    for p in probs:
+        p.close()
+
+
+@pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
+def test_lockstep_groups(method):
+    """Session-sized single-camera problems of one model and focal mode advance in lockstep - ONE launch per optimizer step for the
+    whole group (k_gram1v_batch): members of different sizes (different iteration counts, different row counts - the grid is the
+    largest one's), a member that finishes early, LM rejections on one member only, a member whose frames do not cover every slot
+    (its starting point arrives through k_unpack1 instead of the first launch), host pointers and the device-resident form; two
+    groups (EUCM and one-focal KB4) plus a rig that takes the per-context path in the same call."""
+    import dataclasses
+    sps = [synth.make_problem(300, "eucm", seed=31, outlier_frac=0.02), synth.make_problem(120, "eucm", seed=32, ragged=True),
+           synth.make_problem(12, "eucm", seed=1, outlier_frac=0.05, ragged=True, init_perturb=0.8),          # LM rejects steps here
+           synth.make_problem(625, "eucm", seed=34), synth.make_problem(200, "kb4", seed=35, xy_same_focal=True),
+           synth.make_problem(90, "kb4", seed=36, xy_same_focal=True, ragged=True), synth.make_problem(30, "eucm", n_cams=2, seed=37)]
+    # member 1: drop the last slot's frame -> not every slot observed (no fold)
+    s1 = sps[1]
+    keep = np.nonzero(s1.obs_slot != s1.n_slots - 1)[0]
+    offs = np.concatenate([[0], np.cumsum((s1.obs_offsets[1:] - s1.obs_offsets[:-1])[keep])]).astype(np.int64)
+    idx = np.concatenate([np.arange(s1.obs_offsets[o], s1.obs_offsets[o + 1]) for o in keep])
+    sps[1] = dataclasses.replace(s1, obs_cam=s1.obs_cam[keep].copy(), obs_slot=s1.obs_slot[keep].copy(), obs_offsets=offs,
+                                 p3d=s1.p3d[idx].copy(), p2d=s1.p2d[idx].copy())
+    ctxs = [Context(0) for _ in sps]
+    probs = [Problem.from_synth(c, s) for c, s in zip(ctxs, sps)]
+    for p in probs:
+        p.apply_reference_bounds()
+    opts = default_opts(method)
+    seq = [p.solve(s.intr0, s.poses0, s.extr0, opts=opts, raise_on_error=False) for p, s in zip(probs, sps)]
+    if method == _ffi.METHOD_LM:
+        assert seq[2][3].lm_rejected >= 1
+    for rep_i in range(2):                            # twice: the second batch starts behind the first one's last launches
+        reps, res = Problem.solve_batch(probs, opts, starts=[(s.intr0, s.poses0, s.extr0) for s in sps])
+        for (i0, p0, e0, r0), rep, (i1, p1, e1) in zip(seq, reps, res):
+            assert (rep.status, rep.iterations, rep.lm_accepted, rep.lm_rejected) == (r0.status, r0.iterations, r0.lm_accepted, r0.lm_rejected)
+            np.testing.assert_allclose(rep.final_cost, r0.final_cost, rtol=1e-11)
+            np.testing.assert_allclose(i1, i0, rtol=1e-11, atol=1e-13); np.testing.assert_allclose(p1, p0, rtol=1e-11, atol=1e-13)
+    for p, s in zip(probs, sps):
+        p.upload_params(s.intr0, s.poses0, s.extr0)
+    reps2, _ = Problem.solve_batch(probs, opts)
+    for p, (i0, p0, e0, r0), rep in zip(probs, seq, reps2):
+        i1, p1, e1 = p.download_params()
+        assert (rep.status, rep.iterations) == (r0.status, r0.iterations)
+        np.testing.assert_allclose(i1, i0, rtol=1e-11, atol=1e-13); np.testing.assert_allclose(p1, p0, rtol=1e-11, atol=1e-13)
+    # and a plain ccal_solve on a member afterwards (its own stream again) still gives its result
+    i2, p2, _, r2 = probs[0].solve(sps[0].intr0, sps[0].poses0, opts=opts)
+    np.testing.assert_array_equal(i2, seq[0][0]); np.testing.assert_array_equal(p2, seq[0][1])
     for p in probs:
         p.close()
 
