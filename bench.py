@@ -89,6 +89,57 @@ def _under_rocprofiler() -> bool:
         return False
 
 
+def _eval_kernel_source_hash():
+    """sha256 (16 hex digits) over the sources of the headline kernel: what a committed PMC figure was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("ccal_kernels_eval.hip", "ccal_device.hpp", "ccal_models.hpp"):
+        with open(os.path.join(ROOT, "camera_intrinsic_calibration_rs_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_traffic_now(args):
+    """HBM bytes per k_eval launch measured by THIS run: two short child runs of this file under rocprofv3 - `--pmc FETCH_SIZE`, then
+    `--pmc WRITE_SIZE` (they do not fit one pass; counters alone with --kernel-trace, as MI355X_MICROARCH.md prescribes) - on the same
+    workload, the guide's corrections applied (both counters are KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes:
+    x 2).  Returns (bytes per launch or None, how)."""
+    import csv, shutil, subprocess, tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    means = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ccal_pmc_", dir="/tmp")
+        try:
+            cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "20", "--warmup", "2", "--frames", str(args.frames),
+                   "--model", args.model, "--no-cpu-baseline", "--no-extra"]
+            env = dict(os.environ, CCAL_BENCH_TRAFFIC_CHILD="1", TMPDIR="/tmp")
+            r = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=300)
+            path = None
+            for dp, _dn, fn in os.walk(d):
+                for f in fn:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(dp, f)
+            if r.returncode != 0 or path is None:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode})"
+            per_dispatch = {}
+            for row in csv.DictReader(open(path)):
+                if "k_eval" in row["Kernel_Name"] and row["Counter_Name"] == ctr:
+                    per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])      # one row per XCD / instance
+            if not per_dispatch:
+                return None, f"no k_eval dispatches in the {ctr} pass"
+            means[ctr] = sum(per_dispatch.values()) / len(per_dispatch)
+        except Exception as e:  # noqa: BLE001
+            return None, f"rocprofv3 --pmc {ctr}: {e!r}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    traffic = 2.0 * means["FETCH_SIZE"] * 1024.0 + means["WRITE_SIZE"] * 1024.0
+    return traffic, ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over child runs of this "
+                     "command on the same workload; KiB units, FETCH_SIZE x 2 (gfx950), mean over the k_eval dispatches")
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -225,6 +276,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary (mode N / solver) measurements")
     ap.add_argument("--no-rig", action="store_true", help="skip the two-camera leg of the secondary measurements")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-run rocprofv3 --pmc passes behind roofline.traffic (two short child runs)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -334,19 +386,34 @@ def main():
         bytes_per_corner = 20 + 16 + 16 * D
         algo_bytes = n_corners * bytes_per_corner + sp.n_slots * 48
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command/workload
-        # (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; profiles/<round>/pmc_summary.json); null otherwise
+        # HBM bytes per launch: MEASURED BY THIS RUN where it can be (two short child runs of this command under rocprofv3 --pmc,
+        # FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, after the timed region); else the committed PMC passes of the same command
+        # and workload (profiles/<round>/pmc_summary.json) - accepted only while the kernel's sources still hash to what the
+        # committed figure was measured on (traffic_stale_if_kernel_changed); null otherwise
         traffic, traffic_source = None, None
-        try:
-            pmc_path = _latest_profile_file("pmc_summary.json")
-            with open(pmc_path) as f:
-                pmc = json.load(f)
-            if pmc.get("k_eval_algorithmic_bytes_per_launch") == algo_bytes:
-                traffic = pmc["k_eval_hbm_traffic_bytes_per_launch"]
-                # not measured by THIS run: the committed PMC passes of the same command and workload
-                traffic_source = os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes of this command, committed)"
-        except Exception:  # noqa: BLE001
-            traffic = None
+        kernel_hash = _eval_kernel_source_hash()
+        if world == 1 and not args.no_traffic and not _under_rocprofiler() and os.environ.get("CCAL_BENCH_TRAFFIC_CHILD") != "1":
+            try:
+                traffic, traffic_source = _pmc_traffic_now(args)
+            except Exception as e:  # noqa: BLE001
+                traffic, traffic_source = None, f"in-run PMC measurement failed: {e!r}"
+        traffic_note = traffic_source if traffic is None else None
+        if traffic is None:
+            try:
+                pmc_path = _latest_profile_file("pmc_summary.json")
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                if pmc.get("k_eval_algorithmic_bytes_per_launch") == algo_bytes and pmc.get("k_eval_source_sha256_16") == kernel_hash:
+                    traffic = pmc["k_eval_hbm_traffic_bytes_per_launch"]
+                    # not measured by THIS run: the committed PMC passes of the same command, workload and kernel sources
+                    traffic_source = os.path.relpath(pmc_path, ROOT) + " (rocprofv3 --pmc passes of this command, committed; kernel sources unchanged since)"
+                elif pmc.get("k_eval_algorithmic_bytes_per_launch") == algo_bytes:
+                    traffic_source = (os.path.relpath(pmc_path, ROOT) + " is STALE: the kernel's sources changed since it was measured (" +
+                                      str(pmc.get("k_eval_source_sha256_16")) + " -> " + kernel_hash + "); traffic left null")
+            except Exception:  # noqa: BLE001
+                traffic = None
+            if traffic_note and traffic_source:
+                traffic_source += f" [in-run measurement: {traffic_note}]"
         out = {
             "metric": "corner residual+Jacobian evals/sec; LM iters/sec to converge (EUCM, TUM-VI cam0)",
             "value": total_corners * args.steps / elapsed,
@@ -364,6 +431,7 @@ def main():
                        "clock_ramp_s": CLOCK_RAMP_S, "clock_ramp_untimed_launches": ramp_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "traffic_stale_if_kernel_changed": kernel_hash,
                          "kernel": "k_eval", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": algo_bytes},
         }
 

@@ -214,6 +214,12 @@ __device__ __forceinline__ void head_wave(const HeadIO& a, HeadShared& hs, const
     }
 }
 
+// PUBLISH-LAST INVARIANT (FusedJob::end relies on it): the host copies the result out of pinned memory as soon as it reads a
+// status word that says `done`, without synchronising the stream.  That is correct only because (1) every store of the result below
+// precedes the system-scope fence, (2) the fence and a workgroup barrier precede the store of the status word, and (3) NOTHING
+// is written to result_host - or to anything else the host reads on `done` - after the word.  A future store behind the publish
+// breaks the host's result silently; tests/test_gpu_iter.py::test_zero_copy_result_is_the_device_state holds the host's copy
+// against the device's after a synchronise.
 // The whole workgroup of the writer, behind head_wave and a workgroup barrier: a group that finishes the solve copies the
 // accepted point straight to the caller's side of the bus (session-sized solves with host pointers, result_host != NULL) -
 // every wavefront of the workgroup, 16-byte stores (tools/ubench/host_publish.hip: 30 KB in 2.9 us with four wavefronts,

@@ -98,12 +98,19 @@ __global__ __launch_bounds__(256) void k_sel_hist(const double* __restrict__ val
     for (int b = threadIdx.x; b < 2 * kSelBins; b += 256) (&hist[0][0])[b] = 0;
     __syncthreads();
     const unsigned long long* keys = reinterpret_cast<const unsigned long long*>(vals);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        const unsigned long long k = keys[i];
-        const uint32_t d = (uint32_t)(k >> shift) & (uint32_t)(nb - 1);
-        const unsigned long long hi = pass == 0 ? 0ull : (k >> hi_shift);
-        if (pass == 0 || hi == st.prefix[0]) atomicAdd(&hist[0][d], 1u);
-        if (pass == 0 || hi == st.prefix[1]) atomicAdd(&hist[1][d], 1u);
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        unsigned long long k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = i0 + u * stride < n ? keys[i0 + u * stride] : 0ull;       // four loads in flight
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * stride >= n) continue;
+            const uint32_t d = (uint32_t)(k[u] >> shift) & (uint32_t)(nb - 1);
+            const unsigned long long hi = pass == 0 ? 0ull : (k[u] >> hi_shift);
+            if (pass == 0 || hi == st.prefix[0]) atomicAdd(&hist[0][d], 1u);
+            if (pass == 0 || hi == st.prefix[1]) atomicAdd(&hist[1][d], 1u);
+        }
     }
     __syncthreads();
     for (int b = threadIdx.x; b < 2 * kSelBins; b += 256) {
@@ -149,10 +156,10 @@ __global__ __launch_bounds__(64) void k_sel_finish(SelWork* w, const int n_part,
     w->out[1] = avg;
 }
 
-// The whole selection in ONE launch of one workgroup for session-sized arrays (a camera session's ~50 000 errors: nine launches
-// of the general form are ~45 us of launch latency for ~3 us of work).  Same digits, same keys, the same fixed-point sum: the same
-// bits as the general form.
-constexpr int kSelOneMax = 1 << 17;
+// The whole selection in ONE launch of one workgroup for small arrays (a few thousand errors: nine launches of the general form are
+// ~45 us of launch latency for no work; beyond ~8 000 values one workgroup's loads are the slower way - measured: 51 000 values 0.1 ms).
+// Same digits, same keys, the same fixed-point sum: the same bits as the general form.
+constexpr int kSelOneMax = 1 << 13;
 __global__ __launch_bounds__(1024) void k_sel_one(const double* __restrict__ vals, const int n, SelWork* w, const double inv,
                                                   const long long rank0, const long long rank1, const int have99) {
     __shared__ uint32_t hist[2][kSelBins];
@@ -278,11 +285,12 @@ static inline size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
 // One camera's errors out of the per-corner errors of the whole problem (device), packed in observation-frame order into the
 // problem's scratch block [offsets | values | room for the statistics' work area] (*d_out: the values, valid until the next call
 // that uses the scratch; *n_out doubles; complete when the function returns).  A camera without corners: *d_out = NULL, *n_out = 0.
-hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s) {
+static hipError_t gather_camera_errors(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s,
+                                       std::vector<int64_t>& dst, bool sync) {
     *d_out = nullptr; *n_out = 0;
     const CamLayout& cl = p->cams[cam];
     const int n_list = (int)cl.obs.size();
-    std::vector<int64_t> dst(n_list + 1, 0);
+    dst.assign((size_t)n_list + 1, 0);
     for (int i = 0; i < n_list; ++i) dst[i + 1] = dst[i] + (p->h_obs_off[cl.obs[i] + 1] - p->h_obs_off[cl.obs[i]]);
     const int64_t n = dst[n_list];
     if (n <= 0) return hipSuccess;
@@ -293,10 +301,15 @@ hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, d
     double* d_a = reinterpret_cast<double*>(p->d_scratch + b_off);
     e = hipMemcpyAsync(d_dst, dst.data(), (size_t)(n_list + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) { hipLaunchKernelGGL(k_gather_err, dim3(n_list), dim3(256), 0, s, d_err, p->d_obs_off, cl.d_obs, n_list, d_dst, d_a); e = hipGetLastError(); }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);       // (dst is a host vector of this frame; the multi-GPU form copies d_a across devices next)
+    if (e == hipSuccess && sync) e = hipStreamSynchronize(s);       // (the multi-GPU form copies d_a across devices next; else the caller's own
+                                                                    // synchronise covers `dst`, which it keeps until then)
     if (e != hipSuccess) return e;
     *d_out = d_a; *n_out = n;
     return hipSuccess;
+}
+hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s) {
+    std::vector<int64_t> dst;
+    return gather_camera_errors(p, cam, d_err, d_out, n_out, s, dst, true);
 }
 
 // d_err: per-corner errors of the whole problem (device).  Returns the two statistics of camera `cam`: the gather above, then the
@@ -305,7 +318,8 @@ hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, d
 hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s) {
     double* d_a = nullptr;
     int64_t n = 0;
-    hipError_t e = camera_errors_device(p, cam, d_err, &d_a, &n, s);
+    std::vector<int64_t> dst;                               // (read by an asynchronous copy: alive until order_stats_device has synchronised)
+    hipError_t e = gather_camera_errors(p, cam, d_err, &d_a, &n, s, dst, false);
     if (e != hipSuccess) return e;
     if (n <= 0) return hipErrorInvalidValue;
     char* work = reinterpret_cast<char*>(d_a) + up256((size_t)n * sizeof(double));

@@ -123,7 +123,9 @@ def main() -> None:
         rd = 2.0 * out_c[ev]["FETCH_SIZE"]["mean"] * 1024.0
         wr = out_c[ev]["WRITE_SIZE"]["mean"] * 1024.0
         summary.update(k_eval_hbm_traffic_bytes_per_launch=rd + wr, k_eval_read_bytes=rd, k_eval_write_bytes=wr,
-                       k_eval_algorithmic_bytes_per_launch=bench["roofline"]["algorithmic_bytes_per_launch"])
+                       k_eval_algorithmic_bytes_per_launch=bench["roofline"]["algorithmic_bytes_per_launch"],
+                       # what the figure was measured on: bench.py accepts it only while the kernel's sources still hash to this
+                       k_eval_source_sha256_16=bench["roofline"].get("traffic_stale_if_kernel_changed"))
     summary["counters"] = out_c
     with open(os.path.join(dst, "pmc_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)

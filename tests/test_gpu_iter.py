@@ -220,3 +220,24 @@ def test_candidate_poses_formed_in_the_gram_prologue_equal_k_backsub(oracle):
             assert (v1[0], v1[1]) == (ro.status, ro.iterations)
             if ro.status == 0:
                 np.testing.assert_allclose(p1, po, rtol=0, atol=1e-6); np.testing.assert_allclose(e1, eo, rtol=0, atol=1e-6)
+
+
+def test_zero_copy_result_is_the_device_state(gpu_ctx):
+    """Session-sized ccal_solve returns from its poll of the status word without a copy and without a synchronise: the launch that
+    said `done` wrote intrinsics and poses into pinned host memory BEFORE it published the word (head_finish's publish-last
+    invariant).  The host's copy must be what the device holds once the stream has drained - for the single-launch form, the
+    three-launch form's sizes (2 000+ frames: staged copies) and LM, repeated (a stale word of the previous solve must not end the
+    next one early)."""
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.engine import Problem, default_opts
+    for frames, model in ((60, "eucm"), (625, "eucm"), (300, "kb4"), (2500, "eucm")):
+        sp = synth.make_problem(frames, model, seed=frames, outlier_frac=0.01)
+        gp = Problem.from_synth(gpu_ctx, sp)
+        for method in (0, 1, 0):
+            i, p, _, r = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+            i_d, p_d, _ = gp.download_params()              # synchronises the stream, reads the accepted set
+            assert r.status == 0
+            np.testing.assert_array_equal(p, p_d)
+            P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+            np.testing.assert_array_equal(i[0, :P], i_d[0, :P])
+        gp.close()
