@@ -10,6 +10,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $REPO/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 timeout 600 python3 $REPO/bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err
+# the headline command alone (--no-extra): k_eval's average here is the figure that must agree with roofline.kernel_ms (the full
+# command below also launches k_eval on half problems - extra.multi_eval - which would drag the average down)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -o stats -- $BENCH --no-extra --no-traffic > $OUT/stats_headline_bench.json 2> $OUT/stats_headline.err
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.json 2> $OUT/stats.err
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $BENCH --no-extra > $OUT/pmc_fetch_bench.json 2> $OUT/pmc_fetch.err
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- $BENCH --no-extra > $OUT/pmc_write_bench.json 2> $OUT/pmc_write.err

@@ -36,6 +36,9 @@ def main() -> None:
     dst = os.path.join(ROOT, "profiles", tag)
     os.makedirs(dst, exist_ok=True)
     shutil.copyfile(os.path.join(src, "stats", "stats_kernel_stats.csv"), os.path.join(dst, "kernel_stats_bench_steps50.csv"))
+    hl = os.path.join(src, "stats_headline", "stats_kernel_stats.csv")       # the headline command alone: k_eval's average = roofline.kernel_ms
+    if os.path.exists(hl):
+        shutil.copyfile(hl, os.path.join(dst, "kernel_stats_headline.csv"))
     line = [l for l in open(os.path.join(src, "bench_full.json")) if l.startswith("{")][-1]
     with open(os.path.join(dst, "bench_full.json"), "w") as f:
         f.write(line)

@@ -339,3 +339,27 @@ def test_native_rccl_two_ranks(model, n_cams, method):
     np.testing.assert_allclose(i0, intr1, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(np.concatenate([p0, p1]), poses1, rtol=0, atol=1e-9)
     assert abs(c0 - rep1.final_cost) <= 1e-10 * rep1.final_cost
+
+
+def test_bench_launches_its_own_ranks_on_the_gpu():
+    """`python bench.py --gpus 2` with no launcher around it, on the GPU: bench.py's own parent starts two workers (CCAL_BENCH_BACKEND=gloo
+    lets both ranks share the box's one GPU - the numbers mean nothing, the code path is the multi-rank one: per-rank mode E, the
+    max-over-ranks protocol, the frame-sharded solves with one collective per step through the callback transport, the split
+    problem cut by ccal_partition_slots) and relays rank 0's line."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CCAL_BENCH_BACKEND="gloo", CCAL_BENCH_CONFIG3_FRAMES="2000", CCAL_BENCH_NO_CONCURRENT="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--frames", "1000",
+                        "--no-cpu-baseline", "--no-rig", "--no-traffic"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["launcher"]["workers_spawned"] == 2 and out["launcher"]["worker_exit_codes"] == [0, 0]
+    assert out["config"]["frames_total"] == 2000 and out["value"] > 0
+    sh = out["extra"]["sharded_solve"]
+    assert "error" not in sh and sh["gn"]["status"] == 0 and sh["lm"]["status"] == 0 and sh["frames_total"] == 2000
+    c3 = out["extra"]["config3_split"]
+    assert "error" not in c3 and c3["gn"]["status"] == 0 and c3["frames_total"] == 2000

@@ -13,11 +13,36 @@ ap.add_argument("--seconds", type=float, default=60.0)
 ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--shards", type=int, default=0, help="also solve every case through ccal_multi_solve over this many shards of GPU 0 "
                 "(in-process transport) and hold it against the unsharded device solve: verdict, iterations, intrinsics")
+ap.add_argument("--batch", type=int, default=0, help="also re-solve the cases in groups of this many through ONE ccal_solve_batch call per group "
+                "(lockstep groups for session-sized single-camera problems of one model, per-context drivers for the rest) and hold every member "
+                "against its own ccal_solve: verdict, iterations, intrinsics, poses")
 args = ap.parse_args()
 mctx = MultiContext([0] * args.shards) if args.shards > 1 else None
 worst_sh = {"intr": 0.0, "poses": 0.0}; n_sh = 0
 rng = np.random.default_rng(args.seed)
 ctx = Context(0, lib=_ffi.load_for_switches())      # developer switches (CCAL_SCHURQ=1, ...) live in the second library
+pending = {0: [], 1: []}; n_batched = 0; worst_b = {"intr": 0.0, "poses": 0.0}
+def flush_batch(method, lst):
+    """ONE ccal_solve_batch over the pending problems of one method; every member against its own earlier ccal_solve."""
+    global n_batched
+    probs = [e[0] for e in lst]
+    try:
+        reps, res = Problem.solve_batch(probs, default_opts(method), starts=[(e[1].intr0, e[1].poses0, e[1].extr0) for e in lst])
+    except CcalError as ex:
+        fails.append(dict(what="solve_batch raised", err=repr(ex), cases=[e[4] for e in lst][:3])); reps = None
+    if reps is not None:
+        for (gp_, sp_, g_, gs_, case_), rep, r in zip(lst, reps, res):
+            n_batched += 1
+            bs = (rep.status, rep.iterations if rep.status == 0 else -1)
+            if bs[0] != gs_[0] or (gs_[0] == 0 and bs[1] != gs_[1]):
+                fails.append(dict(case=case_, what="batch vs single verdict", batch=bs, single=gs_, method=method))
+            elif gs_[0] == 0:
+                dbi = float((np.abs(r[0] - g_[0]) / np.maximum(np.abs(g_[0]), 1e-3)).max()); dbp = float(np.abs(r[1] - g_[1]).max())
+                worst_b["intr"] = max(worst_b["intr"], dbi); worst_b["poses"] = max(worst_b["poses"], dbp)
+                if dbi > 1e-7 or dbp > 1e-7:
+                    fails.append(dict(case=case_, what="batch vs single result", d_intr=dbi, d_poses=dbp, method=method))
+    for e in lst:
+        e[0].close()
 t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []; both_none = []
 while time.time() - t0 < args.seconds:
     model = rng.choice(["ucm", "eucm", "kb4", "opencv5"])
@@ -94,6 +119,15 @@ while time.time() - t0 < args.seconds:
                 fails.append(dict(case=case, what="solve", gpu=gs, oracle=os_, d_intr=di, d_poses=dp, method=method))
     except Exception as e:  # noqa: BLE001
         fails.append(dict(case=case, what="exception", err=repr(e)))
-    gp.close(); n += 1
-print(json.dumps(dict(cases=n, worst=worst, sharded_cases=n_sh, shards=args.shards, worst_sharded_vs_unsharded=worst_sh, n_fail=len(fails), fails=fails[:6], n_both_none_different_code=len(both_none),
+        g = None
+    n += 1
+    if args.batch > 1 and g is not None and frames <= 2300:
+        pending[method].append((gp, sp, g, gs, case))
+        if len(pending[method]) >= args.batch:
+            flush_batch(method, pending[method]); pending[method] = []
+    else:
+        gp.close()
+for mth, lst in pending.items():
+    if lst: flush_batch(mth, lst)
+print(json.dumps(dict(cases=n, worst=worst, batched_cases=n_batched, batch=args.batch, worst_batch_vs_single=worst_b, sharded_cases=n_sh, shards=args.shards, worst_sharded_vs_unsharded=worst_sh, n_fail=len(fails), fails=fails[:6], n_both_none_different_code=len(both_none),
                       both_none=both_none[:3]), indent=1))
