@@ -190,15 +190,7 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     auto up256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
     size_t total = 5 * up256((nc + 1) * sizeof(float)) + 2 * up256((p->h_obs_off.size() + 1) * sizeof(int64_t)) +
                    2 * up256((p->h_obs_cam.size() + 1) * sizeof(int32_t)) + 2 * (up256(ni * 8) + up256(np6 * 8) + up256(ne * 8));
-    for (int c = 0; c < d->n_cams; ++c) {
-        CamLayout& cl = p->cams[c];
-        cl.items.clear();
-        for (int32_t o : cl.obs) {
-            const int64_t n = p->h_obs_off[(size_t)o + 1] - p->h_obs_off[(size_t)o];
-            for (int64_t b0 = 0; b0 < n; b0 += 64) cl.items.push_back((int64_t)(uint32_t)o | (b0 << 32));
-        }
-        total += up256((cl.obs.size() + 1) * sizeof(int32_t)) + up256((cl.items.size() + 1) * sizeof(int64_t));
-    }
+    for (int c = 0; c < d->n_cams; ++c) total += up256((p->cams[c].obs.size() + 1) * sizeof(int32_t));
     HIP_TRY(ctx, hipMalloc((void**)&p->d_block, total));
     HIP_TRY(ctx, hipMemsetAsync(p->d_block, 0, total, ctx->stream));
     {
@@ -216,7 +208,6 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
         HIP_TRY(ctx, put(&p->d_obs_cam, (const int32_t*)p->h_obs_cam.data(), p->h_obs_cam.size()));
         HIP_TRY(ctx, put(&p->d_obs_slot, (const int32_t*)p->h_obs_slot.data(), p->h_obs_slot.size()));
         for (int c = 0; c < d->n_cams; ++c) HIP_TRY(ctx, put(&p->cams[c].d_obs, (const int32_t*)p->cams[c].obs.data(), p->cams[c].obs.size()));
-        for (int c = 0; c < d->n_cams; ++c) HIP_TRY(ctx, put(&p->cams[c].d_items, (const int64_t*)p->cams[c].items.data(), p->cams[c].items.size()));
         double** bufs[6] = { &p->d_intr, &p->d_poses, &p->d_extr, &p->d_intr_c, &p->d_poses_c, &p->d_extr_c };
         const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
         for (int i = 0; i < 6; ++i) { *bufs[i] = reinterpret_cast<double*>(q); q += up256(sz[i] * 8); }
@@ -348,7 +339,6 @@ static KArgs make_args(const ccal_problem* p, int cam) {
     a.x = p->d_x; a.y = p->d_y; a.z = p->d_z; a.u = p->d_u; a.v = p->d_v;
     a.obs_off = p->d_obs_off; a.obs_slot = p->d_obs_slot; a.joff = p->d_joff;
     a.list = p->cams[cam].d_obs; a.n_list = (int32_t)p->cams[cam].obs.size(); a.cam = cam;
-    a.items = p->cams[cam].d_items; a.n_items = (int32_t)p->cams[cam].items.size();
     a.intr = p->d_intr; a.poses = p->d_poses; a.extr = p->d_extr;
     a.huber_delta = p->huber_delta; a.rt = model_rt(p->ctx);
     return a;

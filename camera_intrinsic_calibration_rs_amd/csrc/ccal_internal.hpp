@@ -27,8 +27,6 @@ struct KArgs {
     const int64_t* joff;           // [n_obs] offset (doubles) of the frame's block Jacobians in J_out
     const int32_t* list;           // observation frames of this camera
     int32_t n_list;
-    const int64_t* items;          // mode E by PASS: observation frame | first corner of the pass << 32, one per 64 corners of a frame
-    int32_t n_items;
     int32_t cam;
     const double* intr;            // [n_cams][CCAL_PMAX] full params
     const double* poses;           // [n_slots][6]
@@ -49,8 +47,6 @@ struct CamLayout {
     double width = 0, height = 0;
     std::vector<int32_t> obs;          // host copy of the camera's observation frames
     int32_t* d_obs = nullptr;
-    std::vector<int64_t> items;        // mode E work items: observation frame | first corner << 32, one per 64 corners of a frame
-    int64_t* d_items = nullptr;
 };
 
 }  // namespace ccal

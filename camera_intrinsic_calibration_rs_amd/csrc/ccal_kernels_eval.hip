@@ -54,12 +54,10 @@ template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : FC_N
 // trip count the compiler cannot count the stores in flight and drains them all (s_waitcnt vmcnt(0)) before the next pass may
 // use its - long since arrived - corner rows; counted, the next pass computes under the stores of this one (what holds the wide
 // blocks back is wavefront-level concurrency).
-// ITEMS: one wavefront per PASS (64 corners of a frame; KArgs::items) instead of per frame.  A lone launch loses ~5 us to its tail:
-// when the queue of workgroups runs dry every slot still finishes the wavefront it holds, and a frame-sized wavefront stays ~13 us
-// (T(frames) = 5.3 us + 4.7 us per 1 000 frames: 6.96 TB/s asymptotically against 6.3 at 10 000 frames).  A pass-sized wavefront
-// stays a third of that, never waits for its own stores, and its slot is free again while they drain.  The frame constants are
-// computed per pass (three times per 144-corner frame: the VALU has the room).
-template <int MODEL, bool OF, bool OTHER, bool PF, bool AL, bool ITEMS>
+// (A launch's time is T(frames) = 5.3 us + 4.7 us per 1 000 frames - 6.96 TB/s asymptotically, 6.3 at 10 000 frames.  One wavefront
+//  per PASS instead of per frame, to shorten the tail, was built and measured in round 5: it loses 6-22 % - every pass then walks the
+//  list -> slot -> pose -> exponential-map chain; EXPERIMENTS.md.)
+template <int MODEL, bool OF, bool OTHER, bool PF, bool AL>
 __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int TW = 2 * D;            // doubles per block Jacobian
@@ -73,15 +71,9 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double* fc = smem + wave * WS;
     double* tile = fc + FCN;
-    const int n_work = ITEMS ? a.n_items : a.n_list;
-    const int wstride = (!ITEMS && CCAL_EVAL_PERSIST > 0) ? (int)gridDim.x * CCAL_EVAL_WPB : n_work;
-    for (int widx = blockIdx.x * CCAL_EVAL_WPB + wave; widx < n_work; widx += wstride) {   // no workgroup barrier inside
-    int item_base = 0;
-    int o;
-    if constexpr (ITEMS) {
-        const int64_t it = a.items[widx];
-        o = __builtin_amdgcn_readfirstlane((int)(it & 0xffffffff)); item_base = __builtin_amdgcn_readfirstlane((int)(it >> 32));
-    } else o = __builtin_amdgcn_readfirstlane(a.list[widx]);
+    const int wstride = CCAL_EVAL_PERSIST > 0 ? (int)gridDim.x * CCAL_EVAL_WPB : a.n_list;
+    for (int widx = blockIdx.x * CCAL_EVAL_WPB + wave; widx < a.n_list; widx += wstride) {   // no workgroup barrier inside
+    const int o = __builtin_amdgcn_readfirstlane(a.list[widx]);
     const int slot = __builtin_amdgcn_readfirstlane(a.obs_slot[o]);
     const int64_t start = a.obs_off[o];
     const int n = (int)(a.obs_off[o + 1] - start);
@@ -93,9 +85,9 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     // every later pass one pass ahead - one exposed memory latency per frame instead of one per pass (it is the read
     // latency under a saturated write stream that limits this kernel once the inputs no longer sit in the Infinity Cache)
     float pX = 0.f, pY = 0.f, pZ = 0.f, pU = 0.f, pV = 0.f;
-    if constexpr (PF || ITEMS) {
+    if constexpr (PF) {
         if (n > 0) {                      // an empty last frame has start == n_corners: nothing to read there
-            const int64_t g0 = start + (item_base + lane < n ? item_base + lane : 0);
+            const int64_t g0 = start + (lane < n ? lane : 0);
             pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
         }
     }
@@ -127,9 +119,7 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         const bool valid = FULL || c < n;
         const int64_t g = start + (valid ? c : 0);
         double X, Y, Z, uo, vo;
-        if constexpr (ITEMS) {
-            X = pX; Y = pY; Z = pZ; uo = pU; vo = pV;
-        } else if constexpr (PF) {
+        if constexpr (PF) {
             X = pX; Y = pY; Z = pZ; uo = pU; vo = pV;
             if (base + 64 < n) {          // wave-uniform: the next pass's rows are in flight while this one computes and stores
                 const int cn = base + 64 + lane;
@@ -193,13 +183,9 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         }
         wave_lds_sync();
     };
-    if constexpr (ITEMS) {
-        if (n - item_base >= 64) pass(std::true_type{}, item_base); else pass(std::false_type{}, item_base);
-    } else {
-        const int n_full = n & ~63;
-        for (int base = 0; base < n_full; base += 64) pass(std::true_type{}, base);
-        if (n_full < n) pass(std::false_type{}, n_full);
-    }
+    const int n_full = n & ~63;
+    for (int base = 0; base < n_full; base += 64) pass(std::true_type{}, base);
+    if (n_full < n) pass(std::false_type{}, n_full);
     }
 }
 
@@ -245,21 +231,17 @@ __global__ __launch_bounds__(256) void k_reproj_err(const KArgs a) {
     }
 }
 
-#ifndef CCAL_EVAL_ITEMS
-#define CCAL_EVAL_ITEMS 0        // 1: one wavefront per pass of 64 corners (k_eval<..., ITEMS>)
-#endif
 template <int MODEL, bool OF, bool OTHER, bool PF, bool AL>
 static hipError_t launch_eval_pf(const KArgs& a, hipStream_t s) {
-    constexpr bool ITEMS = CCAL_EVAL_ITEMS != 0;
     constexpr int D = block_dim(MODEL, OF, OTHER);
     constexpr int WS = fc_doubles<OTHER>() + 64 * eval_tile_stride(D);
     const size_t lds = sizeof(double) * WS * CCAL_EVAL_WPB;
-    int blocks = ((ITEMS ? a.n_items : a.n_list) + CCAL_EVAL_WPB - 1) / CCAL_EVAL_WPB;
+    int blocks = (a.n_list + CCAL_EVAL_WPB - 1) / CCAL_EVAL_WPB;
     if (blocks == 0) return hipSuccess;
-    if (!ITEMS && CCAL_EVAL_PERSIST > 0) blocks = std::min(blocks, 256 * CCAL_EVAL_PERSIST);
+    if (CCAL_EVAL_PERSIST > 0) blocks = std::min(blocks, 256 * CCAL_EVAL_PERSIST);
     static DynLdsGuard lds_guard;
-    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER, PF && !ITEMS, AL, ITEMS>), lds, lds_guard); e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER, PF && !ITEMS, AL, ITEMS>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(&k_eval<MODEL, OF, OTHER, PF, AL>), lds, lds_guard); e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_eval<MODEL, OF, OTHER, PF, AL>), dim3(blocks), dim3(64 * CCAL_EVAL_WPB), lds, s, a);
     return hipGetLastError();
 }
 // blocks for which the prefetching form wins whatever the input size (measured; 0 = none yet: CCAL_EVAL_PF_MIN_D)
