@@ -359,7 +359,7 @@ __device__ __forceinline__ void project_uv(const double* th, double x, double y,
 // PHI (camera-0 blocks of the single-camera Gram kernels): the three rotation columns are taken with respect to a LEFT
 // perturbation phi of the rotation, d(R X) = phi x (R X), i.e. row (R X) x ju - no frame constants a_k, a third of the
 // arithmetic.  d/d rvec = (d/d phi) J_l(rvec) with the frame's 3 x 3 left Jacobian, which the per-frame elimination
-// applies ONCE to the frame's reduced Gram blocks (k_schur1 / k_schur1m) instead of every corner applying it to its rows.
+// applies ONCE to the frame's reduced Gram blocks (eliminate_frame, ccal_gram_common.hpp) instead of every corner applying it to its rows.
 template <int MODEL, bool ONE_FOCAL, bool OTHER, bool PHI = false>
 __device__ __forceinline__ void corner_block(const double* th, const double* fc,
                                              double X, double Y, double Z, double uo, double vo,

@@ -138,7 +138,7 @@ int rccl_allreduce_sum(ccal_ctx* ctx, void* comm, double* buf, size_t count, hip
 // ccal_solver.hip: wait for the early-exit groups a finished solve left in the stream (no-op if there are none)
 int drain_pending_groups(ccal_problem* p);
 // ccal_kernels_stats.hip
-// first size of ccal_problem::d_scratch: what ccal_init_poses and validation() of every camera need (gather + sort buffers + hipCUB's temporary)
+// first size of ccal_problem::d_scratch: what ccal_init_poses and validation() of every camera need (gathered values + the selection's work area)
 inline size_t problem_scratch_hint(const ccal_problem* p) {
     return (size_t)std::max<int64_t>(p->n_corners, 1) * 32 + (size_t)(std::max(p->n_obs, 1) + 1) * 64 + (size_t)384 * 1024;
 }

@@ -56,7 +56,8 @@ template <bool OTHER> constexpr int fc_doubles() { return OTHER ? FC_SIZE : FC_N
 // blocks back is wavefront-level concurrency).
 // (A launch's time is T(frames) = 5.3 us + 4.7 us per 1 000 frames - 6.96 TB/s asymptotically, 6.3 at 10 000 frames.  One wavefront
 //  per PASS instead of per frame, to shorten the tail, was built and measured in round 5: it loses 6-22 % - every pass then walks the
-//  list -> slot -> pose -> exponential-map chain; EXPERIMENTS.md.)
+//  list -> slot -> pose -> exponential-map chain.  Persistent wavefronts striding over frames: -4 %.  Two / four frames per wavefront
+//  as one corner stream (lane utilisation 75 % -> 90 / 100 %): -6 / -11 %.  Many short wavefronts are what this chip wants; EXPERIMENTS.md.)
 template <int MODEL, bool OF, bool OTHER, bool PF, bool AL>
 __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
     constexpr int D = block_dim(MODEL, OF, OTHER);

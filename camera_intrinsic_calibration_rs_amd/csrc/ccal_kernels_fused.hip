@@ -1,18 +1,18 @@
 // Single-camera fast path of the optimizer: the whole Gauss-Newton / LM iteration is device-resident,
 // the host only enqueues kernels and watches a status word in pinned memory.
 //
-//   k_unpack1    distributes the one-copy staging block of a solve's starting point
-//   k_gram1v/w   16-64 lanes per frame, register (+ LDS) Gram accumulators: the default Gram kernels (see below)
-//   k_gram1      one wavefront per frame: weighted rows sqrt(w) [J | r] -> LDS (32 corners at a time)
-//                -> v_mfma_f64_16x16x4_f64 Gram -> compact record per frame:
-//                C = H_pp (21) | [B | g_p] (6 x (K+1)) | A = [J_c | r]^T W [J_c | r] ((K+1)^2)
-//   k_schur1m    four frames per wavefront: 6x6 Cholesky (+ LM damping), Y = L^-1 [B|g], per-slot record for the
-//                next back-substitution, A_dir and Y^T Y summed per workgroup in a fixed order (no atomics).
-//                An LM rejection re-runs only this kernel.  (k_schur1: one frame per wavefront, problems too large
-//                for one pass and the opt-in fused reduce + decide tail.)
-//   k_reduce1    fixed-order sum over waves -> red (the all-reduce buffer of sharded solves)
-//   k_head       one wavefront: accept / reject / convergence tests (tiny-solver's rules or the Ceres-style
-//                trust region), K x K solve, candidate intrinsics, status to pinned host memory
+//   k_unpack1       the starting point of a solve (state, column table, intrinsics in the argument block; poses from pinned host memory)
+//   k_gram1v        LPF lanes per frame, the whole upper triangle of [J | r]^T W [J | r] in registers, the frame's pose block
+//                   eliminated in the kernel's tail (gram_fused_tail): one row of partial sums per wavefront.  KB4 at every size,
+//                   UCM / EUCM below 2 000 frames (k_gram2, ccal_kernels_gram2.hip, elsewhere)
+//   k_gram1v<ITER>  the same with the PREVIOUS launch's rows summed, the decision taken and the camera system solved in front of
+//                   the evaluation: a whole optimizer step in one launch (session sizes)
+//   k_gram1v_batch  that launch for a whole batch of problems (ccal_solve_batch: blockIdx.y = problem, lockstep)
+//   k_reduce1       fixed-order sum over the rows -> red (the all-reduce buffer of sharded solves)
+//   k_head          one wavefront: accept / reject / convergence tests (tiny-solver's rules or the Ceres-style trust region),
+//                   K x K solve, candidate intrinsics, status to pinned host memory; in-process transport: adds the ranks' sums
+//   second library only (-DCCAL_LEGACY_KERNELS / -DCCAL_DEV_SWITCHES): k_gram1 (matrix core), k_gram1w (LDS accumulators),
+//                   k_schur1m (the separate elimination launch), the OPENCV5 instantiations of k_gram1v
 // Same arithmetic and decision sequence as the general loop in ccal_solver.hip (multi-camera problems);
 // parity tests cover both.
 #include <algorithm>
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, CCAL_GRAM_MINW) void k_gram1(const FusedArgs a
         rec[21 + 6 * K1 + e] = G[(i < K ? i : D) * 16 + (j < K ? j : D)];
     }
     if (lane == 0) a.cost_f[f] = G[D * 16 + D];
-    if (lane < 9) rec[praw_jl_off(K) + lane] = fc[FC_A + lane];      // the frame's left Jacobian: k_schur1(m) maps phi -> rvec with it
+    if (lane < 9) rec[praw_jl_off(K) + lane] = fc[FC_A + lane];      // the frame's left Jacobian: the elimination maps phi -> rvec with it
 }
 
 #endif  // CCAL_LEGACY_KERNELS
@@ -667,7 +667,7 @@ __device__ __forceinline__ void gram1v_body(const FusedArgs& a, const IterDyn& d
             }
         }
     }
-    // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
+    // the frame's left Jacobian (phi -> rvec map of the elimination)
     if (!GEN && active && keep_rec) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
     if constexpr (!GEN) {
         if (fuse) {
@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, 2) void k_gram1w(const FusedAr
             }
         }
     }
-    // the frame's left Jacobian (phi -> rvec map of k_schur1 / k_schur1m)
+    // the frame's left Jacobian (phi -> rvec map of the elimination)
     if (!GEN && active && keep_rec) for (int e = gl; e < 9; e += LPF) a.praw[es][(int64_t)f * a.PRAW + praw_jl_off(K) + e] = fc[FC_A + e];
     if constexpr (!GEN) {
         if (fuse) {

@@ -196,8 +196,8 @@ struct ccal_multi_problem {
     std::vector<ccal_problem*> shard;
     std::vector<int32_t> first;                // [n + 1] slot range of every shard
     std::vector<std::vector<int32_t>> obs_of;  // shard -> its observation frames (indices into the caller's description)
-    // ccal_multi_validation: where the shards' errors of one camera meet on the first shard's GPU - [values | sort buffer | sum |
-    // hipCUB's temporary], grown on demand and kept between calls (like ccal_problem::d_scratch for the single-GPU validation())
+    // ccal_multi_validation: where the shards' errors of one camera meet on the first shard's GPU - [values |
+    // selection's work area], grown on demand and kept between calls (like ccal_problem::d_scratch for the single-GPU validation())
     char* d_gather = nullptr; size_t gather_bytes = 0;
 };
 

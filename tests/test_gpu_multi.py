@@ -2,7 +2,7 @@
 The reference's calib_camera is one blocking call of one process (src/util.rs:384-390): this is the entry a Rust
 calib_camera body uses to reach every GPU of a node.
   * on the 1-GPU box the device set is [0, 0, ...]: several contexts on device 0 and the library's in-process transport
-    (HIP events + a device-side add in shard order) - LM rejections, a pose block that fails on ONE shard, an empty shard;
+    (HIP events; the deciding kernel of every shard adds all shards' sums in shard order) - LM rejections, a pose block that fails on ONE shard, an empty shard;
   * with two or more GPUs visible the same tests also run on range(device_count) with native RCCL (ncclCommInitAll).
 Every solve runs in a fresh child process that the parent kills when it hangs (never a re-exec of a process that has
 touched the GPU); the library itself verifies that the camera block is bit-identical on all shards."""
