@@ -397,10 +397,10 @@ hipError_t launch_unpack1(const UnpackArgs& a, hipStream_t s);
 hipError_t launch_gram1(int model, bool one_focal, const FusedArgs& a, hipStream_t s);     // MFMA Gram (any model)
 hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s);    // register (VALU) Gram, any model
 // rows of partial sums (= workgroups) a single-launch group of this problem would have; 0: that form does not apply
-int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share);
+int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share, bool batch = false);     // batch: a member of a lockstep batch (OPENCV5 takes the form only there)
 hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s);  // k_gram1v<.., ITER>; a.it filled in
 int fused_iter_lpf(int n_obs, int avg_corners, int share);                           // the lane mapping of that launch
-// ccal_solve_batch: launch number s_no of a whole batch of session-sized problems (UCM / EUCM / KB4, one model, focal mode and lane
+// ccal_solve_batch: launch number s_no of a whole batch of session-sized problems (one model, focal mode and lane
 // mapping); tab: n argument blocks in DEVICE memory with it.st_in = the first of the two state buffers, partial = the partial-sum
 // buffer's base, n_part = the problem's rows, it.fold = the first launch unpacks; max_rows = the largest n_part
 hipError_t launch_gram_iter_batch(int model, bool one_focal, int lpf, const FusedArgs* tab, int n, int max_rows, int s_no, hipStream_t s);

@@ -1215,6 +1215,22 @@ static int iter_rows_t(int n_obs, int avg_corners, int share, bool launch, Fused
     if (lds + iter_static_lds<MODEL, OF>() > kLdsPerCu) return 0;
     return rows;
 }
+// rows (= workgroups) of a single-launch group without reference to a launcher: 0 if the form does not apply
+template <int MODEL, bool OF>
+static int iter_rows_only(int n_obs, int avg_corners, int share) {
+    if (n_obs <= 0) return 0;
+    const int lpf = gram_lanes_per_frame(n_obs, avg_corners, 1024, (int64_t)1 << 40, share);
+    const int g = 64 / lpf, rows = (n_obs + g * kIterWpb - 1) / (g * kIterWpb);
+    if (rows > 256) return 0;
+    size_t lds = 0;
+    switch (lpf) {
+        case 6: lds = iter_lds_bytes<MODEL, OF, 6>(); break;   case 8: lds = iter_lds_bytes<MODEL, OF, 8>(); break;
+        case 12: lds = iter_lds_bytes<MODEL, OF, 12>(); break; case 16: lds = iter_lds_bytes<MODEL, OF, 16>(); break;
+        case 32: lds = iter_lds_bytes<MODEL, OF, 32>(); break; case 64: lds = iter_lds_bytes<MODEL, OF, 64>(); break;
+        default: return 0;
+    }
+    return lds + iter_static_lds<MODEL, OF>() <= kLdsPerCu ? rows : 0;
+}
 static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, int share, bool launch, FusedArgs* a, hipStream_t s, hipError_t* err) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
         case 0: return iter_rows_t<kUCM, false>(n_obs, avg_corners, share, launch, a, s, err);
@@ -1226,6 +1242,10 @@ static int iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, in
 #ifdef CCAL_DEV_SWITCHES
         case 6: return iter_rows_t<kOCV5, false>(n_obs, avg_corners, share, launch, a, s, err);
         case 7: return iter_rows_t<kOCV5, true>(n_obs, avg_corners, share, launch, a, s, err);
+#else
+        // OPENCV5 in the product: only the batched form exists (k_gram1v_batch) - the row count without the single-problem launcher
+        case 6: return launch ? 0 : iter_rows_only<kOCV5, false>(n_obs, avg_corners, share);
+        case 7: return launch ? 0 : iter_rows_only<kOCV5, true>(n_obs, avg_corners, share);
 #endif
         default: return 0;
     }
@@ -1262,18 +1282,21 @@ hipError_t launch_gram_iter_batch(int model, bool one_focal, int lpf, const Fuse
         case 3: return launch_iter_batch_t<kEUCM, true>(lpf, tab, n, max_rows, s_no, s);
         case 4: return launch_iter_batch_t<kKB4, false>(lpf, tab, n, max_rows, s_no, s);
         case 5: return launch_iter_batch_t<kKB4, true>(lpf, tab, n, max_rows, s_no, s);
+        case 6: return launch_iter_batch_t<kOCV5, false>(lpf, tab, n, max_rows, s_no, s);
+        case 7: return launch_iter_batch_t<kOCV5, true>(lpf, tab, n, max_rows, s_no, s);
         default: return hipErrorNotSupported;
     }
 }
 // the lane mapping a single-launch group of this problem takes (what launch_gram_iter dispatches on)
 int fused_iter_lpf(int n_obs, int avg_corners, int share) { return gram_lanes_per_frame(n_obs, avg_corners, 1024, (int64_t)1 << 40, share); }
 
-int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share) {
+int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share, bool batch) {
     if (K != block_dim(model, one_focal, false) - 6) return 0;      // (the kernel's compile-time column count is the problem's)
-    // OPENCV5: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch
-    // form (112-double rows: two chunks per lane to sum, 4.9 us).  CCAL_ITER_OCV5=1 forces the single-launch form.
+    // OPENCV5 alone: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch
+    // form (112-double rows: two chunks per lane to sum, 4.9 us) - so only members of a lockstep batch take it (one launch per step
+    // for the whole batch beats n x three).  The second library's CCAL_ITER_OCV5=1 forces the single-launch form.
     static const bool ocv5 = dev_env_int("CCAL_ITER_OCV5", 0) == 1;
-    if (model == kOCV5 && !ocv5) return 0;
+    if (model == kOCV5 && !ocv5 && !batch) return 0;
     return iter_rows_m(model, one_focal, n_obs, avg_corners, share, false, nullptr, nullptr, nullptr);
 }
 hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s) {

@@ -629,7 +629,7 @@ struct FusedJob : SolveJob {
         fa.share = share;
         iter_rows = 0;
         if (!sharded && f->fuse_elim && fused_use_valu_gram(p)) {
-            const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K, share);
+            const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K, share, batch_member);
             if (rows > 0 && 2 * rows <= f->n_pw) iter_rows = rows;
         }
         {
@@ -1106,9 +1106,8 @@ struct IterGroupKey { int device, model, one_focal, lpf; bool operator==(const I
 // the lane mapping of the problem's single-launch groups when it is one of `share` problems side by side (0: that form does not apply)
 static int batch_iter_lpf(const ccal_problem* p, int share) {
     if (p->n_cams != 1 || p->sharded() || p->n_obs <= 0 || p->K > kFusedMaxK || dev_env("CCAL_DISABLE_FUSED") || dev_env("CCAL_BATCH_LOCKSTEP_OFF")) return 0;
-    if (p->cams[0].model == kOCV5) return 0;                                   // (k_gram2 + reduce + head there)
     const int avg = (int)(p->n_corners / std::max(p->n_obs, 1));
-    const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, avg, p->K, share);
+    const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, avg, p->K, share, true);
     if (rows <= 0 || 2 * rows > fused_partial_rows(p->n_obs)) return 0;
     return fused_iter_lpf(p->n_obs, avg, share);
 }

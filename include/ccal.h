@@ -252,9 +252,9 @@ int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,
 int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* opts, ccal_report* report);
 /* n INDEPENDENT problems solved side by side in ONE call (the per-camera calib_camera calls of a rig, the retries of
  * src/bin/camera_calibration.rs:205-246, many sessions of a service): a session-sized problem (a few hundred frames) leaves
- * the GPU almost idle - one latency-bound launch per optimizer step.  Session-sized single-camera problems (UCM / EUCM / KB4) of one
+ * the GPU almost idle - one latency-bound launch per optimizer step.  Session-sized single-camera problems of one
  * GPU, model and focal mode advance in LOCKSTEP: ONE launch per step serves all of them (the problems' workgroups side by side), so
- * a batch of eight costs the host what one solve costs.  Everything else (rigs, large problems, OPENCV5) is driven per context by a
+ * a batch of eight costs the host what one solve costs.  Everything else (rigs, large problems) is driven per context by a
  * host thread of its own (create such problems on contexts of their own - ccal_ctx_create with stream NULL - to make them overlap;
  * those that share a context are solved one after the other).  A problem's launches are sized for its share of the GPU (the batch's
  * problems on that device): fewer, longer wavefronts than a lone ccal_solve takes - same verdicts and iteration counts as n

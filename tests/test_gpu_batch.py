@@ -54,12 +54,14 @@ def test_lockstep_groups(method):
     whole group (k_gram1v_batch): members of different sizes (different iteration counts, different row counts - the grid is the
     largest one's), a member that finishes early, LM rejections on one member only, a member whose frames do not cover every slot
     (its starting point arrives through k_unpack1 instead of the first launch), host pointers and the device-resident form; two
-    groups (EUCM and one-focal KB4) plus a rig that takes the per-context path in the same call."""
+    groups (EUCM, one-focal KB4, OPENCV5 - which takes the single-launch form only as a batch member) plus a rig that takes the
+    per-context path in the same call."""
     import dataclasses
     sps = [synth.make_problem(300, "eucm", seed=31, outlier_frac=0.02), synth.make_problem(120, "eucm", seed=32, ragged=True),
            synth.make_problem(12, "eucm", seed=1, outlier_frac=0.05, ragged=True, init_perturb=0.8),          # LM rejects steps here
            synth.make_problem(625, "eucm", seed=34), synth.make_problem(200, "kb4", seed=35, xy_same_focal=True),
-           synth.make_problem(90, "kb4", seed=36, xy_same_focal=True, ragged=True), synth.make_problem(30, "eucm", n_cams=2, seed=37)]
+           synth.make_problem(90, "kb4", seed=36, xy_same_focal=True, ragged=True), synth.make_problem(30, "eucm", n_cams=2, seed=37),
+           synth.make_problem(150, "opencv5", seed=38), synth.make_problem(260, "opencv5", seed=39, outlier_frac=0.01)]
     # member 1: drop the last slot's frame -> not every slot observed (no fold)
     s1 = sps[1]
     keep = np.nonzero(s1.obs_slot != s1.n_slots - 1)[0]
