@@ -133,7 +133,13 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
         double ru, rv, J[TW];
         double* Ju = J;
         double* Jv = J + D;
+#if defined(CCAL_EVAL_DIAG) && CCAL_EVAL_DIAG == 2       // diagnostic build: no projection / chain rule - the store path alone
+        ru = X + uo; rv = Y + vo;
+#pragma unroll
+        for (int i = 0; i < D; ++i) { Ju[i] = X * (double)(i + 1) + fc[0]; Jv[i] = Z * (double)(i + 1) + vo; }
+#else
         corner_block<MODEL, OF, OTHER>(th, fc, X, Y, Z, uo, vo, ru, rv, Ju, Jv);
+#endif
         if constexpr (AL) {
             const double sw = huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta);
             ru *= sw; rv *= sw;
@@ -168,6 +174,9 @@ __global__ __launch_bounds__(64 * CCAL_EVAL_WPB) void k_eval(const KArgs a) {
             const int cr = e / TW;
             const int k = e - cr * TW;
             const double2 val = *reinterpret_cast<const double2*>(tile + cr * TS + k);
+#if defined(CCAL_EVAL_DIAG) && CCAL_EVAL_DIAG == 1       // diagnostic build: the computation and the LDS round trip alone (one store per pass keeps them alive)
+            if (e != lane * 2 || val.x != 12345.678) return;
+#endif
 #if CCAL_EVAL_NT
             __builtin_nontemporal_store(val.x, dst + e);
             __builtin_nontemporal_store(val.y, dst + e + 1);
