@@ -182,6 +182,9 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     }
     p->h_joff[d->n_obs] = j; p->j_len = j;
     p->n_corners = p->h_obs_off[d->n_obs];
+    // the Gram kernels address a problem's corner rows by 32-bit byte offsets (ccal_kernels_gram2.hip); 2^30 corners are 21 GB of
+    // inputs and 245 GB of mode-E outputs - beyond that, shard the frames (ccal_multi_*)
+    if (p->n_corners >= ((int64_t)1 << 30)) return fail(ctx, CCAL_ERR_INVALID_ARG, "more than 2^30 - 1 corners in one problem: shard the frames (ccal_multi_problem_create)");
     const size_t nc = (size_t)p->n_corners;
     if (nc && (!d->p3d_x || !d->p3d_y || !d->p3d_z || !d->p2d_u || !d->p2d_v)) return fail(ctx, CCAL_ERR_INVALID_ARG, "null corner arrays");
     // ONE device allocation, cleared once, sliced (a calibration session creates its problem once: sixteen hipMalloc + memset pairs

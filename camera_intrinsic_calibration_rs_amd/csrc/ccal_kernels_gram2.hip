@@ -26,9 +26,21 @@
 namespace ccal {
 
 // ---- compile-time maps -------------------------------------------------------------------------------------------
+// The v lanes work in MIRRORED coordinates (x and y of the camera-frame point exchanged, see the kernel): their row-local
+// columns are the u lanes' with  phi_0 <-> phi_1,  t_0 <-> t_1  (OPENCV5: p1 <-> p2)  and the three phi columns negated.
+template <int MODEL>
+__host__ __device__ constexpr int g2_mirror(int a) {
+    constexpr int ND = model_np(MODEL) - 4, PH = 2 + ND, T = PH + 3;
+    if (a == PH || a == PH + 1) return PH + 1 - (a - PH);
+    if (a == T || a == T + 1) return T + 1 - (a - T);
+    if (MODEL == kOCV5 && (a == 2 + OCV5_P1 - 4 || a == 2 + OCV5_P2 - 4)) return a == 2 + OCV5_P1 - 4 ? 2 + OCV5_P2 - 4 : 2 + OCV5_P1 - 4;
+    return a;
+}
+template <int MODEL> __host__ __device__ constexpr bool g2_is_phi(int a) { return a >= model_np(MODEL) - 2 && a < model_np(MODEL) + 1; }
 // full column (order of the block Jacobian: camera P_eff | pose 6 | r) of row-local column a of row `row` (0 = u, 1 = v)
 template <int MODEL, bool OF>
 __host__ __device__ constexpr int g2_fullcol(int row, int a) {
+    if (row) a = g2_mirror<MODEL>(a);
     if (OF) return a == 0 ? 0 : (a == 1 ? (row ? 2 : 1) : a + 1);
     return a == 0 ? (row ? 1 : 0) : (a == 1 ? (row ? 3 : 2) : a + 2);
 }
@@ -53,10 +65,13 @@ __host__ __device__ constexpr uint32_t g2_rec_dst(int i, int j) {
     }
     return a | (b << 16);
 }
-// One ITEM per entry of the full triangle, in the order of the accumulator t it is summed from:
-//   src = t | mask << 12   (mask bit 0: the u lanes contribute, bit 1: the v lanes; 0: a structural zero of the block)
+// One ITEM per entry (i <= j) of the full triangle:
+//   src = t_u | t_v << 8 | mask << 16 | neg << 18    the accumulator the u lanes hold it in, the one the v lanes hold it in (the
+//         mirrored pair), mask bit 0 / 1: the u / v lanes contribute (0: a structural zero of the block), neg: the v lanes' sum
+//         enters negated (exactly one of its two columns is a phi column)
 //   rec = where it goes in the record
-// NS = number of slices the accumulators are reduced in (LDS per wavefront = 64 x slice); first[s] = first item of slice s.
+// The accumulators are reduced in NS slices (LDS per wavefront = 64 x slice); they are NUMBERED so that an entry and its mirror
+// image sit in the same slice (`where`): an item finds both its sources in one pass.  first[s] = first item of slice s.
 // (The four-role form of round 3 - the row-local triangle split between two lane roles, rows staged in LDS - was measured slower
 //  for every model and is gone: EXPERIMENTS.md.)
 template <int MODEL, bool OF, bool GEN, int NS>
@@ -66,37 +81,62 @@ struct RowMap {
     static constexpr int NER = NCR * (NCR + 1) / 2;      // accumulators per lane
     static constexpr int CH = (NER + NS - 1) / NS;
     uint32_t rec[NEF];
-    uint16_t src[NEF];
+    uint32_t src[NEF];
     int first[NS + 1];
-    // accumulator t of the row-local pair p <= q
-    static constexpr int where(int p, int q) { int t = 0; for (int a = 0; a < p; ++a) t += NCR - a; return t + (q - p); }
-    constexpr RowMap() : rec{}, src{}, first{} {
-        bool seen[NCF][NCF] = {};
-        int n = 0;
-        for (int s = 0; s <= NS; ++s) first[s] = -1;
-        // items in ascending accumulator order t (slices are ranges of t)
-        for (int t = 0; t < NER; ++t)
-            for (int a = 0; a < NCR; ++a)
-                for (int b = a; b < NCR; ++b) {
-                    const int ht = where(a, b);
-                    if ((ht & 0xff) != t) continue;
-                    const int sl = t / CH;
-                    if (first[sl] < 0) first[sl] = n;
-                    const int iu = g2_fullcol<MODEL, OF>(0, a), ju = g2_fullcol<MODEL, OF>(0, b);
-                    const int iv = g2_fullcol<MODEL, OF>(1, a), jv = g2_fullcol<MODEL, OF>(1, b);
-                    if (iu == iv && ju == jv) {
-                        rec[n] = g2_rec_dst<K, GEN>(iu, ju); src[n] = (uint16_t)(ht | (3 << 12)); ++n; seen[iu][ju] = true;
-                    } else {
-                        rec[n] = g2_rec_dst<K, GEN>(iu, ju); src[n] = (uint16_t)(ht | (1 << 12)); ++n; seen[iu][ju] = true;
-                        rec[n] = g2_rec_dst<K, GEN>(iv, jv); src[n] = (uint16_t)(ht | (2 << 12)); ++n; seen[iv][jv] = true;
+    uint8_t num[NCR][NCR];                               // accumulator of the row-local pair (p <= q)
+    bool ok;                                             // every slice filled without splitting a mirrored pair
+    constexpr int where(int p, int q) const { return p <= q ? num[p][q] : num[q][p]; }
+    constexpr RowMap() : rec{}, src{}, first{}, num{}, ok(true) {
+        // number the accumulators: slice by slice, mirrored pairs first (never split), entries that are their own image after
+        bool placed[NCR][NCR] = {};
+        int t = 0;
+        for (int s = 0; s < NS; ++s) {
+            const int end = (s + 1) * CH < NER ? (s + 1) * CH : NER;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int p = 0; p < NCR; ++p)
+                    for (int q = p; q < NCR; ++q) {
+                        int mp = g2_mirror<MODEL>(p), mq = g2_mirror<MODEL>(q);
+                        if (mp > mq) { const int x = mp; mp = mq; mq = x; }
+                        const bool self = mp == p && mq == q;
+                        if (placed[p][q] || self != (pass == 1) || t + (self ? 1 : 2) > end) continue;
+                        num[p][q] = (uint8_t)t++; placed[p][q] = true;
+                        if (!self) { num[mp][mq] = (uint8_t)t++; placed[mp][mq] = true; }
                     }
+            if (t != end) ok = false;
+        }
+        // what the u lanes / the v lanes hold of every entry of the full triangle
+        int tu_of[NCF][NCF] = {}, tv_of[NCF][NCF] = {};
+        bool neg_of[NCF][NCF] = {};
+        for (int i = 0; i < NCF; ++i) for (int j = 0; j < NCF; ++j) { tu_of[i][j] = -1; tv_of[i][j] = -1; }
+        for (int a = 0; a < NCR; ++a)
+            for (int b = a; b < NCR; ++b) {
+                const int iu = g2_fullcol<MODEL, OF>(0, a), ju = g2_fullcol<MODEL, OF>(0, b);
+                int iv = g2_fullcol<MODEL, OF>(1, a), jv = g2_fullcol<MODEL, OF>(1, b);
+                if (iv > jv) { const int x = iv; iv = jv; jv = x; }
+                tu_of[iu][ju] = where(a, b);
+                tv_of[iv][jv] = where(a, b);
+                neg_of[iv][jv] = g2_is_phi<MODEL>(a) != g2_is_phi<MODEL>(b);
+            }
+        // items, slice by slice
+        int n = 0;
+        for (int s = 0; s < NS; ++s) {
+            first[s] = n;
+            for (int i = 0; i < NCF; ++i)
+                for (int j = i; j < NCF; ++j) {
+                    int tu = tu_of[i][j], tv = tv_of[i][j];
+                    const int sl = tu >= 0 ? tu / CH : (tv >= 0 ? tv / CH : NS - 1);        // structural zeros of the block: last slice
+                    if (sl != s) continue;
+                    if (tu >= 0 && tv >= 0 && tv / CH != s) ok = false;
+                    const int mask = (tu >= 0 ? 1 : 0) | (tv >= 0 ? 2 : 0);
+                    if (tu < 0) tu = tv >= 0 ? tv : s * CH;
+                    if (tv < 0) tv = tu;
+                    rec[n] = g2_rec_dst<K, GEN>(i, j);
+                    src[n] = (uint32_t)tu | ((uint32_t)tv << 8) | ((uint32_t)mask << 16) | ((uint32_t)(neg_of[i][j] ? 1 : 0) << 18);
+                    ++n;
                 }
-        // the block's structural zeros (fx x fy, fx x cy, fy x cx, cx x cy; one focal: cx x cy): written as zeros, last slice
-        for (int i = 0; i < NCF; ++i)
-            for (int j = i; j < NCF; ++j)
-                if (!seen[i][j]) { rec[n] = g2_rec_dst<K, GEN>(i, j); src[n] = (uint16_t)((NS - 1) * CH); ++n; }
+        }
         first[NS] = n;
-        for (int s = NS - 1; s >= 0; --s) if (first[s] < 0) first[s] = first[s + 1];
+        if (n != NEF) ok = false;
     }
     static constexpr int max_items() {              // most items any slice holds
         RowMap m;
@@ -115,12 +155,24 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 // in the per-frame scratch (8 stamps per wavefront)
 #ifdef CCAL_STAMPS       // kept in (scalar) registers, stored once at the end: a store per stamp would sit in front of the next fence
 #define G2_STAMP(i) do { g2_stamps[i] = wall_clock64(); } while (0)
-#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }
-#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[8 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; } } while (0)
+#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }; long long g2_cyc[5] = { 0, 0, 0, 0, 0 }; long long g2_c0 = 0
+#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[16 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
+                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[16 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; } } while (0)
+// -DCCAL_STAMPS=2: shader cycles (s_memtime) spent in the sections of the corner loop, summed over the passes:
+// 0 transform + projection, 2 rows + DPP, 3 Gram products, 4 passes
+#if CCAL_STAMPS >= 2
+#define G2_CYC_BEGIN() do { __builtin_amdgcn_sched_barrier(0); g2_c0 = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define G2_CYC(i) do { __builtin_amdgcn_sched_barrier(0); const long long c_ = clock64(); g2_cyc[i] += c_ - g2_c0; g2_c0 = c_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define G2_CYC_BEGIN() do { } while (0)
+#define G2_CYC(i) do { } while (0)
+#endif
 #else
 #define G2_STAMP(i) do { } while (0)
 #define G2_STAMPS_DECL do { } while (0)
 #define G2_STAMPS_FLUSH do { } while (0)
+#define G2_CYC_BEGIN() do { } while (0)
+#define G2_CYC(i) do { } while (0)
 #endif
 // wavefronts per SIMD the kernel is compiled for: two where 2 NER accumulators + two rows fit 256 registers (UCM, EUCM);
 // KB4 / OPENCV5 (182 / 210 + 52 / 56) do not without scratch or LDS accumulators, both of which cost more than they buy
@@ -132,21 +184,31 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 #ifndef CCAL_G2_HOIST
 #define CCAL_G2_HOIST(MODEL) ((MODEL) == kUCM)
 #endif
-// accumulators kept in LDS ([entry][lane], stride 65: lane-private ds_add_f64, fire and forget) instead of registers: the
-// first NLA entries of the row-local triangle, as many as keeps the kernel inside 256 registers without scratch
-#ifndef CCAL_G2_NLA
-#define CCAL_G2_NLA(MODEL) 0
-#endif
 
-// LPF = lanes per frame, EVEN: LPF / 2 corners of a frame per pass.  The frame's lanes are contiguous (grp = lane / LPF), so
+// R | t of a frame with the x and y rows exchanged: what the v lanes transform their corners with
+__device__ __forceinline__ void g2_store_mirrored(const double* fcr, double* dst) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dst[i] = fcr[3 + i]; dst[3 + i] = fcr[i]; dst[6 + i] = fcr[6 + i]; }
+    dst[9] = fcr[10]; dst[10] = fcr[9]; dst[11] = fcr[11];
+}
+// the value of the neighbouring lane (lane ^ 1): two v_mov_b32 with a quad_perm [1,0,3,2] DPP control
+__device__ __forceinline__ double g2_from_partner(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true);      // (every lane has a source: nothing is kept of the old value)
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+// LPF = lanes per frame, EVEN: LPF corners of a frame per pass, every lane evaluates one.  The frame's lanes are contiguous (grp = lane / LPF), so
 // the prologue and the fused tail are those of k_gram1w.
 template <int MODEL, bool OF, int LPF, bool GEN>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2(const FusedArgs a) {
-    static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 in each half of the wavefront");
+    static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 pairs of a u lane and a v lane");
     constexpr int NS = g2_slices<MODEL>();
     using Map = RowMap<MODEL, OF, GEN, NS>;
-    constexpr int L2 = LPF / 2;                     // lanes of a frame in each half of the wavefront
+    static_assert(Map().ok, "accumulator numbering: a slice splits a mirrored pair");
+    constexpr int L2 = LPF / 2;                     // pairs of lanes per frame
     constexpr int G = 32 / L2;                      // frames per wavefront
+    constexpr int FCS = FC_N0P + 12;                // a frame's constants + R, t once more with the x and y rows exchanged (v lanes)
     constexpr int P = model_np(MODEL), ND = P - 4;
     constexpr int D = block_dim(MODEL, OF, false);
     constexpr int K = D - 6, K1 = K + 1;
@@ -154,18 +216,18 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     constexpr int LS = CH | 1;                      // odd row stride (doubles): conflict-free column sums
     constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
     constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
-    constexpr int WSL = (G * FC_N0P + RED + NEF + 1) & ~1;     // per wave: G frames' constants | reduction buffer / records | item table
+    constexpr int WSL = (G * FCS + RED + NEF + 1) & ~1;        // per wave: G frames' constants | reduction buffer / records | item table
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevState* st = a.st;
     const bool fuse = !GEN && a.fuse_elim != 0;
     const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
     if (st->done || (st->redo && !fuse)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // frame g: lanes [g L2, (g + 1) L2) of BOTH halves; gl = the lane's index within its frame (u half first)
-    const int half = lane >> 5, l31 = lane & 31;
-    const bool lane_ok = l31 < G * L2;
-    const int grp = lane_ok ? l31 / L2 : G - 1;
-    const int gl = l31 % L2 + half * L2;
+    // frame g: lanes [g LPF, (g + 1) LPF); even lanes take the u rows, odd lanes the v rows; gl = the lane's index within its frame
+    const int role = lane & 1;
+    const bool lane_ok = lane < G * LPF;
+    const int grp = lane_ok ? lane / LPF : G - 1;
+    const int gl = lane_ok ? lane - grp * LPF : (lane & 1);
     G2_STAMPS_DECL;
     G2_STAMP(0);
     const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
@@ -173,8 +235,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);
     const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
-    double* fc = fcw + grp * FC_N0P;
-    double* red = fcw + G * FC_N0P;
+    double* fc = fcw + grp * FCS;
+    double* red = fcw + G * FCS;
     // the per-item tables of the reduction (src | rec << 32), requested NOW and parked in LDS before the corner loop: the
     // reduction and the scatter then look them up at LDS latency instead of waiting for global memory twice per slice
     unsigned long long* tab = reinterpret_cast<unsigned long long*>(red + RED);
@@ -211,12 +273,23 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     const double* th_g = a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0);
     double th[th_len<MODEL>()];
     load_theta<MODEL, OF>(th_g, a.rt, th);
+    // the lane's view of the intrinsics: MINE = the row it accumulates (u lanes: fx, cx; v lanes: fy, cy), OTHER = the row it
+    // forms for its partner; the v lanes see the distortion in mirrored coordinates (OPENCV5: p1 and p2 exchanged)
+    if (role) {
+        if constexpr (!OF) { const double x = th[0]; th[0] = th[1]; th[1] = x; }
+        { const double x = th[2]; th[2] = th[3]; th[3] = x; }
+        if constexpr (MODEL == kOCV5) { const double x = th[OCV5_P1]; th[OCV5_P1] = th[OCV5_P2]; th[OCV5_P2] = x; }
+    }
     const int64_t start = a.obs_off[fa_];
     const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
+    // corner rows by 32-bit byte offsets from the (wave-uniform) stream pointers: no 64-bit address arithmetic per load
+    // (ccal_problem_create refuses more than 2^30 - 1 corners per problem)
+    auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+    const uint32_t ob0 = (uint32_t)start * 4u;
     float pX, pY, pZ, pU, pV;
     {
-        const int64_t g0 = start + (cl < n ? cl : 0);
-        pX = a.x[g0]; pY = a.y[g0]; pZ = a.z[g0]; pU = a.u[g0]; pV = a.v[g0];
+        const uint32_t g0 = ob0 + 4u * (uint32_t)(cl < n ? cl : 0);
+        pX = ldf(a.x, g0); pY = ldf(a.y, g0); pZ = ldf(a.z, g0); pU = ldf(a.u, g0); pV = ldf(a.v, g0);
     }
     {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants; the lanes of
@@ -282,6 +355,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
 #pragma unroll
                 for (int i = 0; i < 12; ++i) fc[i] = fcr[i];
             }
+            if (gl == 1 && lane_ok) g2_store_mirrored(fcr, fc + FC_N0P);
             if (gl == 0 && active) {
                 double ec[GEN_EC];
                 gen_et_compact(ept, ec);
@@ -296,6 +370,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
 #pragma unroll
                 for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
             }
+            if (gl == 1 && lane_ok) g2_store_mirrored(fcr, fc + FC_N0P);
         }
     }
     wsync();
@@ -311,25 +386,25 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
 #pragma unroll
     for (int q = 0; q < NTQ; ++q) if (lane + 64 * q < NEF) tab[lane + 64 * q] = tabv[q];
     constexpr bool HOIST = CCAL_G2_HOIST(MODEL);
-    constexpr int NLA = CCAL_G2_NLA(MODEL);
-    constexpr int LSA = 65;
-    static_assert(NLA * LSA <= RED, "the LDS accumulators fit the reduction buffer");
-    if constexpr (NLA > 0) {
-#pragma unroll
-        for (int t = 0; t < NLA; ++t) red[t * LSA + lane] = 0.0;
-    }
     // a corner needs R and t only (phi basis): in registers where they fit, else re-read from LDS per corner
+    const double* fcm = role ? fc + FC_N0P : fc;           // v lanes: x and y rows of R, t exchanged
     double fcl[12];
     if constexpr (HOIST) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) fcl[i] = fc[i];
+        for (int i = 0; i < 12; ++i) fcl[i] = fcm[i];
     }
-    const double* fcp = HOIST ? fcl : fc;
+    const double* fcp = HOIST ? fcl : fcm;
     // One corner in two steps.  A: transform, projection and its partials, residual - a long dependent chain (square root,
-    // reciprocal, atan / polynomials) that touches neither the accumulators nor the rows.  B: weight, the two scaled rows in
+    // reciprocal, atan / polynomials) that touches neither the accumulators nor the rows.  B: weight and the two scaled rows in
     // row-local column order [f | c | distortion | phi | t | r] (the weight rides on the focal length, so every Jacobian entry
-    // but d / d f and the residual comes out scaled at no cost), and the trade with the lane 32 away: lanes 0-31 end up with
-    // (own u, partner's u), lanes 32-63 with (partner's v, own v).
+    // but d / d f and the residual comes out scaled at no cost): MINE, the row of the lane's own kind, and OTHER, the row its
+    // neighbour accumulates, which it gets from there by DPP.
+    // The v lanes do all this in MIRRORED coordinates - x and y of the camera-frame point exchanged (their R, t come from the
+    // exchanged copy in LDS), fx / fy, cx / cy, the observed u / v (and OPENCV5's p1 / p2) exchanged: every model here is
+    // symmetric under that reflection, so the SAME instructions give a v lane its v row as "the first row" and the u row as
+    // "the second" - no per-lane selects.  In mirrored coordinates the pose columns come out as t' = (t_y, t_x, t_z),
+    // phi' = -(phi_y, phi_x, phi_z); OTHER is written in the PARTNER's convention (components exchanged, cross product
+    // reversed: free), and RowMap un-mirrors the v lanes' sums where the frame's lanes meet.
     struct Proj { double mx, my, dmx[3], dmy[3], ddx[ND > 0 ? ND : 1], ddy[ND > 0 ? ND : 1], rx, ry, rz, ru, rv; };
     auto step_a = [&](double X, double Y, double Z, double uo, double vo, Proj& p) {
         if constexpr (!HOIST) asm volatile("" ::: "memory");       // the frame constants stay in LDS
@@ -342,62 +417,95 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     auto step_b = [&](const Proj& p, bool valid, double* su, double* sv) {
         const double sw = valid ? huber_sqrt_weight(p.ru * p.ru + p.rv * p.rv, a.huber_delta) : 0.0;
         const double fxs = sw * th[0], fys = sw * th[1];
-        su[0] = sw * p.mx;              sv[0] = sw * p.my;
-        su[1] = sw;                     sv[1] = sw;                              // d u / d cx = d v / d cy = 1
+        double so[NCR];                                                           // OTHER
+        su[0] = sw * p.mx;              so[0] = sw * p.my;
+        su[1] = sw;                     so[1] = sw;                              // d u / d cx = d v / d cy = 1
 #pragma unroll
-        for (int i = 0; i < ND; ++i) { su[2 + i] = fxs * p.ddx[i]; sv[2 + i] = fys * p.ddy[i]; }
+        for (int i = 0; i < ND; ++i) { su[2 + i] = fxs * p.ddx[i]; so[g2_mirror<MODEL>(2 + i)] = fys * p.ddy[i]; }
         const double u0 = fxs * p.dmx[0], u1 = fxs * p.dmx[1], u2 = fxs * p.dmx[2];
         const double v0 = fys * p.dmy[0], v1 = fys * p.dmy[1], v2 = fys * p.dmy[2];
         su[2 + ND + 0] = p.ry * u2 - p.rz * u1; su[2 + ND + 1] = p.rz * u0 - p.rx * u2; su[2 + ND + 2] = p.rx * u1 - p.ry * u0;   // (R X) x j
-        sv[2 + ND + 0] = p.ry * v2 - p.rz * v1; sv[2 + ND + 1] = p.rz * v0 - p.rx * v2; sv[2 + ND + 2] = p.rx * v1 - p.ry * v0;
+        so[2 + ND + 0] = p.rx * v2 - p.rz * v0; so[2 + ND + 1] = p.rz * v1 - p.ry * v2; so[2 + ND + 2] = p.ry * v0 - p.rx * v1;   // the partner's convention
         su[2 + ND + 3] = u0; su[2 + ND + 4] = u1; su[2 + ND + 5] = u2;
-        sv[2 + ND + 3] = v0; sv[2 + ND + 4] = v1; sv[2 + ND + 5] = v2;
-        su[NCR - 1] = sw * p.ru;        sv[NCR - 1] = sw * p.rv;
+        so[2 + ND + 3] = v1; so[2 + ND + 4] = v0; so[2 + ND + 5] = v2;
+        su[NCR - 1] = sw * p.ru;        so[NCR - 1] = sw * p.rv;
 #pragma unroll
-        for (int i = 0; i < NCR; ++i) {
-            typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-            const u2 lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(su[i]), (unsigned)__double2loint(sv[i]), false, false);
-            const u2 hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(su[i]), (unsigned)__double2hiint(sv[i]), false, false);
-            su[i] = __hiloint2double((int)hi[0], (int)lo[0]); sv[i] = __hiloint2double((int)hi[1], (int)lo[1]);
-        }
+        for (int i = 0; i < NCR; ++i) sv[i] = g2_from_partner(so[i]);
     };
-    auto gram = [&](const double* su, const double* sv) {
-        int e = 0;
+    // UCM / EUCM: steps A and B in one, with the weight and the focal length folded into the two factors every partial of a row
+    // shares (e = sw f / n, a = e m): 9 FP64 instructions fewer per corner than scaling project_partials' outputs
+    auto rows_ucm = [&](double X, double Y, double Z, double uo, double vo, bool valid, double* su, double* sv) {
+        if constexpr (!HOIST) asm volatile("" ::: "memory");
+        const double rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z, ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z, rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
+        const double px = rx + fcp[9], py = ry + fcp[10], pz = rz + fcp[11];
+        const double alpha = th[4], beta = (MODEL == kEUCM) ? th[5] : 1.0;
+        const double r2 = px * px + py * py;
+        double rho, irho;
+        fast_sqrt_rsqrt(beta * r2 + pz * pz, rho, irho);
+        const double inv = fast_rcp(alpha * rho + (1.0 - alpha) * pz);
+        const double mx = px * inv, my = py * inv;
+        const double ru = th[0] * mx + th[2] - uo, rv = th[1] * my + th[3] - vo;
+        const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
+        const double ab = (alpha * beta) * irho;
+        const double nx = ab * px, ny = ab * py, nz = (alpha * pz) * irho + (1.0 - alpha);
+        const double eu = (sw * th[0]) * inv, ev = (sw * th[1]) * inv;
+        const double au = eu * mx, av = ev * my;
+        double so[NCR];
+        su[0] = sw * mx;                so[0] = sw * my;
+        su[1] = sw;                     so[1] = sw;
+        const double na = rho - pz;
+        su[2] = -au * na;               so[2] = -av * na;
+        if constexpr (MODEL == kEUCM) { const double nb = (0.5 * alpha * r2) * irho; su[3] = -au * nb; so[3] = -av * nb; }
+        const double u0 = __builtin_fma(-au, nx, eu), u1 = -au * ny, u2 = -au * nz;
+        const double v0 = -av * nx, v1 = __builtin_fma(-av, ny, ev), v2 = -av * nz;
+        su[2 + ND + 0] = ry * u2 - rz * u1; su[2 + ND + 1] = rz * u0 - rx * u2; su[2 + ND + 2] = rx * u1 - ry * u0;   // (R X) x j
+        so[2 + ND + 0] = rx * v2 - rz * v0; so[2 + ND + 1] = rz * v1 - ry * v2; so[2 + ND + 2] = ry * v0 - rx * v1;   // the partner's convention
+        su[2 + ND + 3] = u0; su[2 + ND + 4] = u1; su[2 + ND + 5] = u2;
+        so[2 + ND + 3] = v1; so[2 + ND + 4] = v0; so[2 + ND + 5] = v2;
+        su[NCR - 1] = sw * ru;          so[NCR - 1] = sw * rv;
+#pragma unroll
+        for (int i = 0; i < NCR; ++i) sv[i] = g2_from_partner(so[i]);
+    };
+    auto gram = [&](const double* su, const double* sv) {       // su: the lane's own corner, sv: its neighbour's - both rows of the lane's kind
+        constexpr Map nm = Map();
 #pragma unroll
         for (int i = 0; i < NCR; ++i) {
 #pragma unroll
             for (int j = i; j < NCR; ++j) {
-                if (e < NLA) {
-                    __hip_atomic_fetch_add(red + e * LSA + lane, __builtin_fma(sv[i], sv[j], su[i] * su[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    acc[e] = __builtin_fma(su[i], su[j], acc[e]);
-                    acc[e] = __builtin_fma(sv[i], sv[j], acc[e]);
-                }
-                ++e;
+                const int e = nm.num[i][j];
+                acc[e] = __builtin_fma(su[i], su[j], acc[e]);
+                acc[e] = __builtin_fma(sv[i], sv[j], acc[e]);
             }
         }
     };
     for (int base = 0; base < nmax; base += LPF) {
         const bool valid = base + cl < n;
-        const double X = pX, Y = pY, Z = pZ, uo = pU, vo = pV;
+        double X = pX, Y = pY, Z = pZ, uo = role ? pV : pU, vo = role ? pU : pV;
+        asm volatile("" : "+v"(X), "+v"(Y), "+v"(Z), "+v"(uo), "+v"(vo));      // converted BEFORE the next rows are requested: they land in the same registers
         if (base + LPF < nmax) {
             const int cn = base + LPF + cl;
-            const int64_t gn = start + (cn < n ? cn : 0);
-            pX = a.x[gn]; pY = a.y[gn]; pZ = a.z[gn]; pU = a.u[gn]; pV = a.v[gn];
+            const uint32_t gn = ob0 + 4u * (uint32_t)(cn < n ? cn : 0);
+            pX = ldf(a.x, gn); pY = ldf(a.y, gn); pZ = ldf(a.z, gn); pU = ldf(a.u, gn); pV = ldf(a.v, gn);
         }
         Proj p;
         double su[NCR], sv[NCR];
-        step_a(X, Y, Z, uo, vo, p);
-        step_b(p, valid, su, sv);
+        G2_CYC_BEGIN();
+        if constexpr (MODEL == kUCM || MODEL == kEUCM) {
+            rows_ucm(X, Y, Z, uo, vo, valid, su, sv);
+        } else {
+            step_a(X, Y, Z, uo, vo, p);
+            G2_CYC(0);
+            step_b(p, valid, su, sv);
+        }
+        G2_CYC(2);
         gram(su, sv);
+        G2_CYC(3);
+#if defined(CCAL_STAMPS) && CCAL_STAMPS >= 2
+        g2_cyc[4] += 1;
+#endif
     }
 
     G2_STAMP(2);
-    if constexpr (NLA > 0) {              // the LDS accumulators join the others (the rows are dead: registers to spare)
-        wsync();
-#pragma unroll
-        for (int t = 0; t < NLA; ++t) acc[t] = red[t * LSA + lane];
-    }
     const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
     // fused elimination: what its tail needs from memory is requested now, behind the reductions
     int slot_t = 0;
@@ -428,12 +536,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
                 const unsigned long long tv = tab[it];
                 const uint32_t sc = (uint32_t)tv;
                 recm[s][q] = (uint32_t)(tv >> 32);
-                const int t = (int)(sc & 0xff) - s * CH;
                 double s_u = 0.0, s_v = 0.0;
-                const double* src = red + (g * L2) * LS + t;      // the frame's u lanes; its v lanes are 32 lanes on
+                const double* src_u = red + (g * LPF) * LS + ((int)(sc & 0xff) - s * CH);              // the frame's u lanes: the even ones
+                const double* src_v = red + (g * LPF + 1) * LS + ((int)((sc >> 8) & 0xff) - s * CH);   // its v lanes hold the entry under its mirrored number
 #pragma unroll
-                for (int l = 0; l < L2; ++l) { s_u += src[l * LS]; s_v += src[(32 + l) * LS]; }
-                sum = ((sc >> 12) & 1 ? s_u : 0.0) + ((sc >> 13) & 1 ? s_v : 0.0);
+                for (int l = 0; l < L2; ++l) { s_u += src_u[2 * l * LS]; s_v += src_v[2 * l * LS]; }
+                sum = ((sc >> 16) & 1 ? s_u : 0.0) + ((sc >> 17) & 1 ? ((sc >> 18) & 1 ? -s_v : s_v) : 0.0);
             }
             res[s][q] = sum;
         }
@@ -501,7 +609,7 @@ static hipError_t launch_gram2_l(const FusedArgs& a, hipStream_t s) {
     constexpr int LS = Map::CH | 1;
     constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
     constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
-    constexpr int WSL = (G * FC_N0P + RED + Map::NEF + 1) & ~1;
+    constexpr int WSL = (G * (FC_N0P + 12) + RED + Map::NEF + 1) & ~1;
     const size_t lds = sizeof(double) * WSL * CCAL_GRAMV_WPB;
     void (*kern)(const FusedArgs) = k_gram2<MODEL, OF, LPF, GEN>;
     static DynLdsGuard lds_guard;

@@ -197,6 +197,7 @@ int ccal_get_model_conventions(const ccal_ctx* ctx, ccal_model_conventions* out)
 int ccal_set_model_conventions(ccal_ctx* ctx, const ccal_model_conventions* in);
 
 /* ---- problem ---------------------------------------------------------------------------- */
+/* One problem holds at most 2^30 - 1 corners (CCAL_ERR_INVALID_ARG beyond: shard the frames, ccal_multi_problem_create). */
 int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* desc, ccal_problem** out);
 void ccal_problem_destroy(ccal_problem* p);
 int ccal_set_defaults(ccal_solver_opts* opts);   /* tiny-solver OptimizerOptions::default() */

@@ -25,6 +25,19 @@ def test_duplicate_camera_slot_pair_is_rejected(gpu_ctx):
     assert "same (camera, slot)" in gpu_ctx.last_error()
 
 
+def test_more_than_2_pow_30_corners_are_refused(gpu_ctx):
+    """The Gram kernels address a problem's corner rows by 32-bit byte offsets: ccal_problem_create refuses a description with
+    2^30 corners or more (before it reads a single corner) and says what to do instead."""
+    sp = synth.make_problem(2, "eucm")
+    x, y, z, u, v = sp.soa()
+    offs = np.array([0, 1 << 29, 1 << 30], dtype=np.int64)
+    d, keep = make_desc(1, [1], [512.0], [512.0], False, 2, [0, 0], [0, 1], offs, x, y, z, u, v, 1.0)
+    with pytest.raises(CcalError) as ei:
+        Problem(gpu_ctx, d, keep)
+    assert ei.value.code == _ffi.ERR_INVALID_ARG
+    assert "shard" in gpu_ctx.last_error()
+
+
 def test_multi_camera_entry_points_require_extrinsics(gpu_ctx):
     """extr == NULL with a second camera used to evaluate with whatever an earlier solve left on the device."""
     sp = synth.make_problem(4, "eucm", n_cams=2)

@@ -18,7 +18,7 @@ n = min(F * 40, 8 * 16384)
 buf = np.zeros(n, dtype=np.float64)
 lib.ccal_debug_fcbuf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 lib.ccal_debug_fcbuf(p.handle, buf.ctypes.data_as(C.c_void_p), n)
-st = buf.reshape(-1, 8)
+st = buf.reshape(-1, 16)
 ok = st[:, 0] > 0
 st = st[ok]
 t0 = st[:, 0].min()
@@ -31,3 +31,7 @@ for label, sel in (("first half of the dispatch (older on their SIMD)", slice(0,
     d = np.diff(s[:, :6], axis=1) / 100.0
     print(f"  {label}: start {np.median(s[:, 0] - t0) / 100:.2f}  " + "  ".join(f"{nm} {np.median(d[:, i]):.2f}" for i, nm in enumerate(names[1:])) +
           f"  total {np.median(s[:, 5] - s[:, 0]) / 100:.2f}  end {np.median(s[:, 5] - t0) / 100:.2f} us")
+    if s[:, 12].max() > 0:      # -DCCAL_STAMPS=2: shader cycles per pass in the sections of the corner loop
+        per = s[:, 8:12] / np.maximum(s[:, 12:13], 1)
+        print("      cycles per pass: " + "  ".join(f"{nm} {np.median(per[:, i]):.0f}" for i, nm in enumerate(["back", "next rows", "rows + DPP", "Gram + chain"])) +
+              f"  sum {np.median(per.sum(axis=1)):.0f}  ({np.median(s[:, 12]):.0f} passes; loop {np.median(s[:, 2] - s[:, 1]) / 100:.2f} us -> {np.median(per.sum(axis=1) * s[:, 12] / np.maximum(s[:, 2] - s[:, 1], 1)) / 10:.0f} MHz)")

@@ -13,8 +13,12 @@ import numpy as np
 from camera_intrinsic_calibration_rs_amd import synth
 from camera_intrinsic_calibration_rs_amd.engine import Context, MultiContext, MultiProblem, Problem, default_opts
 
+# rigs (per-context helper threads) next to session-sized single-camera problems of one model (the caller's thread drives their
+# lockstep groups while the helpers run the rigs)
 sps = [synth.make_problem(60, "eucm", n_cams=2, seed=1), synth.make_problem(40, "opencv5", n_cams=3, seed=2),
-       synth.make_problem(30, "ucm", n_cams=5, seed=3), synth.make_problem(200, "kb4", seed=4), synth.make_problem(150, "eucm", seed=5)]
+       synth.make_problem(30, "ucm", n_cams=5, seed=3), synth.make_problem(200, "kb4", seed=4), synth.make_problem(150, "eucm", seed=5),
+       synth.make_problem(150, "eucm", seed=7, ragged=True), synth.make_problem(150, "eucm", seed=8), synth.make_problem(200, "kb4", seed=9),
+       synth.make_problem(80, "opencv5", seed=10), synth.make_problem(80, "opencv5", seed=11)]      # equal sizes: one lockstep group per model
 ctxs = [Context(0) for _ in sps]
 probs = [Problem.from_synth(c, s) for c, s in zip(ctxs, sps)]
 for method in (0, 1):
@@ -32,6 +36,10 @@ for model, n_cams in (("eucm", 1), ("kb4", 2)):
         a = mp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
         b = mp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
         assert a[3].status == 0 and np.array_equal(a[0], b[0])
+    # the one-shot entry points over the shards run on the contexts' persistent helpers too
+    po, used = mp.init_poses(sp.intr0)
+    v1 = mp.validation(0, a[0], a[1], a[2]); v2 = mp.validation(0, a[0], a[1], a[2])
+    assert v1 == v2 and used.min() >= 0
     mp.close()
 mc.close()
 print("TSAN-DRIVE-OK", flush=True)
