@@ -181,6 +181,8 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
         p->cams[cam].obs.push_back(o);
     }
     p->h_joff[d->n_obs] = j; p->j_len = j;
+    p->slot_ident = d->n_slots == d->n_obs;
+    for (int o = 0; o < d->n_obs && p->slot_ident; ++o) p->slot_ident = p->h_obs_slot[o] == o;
     p->n_corners = p->h_obs_off[d->n_obs];
     // the Gram kernels address a problem's corner rows by 32-bit byte offsets (ccal_kernels_gram2.hip); 2^30 corners are 21 GB of
     // inputs and 245 GB of mode-E outputs - beyond that, shard the frames (ccal_multi_*)

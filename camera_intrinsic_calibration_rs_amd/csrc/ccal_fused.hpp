@@ -293,6 +293,7 @@ struct FusedArgs {
     const int32_t* list; const int64_t* rec_off;
     int32_t cam; const double* extr[2];
     int32_t avg_corners;           // corners per observation frame on average (lanes-per-frame choice of the Gram launchers)
+    int32_t slot_ident;            // obs_slot[f] == f for every frame (one camera that saw every slot): the prologue does not wait for the table
     // single-camera loop: k_gram1w eliminates the pose blocks of its frames itself (gram_fused_tail): no k_schur1m launch,
     // one row of partial sums per wavefront.  Set by launch_gram1v when the kernel it picks supports it (elim_fused = 1)
     int32_t fuse_elim, elim_fused;

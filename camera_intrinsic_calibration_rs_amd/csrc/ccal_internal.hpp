@@ -90,6 +90,7 @@ struct ccal_problem {
     std::vector<ccal::CamLayout> cams;
     std::vector<int64_t> h_obs_off, h_joff;
     std::vector<int32_t> h_obs_cam, h_obs_slot;
+    bool slot_ident = false;       // h_obs_slot[o] == o for every observation frame
     // device-resident inputs
     char* d_scratch = nullptr; size_t scratch_bytes = 0;      // validation()'s temporaries (grown on demand, kept between calls)
     char* d_block = nullptr;       // ONE device allocation: the corner arrays, the frame tables and the six parameter arrays are slices of it

@@ -461,7 +461,8 @@ __device__ __forceinline__ void gram1v_body(const FusedArgs& a, const IterDyn& d
     {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants;
         // the 16 lanes of a group compute the same values, the 4 groups work on 4 frames at once
-        const int slot = ITER ? slot_p : a.obs_slot[fa_];
+        int slot;                           // (identity table: no round trip in front of the pose and the elimination record)
+        if constexpr (ITER) slot = slot_p; else { if (!GEN && a.slot_ident) slot = fa_; else slot = a.obs_slot[fa_]; }
         double pose[6];
         if constexpr (ITER) {
 #pragma unroll
@@ -1306,15 +1307,15 @@ hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t
 }
 
 // single-camera loop; a.fuse_elim in: fusion allowed, out: fusion done (then a.n_part = rows of partial sums, a.elim_fused = 1)
-// Which register Gram kernel.  k_gram2 (the block's rows traded between lane halves, ccal_kernels_gram2.hip) where it
-// measured faster (10 000 / 2 500 frames, us per build, k_gram2 vs k_gram1v|w): OPENCV5 47.1 / 25.6 vs 51.2 / 27.3, EUCM 35.8 /
-// 21.1 vs 36.9 / 22.2 (from 2 000 frames: two wavefronts per SIMD, no LDS accumulators; 625 frames 15.9 vs 14.2 with k_gram1v),
-// KB4 49.3 vs 49.7 two-focal but 48.2 vs 46.5 one-focal: KB4 stays on k_gram1v.  CCAL_GRAM2=0|1 forces.
+// Which register Gram kernel.  k_gram2 (the block's rows on neighbouring lanes, ccal_kernels_gram2.hip) where it measured faster
+// (10 000 / 2 500 frames, us per build, k_gram2 vs k_gram1v|w): OPENCV5 47.1 / 25.6 vs 51.2 / 27.3, EUCM 35.8 / 21.1 vs 36.9 / 22.2
+// (from 2 000 frames: two wavefronts per SIMD, no LDS accumulators; 625 frames 15.9 vs 14.2 with k_gram1v); KB4 since round 5
+// (neighbouring-lane form): 46.7 / 24.4 vs 49.7 / 25.8, one focal 45.9 vs 47.2.  CCAL_GRAM2=0|1 forces (second library).
 static bool use_gram2(int model, int n_obs) {
     static const int force = [] { const char* e = dev_env("CCAL_GRAM2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     if (force >= 0) return force == 1;
     if (model == kOCV5) return true;
-    return (model == kUCM || model == kEUCM) && n_obs >= 2000;
+    return n_obs >= 2000;
 }
 static int gram2_lpf_force() { static const int v = dev_env_int("CCAL_GRAM2_LPF", 0); return v; }
 hipError_t launch_gram1v(int model, bool one_focal, FusedArgs& a, hipStream_t s) {

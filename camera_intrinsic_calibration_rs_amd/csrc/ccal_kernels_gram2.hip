@@ -159,7 +159,7 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 #define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[16 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
                                                        for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[16 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; } } while (0)
 // -DCCAL_STAMPS=2: shader cycles (s_memtime) spent in the sections of the corner loop, summed over the passes:
-// 0 transform + projection, 2 rows + DPP, 3 Gram products, 4 passes
+// 2 projection + rows + DPP, 3 Gram products, 4 passes
 #if CCAL_STAMPS >= 2
 #define G2_CYC_BEGIN() do { __builtin_amdgcn_sched_barrier(0); g2_c0 = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define G2_CYC(i) do { __builtin_amdgcn_sched_barrier(0); const long long c_ = clock64(); g2_cyc[i] += c_ - g2_c0; g2_c0 = c_; __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -294,7 +294,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants; the lanes of
         // a group compute the same values, the G groups work on G frames at once
-        const int slot = a.obs_slot[fa_];
+        // the frame's slot: the table - or, when the table is the identity, the frame itself: pose and elimination record are
+        // requested with the frame's offsets instead of a memory round trip after them
+        int slot;
+        if (!GEN && a.slot_ident) slot = fa_; else slot = a.obs_slot[fa_];
         double pose[6];
         // GEN: k_backsub has formed the candidate - or, FusedArgs::gen_backsub, it is formed here from the accepted pose
         const bool gbs = GEN && a.gen_backsub != 0 && !first;
@@ -394,77 +397,136 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         for (int i = 0; i < 12; ++i) fcl[i] = fcm[i];
     }
     const double* fcp = HOIST ? fcl : fcm;
-    // One corner in two steps.  A: transform, projection and its partials, residual - a long dependent chain (square root,
-    // reciprocal, atan / polynomials) that touches neither the accumulators nor the rows.  B: weight and the two scaled rows in
-    // row-local column order [f | c | distortion | phi | t | r] (the weight rides on the focal length, so every Jacobian entry
-    // but d / d f and the residual comes out scaled at no cost): MINE, the row of the lane's own kind, and OTHER, the row its
-    // neighbour accumulates, which it gets from there by DPP.
+    // One corner: transform, projection and its partials, residual, weight, and the two scaled rows in row-local column order
+    // [f | c | distortion | phi | t | r] (the weight rides on the focal length, folded into the factors a row's partials share):
+    // MINE, the row of the lane's own kind, and OTHER, the row its neighbour accumulates, which it gets from there by DPP.
     // The v lanes do all this in MIRRORED coordinates - x and y of the camera-frame point exchanged (their R, t come from the
     // exchanged copy in LDS), fx / fy, cx / cy, the observed u / v (and OPENCV5's p1 / p2) exchanged: every model here is
     // symmetric under that reflection, so the SAME instructions give a v lane its v row as "the first row" and the u row as
     // "the second" - no per-lane selects.  In mirrored coordinates the pose columns come out as t' = (t_y, t_x, t_z),
     // phi' = -(phi_y, phi_x, phi_z); OTHER is written in the PARTNER's convention (components exchanged, cross product
     // reversed: free), and RowMap un-mirrors the v lanes' sums where the frame's lanes meet.
-    struct Proj { double mx, my, dmx[3], dmy[3], ddx[ND > 0 ? ND : 1], ddy[ND > 0 ? ND : 1], rx, ry, rz, ru, rv; };
-    auto step_a = [&](double X, double Y, double Z, double uo, double vo, Proj& p) {
-        if constexpr (!HOIST) asm volatile("" ::: "memory");       // the frame constants stay in LDS
-        p.rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z;               // rotated board point: the phi columns need it without the translation
-        p.ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z;
-        p.rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
-        project_partials<MODEL>(th, p.rx + fcp[9], p.ry + fcp[10], p.rz + fcp[11], p.mx, p.my, p.dmx, p.dmy, p.ddx, p.ddy);
-        p.ru = th[0] * p.mx + th[2] - uo; p.rv = th[1] * p.my + th[3] - vo;
-    };
-    auto step_b = [&](const Proj& p, bool valid, double* su, double* sv) {
-        const double sw = valid ? huber_sqrt_weight(p.ru * p.ru + p.rv * p.rv, a.huber_delta) : 0.0;
-        const double fxs = sw * th[0], fys = sw * th[1];
-        double so[NCR];                                                           // OTHER
-        su[0] = sw * p.mx;              so[0] = sw * p.my;
-        su[1] = sw;                     so[1] = sw;                              // d u / d cx = d v / d cy = 1
-#pragma unroll
-        for (int i = 0; i < ND; ++i) { su[2 + i] = fxs * p.ddx[i]; so[g2_mirror<MODEL>(2 + i)] = fys * p.ddy[i]; }
-        const double u0 = fxs * p.dmx[0], u1 = fxs * p.dmx[1], u2 = fxs * p.dmx[2];
-        const double v0 = fys * p.dmy[0], v1 = fys * p.dmy[1], v2 = fys * p.dmy[2];
-        su[2 + ND + 0] = p.ry * u2 - p.rz * u1; su[2 + ND + 1] = p.rz * u0 - p.rx * u2; su[2 + ND + 2] = p.rx * u1 - p.ry * u0;   // (R X) x j
-        so[2 + ND + 0] = p.rx * v2 - p.rz * v0; so[2 + ND + 1] = p.rz * v1 - p.ry * v2; so[2 + ND + 2] = p.ry * v0 - p.rx * v1;   // the partner's convention
+    // (project_partials of ccal_device.hpp, which mode E and k_gram1v use, is the same arithmetic before the folding.)
+    // the pose columns and the residual of both rows from the scaled translation partials (u: MINE, v: OTHER, in the partner's
+    // convention), then the trade
+    auto rows_finish = [&](double rx, double ry, double rz, double u0, double u1, double u2, double v0, double v1, double v2,
+                           double sw, double ru, double rv, double* su, double* so, double* sv) {
+        su[2 + ND + 0] = ry * u2 - rz * u1; su[2 + ND + 1] = rz * u0 - rx * u2; su[2 + ND + 2] = rx * u1 - ry * u0;   // (R X) x j
+        so[2 + ND + 0] = rx * v2 - rz * v0; so[2 + ND + 1] = rz * v1 - ry * v2; so[2 + ND + 2] = ry * v0 - rx * v1;
         su[2 + ND + 3] = u0; su[2 + ND + 4] = u1; su[2 + ND + 5] = u2;
         so[2 + ND + 3] = v1; so[2 + ND + 4] = v0; so[2 + ND + 5] = v2;
-        su[NCR - 1] = sw * p.ru;        so[NCR - 1] = sw * p.rv;
+        su[NCR - 1] = sw * ru;          so[NCR - 1] = sw * rv;
 #pragma unroll
         for (int i = 0; i < NCR; ++i) sv[i] = g2_from_partner(so[i]);
     };
     // UCM / EUCM: steps A and B in one, with the weight and the focal length folded into the two factors every partial of a row
     // shares (e = sw f / n, a = e m): 9 FP64 instructions fewer per corner than scaling project_partials' outputs
     auto rows_ucm = [&](double X, double Y, double Z, double uo, double vo, bool valid, double* su, double* sv) {
-        if constexpr (!HOIST) asm volatile("" ::: "memory");
-        const double rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z, ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z, rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
-        const double px = rx + fcp[9], py = ry + fcp[10], pz = rz + fcp[11];
-        const double alpha = th[4], beta = (MODEL == kEUCM) ? th[5] : 1.0;
-        const double r2 = px * px + py * py;
-        double rho, irho;
-        fast_sqrt_rsqrt(beta * r2 + pz * pz, rho, irho);
-        const double inv = fast_rcp(alpha * rho + (1.0 - alpha) * pz);
-        const double mx = px * inv, my = py * inv;
-        const double ru = th[0] * mx + th[2] - uo, rv = th[1] * my + th[3] - vo;
-        const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
-        const double ab = (alpha * beta) * irho;
-        const double nx = ab * px, ny = ab * py, nz = (alpha * pz) * irho + (1.0 - alpha);
-        const double eu = (sw * th[0]) * inv, ev = (sw * th[1]) * inv;
-        const double au = eu * mx, av = ev * my;
-        double so[NCR];
-        su[0] = sw * mx;                so[0] = sw * my;
-        su[1] = sw;                     so[1] = sw;
-        const double na = rho - pz;
-        su[2] = -au * na;               so[2] = -av * na;
-        if constexpr (MODEL == kEUCM) { const double nb = (0.5 * alpha * r2) * irho; su[3] = -au * nb; so[3] = -av * nb; }
-        const double u0 = __builtin_fma(-au, nx, eu), u1 = -au * ny, u2 = -au * nz;
-        const double v0 = -av * nx, v1 = __builtin_fma(-av, ny, ev), v2 = -av * nz;
-        su[2 + ND + 0] = ry * u2 - rz * u1; su[2 + ND + 1] = rz * u0 - rx * u2; su[2 + ND + 2] = rx * u1 - ry * u0;   // (R X) x j
-        so[2 + ND + 0] = rx * v2 - rz * v0; so[2 + ND + 1] = rz * v1 - ry * v2; so[2 + ND + 2] = ry * v0 - rx * v1;   // the partner's convention
-        su[2 + ND + 3] = u0; su[2 + ND + 4] = u1; su[2 + ND + 5] = u2;
-        so[2 + ND + 3] = v1; so[2 + ND + 4] = v0; so[2 + ND + 5] = v2;
-        su[NCR - 1] = sw * ru;          so[NCR - 1] = sw * rv;
-#pragma unroll
-        for (int i = 0; i < NCR; ++i) sv[i] = g2_from_partner(so[i]);
+      if constexpr (MODEL == kUCM || MODEL == kEUCM) {
+            if constexpr (!HOIST) asm volatile("" ::: "memory");
+            const double rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z, ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z, rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
+            const double px = rx + fcp[9], py = ry + fcp[10], pz = rz + fcp[11];
+            const double alpha = th[4], beta = (MODEL == kEUCM) ? th[5] : 1.0;
+            const double r2 = px * px + py * py;
+            double rho, irho;
+            fast_sqrt_rsqrt(beta * r2 + pz * pz, rho, irho);
+            const double inv = fast_rcp(alpha * rho + (1.0 - alpha) * pz);
+            const double mx = px * inv, my = py * inv;
+            const double ru = th[0] * mx + th[2] - uo, rv = th[1] * my + th[3] - vo;
+            const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
+            const double ab = (alpha * beta) * irho;
+            const double nx = ab * px, ny = ab * py, nz = (alpha * pz) * irho + (1.0 - alpha);
+            const double eu = (sw * th[0]) * inv, ev = (sw * th[1]) * inv;
+            const double au = eu * mx, av = ev * my;
+            double so[NCR];
+            su[0] = sw * mx;                so[0] = sw * my;
+            su[1] = sw;                     so[1] = sw;
+            const double na = rho - pz;
+            su[2] = -au * na;               so[2] = -av * na;
+            if constexpr (MODEL == kEUCM) { const double nb = (0.5 * alpha * r2) * irho; su[3] = -au * nb; so[3] = -av * nb; }
+            const double u0 = __builtin_fma(-au, nx, eu), u1 = -au * ny, u2 = -au * nz;
+            const double v0 = -av * nx, v1 = __builtin_fma(-av, ny, ev), v2 = -av * nz;
+            rows_finish(rx, ry, rz, u0, u1, u2, v0, v1, v2, sw, ru, rv, su, so, sv);
+      }
+    };
+    // KB4 / OPENCV5: the same folding (project_partials' formulas, ccal_device.hpp, with sw f carried into the common factors of a
+    // row's partials): 10 FP64 instructions fewer per corner each
+    auto rows_kb4 = [&](double X, double Y, double Z, double uo, double vo, bool valid, double* su, double* sv) {
+      if constexpr (MODEL == kKB4) {
+            if constexpr (!HOIST) asm volatile("" ::: "memory");
+            const double rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z, ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z, rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
+            const double px = rx + fcp[9], py = ry + fcp[10], pz = rz + fcp[11];
+            const double r2 = px * px + py * py;
+            double r, ir;
+            fast_sqrt_rsqrt(r2, r, ir);          // r2 == 0 gives NaN here and falls into the pinhole branch below
+            double s_, g, sz, t;                 // m = s (x, y);  d m / d (x, y, z) from s, g, sz;  theta
+            if (r > th[model_np(kKB4)]) {          // run-time convention slot (load_theta): ccal_model_conventions.kb4_small_radius
+                t = fast_atan2_pos(r, pz);
+                const double t2 = t * t;
+                const double k1 = th[4], k2 = th[5], k3 = th[6], k4 = th[7];
+                const double td = t * (1.0 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4))));
+                const double tdp = 1.0 + t2 * (3.0 * k1 + t2 * (5.0 * k2 + t2 * (7.0 * k3 + t2 * 9.0 * k4)));
+                s_ = td * ir;
+                const double id2 = fast_rcp(r2 + pz * pz);
+                const double tq = pz * ir * id2, tz = -r * id2;
+                g = ir * (tdp * tq - s_ * ir);
+                sz = ir * tdp * tz;
+            } else {                             // pinhole limit: m = (x, y) / z, no distortion partials
+                const double iz = fast_rcp(pz);
+                s_ = iz; g = 0.0; sz = -iz * iz; t = 0.0; ir = 0.0;
+            }
+            const double mx = px * s_, my = py * s_;
+            const double ru = th[0] * mx + th[2] - uo, rv = th[1] * my + th[3] - vo;
+            const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
+            const double fxs = sw * th[0], fys = sw * th[1];
+            const double A = fxs * px, B = fys * py, Ag = A * g, Bg = B * g;
+            const double u0 = __builtin_fma(Ag, px, fxs * s_), u1 = Ag * py, u2 = A * sz;
+            const double v0 = Bg * px, v1 = __builtin_fma(Bg, py, fys * s_), v2 = B * sz;
+            const double t2 = t * t, t3 = t2 * t, t5 = t3 * t2, t7 = t5 * t2, t9 = t7 * t2;
+            const double Du = A * ir, Dv = B * ir;
+            double so[NCR];
+            su[0] = sw * mx;                so[0] = sw * my;
+            su[1] = sw;                     so[1] = sw;
+            su[2] = Du * t3; su[3] = Du * t5; su[4] = Du * t7; su[5] = Du * t9;
+            so[2] = Dv * t3; so[3] = Dv * t5; so[4] = Dv * t7; so[5] = Dv * t9;
+            rows_finish(rx, ry, rz, u0, u1, u2, v0, v1, v2, sw, ru, rv, su, so, sv);
+      }
+    };
+    auto rows_ocv5 = [&](double X, double Y, double Z, double uo, double vo, bool valid, double* su, double* sv) {
+      if constexpr (MODEL == kOCV5) {
+            if constexpr (!HOIST) asm volatile("" ::: "memory");
+            const double rx = fcp[0] * X + fcp[1] * Y + fcp[2] * Z, ry = fcp[3] * X + fcp[4] * Y + fcp[5] * Z, rz = fcp[6] * X + fcp[7] * Y + fcp[8] * Z;
+            const double px = rx + fcp[9], py = ry + fcp[10], pz = rz + fcp[11];
+            const double k1 = th[OCV5_K1], k2 = th[OCV5_K2], p1 = th[OCV5_P1], p2 = th[OCV5_P2], k3 = th[OCV5_K3];      // (v lanes: p1, p2 exchanged)
+            const double iz = fast_rcp(pz);
+            const double xn = px * iz, yn = py * iz;
+            const double xx = xn * xn, yy = yn * yn, xy = xn * yn;
+            const double r2 = xx + yy;
+            const double rad = 1.0 + r2 * (k1 + r2 * (k2 + r2 * k3));
+            const double drad = k1 + r2 * (2.0 * k2 + r2 * 3.0 * k3);
+            const double txy = 2.0 * xy, qx = r2 + 2.0 * xx, qy = r2 + 2.0 * yy;
+            const double mx = xn * rad + p1 * txy + p2 * qx;
+            const double my = yn * rad + p1 * qy + p2 * txy;
+            const double xd_x = rad + 2.0 * xx * drad + 2.0 * p1 * yn + 6.0 * p2 * xn;
+            const double xd_y = txy * drad + 2.0 * p1 * xn + 2.0 * p2 * yn;
+            const double yd_y = rad + 2.0 * yy * drad + 6.0 * p1 * yn + 2.0 * p2 * xn;
+            const double ru = th[0] * mx + th[2] - uo, rv = th[1] * my + th[3] - vo;
+            const double sw = valid ? huber_sqrt_weight(ru * ru + rv * rv, a.huber_delta) : 0.0;
+            const double fxs = sw * th[0], fys = sw * th[1];
+            const double eu = fxs * iz, ev = fys * iz;
+            const double u0 = eu * xd_x, u1 = eu * xd_y, u2 = -(u0 * xn + u1 * yn);
+            const double v0 = ev * xd_y, v1 = ev * yd_y, v2 = -(v0 * xn + v1 * yn);
+            const double Xu = fxs * xn, Yv = fys * yn;
+            const double r4 = r2 * r2, r6 = r4 * r2;
+            double so[NCR];
+            su[0] = sw * mx;                so[0] = sw * my;
+            su[1] = sw;                     so[1] = sw;
+            su[2 + OCV5_K1 - 4] = Xu * r2; su[2 + OCV5_K2 - 4] = Xu * r4; su[2 + OCV5_K3 - 4] = Xu * r6;
+            su[2 + OCV5_P1 - 4] = fxs * txy; su[2 + OCV5_P2 - 4] = fxs * qx;
+            so[2 + OCV5_K1 - 4] = Yv * r2; so[2 + OCV5_K2 - 4] = Yv * r4; so[2 + OCV5_K3 - 4] = Yv * r6;
+            so[2 + OCV5_P2 - 4] = fys * qy; so[2 + OCV5_P1 - 4] = fys * txy;          // d v / d p1, d v / d p2 in the partner's (mirrored) columns
+            rows_finish(rx, ry, rz, u0, u1, u2, v0, v1, v2, sw, ru, rv, su, so, sv);
+      }
     };
     auto gram = [&](const double* su, const double* sv) {       // su: the lane's own corner, sv: its neighbour's - both rows of the lane's kind
         constexpr Map nm = Map();
@@ -487,16 +549,11 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
             const uint32_t gn = ob0 + 4u * (uint32_t)(cn < n ? cn : 0);
             pX = ldf(a.x, gn); pY = ldf(a.y, gn); pZ = ldf(a.z, gn); pU = ldf(a.u, gn); pV = ldf(a.v, gn);
         }
-        Proj p;
         double su[NCR], sv[NCR];
         G2_CYC_BEGIN();
-        if constexpr (MODEL == kUCM || MODEL == kEUCM) {
-            rows_ucm(X, Y, Z, uo, vo, valid, su, sv);
-        } else {
-            step_a(X, Y, Z, uo, vo, p);
-            G2_CYC(0);
-            step_b(p, valid, su, sv);
-        }
+        if constexpr (MODEL == kUCM || MODEL == kEUCM) rows_ucm(X, Y, Z, uo, vo, valid, su, sv);
+        else if constexpr (MODEL == kKB4) rows_kb4(X, Y, Z, uo, vo, valid, su, sv);
+        else rows_ocv5(X, Y, Z, uo, vo, valid, su, sv);
         G2_CYC(2);
         gram(su, sv);
         G2_CYC(3);
@@ -511,7 +568,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     int slot_t = 0;
     double mc_t = 0.0;
     if constexpr (!GEN) {
-        if (fuse && active) { slot_t = a.obs_slot[f]; if (gl == 0) mc_t = a.mc_f[f]; }
+        if (fuse && active) { slot_t = a.slot_ident ? f : a.obs_slot[f]; if (gl == 0) mc_t = a.mc_f[f]; }
     }
     // the frame's LPF partial row Grams -> one Gram of the block, through LDS, slice by slice: an item = one entry of the
     // full triangle = the sum over the frame's u lanes and / or v lanes of one row-local entry

@@ -407,7 +407,7 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     const FusedWs* f = w->fws;
     FusedArgs fa = {};
     fa.x = p->d_x; fa.y = p->d_y; fa.z = p->d_z; fa.u = p->d_u; fa.v = p->d_v;
-    fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot;
+    fa.obs_off = p->d_obs_off; fa.obs_slot = p->d_obs_slot; fa.slot_ident = p->slot_ident ? 1 : 0;
     fa.n_obs = p->n_obs; fa.K = p->K; fa.PF = w->PF; fa.PRAW = f->PRAW; fa.n_pw = f->n_pw;
     fa.fcbuf = f->fcbuf; fa.mc_f = f->mc_f; fa.cost_f = f->cost_f;
     fa.huber_delta = p->huber_delta; fa.min_diag = min_diag; fa.max_diag = max_diag; fa.rt = model_rt(p->ctx);
