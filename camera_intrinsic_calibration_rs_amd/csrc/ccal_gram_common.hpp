@@ -21,12 +21,29 @@ __device__ __forceinline__ double clampd1(double v, double lo, double hi) { retu
 // Ym = 6 x K1 doubles of LDS behind it.  phi -> rvec map of C and [B|g], C + lambda clamp(diag C) = L L^T (every lane of the
 // frame runs the same 6 x 6 factorisation), Y = L^-1 [B|g]; the slot's record pf = L (inverted diagonal) | Y | g_p | diag C.
 // Returns this lane's entries e = gl + LPE q of A (accA) and of Y^T Y (accY), and whether the block was positive definite.
-template <int K, int LPE>
+#ifdef CCAL_STAMPS      // diagnostic builds: the 100 MHz clock at the stations of the fused tail (tools/stamps_g2.py)
+#define CCAL_TAIL_STAMP(i) do { if (dbg) dbg[i] = wall_clock64(); } while (0)
+#define CCAL_TAIL_DBG_PARAM , long long* dbg = nullptr
+#define CCAL_TAIL_DBG_ARG , dbg
+#else
+#define CCAL_TAIL_STAMP(i) do { } while (0)
+#define CCAL_TAIL_DBG_PARAM
+#define CCAL_TAIL_DBG_ARG
+#endif
+// (i << 4 | j) of the e-th entry i <= j of a K1 x K1 triangle, row by row: Y^T Y is symmetric - a frame's lanes compute the
+// K1 (K1 + 1) / 2 entries of the triangle and park each on both sides (SYM; the sums are the same bits: fma(a, b, c) = fma(b, a, c))
+template <int K1> struct TriTable {
+    uint8_t ij[K1 * (K1 + 1) / 2];
+    constexpr TriTable() : ij{} { int n = 0; for (int i = 0; i < K1; ++i) for (int j = i; j < K1; ++j) ij[n++] = (uint8_t)(i << 4 | j); }
+};
+template <int K1> __device__ const TriTable<K1> g_tri_table = TriTable<K1>();
+template <int K, int LPE, bool SYM = false>
 __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int gl, const bool active, const double lambda,
                                                 const double min_diag, const double max_diag, double* pf, const int PF,
-                                                double* accA, double* accY) {
+                                                double* accA, double* accY, const uint8_t* tri_ij = nullptr CCAL_TAIL_DBG_PARAM) {
     constexpr int K1 = K + 1, NA = K1 * K1;
     constexpr int NQ = (NA + LPE - 1) / LPE;
+    static_assert(K1 <= 16, "TriTable packs (i, j) in a byte");
     bool ok = true;
     if (active) {
         double Cr[21], jl[9];
@@ -35,6 +52,7 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
 #pragma unroll
         for (int i = 0; i < 9; ++i) jl[i] = R[praw_jl_off(K) + i];
         phi_to_rvec_C(Cr, jl);
+        CCAL_TAIL_STAMP(0);
         double L[21], dC[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -55,6 +73,7 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
                 }
             }
         }
+        CCAL_TAIL_STAMP(1);
         const double* Bm = R + 21;
         if (!ok) {
             for (int e = gl; e < PF; e += LPE) pf[e] = 0.0;
@@ -89,10 +108,26 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
             }
         }
     }
+    CCAL_TAIL_STAMP(2);
     wsync();
     if (active && ok) {
         for (int e = gl; e < 21; e += LPE) pf[e] = R[e];
         for (int e = gl; e < 6; e += LPE) pf[21 + 6 * K1 + 6 + e] = R[21 + e];
+        if constexpr (SYM) {
+            constexpr int NT = K1 * (K1 + 1) / 2, NQT = (NT + LPE - 1) / LPE;
+#pragma unroll
+            for (int q = 0; q < NQT; ++q) {
+                if (gl + LPE * q < NT) {
+                    const int i = tri_ij[q] >> 4, j = tri_ij[q] & 15;
+                    double t = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
+                    accY[q] = t;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { const int e = gl + LPE * q; if (e < NA) accA[q] = R[21 + 6 * K1 + e]; }
+        } else {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int e = gl + LPE * q;
@@ -105,13 +140,23 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
                 accA[q] = R[21 + 6 * K1 + e];
             }
         }
+        }
     } else if (active) {
+        if constexpr (SYM) {
+            constexpr int NQT = (K1 * (K1 + 1) / 2 + LPE - 1) / LPE;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = gl + LPE * q;
-            if (e < NA) { accY[q] = 0.0; accA[q] = R[21 + 6 * K1 + e]; }
+            for (int q = 0; q < NQT; ++q) accY[q] = 0.0;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) { const int e = gl + LPE * q; if (e < NA) accA[q] = R[21 + 6 * K1 + e]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int e = gl + LPE * q;
+                if (e < NA) { accY[q] = 0.0; accA[q] = R[21 + 6 * K1 + e]; }
+            }
         }
     }
+    CCAL_TAIL_STAMP(3);
     return ok;
 }
 
@@ -122,27 +167,39 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
 template <int K, int LPF>
 __device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const double lambda, double* red, double* row,
                                                 const int grp, const int gl, const bool lane_ok, const bool active, const int slot,
-                                                const int set, const double mcv) {
+                                                const int set, const double mcv CCAL_TAIL_DBG_PARAM) {
     constexpr int G = 64 / LPF, K1 = K + 1, NA = K1 * K1;
     constexpr int REC = praw_jl_off(K) + 9, GS = (REC + 6 * K1 + 1) & ~1, NQ = (NA + LPF - 1) / LPF;
     static_assert(2 * NA + 2 <= GS, "a frame's sums reuse its record row");
     double* R = red + grp * GS;
     double* Ym = R + REC;
-    double accA[NQ], accY[NQ];
+    constexpr int NT = K1 * (K1 + 1) / 2, NQT = (NT + LPF - 1) / LPF;
+    double accA[NQ], accY[NQT];
+    uint8_t tri_ij[NQT];                   // which entries of the triangle of Y^T Y this lane takes: requested now, needed after the factorisation
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) { accA[q] = 0.0; accY[q] = 0.0; }
-    const bool ok = eliminate_frame<K, LPF>(R, Ym, gl, active, lambda, a.min_diag, a.max_diag,
-                                           a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY);
+    for (int q = 0; q < NQT; ++q) tri_ij[q] = g_tri_table<K1>.ij[gl + LPF * q < NT ? gl + LPF * q : 0];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) accA[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQT; ++q) accY[q] = 0.0;
+    const bool ok = eliminate_frame<K, LPF, true>(R, Ym, gl, active, lambda, a.min_diag, a.max_diag,
+                                                 a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY, tri_ij CCAL_TAIL_DBG_ARG);
     wsync();
     if (lane_ok) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = gl + LPF * q;
-            if (e < NA) { R[e] = accA[q]; R[NA + e] = accY[q]; }
+        for (int q = 0; q < NQ; ++q) { const int e = gl + LPF * q; if (e < NA) R[e] = accA[q]; }
+#pragma unroll
+        for (int q = 0; q < NQT; ++q) {
+            if (gl + LPF * q < NT) {
+                const int i = tri_ij[q] >> 4, j = tri_ij[q] & 15;
+                R[NA + i * K1 + j] = accY[q];
+                R[NA + j * K1 + i] = accY[q];
+            }
         }
         if (gl == 0) { R[2 * NA] = active ? mcv : 0.0; R[2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
     }
     wsync();
+    CCAL_TAIL_STAMP(4);
     const int lane = threadIdx.x & 63;
     for (int e = lane; e < 2 * NA + 2; e += 64) {
         double t = 0.0;

@@ -155,9 +155,12 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 // in the per-frame scratch (8 stamps per wavefront)
 #ifdef CCAL_STAMPS       // kept in (scalar) registers, stored once at the end: a store per stamp would sit in front of the next fence
 #define G2_STAMP(i) do { g2_stamps[i] = wall_clock64(); } while (0)
-#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }; long long g2_cyc[5] = { 0, 0, 0, 0, 0 }; long long g2_c0 = 0
-#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[16 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
-                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[16 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; } } while (0)
+#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }; long long g2_cyc[5] = { 0, 0, 0, 0, 0 }; long long g2_c0 = 0; long long g2_ep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define G2_EP(i) do { g2_ep[i] = wall_clock64(); } while (0)
+#define G2_EP_PTR , g2_ep + 3
+#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[24 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
+                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[24 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; \
+                                                       for (int i_ = 0; i_ < 8; ++i_) a.fcbuf[24 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 16 + i_] = (double)g2_ep[i_]; } } while (0)
 // -DCCAL_STAMPS=2: shader cycles (s_memtime) spent in the sections of the corner loop, summed over the passes:
 // 2 projection + rows + DPP, 3 Gram products, 4 passes
 #if CCAL_STAMPS >= 2
@@ -171,6 +174,8 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 #define G2_STAMP(i) do { } while (0)
 #define G2_STAMPS_DECL do { } while (0)
 #define G2_STAMPS_FLUSH do { } while (0)
+#define G2_EP(i) do { } while (0)
+#define G2_EP_PTR
 #define G2_CYC_BEGIN() do { } while (0)
 #define G2_CYC(i) do { } while (0)
 #endif
@@ -574,8 +579,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     // full triangle = the sum over the frame's u lanes and / or v lanes of one row-local entry
     constexpr Map cm = Map();                                  // slice boundaries: compile-time
     constexpr int NQM = (G * Map::max_items() + 63) / 64;      // items per lane and slice
+    constexpr int RLEN = GEN ? gen_e_off(K) : REC_;              // doubles of a record that this kernel forms (GEN: E^T went out in the prologue)
+    constexpr int RSTR = GEN ? ((RLEN + 1) & ~1) : GS_;           // stride of a frame's record in LDS
+    static_assert(G * RSTR <= RED, "the frames' records fit the reduction buffer");
     double res[NS][NQM];
-    uint32_t recm[NS][NQM];
+    int dst_a[NS][NQM], dst_b[NS][NQM];       // where the item goes in the LDS records (second place: the mirror entry of A, or -1): worked out
+                                              // here, in the shadow of the LDS reads, so that the assembly pass is one or two writes per item
     static_assert(cm.first[NS] == NEF, "one item per entry of the full triangle");
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
@@ -583,6 +592,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
 #pragma unroll
         for (int t = 0; t < CH; ++t) { const int e = s * CH + t; if (e < NER) red[lane * LS + t] = acc[e < NER ? e : 0]; }
         wsync();
+        if (s == 0) G2_EP(0);
         const int i0 = cm.first[s], ni = cm.first[s + 1] - i0;
 #pragma unroll
         for (int q = 0; q < NQM; ++q) {
@@ -592,7 +602,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
                 const int g = idx / ni, it = i0 + (idx - g * ni);
                 const unsigned long long tv = tab[it];
                 const uint32_t sc = (uint32_t)tv;
-                recm[s][q] = (uint32_t)(tv >> 32);
+                const uint32_t m = (uint32_t)(tv >> 32);
+                dst_a[s][q] = g * RSTR + (int)(m & 0xffff);
+                dst_b[s][q] = (m >> 16) != 0xffff ? g * RSTR + (int)(m >> 16) : -1;
                 double s_u = 0.0, s_v = 0.0;
                 const double* src_u = red + (g * LPF) * LS + ((int)(sc & 0xff) - s * CH);              // the frame's u lanes: the even ones
                 const double* src_v = red + (g * LPF + 1) * LS + ((int)((sc >> 8) & 0xff) - s * CH);   // its v lanes hold the entry under its mirrored number
@@ -602,27 +614,23 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
             }
             res[s][q] = sum;
         }
+        if (s == 0) G2_EP(1);
+        if (s == NS - 1) G2_EP(2);
     }
     wsync();
     G2_STAMP(3);
     // The records are ASSEMBLED IN LDS - C (21) | [B|g] (6 x K1) | A (K1 x K1) | J_l (9), or the general loop's record
     // C (36) | [B|g]^T | A - with one or two ds_write per item (every sum is in registers: the reduction buffer is free), and
     // go out to HBM as whole records with coalesced stores (they were 8-byte stores scattered by a table: ~180 per lane)
-    constexpr int RLEN = GEN ? gen_e_off(K) : REC_;              // doubles of a record that this kernel forms (GEN: E^T went out in the prologue)
-    constexpr int RSTR = GEN ? ((RLEN + 1) & ~1) : GS_;           // stride of a frame's record in LDS
-    static_assert(G * RSTR <= RED, "the frames' records fit the reduction buffer");
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        const int i0 = cm.first[s], ni = cm.first[s + 1] - i0;
+        const int ni = cm.first[s + 1] - cm.first[s];
 #pragma unroll
         for (int q = 0; q < NQM; ++q) {
-            const int idx = lane + 64 * q;
-            if (idx < G * ni) {
-                const int g = idx / ni;
-                const uint32_t m = recm[s][q];
+            if (lane + 64 * q < G * ni) {
                 const double v = res[s][q];
-                red[g * RSTR + (m & 0xffff)] = v;
-                if ((m >> 16) != 0xffff) red[g * RSTR + (m >> 16)] = v;
+                red[dst_a[s][q]] = v;
+                if (dst_b[s][q] >= 0) red[dst_b[s][q]] = v;
             }
         }
     }
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         if (fuse) {
             if (keep_rec) wsync();                                     // the tail reuses the records' rows
             G2_STAMP(4);
-            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
         }
     }
     G2_STAMP(5);
