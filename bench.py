@@ -49,10 +49,10 @@ def _latest_profile_file(name):
 
 def _gram_kernel_key(model, one_focal, frames):
     """Which Gram kernel the launchers (use_gram2 / launch_gram1v_t, ccal_kernels_fused.hip) pick for a single camera, as a key of
-    profiles/*/flops.json: k_gram2 (rows traded between the lane halves) for OPENCV5 and, from 2 000 frames, UCM / EUCM;
-    k_gram1v (all accumulators in registers / AGPRs) for KB4 and for small UCM / EUCM problems."""
+    profiles/*/flops.json: k_gram2 (the block's rows on neighbouring lanes) for OPENCV5 and, from 2 000 frames, every model;
+    k_gram1v (all accumulators in registers / AGPRs) for smaller UCM / EUCM / KB4 problems."""
     of = "one-focal" if one_focal else "two-focal"
-    if model == "opencv5" or (model in ("ucm", "eucm") and frames >= 2000):
+    if model == "opencv5" or frames >= 2000:
         return f"k_gram2<{model.upper()},{of}>"
     return f"k_gram1v<{model.upper()},{of}>"
 
