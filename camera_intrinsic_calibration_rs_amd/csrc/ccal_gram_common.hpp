@@ -30,20 +30,24 @@ __device__ __forceinline__ double clampd1(double v, double lo, double hi) { retu
 #define CCAL_TAIL_DBG_PARAM
 #define CCAL_TAIL_DBG_ARG
 #endif
-// (i << 4 | j) of the e-th entry i <= j of a K1 x K1 triangle, row by row: Y^T Y is symmetric - a frame's lanes compute the
-// K1 (K1 + 1) / 2 entries of the triangle and park each on both sides (SYM; the sums are the same bits: fma(a, b, c) = fma(b, a, c))
+// The e-th entry i <= j of a K1 x K1 triangle, row by row: i | j << 4 | (i K1 + j) << 8 | (j K1 + i) << 16.  Y^T Y is symmetric - a
+// frame's lanes compute the K1 (K1 + 1) / 2 entries of the triangle and park each on both sides (SYM; the sums are the same bits:
+// fma(a, b, c) = fma(b, a, c))
 template <int K1> struct TriTable {
-    uint8_t ij[K1 * (K1 + 1) / 2];
-    constexpr TriTable() : ij{} { int n = 0; for (int i = 0; i < K1; ++i) for (int j = i; j < K1; ++j) ij[n++] = (uint8_t)(i << 4 | j); }
+    uint32_t ij[K1 * (K1 + 1) / 2];
+    constexpr TriTable() : ij{} {
+        int n = 0;
+        for (int i = 0; i < K1; ++i) for (int j = i; j < K1; ++j) ij[n++] = (uint32_t)(i | j << 4 | (i * K1 + j) << 8 | (j * K1 + i) << 16);
+    }
 };
 template <int K1> __device__ const TriTable<K1> g_tri_table = TriTable<K1>();
 template <int K, int LPE, bool SYM = false>
 __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int gl, const bool active, const double lambda,
                                                 const double min_diag, const double max_diag, double* pf, const int PF,
-                                                double* accA, double* accY, const uint8_t* tri_ij = nullptr CCAL_TAIL_DBG_PARAM) {
+                                                double* accA, double* accY, const uint32_t* tri_ij = nullptr CCAL_TAIL_DBG_PARAM) {
     constexpr int K1 = K + 1, NA = K1 * K1;
     constexpr int NQ = (NA + LPE - 1) / LPE;
-    static_assert(K1 <= 16, "TriTable packs (i, j) in a byte");
+    static_assert(K1 <= 15, "TriTable packs i, j in four bits and the positions in eight");
     bool ok = true;
     if (active) {
         double Cr[21], jl[9];
@@ -79,10 +83,17 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
             for (int e = gl; e < PF; e += LPE) pf[e] = 0.0;
             for (int e = gl; e < 6 * K1; e += LPE) Ym[e] = 0.0;
         } else {
-            for (int c = gl; c < K1; c += LPE) {
-                double bc[6], y[6];
+            // a lane's columns c = gl, gl + LPE, ... side by side: the arithmetic runs unconditionally on a clamped column (two
+            // forward substitutions interleave where K1 > LPE: KB4 / OPENCV5 with six lanes per frame), only the stores are guarded
+            constexpr int NCQ = (K1 + LPE - 1) / LPE;
+            double bcq[NCQ][6], yq[NCQ][6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + c];
+            for (int q = 0; q < NCQ; ++q) {
+                const int c = gl + LPE * q, cc = c < K1 ? c : K1 - 1;
+                double* bc = bcq[q];
+                double* y = yq[q];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) bc[i] = Bm[i * K1 + cc];
                 phi_to_rvec_col(bc, jl);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
@@ -90,12 +101,18 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
 #pragma unroll
                     for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
                     y[i] = t * L[i * (i + 1) / 2 + i];
-                    Ym[i * K1 + c] = y[i];
-                    pf[21 + i * K1 + c] = y[i];
                 }
-                if (c == K) {                      // g_p in the rvec basis
+            }
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bc[i];
+            for (int q = 0; q < NCQ; ++q) {
+                const int c = gl + LPE * q;
+                if (c < K1) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) { Ym[i * K1 + c] = yq[q][i]; pf[21 + i * K1 + c] = yq[q][i]; }
+                    if (c == K) {                  // g_p in the rvec basis
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) pf[21 + 6 * K1 + i] = bcq[q][i];
+                    }
                 }
             }
             // L and diag C: every lane holds them; lane 0 of the frame parks them in the record's C | B area (read above,
@@ -118,7 +135,7 @@ __device__ __forceinline__ bool eliminate_frame(double* R, double* Ym, const int
 #pragma unroll
             for (int q = 0; q < NQT; ++q) {
                 if (gl + LPE * q < NT) {
-                    const int i = tri_ij[q] >> 4, j = tri_ij[q] & 15;
+                    const int i = tri_ij[q] & 15, j = (tri_ij[q] >> 4) & 15;
                     double t = 0.0;
 #pragma unroll
                     for (int k = 0; k < 6; ++k) t += Ym[k * K1 + i] * Ym[k * K1 + j];
@@ -173,27 +190,31 @@ __device__ __forceinline__ void gram_fused_tail(const FusedArgs& a, const double
     static_assert(2 * NA + 2 <= GS, "a frame's sums reuse its record row");
     double* R = red + grp * GS;
     double* Ym = R + REC;
+    // the triangle of Y^T Y where that takes fewer rounds of the frame's lanes than the square (many lanes per frame: one round either way)
     constexpr int NT = K1 * (K1 + 1) / 2, NQT = (NT + LPF - 1) / LPF;
-    double accA[NQ], accY[NQT];
-    uint8_t tri_ij[NQT];                   // which entries of the triangle of Y^T Y this lane takes: requested now, needed after the factorisation
+    constexpr bool SYM = NQT < NQ;
+    constexpr int NQY = SYM ? NQT : NQ;
+    double accA[NQ], accY[NQY];
+    uint32_t tri_ij[NQY];                  // SYM: which entries of the triangle this lane takes: requested now, needed after the factorisation
 #pragma unroll
-    for (int q = 0; q < NQT; ++q) tri_ij[q] = g_tri_table<K1>.ij[gl + LPF * q < NT ? gl + LPF * q : 0];
+    for (int q = 0; q < NQY; ++q) tri_ij[q] = SYM ? g_tri_table<K1>.ij[gl + LPF * q < NT ? gl + LPF * q : 0] : 0u;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) accA[q] = 0.0;
 #pragma unroll
-    for (int q = 0; q < NQT; ++q) accY[q] = 0.0;
-    const bool ok = eliminate_frame<K, LPF, true>(R, Ym, gl, active, lambda, a.min_diag, a.max_diag,
-                                                 a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY, tri_ij CCAL_TAIL_DBG_ARG);
+    for (int q = 0; q < NQY; ++q) accY[q] = 0.0;
+    const bool ok = eliminate_frame<K, LPF, SYM>(R, Ym, gl, active, lambda, a.min_diag, a.max_diag,
+                                                a.pf[set] + (int64_t)slot * a.PF, a.PF, accA, accY, tri_ij CCAL_TAIL_DBG_ARG);
     wsync();
     if (lane_ok) {
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) { const int e = gl + LPF * q; if (e < NA) R[e] = accA[q]; }
+        for (int q = 0; q < NQ; ++q) { const int e = gl + LPF * q; if (e < NA) { R[e] = accA[q]; if constexpr (!SYM) R[NA + e] = accY[q]; } }
+        if constexpr (SYM) {
 #pragma unroll
-        for (int q = 0; q < NQT; ++q) {
-            if (gl + LPF * q < NT) {
-                const int i = tri_ij[q] >> 4, j = tri_ij[q] & 15;
-                R[NA + i * K1 + j] = accY[q];
-                R[NA + j * K1 + i] = accY[q];
+            for (int q = 0; q < NQY; ++q) {
+                if (gl + LPF * q < NT) {
+                    R[NA + ((tri_ij[q] >> 8) & 255)] = accY[q];
+                    R[NA + (tri_ij[q] >> 16)] = accY[q];
+                }
             }
         }
         if (gl == 0) { R[2 * NA] = active ? mcv : 0.0; R[2 * NA + 1] = (active && !ok) ? 1.0 : 0.0; }
