@@ -31,7 +31,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6         # FP64 vector = matrix peak (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
-CLOCK_RAMP_S = 0.1              # untimed launches before the W warm-up steps (idle power state -> run clocks)
+CLOCK_RAMP_S = float(os.environ.get("CCAL_BENCH_CLOCK_RAMP_S", "0.1"))      # untimed launches before the W warm-up steps (idle power state ->
+                                # run clocks); the variable exists for with / without-ramp A/B tables (tools/gpu_r05_ab.sh), the default is what counts
 
 
 def _latest_profile_file(name):
