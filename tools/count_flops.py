@@ -67,6 +67,7 @@ def summarize(c):
             "lds_add_f64": c.get("ds_add_f64", 0),
             "f64_valu_instructions": sum(v for k, v in f64.items() if k.startswith("v_")),
             "all_instructions": sum(c.values()),
+            "valu_instructions": sum(v for k, v in c.items() if k.startswith("v_")),
             "lds_instructions": sum(v for k, v in c.items() if k.startswith("ds_")),
             # register-file traffic that is not arithmetic: AGPR <-> VGPR copies (accumulators that do not fit the 256 registers
             # the VALU addresses), the row trade of k_gram2, scratch
