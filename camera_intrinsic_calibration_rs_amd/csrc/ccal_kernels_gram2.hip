@@ -36,6 +36,12 @@ __host__ __device__ constexpr int g2_mirror(int a) {
     if (MODEL == kOCV5 && (a == 2 + OCV5_P1 - 4 || a == 2 + OCV5_P2 - 4)) return a == 2 + OCV5_P1 - 4 ? 2 + OCV5_P2 - 4 : 2 + OCV5_P1 - 4;
     return a;
 }
+// KB4: the distortion columns of a row are  D t^3, D t^5, D t^7, D t^9  (D = sw f x / r): the product of columns i and j depends on i + j
+// only - a Hankel block, 7 different sums instead of the 10 of its triangle.  Pairs (p <= q) of one anti-diagonal share ONE accumulator;
+// the pair with the smallest p is the one the corner loop adds.
+template <int MODEL> __host__ __device__ constexpr bool g2_hankel(int p, int q) { return MODEL == kKB4 && p >= 2 && q < 6; }
+template <int MODEL> __host__ __device__ constexpr int g2_hankel_rep_p(int p, int q) { const int s_ = p + q - 4; return (s_ > 3 ? s_ - 3 : 0) + 2; }
+template <int MODEL> __host__ __device__ constexpr bool g2_is_rep(int p, int q) { return !g2_hankel<MODEL>(p, q) || p == g2_hankel_rep_p<MODEL>(p, q); }
 template <int MODEL> __host__ __device__ constexpr bool g2_is_phi(int a) { return a >= model_np(MODEL) - 2 && a < model_np(MODEL) + 1; }
 // full column (order of the block Jacobian: camera P_eff | pose 6 | r) of row-local column a of row `row` (0 = u, 1 = v)
 template <int MODEL, bool OF>
@@ -78,7 +84,7 @@ template <int MODEL, bool OF, bool GEN, int NS>
 struct RowMap {
     static constexpr int P = model_np(MODEL), ND = P - 4, K = P - (OF ? 1 : 0), D = K + 6, NCF = D + 1, NEF = NCF * (NCF + 1) / 2;
     static constexpr int NCR = ND + 9;
-    static constexpr int NER = NCR * (NCR + 1) / 2;      // accumulators per lane
+    static constexpr int NER = NCR * (NCR + 1) / 2 - (MODEL == kKB4 ? 3 : 0);      // accumulators per lane (KB4: the Hankel block's 7 for 10)
     static constexpr int CH = (NER + NS - 1) / NS;
     uint32_t rec[NEF];
     uint32_t src[NEF];
@@ -98,12 +104,16 @@ struct RowMap {
                         int mp = g2_mirror<MODEL>(p), mq = g2_mirror<MODEL>(q);
                         if (mp > mq) { const int x = mp; mp = mq; mq = x; }
                         const bool self = mp == p && mq == q;
+                        if (!g2_is_rep<MODEL>(p, q)) continue;                    // (numbered below, like its anti-diagonal's first pair)
                         if (placed[p][q] || self != (pass == 1) || t + (self ? 1 : 2) > end) continue;
                         num[p][q] = (uint8_t)t++; placed[p][q] = true;
                         if (!self) { num[mp][mq] = (uint8_t)t++; placed[mp][mq] = true; }
                     }
             if (t != end) ok = false;
         }
+        for (int p = 0; p < NCR; ++p)
+            for (int q = p; q < NCR; ++q)
+                if (!g2_is_rep<MODEL>(p, q)) { const int rp = g2_hankel_rep_p<MODEL>(p, q); num[p][q] = num[rp][p + q - rp]; }
         // what the u lanes / the v lanes hold of every entry of the full triangle
         int tu_of[NCF][NCF] = {}, tv_of[NCF][NCF] = {};
         bool neg_of[NCF][NCF] = {};
@@ -539,6 +549,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         for (int i = 0; i < NCR; ++i) {
 #pragma unroll
             for (int j = i; j < NCR; ++j) {
+                if (!g2_is_rep<MODEL>(i, j)) continue;                  // (KB4's Hankel block: one pair per anti-diagonal)
                 const int e = nm.num[i][j];
                 acc[e] = __builtin_fma(su[i], su[j], acc[e]);
                 acc[e] = __builtin_fma(sv[i], sv[j], acc[e]);
