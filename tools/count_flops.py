@@ -109,11 +109,11 @@ def main():
             focal = "one-focal" if of else "two-focal"
             # the per-corner count does not depend on the lanes-per-frame instantiation: read it off the 12-lane one
             want[f"k_gram1w<{nm},{focal}>"] = f"k_gram1wILi{m}ELb{of}ELi12ELb0EE"
-            want[f"k_gram1v<{nm},{focal}>"] = f"k_gram1vILi{m}ELb{of}ELi12ELb0EE"
+            want[f"k_gram1v<{nm},{focal}>"] = f"k_gram1vILi{m}ELb{of}ELi12ELb0ELb0EE"       # <MODEL, OF, LPF, GEN = false, ITER = false>
             want[f"k_gram1<{nm},{focal}>"] = f"k_gram1ILi{m}ELb{of}EE"
             want[f"k_gram2<{nm},{focal}>"] = f"k_gram2ILi{m}ELb{of}ELi12ELb0EE"         # <MODEL, OF, LPF, GEN = false>
             # KB4 / OPENCV5 run 10 frames per wavefront at 10 000 frames (6 lanes per frame): the instantiation the bench times
-            want[f"k_gram1v<{nm},{focal},6 lanes>"] = f"k_gram1vILi{m}ELb{of}ELi6ELb0EE"
+            want[f"k_gram1v<{nm},{focal},6 lanes>"] = f"k_gram1vILi{m}ELb{of}ELi6ELb0ELb0EE"
             want[f"k_gram2<{nm},{focal},6 lanes>"] = f"k_gram2ILi{m}ELb{of}ELi6ELb0EE"
     for name, key in want.items():
         hits = [k for k in bodies if key in k]
