@@ -43,7 +43,7 @@ def flush_batch(method, lst):
                     fails.append(dict(case=case_, what="batch vs single result", d_intr=dbi, d_poses=dbp, method=method))
     for e in lst:
         e[0].close()
-t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []; both_none = []
+t0 = time.time(); n = 0; worst = {"r": 0.0, "J": 0.0, "S": 0.0, "intr": 0.0, "poses": 0.0}; fails = []; both_none = []; both_none_sh = []
 while time.time() - t0 < args.seconds:
     model = rng.choice(["ucm", "eucm", "kb4", "opencv5"])
     n_cams = int(rng.choice([1, 1, 1, 1, 2, 2, 3, 3, 5, 8]))      # 5 and 8 cameras: reduced systems of 64 .. 114 columns
@@ -96,7 +96,11 @@ while time.time() - t0 < args.seconds:
             except CcalError as e:
                 m = None; ms = (e.code, -1)
             mp.close(); n_sh += 1
-            if ms[0] != gs[0] or (gs[0] == 0 and ms[1] != gs[1]):
+            if ms[0] != 0 and gs[0] != 0 and ms[0] != gs[0]:
+                # NEITHER form converges, with different codes (a system singular to rounding: NOT_PD after a few steps in one order of
+                # summation, iterations exhausted in the other - the oracle is a third opinion): counted apart, like gpu-vs-oracle below
+                both_none_sh.append(dict(case=case, sharded=ms, unsharded=gs, oracle=os_))
+            elif ms[0] != gs[0] or (gs[0] == 0 and ms[1] != gs[1]):
                 # a verdict that differs between the sharded and the unsharded DEVICE solve (summation order can move a marginal
                 # convergence test by one iteration on a flat optimum: reported, judged with the deviations below)
                 fails.append(dict(case=case, what="sharded vs unsharded verdict", sharded=ms, unsharded=gs, method=method))
@@ -130,4 +134,4 @@ while time.time() - t0 < args.seconds:
 for mth, lst in pending.items():
     if lst: flush_batch(mth, lst)
 print(json.dumps(dict(cases=n, worst=worst, batched_cases=n_batched, batch=args.batch, worst_batch_vs_single=worst_b, sharded_cases=n_sh, shards=args.shards, worst_sharded_vs_unsharded=worst_sh, n_fail=len(fails), fails=fails[:6], n_both_none_different_code=len(both_none),
-                      both_none=both_none[:3]), indent=1))
+                      both_none=both_none[:3], n_sharded_both_none_different_code=len(both_none_sh), sharded_both_none=both_none_sh[:3]), indent=1))

@@ -4,5 +4,5 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 O=gpurun_out/r05y; mkdir -p $O
-python tools/fuzz_parity.py --seconds 200 --seed 60606 --shards 3 --batch 6 > $O/fuzz_default.json 2> $O/fuzz_default.err; tail -c 600 $O/fuzz_default.json
-CCAL_GRAM2=1 python tools/fuzz_parity.py --seconds 200 --seed 70707 > $O/fuzz_gram2.json 2> $O/fuzz_gram2.err; tail -c 600 $O/fuzz_gram2.json
+python tools/fuzz_parity.py --seconds 300 --seed 61616 --shards 3 --batch 6 > $O/fuzz_default.json 2> $O/fuzz_default.err; tail -c 600 $O/fuzz_default.json
+CCAL_GRAM2=1 python tools/fuzz_parity.py --seconds 300 --seed 71717 > $O/fuzz_gram2.json 2> $O/fuzz_gram2.err; tail -c 600 $O/fuzz_gram2.json
