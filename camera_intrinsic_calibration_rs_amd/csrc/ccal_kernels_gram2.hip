@@ -165,12 +165,14 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 // in the per-frame scratch (8 stamps per wavefront)
 #ifdef CCAL_STAMPS       // kept in (scalar) registers, stored once at the end: a store per stamp would sit in front of the next fence
 #define G2_STAMP(i) do { g2_stamps[i] = wall_clock64(); } while (0)
-#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }; long long g2_cyc[5] = { 0, 0, 0, 0, 0 }; long long g2_c0 = 0; long long g2_ep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }
+#define G2_STAMPS_DECL long long g2_stamps[6] = { 0, 0, 0, 0, 0, 0 }; long long g2_cyc[5] = { 0, 0, 0, 0, 0 }; long long g2_c0 = 0; long long g2_ep[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }; long long g2_pro[4] = { 0, 0, 0, 0 }
 #define G2_EP(i) do { g2_ep[i] = wall_clock64(); } while (0)
+#define G2_PRO(i, dep) do { asm volatile("" :: "v"(dep)); g2_pro[i] = wall_clock64(); } while (0)     /* a station of the prologue: once `dep` has arrived */
 #define G2_EP_PTR , g2_ep + 3
-#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[24 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
-                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[24 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; \
-                                                       for (int i_ = 0; i_ < 8; ++i_) a.fcbuf[24 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 16 + i_] = (double)g2_ep[i_]; } } while (0)
+#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
+                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; \
+                                                       for (int i_ = 0; i_ < 8; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 16 + i_] = (double)g2_ep[i_]; \
+                                                       for (int i_ = 0; i_ < 4; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 24 + i_] = (double)g2_pro[i_]; } } while (0)
 // -DCCAL_STAMPS=2: shader cycles (s_memtime) spent in the sections of the corner loop, summed over the passes:
 // 2 projection + rows + DPP, 3 Gram products, 4 passes
 #if CCAL_STAMPS >= 2
@@ -185,6 +187,7 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 #define G2_STAMPS_DECL do { } while (0)
 #define G2_STAMPS_FLUSH do { } while (0)
 #define G2_EP(i) do { } while (0)
+#define G2_PRO(i, dep) do { } while (0)
 #define G2_EP_PTR
 #define G2_CYC_BEGIN() do { } while (0)
 #define G2_CYC(i) do { } while (0)
@@ -235,8 +238,6 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevState* st = a.st;
     const bool fuse = !GEN && a.fuse_elim != 0;
-    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
-    if (st->done || (st->redo && !fuse)) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // frame g: lanes [g LPF, (g + 1) LPF); even lanes take the u rows, odd lanes the v rows; gl = the lane's index within its frame
     const int role = lane & 1;
@@ -265,6 +266,23 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
             tabv[q] = it < NEF ? ((unsigned long long)gmap.src[it] | ((unsigned long long)gmap.rec[it] << 32)) : 0ull;
         }
     }
+    // Single-camera loop: everything the prologue needs from memory that does NOT depend on the optimizer state is requested before
+    // the state is looked at - the frame's offsets and slot, its pose and the intrinsics in BOTH parameter sets (the state picks one),
+    // the first corner rows: one memory round trip in front of the exponential map instead of three (stations of the -DCCAL_STAMPS
+    // build, 10 000 frames: state + intrinsics 0.8 us, then pose 0.9, then exponential map 0.3, first rows 0.6)
+    double th_b[2][th_len<MODEL>()], pose_b[2][6];
+    int slot_e = 0;
+    int64_t start_e = 0, end_e = 0;
+    if constexpr (!GEN) {
+        load_theta<MODEL, OF>(a.intr[0], a.rt, th_b[0]);
+        load_theta<MODEL, OF>(a.intr[1], a.rt, th_b[1]);
+        start_e = a.obs_off[fa_]; end_e = a.obs_off[fa_ + 1];
+        if (a.slot_ident) slot_e = fa_; else slot_e = a.obs_slot[fa_];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { pose_b[0][i] = a.poses[0][(int64_t)slot_e * 6 + i]; pose_b[1][i] = a.poses[1][(int64_t)slot_e * 6 + i]; }
+    }
+    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
+    if (st->done || (st->redo && !fuse)) return;
     const int cur = st->cur, first = st->first;
     const int es = first ? cur : (cur ^ 1);
     if constexpr (!GEN) {
@@ -285,9 +303,15 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         }
     }
     const int cl = gl;                              // every lane has its own corner: LPF corners of a frame per pass
-    const double* th_g = a.intr[es] + ((GEN && a.obs_cam) ? camf * CCAL_PMAX : 0);
     double th[th_len<MODEL>()];
-    load_theta<MODEL, OF>(th_g, a.rt, th);
+    if constexpr (GEN) {
+        const double* th_g = a.intr[es] + (a.obs_cam ? camf * CCAL_PMAX : 0);
+        load_theta<MODEL, OF>(th_g, a.rt, th);
+    } else {
+#pragma unroll
+        for (int i = 0; i < th_len<MODEL>(); ++i) th[i] = es ? th_b[1][i] : th_b[0][i];
+    }
+    G2_PRO(0, th[0] + (double)first);
     // the lane's view of the intrinsics: MINE = the row it accumulates (u lanes: fx, cx; v lanes: fy, cy), OTHER = the row it
     // forms for its partner; the v lanes see the distortion in mirrored coordinates (OPENCV5: p1 and p2 exchanged)
     if (role) {
@@ -295,8 +319,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         { const double x = th[2]; th[2] = th[3]; th[3] = x; }
         if constexpr (MODEL == kOCV5) { const double x = th[OCV5_P1]; th[OCV5_P1] = th[OCV5_P2]; th[OCV5_P2] = x; }
     }
-    const int64_t start = a.obs_off[fa_];
-    const int n = active ? (int)(a.obs_off[fa_ + 1] - start) : 0;
+    const int64_t start = GEN ? a.obs_off[fa_] : start_e;
+    const int n = active ? (int)((GEN ? a.obs_off[fa_ + 1] : end_e) - start) : 0;
     // corner rows by 32-bit byte offsets from the (wave-uniform) stream pointers: no 64-bit address arithmetic per load
     // (ccal_problem_create refuses more than 2^30 - 1 corners per problem)
     auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
@@ -312,12 +336,17 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         // the frame's slot: the table - or, when the table is the identity, the frame itself: pose and elimination record are
         // requested with the frame's offsets instead of a memory round trip after them
         int slot;
-        if (!GEN && a.slot_ident) slot = fa_; else slot = a.obs_slot[fa_];
+        if constexpr (GEN) slot = a.obs_slot[fa_]; else slot = slot_e;
         double pose[6];
         // GEN: k_backsub has formed the candidate - or, FusedArgs::gen_backsub, it is formed here from the accepted pose
         const bool gbs = GEN && a.gen_backsub != 0 && !first;
+        if constexpr (GEN) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pose[i] = a.poses[(GEN && !gbs) ? es : cur][(int64_t)slot * 6 + i];
+            for (int i = 0; i < 6; ++i) pose[i] = a.poses[!gbs ? es : cur][(int64_t)slot * 6 + i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) pose[i] = cur ? pose_b[1][i] : pose_b[0][i];
+        }
         if constexpr (GEN) {
             if (gbs) {
                 const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, st->lambda_solve, pose, red, grp, gl, lane_ok);
@@ -382,8 +411,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
                 for (int i = 0; i < GEN_EC / 2; ++i) rec[i] = make_double2(ec[2 * i], ec[2 * i + 1]);
             }
         } else {
+            G2_PRO(1, pose[0] + pose[5]);
             double fcr[FC_N0];
             frame_setup<false>(pose, nullptr, fcr);
+            G2_PRO(2, fcr[0] + fcr[FC_N0 - 1]);
             if (gl == 0 && lane_ok) {
 #pragma unroll
                 for (int i = 0; i < FC_N0; ++i) fc[i] = fcr[i];
@@ -391,6 +422,7 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
             if (gl == 1 && lane_ok) g2_store_mirrored(fcr, fc + FC_N0P);
         }
     }
+    G2_PRO(3, pX + pV);                             // (the first pass's corner rows)
     wsync();
     G2_STAMP(1);
 

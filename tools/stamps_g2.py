@@ -14,11 +14,11 @@ p.upload_params(sp.intr0, sp.poses0, sp.extr0)
 for _ in range(30): p.build_normal_dev(0.0)
 torch.cuda.synchronize()
 lib = _ffi.load()
-n = min(F * 40, 8 * 16384) // 24 * 24
+n = min(F * 40, 8 * 16384) // 32 * 32
 buf = np.zeros(n, dtype=np.float64)
 lib.ccal_debug_fcbuf.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
 lib.ccal_debug_fcbuf(p.handle, buf.ctypes.data_as(C.c_void_p), n)
-st = buf.reshape(-1, 24)
+st = buf.reshape(-1, 32)
 ok = st[:, 0] > 0
 st = st[ok]
 t0 = st[:, 0].min()
@@ -31,6 +31,10 @@ for label, sel in (("first half of the dispatch (older on their SIMD)", slice(0,
     d = np.diff(s[:, :6], axis=1) / 100.0
     print(f"  {label}: start {np.median(s[:, 0] - t0) / 100:.2f}  " + "  ".join(f"{nm} {np.median(d[:, i]):.2f}" for i, nm in enumerate(names[1:])) +
           f"  total {np.median(s[:, 5] - s[:, 0]) / 100:.2f}  end {np.median(s[:, 5] - t0) / 100:.2f} us")
+    if s[:, 24].max() > 0:      # stations of the prologue: state + intrinsics arrived | pose arrived | exponential map done | first corner rows arrived | constants in LDS
+        pro = np.concatenate([s[:, 0:1], s[:, 24:28], s[:, 1:2]], axis=1)
+        dp = np.diff(pro, axis=1) / 100.0
+        print("      prologue: " + "  ".join(f"{n} {np.median(dp[:, i]):.2f}" for i, n in enumerate(["state + intrinsics", "pose", "exp map", "first rows", "LDS + barrier"])))
     if s[:, 16].max() > 0:      # stations of the epilogue (100 MHz): slice 0 parked | slice 0 summed | last slice summed || tail: C in rvec basis | Cholesky | Y | Y^T Y | sums parked
         ep = s[:, 16:24]
         seq = np.concatenate([s[:, 2:3], ep[:, 0:3], s[:, 3:5], ep[:, 3:8], s[:, 5:6]], axis=1)
