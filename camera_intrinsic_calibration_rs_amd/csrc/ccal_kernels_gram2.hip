@@ -270,16 +270,22 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     // the state is looked at - the frame's offsets and slot, its pose and the intrinsics in BOTH parameter sets (the state picks one),
     // the first corner rows: one memory round trip in front of the exponential map instead of three (stations of the -DCCAL_STAMPS
     // build, 10 000 frames: state + intrinsics 0.8 us, then pose 0.9, then exponential map 0.3, first rows 0.6)
-    double th_b[2][th_len<MODEL>()], pose_b[2][6];
-    int slot_e = 0;
-    int64_t start_e = 0, end_e = 0;
-    if constexpr (!GEN) {
-        load_theta<MODEL, OF>(a.intr[0], a.rt, th_b[0]);
-        load_theta<MODEL, OF>(a.intr[1], a.rt, th_b[1]);
-        start_e = a.obs_off[fa_]; end_e = a.obs_off[fa_ + 1];
-        if (a.slot_ident) slot_e = fa_; else slot_e = a.obs_slot[fa_];
+    // (rigs: the camera's extrinsics of both sets too; a set that another wavefront is writing - the candidate poses of
+    // FusedArgs::gen_backsub - is the one the state does NOT pick)
+    double th_b[2][th_len<MODEL>()], pose_b[2][6], ex_b[2][GEN ? 6 : 1];
+    int slot_e;
+    if (!GEN && a.slot_ident) slot_e = fa_; else slot_e = a.obs_slot[fa_];
+    const int64_t start_e = a.obs_off[fa_], end_e = a.obs_off[fa_ + 1];
+    {
+        const int th_off = (GEN && a.obs_cam) ? camf * CCAL_PMAX : 0;
+        load_theta<MODEL, OF>(a.intr[0] + th_off, a.rt, th_b[0]);
+        load_theta<MODEL, OF>(a.intr[1] + th_off, a.rt, th_b[1]);
 #pragma unroll
         for (int i = 0; i < 6; ++i) { pose_b[0][i] = a.poses[0][(int64_t)slot_e * 6 + i]; pose_b[1][i] = a.poses[1][(int64_t)slot_e * 6 + i]; }
+        if constexpr (GEN) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { ex_b[0][i] = camf > 0 ? a.extr[0][camf * 6 + i] : 0.0; ex_b[1][i] = camf > 0 ? a.extr[1][camf * 6 + i] : 0.0; }
+        }
     }
     const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
     if (st->done || (st->redo && !fuse)) return;
@@ -304,13 +310,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     }
     const int cl = gl;                              // every lane has its own corner: LPF corners of a frame per pass
     double th[th_len<MODEL>()];
-    if constexpr (GEN) {
-        const double* th_g = a.intr[es] + (a.obs_cam ? camf * CCAL_PMAX : 0);
-        load_theta<MODEL, OF>(th_g, a.rt, th);
-    } else {
 #pragma unroll
-        for (int i = 0; i < th_len<MODEL>(); ++i) th[i] = es ? th_b[1][i] : th_b[0][i];
-    }
+    for (int i = 0; i < th_len<MODEL>(); ++i) th[i] = es ? th_b[1][i] : th_b[0][i];
     G2_PRO(0, th[0] + (double)first);
     // the lane's view of the intrinsics: MINE = the row it accumulates (u lanes: fx, cx; v lanes: fy, cy), OTHER = the row it
     // forms for its partner; the v lanes see the distortion in mirrored coordinates (OPENCV5: p1 and p2 exchanged)
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         { const double x = th[2]; th[2] = th[3]; th[3] = x; }
         if constexpr (MODEL == kOCV5) { const double x = th[OCV5_P1]; th[OCV5_P1] = th[OCV5_P2]; th[OCV5_P2] = x; }
     }
-    const int64_t start = GEN ? a.obs_off[fa_] : start_e;
-    const int n = active ? (int)((GEN ? a.obs_off[fa_ + 1] : end_e) - start) : 0;
+    const int64_t start = start_e;
+    const int n = active ? (int)(end_e - start) : 0;
     // corner rows by 32-bit byte offsets from the (wave-uniform) stream pointers: no 64-bit address arithmetic per load
     // (ccal_problem_create refuses more than 2^30 - 1 corners per problem)
     auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
@@ -335,18 +336,13 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         // a group compute the same values, the G groups work on G frames at once
         // the frame's slot: the table - or, when the table is the identity, the frame itself: pose and elimination record are
         // requested with the frame's offsets instead of a memory round trip after them
-        int slot;
-        if constexpr (GEN) slot = a.obs_slot[fa_]; else slot = slot_e;
+        const int slot = slot_e;
         double pose[6];
         // GEN: k_backsub has formed the candidate - or, FusedArgs::gen_backsub, it is formed here from the accepted pose
         const bool gbs = GEN && a.gen_backsub != 0 && !first;
-        if constexpr (GEN) {
+        const int pset = (GEN && !gbs) ? es : cur;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) pose[i] = a.poses[!gbs ? es : cur][(int64_t)slot * 6 + i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) pose[i] = cur ? pose_b[1][i] : pose_b[0][i];
-        }
+        for (int i = 0; i < 6; ++i) pose[i] = pset ? pose_b[1][i] : pose_b[0][i];
         if constexpr (GEN) {
             if (gbs) {
                 const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, st->lambda_solve, pose, red, grp, gl, lane_ok);
@@ -393,10 +389,9 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         }
         if (!GEN && active && gl == 0) a.mc_f[f] = mc;
         if constexpr (GEN) {
-            const bool other = camf > 0;
             double ex[6], fcr[12], ept[GEN_EPT];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) ex[i] = other ? a.extr[es][camf * 6 + i] : 0.0;
+            for (int i = 0; i < 6; ++i) ex[i] = es ? ex_b[1][i] : ex_b[0][i];
             frame_setup_composed(pose, ex, fcr, ept);
             if (gl == 0 && lane_ok) {
 #pragma unroll
