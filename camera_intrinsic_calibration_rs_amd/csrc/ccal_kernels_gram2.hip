@@ -1,24 +1,23 @@
-// k_gram2: the register Gram kernel with the block's two rows accumulated on two lanes (u rows in lanes 0-31 of the
-// wavefront, v rows in lanes 32-63), rows exchanged with v_permlane32_swap.
+// k_gram2: the register Gram kernel with the block's two rows accumulated on two NEIGHBOURING lanes (even lanes: u rows, odd lanes:
+// v rows), rows traded with v_mov_b32_dpp quad_perm:[1,0,3,2].
 //
-// What k_gram1v / k_gram1w (ccal_kernels_fused.hip) keep per lane is the upper triangle of [J | r]^T W [J | r] of a whole
-// 2-row block: 91 (EUCM) ... 136 (OPENCV5) f64 accumulators next to two scaled rows of 13 ... 16 doubles - more than the
-// 256 registers the VALU can address, hence 18 LDS accumulators (UCM / EUCM) or 105-136 accumulators spilled to AGPRs
-// behind v_accvgpr copies (KB4 / OPENCV5: 176-224 of the 600-625 instructions of a corner pass, one wavefront per SIMD).
+// What k_gram1v (ccal_kernels_fused.hip) keeps per lane is the upper triangle of [J | r]^T W [J | r] of a whole 2-row block: 91 (EUCM)
+// ... 136 (OPENCV5) f64 accumulators next to two scaled rows of 13 ... 16 doubles - more than the 256 registers the VALU can address,
+// hence 105-136 accumulators behind v_accvgpr copies for KB4 / OPENCV5 (176-224 of the 600-625 instructions of a corner pass).
 //
-// The block's u row does not touch fy, cy and its v row does not touch fx, cx (one focal: f is shared).  In ROW-LOCAL
-// column order
+// The block's u row does not touch fy, cy and its v row does not touch fx, cx (one focal: f is shared).  In ROW-LOCAL column order
 //       [ f_row | c_row | distortion (ND) | phi (3) | t (3) | r_row ]                    NCR = ND + 9 columns
-// both rows have the SAME dense structure.  Every lane still evaluates ONE corner completely (transform, projection, both
-// Jacobian rows: nothing is computed twice), then lane l < 32 and lane l + 32 - two corners of the same frame - trade
-// rows: ONE v_permlane32_swap per register swaps the upper half of the u-row register with the lower half of the v-row
-// register, in place, after which lanes 0-31 hold the u rows of both corners and lanes 32-63 both v rows.  A lane adds the
-// two rows it holds into NCR (NCR + 1) / 2 accumulators (UCM 55, EUCM 66, KB4 91, OPENCV5 105) - the same number of FMAs per
-// corner as before, half the accumulators (and no structural zeros left to skip).  The per-frame reduction adds the two
-// rows' Grams where they meet (distortion, pose and residual columns; f with one focal) and lands in the same per-frame
-// record as before, so the pose update in front of the loop and the fused elimination behind it (ccal_gram_common.hpp)
-// are those of k_gram1w.
-//   KB4: 91 accumulators + two rows of 13 = 234 registers' worth: no AGPR copies, two wavefronts per SIMD.
+// both rows have the SAME dense structure.  Every lane evaluates ONE corner completely (transform, projection, both Jacobian rows:
+// nothing is computed twice), then lanes 2 k and 2 k + 1 - two corners of the same frame - trade the row the other one accumulates.
+// The odd lanes work in MIRRORED coordinates (x and y of the camera-frame point, fx / fy, cx / cy, observed u / v, OPENCV5's p1 / p2
+// exchanged): every model is symmetric under that reflection, so one instruction stream forms "the row of my kind" and "the row for my
+// neighbour" on every lane, and the trade is one DPP move per register half (round 4 traded between lanes 32 apart with
+// v_permlane32_swap: twice the cost).  A lane adds the two rows of its kind into NCR (NCR + 1) / 2 accumulators (UCM 55, EUCM 66, KB4
+// 91 - 3 for its Hankel block, OPENCV5 105) - the same number of FMAs per corner as the whole triangle, half the accumulators, no
+// structural zeros left to skip.  The per-frame reduction un-mirrors the odd lanes' sums (RowMap), adds the two rows' Grams where they
+// meet (distortion, pose and residual columns; f with one focal) and lands in the same per-frame record as k_gram1v's, so the pose
+// update in front of the loop and the fused elimination behind it (ccal_gram_common.hpp) are shared.
+//   UCM / EUCM: two wavefronts per SIMD (226 registers); KB4 / OPENCV5: one (296 / 322 registers, 30 / 65 AGPR copies per pass).
 #include <algorithm>
 
 #include "ccal_gram_common.hpp"
