@@ -3,8 +3,8 @@
 //
 //   k_unpack1       the starting point of a solve (state, column table, intrinsics in the argument block; poses from pinned host memory)
 //   k_gram1v        LPF lanes per frame, the whole upper triangle of [J | r]^T W [J | r] in registers, the frame's pose block
-//                   eliminated in the kernel's tail (gram_fused_tail): one row of partial sums per wavefront.  KB4 at every size,
-//                   UCM / EUCM below 2 000 frames (k_gram2, ccal_kernels_gram2.hip, elsewhere)
+//                   eliminated in the kernel's tail (gram_fused_tail): one row of partial sums per wavefront.  UCM / EUCM / KB4
+//                   below 2 000 frames (k_gram2, ccal_kernels_gram2.hip, from there on and for OPENCV5)
 //   k_gram1v<ITER>  the same with the PREVIOUS launch's rows summed, the decision taken and the camera system solved in front of
 //                   the evaluation: a whole optimizer step in one launch (session sizes)
 //   k_gram1v_batch  that launch for a whole batch of problems (ccal_solve_batch: blockIdx.y = problem, lockstep)
