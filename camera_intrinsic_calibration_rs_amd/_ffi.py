@@ -40,7 +40,11 @@ class SolverOpts(C.Structure):
         ("min_abs_error_decrease", C.c_double), ("min_rel_error_decrease", C.c_double), ("min_error", C.c_double),
         ("lm_initial_radius", C.c_double), ("lm_min_diagonal", C.c_double), ("lm_max_diagonal", C.c_double),
         ("verbose", C.c_int32), ("timeout_s", C.c_int32),
+        ("error_metric", C.c_int32), ("reserved_", C.c_int32),
     ]
+
+
+ERROR_SQUARED_NORM, ERROR_NORM = 0, 1          # ccal_error_metric (ccal_solver_opts.error_metric)
 
 
 class Report(C.Structure):
@@ -105,6 +109,7 @@ SYMBOLS = [
                                    C.POINTER(Report)]),
     ("ccal_init_poses", C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
     ("ccal_init_camera_extrinsic", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(Report)]),
+    ("ccal_init_camera_extrinsic_opts", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(SolverOpts), C.POINTER(Report)]),
     ("ccal_se3_factor", C.c_int, [_dp, _dp, _dp, _dp, _dp]),
     # one process, several GPUs
     ("ccal_solve_sharded", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(SolverOpts), _dp, C.POINTER(_dp), _dp, C.POINTER(Report)]),

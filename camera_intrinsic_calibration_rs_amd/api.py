@@ -409,9 +409,10 @@ def calib_all_camera_with_extrinsics(cameras: Sequence[GenericModel], t_cam_i_0:
         return out_models, t_i_0, {fi: RvecTvec.from6(poses[s]) for s, fi in enumerate(slots)}
 
 
-def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]]) -> List[RvecTvec]:
+def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]], opts=None) -> List[RvecTvec]:
     """util::init_camera_extrinsic (src/util.rs:511-561): T_i_0 of every camera from the frames both it and
-    camera 0 have a board pose for (SE3Factor + HuberLoss(0.5) + Gauss-Newton, in the library's host code)."""
+    camera 0 have a board pose for (SE3Factor + HuberLoss(0.5) + Gauss-Newton, in the library's host code).
+    opts: the optimizer's stop rules (None = GaussNewtonOptimizer::default(), as the reference)."""
     lib = _ffi.load()
     out = [RvecTvec((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))]
     for cam_i in range(1, len(cam_rtvecs)):
@@ -422,8 +423,9 @@ def init_camera_extrinsic(cam_rtvecs: Sequence[Dict[int, RvecTvec]]) -> List[Rve
         pi = np.ascontiguousarray(np.stack([cam_rtvecs[cam_i][k].as6() for k in keys]))
         x = np.zeros(6)
         rep = _ffi.Report()
-        rc = lib.ccal_init_camera_extrinsic(p0.ctypes.data_as(C.POINTER(C.c_double)), pi.ctypes.data_as(C.POINTER(C.c_double)),
-                                            len(keys), x.ctypes.data_as(C.POINTER(C.c_double)), 0, C.byref(rep))
+        rc = lib.ccal_init_camera_extrinsic_opts(p0.ctypes.data_as(C.POINTER(C.c_double)), pi.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 len(keys), x.ctypes.data_as(C.POINTER(C.c_double)), 0,
+                                                 C.byref(opts) if opts is not None else None, C.byref(rep))
         if rc != _ffi.OK:
             raise CcalError(rc, "ccal_init_camera_extrinsic")                        # `.unwrap()` in the reference
         out.append(RvecTvec.from6(x))

@@ -126,6 +126,7 @@ int ccal_set_defaults(ccal_solver_opts* o) {
     o->min_abs_error_decrease = 1e-5; o->min_rel_error_decrease = 1e-5; o->min_error = 1e-10;
     o->lm_initial_radius = 1e4; o->lm_min_diagonal = 1e-6; o->lm_max_diagonal = 1e32;
     o->verbose = 0; o->timeout_s = 0;
+    o->error_metric = CCAL_ERROR_SQUARED_NORM; o->reserved_ = 0;
     return CCAL_OK;
 }
 

@@ -309,10 +309,11 @@ extern "C" int ccal_convert_model(ccal_ctx* ctx, int src_model, const double* sr
         cur = huber_w(s, 1.0) * s;
         R.iterations++;
         if (o.verbose) std::printf("[ccal convert_model] iter %d cost %.12g\n", it, cur);
-        if (cur < o.min_error) break;
+        const double le = o.error_metric ? std::sqrt(std::max(last, 0.0)) : last, ce = o.error_metric ? std::sqrt(std::max(cur, 0.0)) : cur;
+        if (ce < o.min_error) break;
         if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
-        if (std::fabs(last - cur) < o.min_abs_error_decrease) break;
-        if (std::fabs(last - cur) / last < o.min_rel_error_decrease) break;
+        if (std::fabs(le - ce) < o.min_abs_error_decrease) break;
+        if (std::fabs(le - ce) / le < o.min_rel_error_decrease) break;
         if (it == o.max_iterations - 1) status = CCAL_ERR_NO_CONVERGENCE;
     }
     R.final_cost = cur; R.status = status;

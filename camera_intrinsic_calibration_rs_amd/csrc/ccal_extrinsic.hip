@@ -127,10 +127,14 @@ extern "C" int ccal_se3_factor(const double* pose_0_b, const double* pose_i_b, c
     return CCAL_OK;
 }
 
-extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common, double* t_i_0_io,
-                                          int use_initial, ccal_report* rep) {
+extern "C" int ccal_init_camera_extrinsic_opts(const double* poses_cam0, const double* poses_cami, int n_common, double* t_i_0_io,
+                                               int use_initial, const ccal_solver_opts* opts, ccal_report* rep) {
     if (!poses_cam0 || !poses_cami || n_common < 1 || !t_i_0_io) return CCAL_ERR_INVALID_ARG;
     CCAL_API_TRY
+    // GaussNewtonOptimizer::default() (src/util.rs:543) unless the caller says otherwise; only the stop rules are read
+    const int max_it = opts ? opts->max_iterations : 100, em = opts ? opts->error_metric : 0;
+    const double min_err = opts ? opts->min_error : 1e-10, min_abs = opts ? opts->min_abs_error_decrease : 1e-5,
+                 min_rel = opts ? opts->min_rel_error_decrease : 1e-5;
     const double delta = 0.5;                                   // HuberLoss::new(0.5), src/util.rs:539
     std::vector<Iso> a(n_common), binv(n_common);
     for (int k = 0; k < n_common; ++k) { a[k] = iso_from6(poses_cam0 + 6 * k); binv[k] = iso_inv(iso_from6(poses_cami + 6 * k)); }
@@ -141,7 +145,7 @@ extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double
     double cur = cost(a, binv, x, delta);
     R.initial_cost = cur;
     int status = CCAL_OK;
-    for (int it = 0; it < 100; ++it) {
+    for (int it = 0; it < max_it; ++it) {
         const double last = cur;
         double H[36] = { 0 }, g[6] = { 0 };
         for (int k = 0; k < n_common; ++k) {
@@ -170,14 +174,19 @@ extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double
         for (int i = 0; i < 6; ++i) x[i] += dx[i];
         cur = cost(a, binv, x, delta);
         R.iterations++;
-        if (cur < 1e-10) break;
+        const double le = em ? std::sqrt(std::max(last, 0.0)) : last, ce = em ? std::sqrt(std::max(cur, 0.0)) : cur;
+        if (ce < min_err) break;
         if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
-        if (std::fabs(last - cur) < 1e-5) break;
-        if (std::fabs(last - cur) / last < 1e-5) break;
+        if (std::fabs(le - ce) < min_abs) break;
+        if (std::fabs(le - ce) / le < min_rel) break;
     }
     R.final_cost = cur; R.status = status;
     if (rep) *rep = R;
     if (status == CCAL_OK) std::memcpy(t_i_0_io, x, sizeof x);
     return status;
     CCAL_API_CATCH((ccal_ctx*)nullptr)
+}
+extern "C" int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common, double* t_i_0_io,
+                                          int use_initial, ccal_report* rep) {
+    return ccal_init_camera_extrinsic_opts(poses_cam0, poses_cami, n_common, t_i_0_io, use_initial, nullptr, rep);
 }

@@ -35,6 +35,8 @@ struct DevState {                 // lives in device memory; updated by the deci
     int32_t cam_failed;           // the camera system that produced the candidate was not positive definite
     int32_t done_seq;             // sequence number of the step that set `done` (0 while running)
     int32_t spec_hits, spec_misses;   // LM: accepted steps whose speculative elimination was / was not the next system
+    int32_t error_metric;         // ccal_solver_opts::error_metric: what the stop rules compare (0: cost, 1: its square root)
+    int32_t pad_;
 };
 static_assert(sizeof(DevState) % 8 == 0, "DevState is staged as doubles");
 
@@ -67,8 +69,16 @@ __host__ __device__ inline double lm_radius_cap(double radius) { return fmin(1e1
 // tiny-solver's Gauss-Newton rules (src/util.rs:455: accept unconditionally; stop on min_error, |d| < 1e-5,
 // |d| / last < 1e-5, max_iterations) or the Ceres-style trust region of the LM mode.
 // Returns true when the reduced system at hand is the one to solve now.
+// The quantity the stop rules compare (ccal_solver_opts::error_metric): tiny-solver's compute_error is the squared L2 norm of the
+// loss-corrected residuals - or, the other reading of the absent crate, the norm itself.  Metric 0 leaves every expression as it was.
+__host__ __device__ inline double error_of(double cost, int metric) { return metric ? sqrt(fmax(cost, 0.0)) : cost; }
+// LM's predicted decrease in the same metric
+__host__ __device__ inline double model_decrease_of(double cur_cost, double mc, int metric) {
+    return metric ? sqrt(fmax(cur_cost, 0.0)) - sqrt(fmax(cur_cost - mc, 0.0)) : mc;
+}
 __device__ inline bool optimizer_decide(DevState* st, double cost, double mc_pose, bool sys_fail, int seq) {
     const bool lm = st->method == CCAL_METHOD_LM;
+    const int em = st->error_metric;
     int done = 0;
     bool solve = false;
     if (st->redo) {                                   // re-elimination group: the decision was taken one group ago
@@ -84,11 +94,12 @@ __device__ inline bool optimizer_decide(DevState* st, double cost, double mc_pos
         st->cur ^= 1;
         const double last = st->cur_cost, cur = cost;
         st->last_cost = last; st->cur_cost = cur; st->iter += 1;
-        if (cur < st->min_error) done = CCAL_OK + 1;
+        const double le = error_of(last, em), ce = error_of(cur, em);
+        if (ce < st->min_error) done = CCAL_OK + 1;
         else if (!(cur == cur)) done = CCAL_ERR_NONFINITE + 1;
         else if (!(fabs(cur) < 1.7e308)) done = CCAL_ERR_NOT_PD + 1;
-        else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
-        else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
+        else if (fabs(le - ce) < st->min_abs) done = CCAL_OK + 1;
+        else if (fabs(le - ce) / le < st->min_rel) done = CCAL_OK + 1;
         else if (st->iter >= st->max_iter) done = CCAL_ERR_NO_CONVERGENCE + 1;
         solve = true;
     } else {
@@ -97,7 +108,8 @@ __device__ inline bool optimizer_decide(DevState* st, double cost, double mc_pos
         st->iter += 1;
         const bool lin_fail = st->sys_failed || st->cam_failed;      // the candidate came out of a failed linear solve
         const bool fin = fabs(cost) < 1.7e308;
-        if (!lin_fail && fin && mc >= 0.0 && (mc < st->min_abs || mc < st->min_rel * st->cur_cost)) {
+        const double mce = model_decrease_of(st->cur_cost, mc, em);
+        if (!lin_fail && fin && mc >= 0.0 && (mce < st->min_abs || mce < st->min_rel * error_of(st->cur_cost, em))) {
             // predicted decrease below the thresholds: converged (the re-weighted Huber cost is not monotone at the optimum)
             if (cost < st->cur_cost) { st->cur ^= 1; st->last_cost = st->cur_cost; st->cur_cost = cost; st->lm_accepted += 1; }
             done = CCAL_OK + 1;
@@ -108,9 +120,10 @@ __device__ inline bool optimizer_decide(DevState* st, double cost, double mc_pos
             const double t = 2.0 * rho - 1.0;
             st->radius = fmin(1e16, st->radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
             st->dec = 2.0;
-            if (cur < st->min_error) done = CCAL_OK + 1;
-            else if (fabs(last - cur) < st->min_abs) done = CCAL_OK + 1;
-            else if (fabs(last - cur) / last < st->min_rel) done = CCAL_OK + 1;
+            const double le = error_of(last, em), ce = error_of(cur, em);
+            if (ce < st->min_error) done = CCAL_OK + 1;
+            else if (fabs(le - ce) < st->min_abs) done = CCAL_OK + 1;
+            else if (fabs(le - ce) / le < st->min_rel) done = CCAL_OK + 1;
             st->lambda = 1.0 / st->radius;
             if (!done) {
                 if (st->lambda == st->lambda_spec) { solve = true; st->spec_hits += 1; }      // the sums at hand are the next system

@@ -499,6 +499,7 @@ static void init_state(DevState* s, const ccal_solver_opts* o) {
     s->lambda_spec = lm ? 1.0 / lm_radius_cap(o->lm_initial_radius) : 0.0;
     s->min_error = o->min_error; s->min_abs = o->min_abs_error_decrease; s->min_rel = o->min_rel_error_decrease;
     s->cur = 0; s->first = 1; s->max_iter = o->max_iterations; s->method = o->method;
+    s->error_metric = o->error_metric ? 1 : 0;
 }
 // Groups the host may enqueue at most: one per decision plus one re-elimination group per LM decision, plus the first.
 static int max_groups_for(const ccal_solver_opts* o) {

@@ -46,12 +46,11 @@
  * Reduced ("camera") system column order (ccal_build_normal): for c = 0..n_cams-1:
  * theta_c (P_eff(c)), then for c>0 rvec_c_0, tvec_c_0.  K = sum P_eff + 6 (n_cams-1).
  *
- * Environment.  The behaviour contract of this ABI does not depend on the environment: the library reads a number of
- * CCAL_* variables ("Developer switches"), every one of them a developer switch that selects between
- * implementations of the SAME result - which kernel forms a Gram block or eliminates a pose block, lanes per frame, groups
- * enqueued ahead - for A/B measurements and for the tests that hold the implementations against each other.  Results agree to
- * rounding (summation order), statuses and iteration counts are the same; with none of them set the library takes the
- * measured winners.  Some are read once per process or per problem workspace; a binding should set none.
+ * Environment.  The behaviour contract of this ABI does not depend on the environment.  libccal_hip.so reads exactly TWO
+ * variables: CCAL_RCCL_LIB (the RCCL library to dlopen when none is loaded in the process yet) and CCAL_MULTI_TRANSPORT
+ * (inproc | rccl: the transport ccal_multi_create picks when the caller leaves the choice to it).  Neither changes a result.
+ * The A/B developer switches and the test hooks live in a second library that only the parity tests load
+ * (libccal_hip_legacy.so); a binding sets nothing.
  */
 #ifndef CCAL_H
 #define CCAL_H
@@ -152,7 +151,15 @@ typedef struct {
                                       (CCAL_ERR_HIP, "timed out") leaves the shared sequence of collectives while its peers
                                       are inside ncclAllReduce - see "Errors" below: exit or abort the communicator, never
                                       re-exec a process that has touched the GPU */
+    int32_t error_metric;          /* what the stop rules above call "error" - a guess about the absent crate made switchable
+                                      (tiny-solver 0.18, Optimizer::compute_error: squared_norm_l2() or norm_l2() of the
+                                      loss-corrected residuals; call sites src/util.rs:443,455).  CCAL_ERROR_SQUARED_NORM (0,
+                                      the default): sum rho'(s) s, what ccal_report::initial_cost / final_cost hold.
+                                      CCAL_ERROR_NORM (1): its square root - min_error and the absolute / relative decreases are
+                                      then compared on sqrt(cost); the reports still hold the squared norm */
+    int32_t reserved_;             /* 0 */
 } ccal_solver_opts;
+typedef enum { CCAL_ERROR_SQUARED_NORM = 0, CCAL_ERROR_NORM = 1 } ccal_error_metric;
 
 typedef struct {
     int32_t status;                /* ccal_status of the solve */
@@ -355,6 +362,10 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
  * library, needs no context.  poses_* are [n_common][6] rvec,tvec. */
 int ccal_init_camera_extrinsic(const double* poses_cam0, const double* poses_cami, int n_common,
                                double* t_i_0_io, int use_initial, ccal_report* report);
+/* the same with the optimizer's stop rules given (max_iterations, min_error, min_abs / min_rel_error_decrease, error_metric);
+ * opts == NULL: the defaults, i.e. the call above */
+int ccal_init_camera_extrinsic_opts(const double* poses_cam0, const double* poses_cami, int n_common,
+                                    double* t_i_0_io, int use_initial, const ccal_solver_opts* opts, ccal_report* report);
 /* One SE3Factor block (src/optimization/factors.rs:248-271): r[6] = the rvec,tvec of T_i_b^-1 * (T_i_0 * T_0_b) and its
  * 6 x 6 Jacobian (row-major) with respect to x = rvec,tvec of T_i_0 - what tiny-solver's dual numbers evaluate to. */
 int ccal_se3_factor(const double* pose_0_b, const double* pose_i_b, const double* x, double* r_out, double* J_out);

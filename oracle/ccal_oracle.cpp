@@ -500,6 +500,7 @@ double oracle_cost(const ccal_problem_desc* d, const double* intr, const double*
     return total_cost(d, L, intr, poses, extr);
 }
 
+static inline double stop_error(double cost, int metric) { return metric ? std::sqrt(std::max(cost, 0.0)) : cost; }
 // GaussNewtonOptimizer::optimize restated (defaults in ccal_set_defaults) + LM mode.
 // lo/hi/has_bound/fixed: [n_cams][CCAL_PMAX] in eff index space (may be NULL).
 int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi, const uint8_t* has_bound,
@@ -534,10 +535,12 @@ int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi,
             if (allreduce_scalars(&cur, 1, ar, ar_user)) return CCAL_ERR_HIP;
             R.iterations++;
             if (o->verbose) std::printf("[oracle GN] iter %d cost %.12g\n", it, cur);
-            if (cur < o->min_error) break;
+            // what tiny-solver calls "error": squared norm (metric 0) or norm (metric 1) of the loss-corrected residuals
+            const double le = stop_error(last, o->error_metric), ce = stop_error(cur, o->error_metric);
+            if (ce < o->min_error) break;
             if (std::isnan(cur)) { status = CCAL_ERR_NONFINITE; break; }
-            if (std::fabs(last - cur) < o->min_abs_error_decrease) break;
-            if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
+            if (std::fabs(le - ce) < o->min_abs_error_decrease) break;
+            if (std::fabs(le - ce) / le < o->min_rel_error_decrease) break;
             if (it == o->max_iterations - 1) status = CCAL_ERR_NO_CONVERGENCE;
         }
     } else {
@@ -557,8 +560,9 @@ int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi,
             double pair[2] = { st == CCAL_OK ? total_cost(d, L, ic.data(), pc.data(), ec.data()) : NAN, mcp };
             if (allreduce_scalars(pair, 2, ar, ar_user)) return CCAL_ERR_HIP;
             if (st == CCAL_OK) { cand = pair[0]; mc = mcc + pair[1]; rho = (cur - cand) / mc; }
+            const double mce = o->error_metric ? std::sqrt(std::max(cur, 0.0)) - std::sqrt(std::max(cur - mc, 0.0)) : mc;
             if (st == CCAL_OK && std::isfinite(cand) && mc >= 0.0 &&
-                (mc < o->min_abs_error_decrease || mc < o->min_rel_error_decrease * cur)) {
+                (mce < o->min_abs_error_decrease || mce < o->min_rel_error_decrease * stop_error(cur, o->error_metric))) {
                 // predicted decrease below the thresholds: converged
                 if (cand < cur) {
                     std::memcpy(intr, ic.data(), sizeof(double) * ic.size());
@@ -578,9 +582,10 @@ int oracle_solve(const ccal_problem_desc* d, const double* lo, const double* hi,
                 radius = std::min(1e16, radius / std::max(1.0 / 3.0, 1.0 - t * t * t));
                 dec = 2.0;
                 if (o->verbose) std::printf("[oracle LM] iter %d accept cost %.12g rho %.3g radius %.3g\n", it, cur, rho, radius);
-                if (cur < o->min_error) break;
-                if (std::fabs(last - cur) < o->min_abs_error_decrease) break;
-                if (std::fabs(last - cur) / last < o->min_rel_error_decrease) break;
+                const double le = stop_error(last, o->error_metric), ce = stop_error(cur, o->error_metric);
+                if (ce < o->min_error) break;
+                if (std::fabs(le - ce) < o->min_abs_error_decrease) break;
+                if (std::fabs(le - ce) / le < o->min_rel_error_decrease) break;
             } else {
                 R.lm_rejected++;
                 radius /= dec; dec *= 2.0;

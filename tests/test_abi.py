@@ -59,6 +59,21 @@ def test_host_only_entry_points():
     # tiny-solver OptimizerOptions::default() as restated in SURVEY 3.3
     assert (o.method, o.max_iterations) == (0, 100)
     assert (o.min_abs_error_decrease, o.min_rel_error_decrease, o.min_error) == (1e-5, 1e-5, 1e-10)
+    assert (o.error_metric, o.reserved_) == (_ffi.ERROR_SQUARED_NORM, 0)
+
+
+def test_solver_opts_layout_is_the_headers():
+    """ccal_solver_opts in the header, the ctypes binding and the Rust stub: the same fields in the same order (the struct
+    grew by error_metric + reserved_ in round 6: a stale binding would hand the library a short struct)."""
+    src = open(os.path.join(ROOT, "include", "ccal.h")).read()
+    body = re.search(r"typedef struct \{([^}]*)\} ccal_solver_opts;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int32_t|double)\s+([a-z_0-9]+)\s*;", body)
+    assert fields == [f for f, _ in _ffi.SolverOpts._fields_]
+    assert ctypes.sizeof(_ffi.SolverOpts) == 72
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rust = re.search(r"pub struct ccal_solver_opts \{(.*?)\n\}", doc, flags=re.S).group(1)
+    assert re.findall(r"pub ([a-z_0-9]+):", rust) == fields
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

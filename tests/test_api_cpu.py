@@ -99,6 +99,56 @@ def test_init_camera_extrinsic_matches_oracle_and_truth(oracle):
     assert 1 <= iters <= 20
 
 
+def test_oracle_stop_rule_under_both_error_metrics(oracle):
+    """ccal_solver_opts.error_metric in the checker: on a problem whose cost is >> 1 the norm reading stops no later than the
+    squared-norm reading, and the reports carry the squared norm either way."""
+    from camera_intrinsic_calibration_rs_amd import synth
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    sp = synth.make_problem(60, "eucm", seed=9, outlier_frac=0.1, noise_px=0.5)
+    op = oracle.OracleProblem.from_synth(sp)
+    for method in (0, 1):
+        reps = {}
+        for em in (0, 1):
+            _, _, _, reps[em] = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method, error_metric=em))
+            assert reps[em].status == 0
+        # d sqrt(c) / sqrt(c) = dc / 2c: the norm reading meets the relative threshold no later (Gauss-Newton's quadratic
+        # convergence usually crosses both in the same iteration; this LM run stops one iteration earlier)
+        assert reps[1].iterations <= reps[0].iterations
+        if method == 1:
+            assert reps[1].iterations < reps[0].iterations
+        assert reps[0].initial_cost == reps[1].initial_cost > 100.0
+        assert reps[1].final_cost == pytest.approx(reps[0].final_cost, rel=1e-4)
+
+
+def test_init_camera_extrinsic_opts_entry_point():
+    """ccal_init_camera_extrinsic_opts: NULL options = the plain call; max_iterations = 1 stops after one step."""
+    import ctypes as C
+    from camera_intrinsic_calibration_rs_amd import _ffi
+    from camera_intrinsic_calibration_rs_amd.engine import default_opts
+    rng = np.random.default_rng(5)
+    n = 12
+    p0 = np.concatenate([0.2 * rng.standard_normal((n, 3)), rng.standard_normal((n, 3))], axis=1)
+    pi = p0 + 0.01 * rng.standard_normal((n, 6)); pi[:, 3] += 0.1
+    lib = _ffi.load()
+    dp = C.POINTER(C.c_double)
+    def run(opts):
+        x = np.zeros(6); rep = _ffi.Report()
+        rc = lib.ccal_init_camera_extrinsic_opts(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, x.ctypes.data_as(dp), 0,
+                                                 C.byref(opts) if opts is not None else None, C.byref(rep))
+        assert rc == 0
+        return x, rep
+    x_a, r_a = run(None)
+    x_b = np.zeros(6); r_b = _ffi.Report()
+    assert lib.ccal_init_camera_extrinsic(p0.ctypes.data_as(dp), pi.ctypes.data_as(dp), n, x_b.ctypes.data_as(dp), 0, C.byref(r_b)) == 0
+    np.testing.assert_array_equal(x_a, x_b)
+    x_c, r_c = run(default_opts(0))
+    np.testing.assert_array_equal(x_a, x_c)
+    _, r_1 = run(default_opts(0, max_iterations=1))
+    assert r_1.iterations == 1 <= r_a.iterations
+    _, r_n = run(default_opts(0, error_metric=1))
+    assert r_n.iterations <= r_a.iterations
+
+
 def test_convert_model_ucm_to_eucmt_closed_form():
     """src/util.rs:236-243: UCM -> EUCMT inserts beta = 1 and two zero tangential terms; through the Python mirror and
     through the C ABI (a host-only path of ccal_convert_model, no GPU needed); everything else with EUCMT is refused."""

@@ -38,12 +38,15 @@ def test_build_normal_matches_oracle(gpu_ctx, oracle, model, one_focal, n_cams, 
 @pytest.mark.parametrize("model,n_cams,one_focal", [("eucm", 1, False), ("kb4", 1, True), ("opencv5", 1, False),
                                                     ("eucm", 2, False), ("ucm", 3, True)])
 @pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
-def test_solve_matches_oracle(gpu_ctx, oracle, model, n_cams, one_focal, method):
+@pytest.mark.parametrize("error_metric", [_ffi.ERROR_SQUARED_NORM, _ffi.ERROR_NORM])
+def test_solve_matches_oracle(gpu_ctx, oracle, model, n_cams, one_focal, method, error_metric):
+    """Both readings of tiny-solver's compute_error (ccal_solver_opts.error_metric; call sites /root/reference/src/util.rs:443,455):
+    the stop rules on the squared norm and on the norm - GPU and oracle stop after the same number of iterations under each."""
     sp = synth.make_problem(30, model, n_cams=n_cams, xy_same_focal=one_focal, outlier_frac=0.01)
     gp, op = _pair(gpu_ctx, oracle, sp)
     gp.apply_reference_bounds(); op.apply_reference_bounds()
-    intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
-    intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+    intr, poses, extr, rep = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method, error_metric=error_metric))
+    intr_o, poses_o, extr_o, rep_o = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method, error_metric=error_metric))
     assert rep.status == rep_o.status == 0
     assert rep.iterations == rep_o.iterations
     assert abs(rep.initial_cost - rep_o.initial_cost) <= 1e-12 * rep_o.initial_cost
@@ -57,6 +60,31 @@ def test_solve_matches_oracle(gpu_ctx, oracle, model, n_cams, one_focal, method)
         assert (intr[:, 0] == intr[:, 1]).all()              # fy re-inserted (src/util.rs:467-470)
     # and the answer is the right one: close to ground truth
     assert np.abs(intr[:, :4] / sp.intr_gt[:, :4] - 1).max() < 5e-3
+
+
+@pytest.mark.parametrize("frames", [60, 3000])
+def test_error_metric_moves_the_stop_and_both_sides_follow(gpu_ctx, oracle, frames):
+    """The norm reading stops no later than the squared-norm reading (d sqrt(c) / sqrt(c) = dc / 2 c) - one LM iteration earlier on
+    the 60-frame problem: the option is live in the single-launch form (60 frames) and in the three-launch form (3 000), and the
+    oracle follows."""
+    sp = synth.make_problem(frames, "eucm", seed=9, outlier_frac=0.1, noise_px=0.5)
+    gp, op = _pair(gpu_ctx, oracle, sp)
+    its = {}
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        for em in (_ffi.ERROR_SQUARED_NORM, _ffi.ERROR_NORM):
+            _, _, _, r = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method, error_metric=em))
+            rd = None
+            if frames <= 100:
+                _, _, _, ro = op.solve(sp.intr0, sp.poses0, opts=default_opts(method, error_metric=em))
+                assert (r.status, r.iterations) == (ro.status, ro.iterations), (method, em)
+                assert abs(r.final_cost - ro.final_cost) <= 1e-9 * ro.final_cost
+            gp.upload_params(sp.intr0, sp.poses0, sp.extr0)
+            rd = gp.solve_dev(default_opts(method, error_metric=em))
+            assert (rd.status, rd.iterations) == (r.status, r.iterations)
+            its[(method, em)] = r.iterations
+    assert its[(0, 1)] <= its[(0, 0)] and its[(1, 1)] <= its[(1, 0)], its
+    if frames == 60:
+        assert its[(1, 1)] < its[(1, 0)], its       # LM: one iteration less under the norm (the oracle's counts: 4 against 5)
 
 
 def test_gn_and_lm_converge_to_same_intrinsics(gpu_ctx):
