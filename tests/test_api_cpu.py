@@ -145,8 +145,9 @@ def test_init_camera_extrinsic_opts_entry_point():
     np.testing.assert_array_equal(x_a, x_c)
     _, r_1 = run(default_opts(0, max_iterations=1))
     assert r_1.iterations == 1 <= r_a.iterations
-    _, r_n = run(default_opts(0, error_metric=1))
-    assert r_n.iterations <= r_a.iterations
+    x_n, r_n = run(default_opts(0, error_metric=1))       # a cost below 1: the norm's decreases are LARGER - it may stop later
+    assert r_n.status == 0 and r_n.iterations >= r_a.iterations
+    np.testing.assert_allclose(x_n, x_a, atol=1e-6)
 
 
 def test_convert_model_ucm_to_eucmt_closed_form():
