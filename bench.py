@@ -72,7 +72,65 @@ def _stdout_for_the_line_only():
         os.dup2(2, 1)
 
 
+def _sig(x, n=4):
+    """n significant digits (the summary has to stay short)."""
+    try:
+        return float(f"{float(x):.{n}g}")
+    except (TypeError, ValueError):
+        return None
+
+
+def _summary(out):
+    """The numbers this repo claims, in <= 1 500 characters, as the LAST key of the line: the driver keeps the tail of stdout, and
+    the line is ~20 KB.  Every value is copied from the full blocks in front of it (ms unless the key says otherwise; [host
+    pointers, device-resident] pairs for solves; frac = fraction of the 8 TB/s HBM / 78.6 TF FP64 peak)."""
+    ex = out.get("extra") or {}
+    def g(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    def pair(blk, name):
+        return [_sig(g(blk, name, "solve_ms")), _sig(g(blk, name + "_device_resident", "solve_ms"))]
+    s = {"E_ms": _sig(g(out, "roofline", "kernel_ms")), "E_frac_hbm": _sig(g(out, "roofline", "frac")),
+         "N_build_ms": {"eucm": _sig(ex.get("mode_N_build_ms")), "kb4": _sig(g(ex, "config2", "kb4", "mode_N_build_ms")),
+                        "opencv5": _sig(g(ex, "config2", "opencv5", "mode_N_build_ms"))},
+         "N_frac_fp64": {"eucm": _sig(g(ex, "mode_N_roofline", "frac_fp64")), "kb4": _sig(g(ex, "config2", "kb4", "mode_N_roofline", "frac_fp64")),
+                         "opencv5": _sig(g(ex, "config2", "opencv5", "mode_N_roofline", "frac_fp64"))},
+         "gn_ms": {"f10000": [_sig(ex.get("gn_solve_ms")), _sig(g(ex, "gn_device_resident", "solve_ms"))],
+                   "f625": pair(ex.get("frames625"), "gn")},
+         "lm_ms": {"f10000": [_sig(ex.get("lm_solve_ms")), _sig(g(ex, "lm_device_resident", "solve_ms"))],
+                   "f625": pair(ex.get("frames625"), "lm")},
+         "iters": {"gn": ex.get("gn_iterations"), "lm": ex.get("lm_iterations")},
+         "cam2": {"build_ms": _sig(g(ex, "two_cameras", "build_ms")), "gn_ms": pair(ex.get("two_cameras"), "gn")},
+         "config0_total_ms": _sig(g(ex, "config0", "gpu_ms", "total")),
+         "batch8_ms": _sig(g(ex, "concurrent_sessions", "by_sessions", "8", "ms_per_batch"))}
+    for key in ("ragged", "ragged50k"):
+        r = ex.get(key)
+        if isinstance(r, dict) and "error" not in r:
+            s[key] = {"corners": r.get("corners"), "E_ms": _sig(g(r, "mode_E", "kernel_ms")), "E_frac_hbm": _sig(g(r, "mode_E", "frac_hbm")),
+                      "N_build_ms": _sig(g(r, "mode_N", "build_ms")), "N_frac_fp64": _sig(g(r, "mode_N", "frac_fp64")),
+                      "gn_ms": pair(r, "gn"), "lm_ms": pair(r, "lm")}
+        elif r is not None:
+            s[key] = "error"
+    sh = g(ex, "single_process_sharded")
+    if isinstance(sh, dict):
+        s["allreduce_us_per_step"] = {k: _sig(g(sh, k, "allreduce_us_per_step")) for k in ("in_process", "rccl") if isinstance(sh.get(k), dict)}
+    if out.get("allreduce_us_per_step") is not None:
+        s.setdefault("allreduce_us_per_step", {})["rccl_ranks_%s" % out.get("rccl_ranks")] = _sig(out["allreduce_us_per_step"])
+    s["gpu_over_cpu"] = _sig(out.get("gpu_over_cpu"))
+    s["parity_pass"] = g(out, "parity", "pass")
+    return s
+
+
 def _emit(out):
+    if "roofline" in out and "dry_run" not in out:
+        out.pop("summary", None)
+        try:
+            out["summary"] = _summary(out)          # LAST key (the launcher's block, added later, goes in front of it)
+        except Exception as e:  # noqa: BLE001
+            out["summary"] = {"error": repr(e)}
     line = (json.dumps(out) + "\n").encode()
     sys.stdout.flush()
     if _REAL_STDOUT is not None:
@@ -175,23 +233,50 @@ def _launch_workers(n, argv):
                    CCAL_BENCH_SPAWNED="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=None))
-    line = b""
-    try:
-        line, _ = procs[0].communicate(timeout=float(os.environ.get("CCAL_BENCH_LAUNCH_TIMEOUT", "3600")))     # rank 0 prints its one line at the very end
-    except subprocess.TimeoutExpired:
-        print("[bench] rank 0 did not finish in time: stopping the workers", file=sys.stderr, flush=True)
-        for pr in procs:
-            pr.kill()                            # exactly the children started here
-    except Exception:  # noqa: BLE001
-        pass
-    codes = []
-    deadline = time.time() + 120.0               # the other ranks leave their last barrier together with rank 0
-    for pr in procs:
+    # rank 0's pipe is drained by a thread (it prints its one line at the very end); this thread polls EVERY child: the first
+    # worker that exits non-zero - too few GPUs for its rank, an import error, an RCCL initialisation failure - ends the run at once
+    # (its peers would sit in init_process_group or a barrier with no partner until some timeout), as torchrun does
+    import threading
+    chunks = []
+    def drain():
         try:
-            codes.append(pr.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
+            for chunk in iter(lambda: procs[0].stdout.read(65536), b""):
+                chunks.append(chunk)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] reading rank 0's output failed: {e!r}", file=sys.stderr, flush=True)
+    reader = threading.Thread(target=drain, daemon=True)
+    reader.start()
+    limit = float(os.environ.get("CCAL_BENCH_LAUNCH_TIMEOUT", "3600"))
+    t_start = time.time()
+    codes = [None] * n
+    failed = None                                # (rank, code) of the first worker that failed
+    grace = None                                 # once rank 0 is done: the other ranks leave their last barrier together with it
+    while any(c is None for c in codes):
+        for i, pr in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = pr.poll()
+                if codes[i] not in (None, 0) and failed is None:
+                    failed = (i, codes[i])
+        now = time.time()
+        if failed is not None:
+            print(f"[bench] rank {failed[0]} exited with code {failed[1]}: stopping the other workers", file=sys.stderr, flush=True)
+            break
+        if codes[0] is not None and grace is None:
+            grace = now + 120.0
+        if now - t_start > limit:
+            print("[bench] the workers did not finish in time: stopping them", file=sys.stderr, flush=True)
+            break
+        if grace is not None and now > grace:
+            print(f"[bench] workers still running 120 s after rank 0 finished (exit codes so far {codes}): stopping them", file=sys.stderr, flush=True)
+            break
+        time.sleep(0.2)
+    for i, pr in enumerate(procs):
+        if codes[i] is None:
             pr.kill()                            # exactly the child started here
-            codes.append(pr.wait())
+            pr.wait()
+            codes[i] = -9
+    reader.join(timeout=10.0)
+    line = b"".join(chunks)
     out = None
     for ln in line.decode(errors="replace").splitlines():
         ln = ln.strip()
@@ -200,7 +285,7 @@ def _launch_workers(n, argv):
                 out = json.loads(ln)
             except ValueError:
                 pass
-    bad = next((c for c in codes if c != 0), 0)
+    bad = failed[1] if failed is not None else next((c for c in codes if c != 0), 0)
     if out is None:
         print(f"[bench] no JSON line from rank 0 (worker exit codes {codes})", file=sys.stderr, flush=True)
         return bad or 5
@@ -219,6 +304,10 @@ def _dry_run(args, rank, world):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("CCAL_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        # (tests/test_bench_cpu.py: a worker that dies before the rendezvous - its peers wait for it there; the launcher must not)
+        print(f"[bench] dry run: rank {rank} fails on request", file=sys.stderr, flush=True)
+        sys.exit(7)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     from camera_intrinsic_calibration_rs_amd import engine, synth
@@ -323,7 +412,9 @@ def main():
         if world > 1:
             # the library's own cut (ccal_partition_slots: contiguous slot ranges balanced by corner count - what
             # ccal_multi_problem_create does in the single-process form)
-            first = engine.partition_slots(engine.desc_from_synth(sp)[0], world)
+            d_all, keep_all = engine.desc_from_synth(sp)           # (keep_all: the arrays the description points into)
+            first = engine.partition_slots(d_all, world)
+            del d_all, keep_all
             sp = sp.slot_slice(first[rank], first[rank + 1])
         args.frames = sp.n_slots
     else:
@@ -665,6 +756,65 @@ def main():
                     except Exception as e:  # noqa: BLE001
                         cfg2[m2] = {"error": repr(e)}
                 extra["config2"] = cfg2
+            # SURVEY 8(d)'s ragged variant: real frames hold 24 .. 144 corners (src/data_loader.rs:15,61-62: frames with fewer than 24
+            # detections are dropped, a 6 x 6 AprilGrid has 144) - the same frame count with n ~ U{24..144} corners per frame, rows in
+            # the HashMap's (random) order.  Rooflines on the bytes ACTUALLY moved / flops ACTUALLY needed for these corners.
+            if args.model == "eucm" and not strong:
+                for key, nfr, with_lm in (("ragged", args.frames, True), ("ragged50k", 50000, False)):
+                    if key == "ragged50k" and (args.frames != 10000 or os.environ.get("CCAL_BENCH_NO_RAGGED50K")):
+                        continue
+                    try:
+                        spr = synth.make_problem(nfr, args.model, seed=0xC0FFEE + 77, ragged=True)
+                        pr_ = Problem.from_synth(ctx, spr)
+                        Dr = pr_.block_dim(0)
+                        pr_.upload_params(spr.intr0, spr.poses0, spr.extr0)
+                        Jr = torch.empty(pr_.j_len, dtype=torch.float64, device=dev)
+                        rr = torch.empty(pr_.n_corners * 2, dtype=torch.float64, device=dev)
+                        with torch.cuda.stream(stream):
+                            ramp(lambda: pr_.eval_dev(rr.data_ptr(), Jr.data_ptr(), apply_loss=False))
+                            a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                            ne_ = 300 if nfr <= 10000 else 60
+                            a.record(stream)
+                            for _ in range(ne_):
+                                pr_.eval_dev(rr.data_ptr(), Jr.data_ptr(), apply_loss=False)
+                            b.record(stream)
+                            torch.cuda.synchronize()
+                            e_ms = a.elapsed_time(b) / ne_
+                            ramp(lambda: pr_.build_normal_dev(0.0))
+                            nb_ = 100 if nfr <= 10000 else 30
+                            a.record(stream)
+                            for _ in range(nb_):
+                                pr_.build_normal_dev(0.0)
+                            b.record(stream)
+                            torch.cuda.synchronize()
+                            b_ms = a.elapsed_time(b) / nb_
+                        ab = pr_.n_corners * (20 + 16 + 16 * Dr) + spr.n_slots * 48
+                        blk = {"workload": f"{spr.n_slots} frames, n ~ U{{24..144}} corners per frame (mean {pr_.n_corners / spr.n_slots:.1f}), {args.model.upper()}, one camera",
+                               "frames": spr.n_slots, "corners": int(pr_.n_corners),
+                               "mode_E": {"kernel_ms": e_ms, "evals_per_s": pr_.n_corners / (e_ms * 1e-3), "algorithmic_bytes_per_launch": ab,
+                                          "achieved_GBps": ab / (e_ms * 1e-3) / 1e9, "frac_hbm": ab / (e_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+                               "mode_N": {"build_ms": b_ms, "evals_per_s": pr_.n_corners / (b_ms * 1e-3)}}
+                        try:
+                            with open(_latest_profile_file("flops.json")) as f:
+                                flr = json.load(f)["kernels"]
+                            gkr = _gram_kernel_key(args.model, False, nfr)
+                            fl_c = flr[gkr]["per_corner"]["flops"]
+                            fl_f = flr[f"k_schur1m<K={pr_.K}>"]["per_lane_whole_kernel"]["per_frame_flops_16_lanes"]
+                            tf = (fl_c * pr_.n_corners + fl_f * spr.n_slots) / (b_ms * 1e-3) / 1e12
+                            blk["mode_N"].update({"kernel": gkr, "flops_per_corner_gram": fl_c, "achieved_tflops": tf, "frac_fp64": tf / FP64_PEAK_TFLOPS,
+                                                  "counted": "flops needed for the corners that exist (not for the padded passes of a wavefront)"})
+                        except Exception as e:  # noqa: BLE001
+                            blk["mode_N"]["roofline_error"] = repr(e)
+                        blk["gn"] = solve_stats(pr_, spr, 0, False); blk["gn_device_resident"] = solve_stats(pr_, spr, 0, True)
+                        if with_lm:
+                            blk["lm"] = solve_stats(pr_, spr, 1, False); blk["lm_device_resident"] = solve_stats(pr_, spr, 1, True)
+                        intr_r = pr_.download_params()[0]
+                        blk["max_rel_intrinsics_err_vs_gt"] = float(np.abs(intr_r[0, :4] / spr.intr_gt[0, :4] - 1).max())
+                        del Jr, rr
+                        pr_.close()
+                        extra[key] = blk
+                    except Exception as e:  # noqa: BLE001
+                        extra[key] = {"error": repr(e)}
             # ONE process, several GPUs (ccal_multi_*: the reference's single-process shape of a multi-GPU solve; SURVEY 8(b)'s
             # `ccal_create(device_ids, n_dev)`): the headline problem cut by the library over EVERY visible GPU - range(device_count);
             # on a 1-GPU box two shards of the one GPU, where sharding can only cost - with both transports side by side (in-process:
@@ -696,6 +846,12 @@ def main():
                                 row[name] = {"iterations": best[0].iterations, "solve_ms": best[0].solve_ms, "status": best[0].status,
                                              "unsharded_solve_ms": extra.get(f"{name}_solve_ms"),
                                              "max_rel_intrinsics_diff_vs_unsharded": float(np.abs(best[1][0, :6] / i_ref[method][0, :6] - 1).max())}
+                            # what the step's one collective costs on this transport: (sharded - unsharded) solve time over the groups of
+                            # the solve (GN: iterations + 1 groups, one all-reduce each); on [0,0] the two shards also halve each other's chip
+                            try:
+                                row["allreduce_us_per_step"] = 1e3 * (row["gn"]["solve_ms"] - extra["gn_solve_ms"]) / (row["gn"]["iterations"] + 1)
+                            except Exception:  # noqa: BLE001
+                                row["allreduce_us_per_step"] = None
                             sps[leg] = row
                             mpb.close(); mc.close()
                         except Exception as e:  # noqa: BLE001
@@ -773,7 +929,9 @@ def main():
             split_total = int(os.environ.get("CCAL_BENCH_CONFIG3_FRAMES", "50000"))
             split_sp = synth.make_problem(split_total, args.model, seed=0xC0FFEE)
             if world > 1:
-                first3 = engine.partition_slots(engine.desc_from_synth(split_sp)[0], world)
+                d3, keep3 = engine.desc_from_synth(split_sp)
+                first3 = engine.partition_slots(d3, world)
+                del d3, keep3
                 split_sp = split_sp.slot_slice(first3[rank], first3[rank + 1])
             split = Problem.from_synth(ctx, split_sp)
 
@@ -823,6 +981,15 @@ def main():
         if th.is_alive():
             result = {"error": "timeout (180 s) in the sharded solve"}
         if rank == 0:
+            try:
+                # weak scaling: every rank holds what the unsharded solve of `extra` held - per GROUP (iterations + 1; one collective
+                # each), sharded minus unsharded = what the step's all-reduce costs on this node
+                if not strong and "gn_device_resident" in result and "gn_device_resident" in out.get("extra", {}):
+                    sg, ug = result["gn_device_resident"], out["extra"]["gn_device_resident"]
+                    result["allreduce_us_per_step"] = 1e3 * (sg["solve_ms"] / (sg["iterations"] + 1) - ug["solve_ms"] / (ug["iterations"] + 1))
+                    out["allreduce_us_per_step"] = result["allreduce_us_per_step"]
+            except Exception:  # noqa: BLE001
+                pass
             out.setdefault("extra", {})["sharded_solve"] = result
             out["rccl_ranks"] = result.get("rccl_ranks")          # did RCCL see all N ranks: ncclCommCount of the communicator the solves used
             if split is not None:

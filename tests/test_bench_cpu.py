@@ -49,3 +49,17 @@ def test_a_failing_worker_fails_the_launcher():
     r2 = _run(["--gpus", "2", "--model", "nope"], {"CCAL_BENCH_DRYRUN": "1", "CCAL_BENCH_BACKEND": "gloo", "CCAL_BENCH_LAUNCH_TIMEOUT": "120"})
     assert r2.returncode != 0 and r2.stdout.strip() == ""
     assert r.returncode == 0
+
+
+def test_a_worker_that_dies_before_the_rendezvous_ends_the_run_at_once():
+    """rank 1 exits (code 7) before init_process_group; rank 0 would wait in the rendezvous for its partner until the
+    process-group timeout (minutes).  The launcher polls every child: it stops rank 0 and returns rank 1's code within seconds."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"],
+             {"CCAL_BENCH_DRYRUN": "1", "CCAL_BENCH_BACKEND": "gloo", "CCAL_BENCH_DRYRUN_FAIL_RANK": "1"}, timeout=240)
+    dt = time.time() - t0
+    assert r.returncode == 7, (r.returncode, r.stderr[-1500:])
+    assert r.stdout.strip() == ""
+    assert "rank 1 exited with code 7" in r.stderr
+    assert dt < 120.0, dt
