@@ -145,8 +145,8 @@ inline size_t problem_scratch_hint(const ccal_problem* p) {
 }
 hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err, double* avg_99, double* median, hipStream_t s);
 hipError_t camera_errors_device(ccal_problem* p, int cam, const double* d_err, double** d_out, int64_t* n_out, hipStream_t s);     // *d_out: a slice of p->d_scratch
-size_t sorted_stats_scratch_bytes(int64_t n, hipStream_t s);      // block size sorted_stats_device needs for n values (0: sizing failed)
-hipError_t sorted_stats_device(char* block /* values in front */, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s);
+size_t order_stats_block_bytes(int64_t n, hipStream_t s);      // block size order_stats_block needs for n values (0: sizing failed)
+hipError_t order_stats_block(char* block /* values in front */, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s);
 // ccal_api.hip: reprojection errors of every corner at the given parameters into p->d_err (device); ccal_multi.hip uses it per shard
 int reprojection_errors_dev(ccal_problem* p, const double* intr, const double* poses, const double* extr);
 // ccal_kernels_init.hip

@@ -326,10 +326,10 @@ hipError_t validation_stats_device(ccal_problem* p, int cam, const double* d_err
     return order_stats_device(d_a, n, work, avg_99, median, s);
 }
 
-// the multi-GPU form: block = [values (n) | work area], sized by sorted_stats_scratch_bytes and kept by the caller between calls
-size_t sorted_stats_scratch_bytes(int64_t n, hipStream_t) { return n <= 0 ? 0 : up256((size_t)n * sizeof(double)) + order_stats_work_bytes(); }
-hipError_t sorted_stats_device(char* block, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s) {
-    if (n <= 0 || !block || sorted_stats_scratch_bytes(n, s) > block_bytes) return hipErrorInvalidValue;
+// the multi-GPU form: block = [values (n) | work area], sized by order_stats_block_bytes and kept by the caller between calls
+size_t order_stats_block_bytes(int64_t n, hipStream_t) { return n <= 0 ? 0 : up256((size_t)n * sizeof(double)) + order_stats_work_bytes(); }
+hipError_t order_stats_block(char* block, size_t block_bytes, int64_t n, double* avg_99, double* median, hipStream_t s) {
+    if (n <= 0 || !block || order_stats_block_bytes(n, s) > block_bytes) return hipErrorInvalidValue;
     return order_stats_device(reinterpret_cast<const double*>(block), n, block + up256((size_t)n * sizeof(double)), avg_99, median, s);
 }
 

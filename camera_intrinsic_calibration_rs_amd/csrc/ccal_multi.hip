@@ -76,8 +76,11 @@ static bool inproc_wait_posted(InprocComm* c, int q, uint64_t call) {
         if (c->timeout_s > 0 && el > c->timeout_s) { inproc_abort(c); return false; }
         if (el > 50e-6) {
             std::unique_lock<std::mutex> lk(c->m);
-            c->sleepers.fetch_add(1, std::memory_order_acq_rel);
-            c->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return pq.load(std::memory_order_acquire) >= call || c->abort.load(std::memory_order_acquire) != 0; });
+            // store(posted) -> load(sleepers) on the poster's side against add(sleepers) -> load(posted) here is a store-load pair
+            // on each side: only sequentially consistent operations order it (with release / acquire the poster could read
+            // sleepers == 0 while this thread still read the old `posted`, and a wake-up was lost for a 200-us slice)
+            c->sleepers.fetch_add(1, std::memory_order_seq_cst);
+            c->cv.wait_for(lk, std::chrono::microseconds(200), [&] { return pq.load(std::memory_order_seq_cst) >= call || c->abort.load(std::memory_order_seq_cst) != 0; });
             c->sleepers.fetch_sub(1, std::memory_order_acq_rel);
         }
     }
@@ -124,8 +127,8 @@ void inproc_destroy(InprocComm* c) {
 }
 void inproc_abort(InprocComm* c) {
     if (!c) return;
-    c->abort.store(1, std::memory_order_release);
-    if (c->sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(c->m); c->cv.notify_all(); }
+    c->abort.store(1, std::memory_order_seq_cst);
+    if (c->sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(c->m); c->cv.notify_all(); }
 }
 bool inproc_aborted(const InprocComm* c) { return c && c->abort.load(std::memory_order_acquire) != 0; }
 void inproc_set_timeout(InprocComm* c, double seconds) { if (c) c->timeout_s = seconds > 0 ? seconds : 600.0; }
@@ -160,8 +163,8 @@ int inproc_post(void* user, const double* buf, size_t count, void* hip_stream, P
     const uint64_t call = ++c->calls[(size_t)r];
     c->src[(size_t)(par * n + r)] = buf; c->cnt[(size_t)(par * n + r)] = count;
     if (hipEventRecord(c->ready[(size_t)(par * n + r)], st) != hipSuccess) { inproc_abort(c); return 1; }
-    c->posted[(size_t)r].store(call, std::memory_order_release);
-    if (c->sleepers.load(std::memory_order_acquire) > 0) { std::lock_guard<std::mutex> lk(c->m); c->cv.notify_all(); }
+    c->posted[(size_t)r].store(call, std::memory_order_seq_cst);
+    if (c->sleepers.load(std::memory_order_seq_cst) > 0) { std::lock_guard<std::mutex> lk(c->m); c->cv.notify_all(); }
     out->n = n;
     for (int q = 0; q < n; ++q) {
         if (q == r) { out->src[q] = buf; continue; }
@@ -250,6 +253,8 @@ int ccal_multi_create_transport(const int* device_ids, int n_dev, int transport,
         if (force && force[0] == 'r') transport = CCAL_TRANSPORT_RCCL;
         else if (force && force[0] == 'i') transport = CCAL_TRANSPORT_INPROC;
     }
+    if (n_dev == 1 && transport == CCAL_TRANSPORT_INPROC)      // asked for by name: never replaced silently by "none"
+        return bail(CCAL_ERR_UNSUPPORTED, "ccal_multi_create: the in-process transport needs at least two shards (list the device twice)");
     if (n_dev > 1 || transport == CCAL_TRANSPORT_RCCL) {
         bool distinct = true;
         for (int i = 0; i < n_dev; ++i) for (int k = 0; k < i; ++k) distinct = distinct && device_ids[i] != device_ids[k];
@@ -501,11 +506,11 @@ int ccal_multi_validation(ccal_multi_problem* mp, int cam, const double* intr, c
     if (total <= 0) return mfail(m, CCAL_ERR_INVALID_ARG, "camera has no observations");
     ccal_ctx* c0 = m->ctx[0];
     if (hipSetDevice(c0->device) != hipSuccess) return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: hipSetDevice failed");
-    const size_t need = sorted_stats_scratch_bytes(total, c0->stream);
-    if (need == 0) return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: sizing the sort failed");
+    const size_t need = order_stats_block_bytes(total, c0->stream);
+    if (need == 0) return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: sizing the selection's work area failed");
     if (mp->gather_bytes < need) {
         if (mp->d_gather) { (void)hipFree(mp->d_gather); mp->d_gather = nullptr; mp->gather_bytes = 0; }
-        const size_t want = std::max(need, sorted_stats_scratch_bytes(std::max<int64_t>(mp->n_corners, 1), c0->stream));     // every camera of the problem fits
+        const size_t want = std::max(need, order_stats_block_bytes(std::max<int64_t>(mp->n_corners, 1), c0->stream));     // every camera of the problem fits
         if (hipMalloc((void**)&mp->d_gather, want) != hipSuccess) { (void)hipGetLastError(); return mfail(m, CCAL_ERR_NO_MEMORY, "ccal_multi_validation: out of device memory"); }
         mp->gather_bytes = want;
     }
@@ -517,7 +522,7 @@ int ccal_multi_validation(ccal_multi_problem* mp, int cam, const double* intr, c
             return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: gathering the shards' errors failed");
         at += cnt[(size_t)r];
     }
-    if (sorted_stats_device(mp->d_gather, mp->gather_bytes, total, avg_99_percent, median, c0->stream) != hipSuccess)
+    if (order_stats_block(mp->d_gather, mp->gather_bytes, total, avg_99_percent, median, c0->stream) != hipSuccess)
         return mfail(m, CCAL_ERR_HIP, "ccal_multi_validation: the statistics kernels failed");
     return CCAL_OK;
     CCAL_API_CATCH((ccal_ctx*)nullptr)

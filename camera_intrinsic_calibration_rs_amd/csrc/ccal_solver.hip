@@ -1113,19 +1113,26 @@ static int batch_iter_lpf(const ccal_problem* p, int share) {
     return fused_iter_lpf(p->n_obs, avg, share);
 }
 // solve the members of one group; rc / reps per member.  Runs on the caller's thread.
-static void run_iter_group(const IterGroupKey& key, const std::vector<int>& members, ccal_problem** ps, const ccal_solver_opts* o, bool host_io,
-                           double** intr_io, double** poses_io, int share, std::vector<int>& rc, ccal_report* reps) {
-    const int n = (int)members.size();
-    ccal_ctx* c0 = ps[members[0]]->ctx;
+// A member whose own preparation fails (workspace allocation, staging) takes its own code and error text and leaves the group; its
+// neighbours go on (include/ccal.h: every problem's own verdict in reports[i]).  `retry`: members that are fine but do not fit this
+// group after all - the caller solves them on their own.
+static void run_iter_group(const IterGroupKey& key, const std::vector<int>& members_in, ccal_problem** ps, const ccal_solver_opts* o, bool host_io,
+                           double** intr_io, double** poses_io, int share, std::vector<int>& rc, ccal_report* reps, std::vector<int>& retry) {
+    std::vector<int> members;                                   // the members that made it into the launches
+    ccal_ctx* c0 = ps[members_in[0]]->ctx;
     hipStream_t st = c0->stream;
-    auto fail_all = [&](int code, const char* why) { for (int i : members) { rc[i] = code; note_error(ps[i]->ctx, why); } };
-    if (hipSetDevice(c0->device) != hipSuccess) { fail_all(CCAL_ERR_HIP, "hipSetDevice failed"); return; }
+    // failures of the GROUP (its device, its table): every member that is in the launches shares them
+    auto fail_all = [&](const std::vector<int>& who, int code, const char* why) { for (int i : who) { rc[i] = code; note_error(ps[i]->ctx, why); } };
+    if (hipSetDevice(c0->device) != hipSuccess) { fail_all(members_in, CCAL_ERR_HIP, "hipSetDevice failed"); return; }
     std::vector<std::unique_ptr<FusedJob>> jobs;
-    jobs.reserve((size_t)n);
+    jobs.reserve(members_in.size());
     int max_rows = 0, max_groups = 0;
-    for (int i : members) {
+    for (int i : members_in) {
         ccal_problem* p = ps[i];
         int r = normal_ws_ensure(p);
+#ifdef CCAL_TEST_HOOKS      // tests/test_gpu_iter.py (second library only): problem number CCAL_TEST_FAIL_BATCH_MEMBER of the batch fails its preparation
+        if (const char* e = std::getenv("CCAL_TEST_FAIL_BATCH_MEMBER"); e && std::atoi(e) == i) { r = CCAL_ERR_NO_MEMORY; note_error(p->ctx, "injected failure of a batch member (test hook)"); }
+#endif
         std::unique_ptr<FusedJob> j;
         if (r == CCAL_OK) {
             // a stale launch of this problem's last solve may still sit in ITS OWN stream: the group's launches run elsewhere
@@ -1135,12 +1142,22 @@ static void run_iter_group(const IterGroupKey& key, const std::vector<int>& memb
             j->w = p->nws; j->st = st; j->share = share; j->batch_member = true;
             r = j->begin();
             if (r == CCAL_OK && fresh && p->ctx->stream != st && hipStreamSynchronize(p->ctx->stream) != hipSuccess) { r = CCAL_ERR_HIP; note_error(p->ctx, "hipStreamSynchronize failed"); }
-            if (r == CCAL_OK && (j->iter_rows <= 0 || fused_iter_lpf(p->n_obs, j->fa.avg_corners, share) != key.lpf)) { r = CCAL_ERR_INVALID_ARG; note_error(p->ctx, "ccal_solve_batch: lockstep group mismatch"); }
+            if (r == CCAL_OK && (j->iter_rows <= 0 || fused_iter_lpf(p->n_obs, j->fa.avg_corners, share) != key.lpf)) {
+                // prepared, but not in this group's shape after all: solved on its own behind the group (nothing of it was enqueued
+                // on the group's stream but begin()'s staging, which its own solve repeats)
+                (void)hipStreamSynchronize(st);
+                j.reset();
+                retry.push_back(i);
+                continue;
+            }
         }
-        if (r != CCAL_OK) { fail_all(r, ccal_last_error(p->ctx)); (void)hipStreamSynchronize(st); return; }
+        if (r != CCAL_OK) { rc[i] = r; (void)hipStreamSynchronize(st); continue; }      // this member's own code; its context holds the reason
         max_rows = std::max(max_rows, j->iter_rows); max_groups = std::max(max_groups, j->max_groups);
         jobs.push_back(std::move(j));
+        members.push_back(i);
     }
+    const int n = (int)members.size();
+    if (n == 0) return;
     // the table: grown on demand, kept by the group's first context
     const size_t bytes = (size_t)n * sizeof(FusedArgs);
     if (c0->batch_tab_bytes < bytes) {
@@ -1149,7 +1166,7 @@ static void run_iter_group(const IterGroupKey& key, const std::vector<int>& memb
         c0->d_batch_tab = nullptr; c0->h_batch_tab = nullptr; c0->batch_tab_bytes = 0;
         const size_t want = std::max(bytes, (size_t)16 * sizeof(FusedArgs));
         if (hipMalloc((void**)&c0->d_batch_tab, want) != hipSuccess || hipHostMalloc((void**)&c0->h_batch_tab, want, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError(); fail_all(CCAL_ERR_NO_MEMORY, "ccal_solve_batch: out of memory for the batch table"); (void)hipStreamSynchronize(st); return;
+            (void)hipGetLastError(); fail_all(members, CCAL_ERR_NO_MEMORY, "ccal_solve_batch: out of memory for the batch table"); (void)hipStreamSynchronize(st); return;
         }
         c0->batch_tab_bytes = want;
     }
@@ -1241,7 +1258,13 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
     }
     for (size_t g = 0; g < gkeys.size(); ++g) if (gmembers[g].size() >= 2) for (int i : gmembers[g]) grouped[(size_t)i] = 1;
     ctxs.clear();                                                  // contexts that still have problems of their own to drive
-    for (int i = 0; i < n; ++i) if (!grouped[(size_t)i] && std::find(ctxs.begin(), ctxs.end(), ps[i]->ctx) == ctxs.end()) ctxs.push_back(ps[i]->ctx);
+    std::vector<ccal_ctx*> late;                                   // ... those among them that also hold members of a lockstep group
+    auto holds_grouped = [&](const ccal_ctx* c) { for (int i = 0; i < n; ++i) if (grouped[(size_t)i] && ps[i]->ctx == c) return true; return false; };
+    for (int i = 0; i < n; ++i) {
+        if (grouped[(size_t)i]) continue;
+        std::vector<ccal_ctx*>& dst = holds_grouped(ps[i]->ctx) ? late : ctxs;
+        if (std::find(dst.begin(), dst.end(), ps[i]->ctx) == dst.end()) dst.push_back(ps[i]->ctx);
+    }
     auto run_ctx = [&](ccal_ctx* c) noexcept {
         const int n_side = side_by_side(c);
         for (int i = 0; i < n; ++i) {
@@ -1273,12 +1296,17 @@ int ccal_solve_batch(ccal_problem** ps, int n, const ccal_solver_opts* o, double
     if (any_group) {
         for (size_t g = 0; g < gkeys.size(); ++g) {
             if (gmembers[g].size() < 2) continue;
+            std::vector<int> retry;
             try {
-                run_iter_group(gkeys[g], gmembers[g], ps, o, host_io, intr_io, poses_io, side_by_side(ps[gmembers[g][0]]->ctx), rc, reps);
+                run_iter_group(gkeys[g], gmembers[g], ps, o, host_io, intr_io, poses_io, side_by_side(ps[gmembers[g][0]]->ctx), rc, reps, retry);
             } catch (const std::bad_alloc&) { for (int i : gmembers[g]) rc[i] = CCAL_ERR_NO_MEMORY;
             } catch (...) { for (int i : gmembers[g]) rc[i] = CCAL_ERR_HIP; }
-            for (int i : gmembers[g]) if (reps && rc[i] != CCAL_OK && rc[i] != reps[i].status) { reps[i] = ccal_report{}; reps[i].status = rc[i]; }
+            for (int i : retry) { grouped[(size_t)i] = 0; if (std::find(late.begin(), late.end(), ps[i]->ctx) == late.end()) late.push_back(ps[i]->ctx); }
+            for (int i : gmembers[g]) if (grouped[(size_t)i] && reps && rc[i] != CCAL_OK && rc[i] != reps[i].status) { reps[i] = ccal_report{}; reps[i].status = rc[i]; }
         }
+        // contexts that hold members of a group AND problems of their own (or a member sent back): driven here, behind the groups -
+        // never by a helper thread while the group's thread may write the same context's error text
+        for (ccal_ctx* c : late) run_ctx(c);
     } else if (!ctxs.empty()) run_ctx(ctxs[0]);
     for (ccal_ctx_worker* wk : busy) wk->wait();
     for (int i = 0; i < n; ++i)

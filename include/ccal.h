@@ -265,8 +265,11 @@ int ccal_solve_dev(ccal_problem* p, const ccal_solver_opts* opts, ccal_report* r
  * a batch of eight costs the host what one solve costs.  Everything else (rigs, large problems) is driven per context by a
  * host thread of its own (create such problems on contexts of their own - ccal_ctx_create with stream NULL - to make them overlap;
  * those that share a context are solved one after the other).  A problem's launches are sized for its share of the GPU (the batch's
- * problems on that device): fewer, longer wavefronts than a lone ccal_solve takes - same verdicts and iteration counts as n
- * ccal_solve calls, results equal to them up to the order of summation (<= 1e-11 relative).  intr_io == NULL: device-resident like ccal_solve_dev (poses_io / extr_io ignored);
+ * problems on that device): fewer, longer wavefronts than a lone ccal_solve takes - results equal to n ccal_solve calls up to the
+ * order of summation (<= 1e-11 relative; the lane mapping, hence the order, depends on how many problems of the batch share the
+ * GPU: the same problem in another batch may differ in the last bits); verdict and iteration count can differ from a lone
+ * ccal_solve only where a stop threshold is met to within that rounding.  A problem that needs bit-reproducible results
+ * whatever runs beside it is solved with ccal_solve.  intr_io == NULL: device-resident like ccal_solve_dev (poses_io / extr_io ignored);
  * else intr_io[i] / poses_io[i] / extr_io[i] as in ccal_solve.  Every problem's verdict goes to reports[i].status; the return
  * value is CCAL_OK unless a call failed for another reason (then the first such code).  Sharded problems are refused. */
 int ccal_solve_batch(ccal_problem** problems, int n, const ccal_solver_opts* opts,

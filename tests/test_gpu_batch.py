@@ -114,6 +114,37 @@ def test_batch_reports_each_problems_own_verdict():
         p.close()
 
 
+def test_a_failing_member_of_a_lockstep_group_does_not_take_its_neighbours_down(monkeypatch):
+    """when one member's preparation fails (out of memory for its workspace, ...) the others of the lockstep group
+    still solve and every report carries its own problem's verdict; the failing member's context alone holds the reason.  The
+    failure is injected through the second library's test hook (the product has none)."""
+    import ctypes as C
+    lib = _ffi.load_legacy()
+    sps = [synth.make_problem(200, "eucm", seed=40 + i) for i in range(3)]
+    ctxs = [Context(0, lib=lib) for _ in sps]
+    probs = [Problem.from_synth(c, s) for c, s in zip(ctxs, sps)]
+    solo = [p.solve(s.intr0, s.poses0)[3] for p, s in zip(probs, sps)]
+    monkeypatch.setenv("CCAL_TEST_FAIL_BATCH_MEMBER", "1")
+    hs = (C.c_void_p * 3)(*[p.handle for p in probs])
+    reps = (_ffi.Report * 3)()
+    for p, s in zip(probs, sps):
+        p.upload_params(s.intr0, s.poses0, s.extr0)
+    opts = default_opts(0)
+    rc = lib.ccal_solve_batch(hs, 3, C.byref(opts), None, None, None, reps)
+    monkeypatch.delenv("CCAL_TEST_FAIL_BATCH_MEMBER")
+    assert rc == _ffi.ERR_NO_MEMORY                          # the call reports the first non-verdict failure ...
+    assert reps[1].status == _ffi.ERR_NO_MEMORY and "injected" in ctxs[1].last_error()
+    for k in (0, 2):                                         # ... and the neighbours have solved
+        assert reps[k].status == _ffi.OK and reps[k].iterations == solo[k].iterations
+        assert reps[k].final_cost == pytest.approx(solo[k].final_cost, rel=1e-11)
+        assert "injected" not in ctxs[k].last_error()
+    # and the batch works again afterwards, all three
+    reps2, _ = Problem.solve_batch(probs, opts, starts=[(s.intr0, s.poses0, s.extr0) for s in sps])
+    assert [r.status for r in reps2] == [0, 0, 0] and [r.iterations for r in reps2] == [r.iterations for r in solo]
+    for p in probs:
+        p.close()
+
+
 def test_batch_argument_checks():
     sp = synth.make_problem(10, "eucm")
     ctx = Context(0)

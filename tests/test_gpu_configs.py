@@ -119,6 +119,66 @@ def test_config2_models_at_headline_size_sampled(gpu_ctx, oracle, model, one_foc
     gp.close()
 
 
+@pytest.mark.parametrize("model,one_focal", [("eucm", False), ("eucm", True), ("kb4", False), ("opencv5", False), ("ucm", True)])
+def test_ragged_frames_at_headline_size(gpu_ctx, oracle, model, one_focal):
+    """SURVEY 8(d)'s ragged variant at the headline frame count: 10 000 frames of 24 .. 144 corners (src/data_loader.rs:15,61-62), rows
+    in random order.  The Gram launch bins the frames by corner count (its geometry differs from the full-frame case: its own parity
+    case): sampled frames of mode E, the reduced normal equations on all frames against the oracle, and the same bits from a second
+    build (the order of summation is fixed per problem)."""
+    sp = synth.make_problem(10000, model, xy_same_focal=one_focal, ragged=True, seed=0xC0FFEE + 77)
+    n = np.diff(sp.obs_offsets)
+    assert n.min() >= 24 and n.max() <= 144 and 70 < n.mean() < 100
+    gp = Problem.from_synth(gpu_ctx, sp)
+    D = gp.block_dim(0)
+    r, J = gp.eval(sp.intr0, sp.poses0)
+    assert np.isfinite(r).all() and np.isfinite(J).all()
+    J = J.reshape(-1, 2, D)
+    for f in (0, 7, 4999, 8191, 9999, int(n.argmin()), int(n.argmax())):
+        sub = sp.shard(f, 10000)
+        ro, Jo = oracle.OracleProblem.from_synth(sub).eval(sp.intr0, sub.poses0)
+        sl = slice(int(sp.obs_offsets[f]), int(sp.obs_offsets[f + 1]))
+        assert np.abs(r[sl] - ro).max() <= 1e-10
+        assert (np.abs(J[sl].ravel() - Jo) / np.maximum(1.0, np.abs(Jo))).max() <= 1e-11
+    for lam in (0.0, 1e-3):
+        S, b, cost = gp.build_normal(sp.intr0, sp.poses0, lam=lam)
+        So, bo, costo = oracle.OracleProblem.from_synth(sp).build_normal(sp.intr0, sp.poses0, lam=lam)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+        S2, b2, cost2 = gp.build_normal(sp.intr0, sp.poses0, lam=lam)
+        np.testing.assert_array_equal(S, S2); np.testing.assert_array_equal(b, b2); assert cost == cost2
+    # the solve on the ragged set: Gauss-Newton and LM recover the ground truth, twice the same bits
+    for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+        i1, p1, _, r1 = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+        i2, p2, _, r2 = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+        assert r1.status == r2.status == 0 and r1.iterations == r2.iterations
+        np.testing.assert_array_equal(i1, i2); np.testing.assert_array_equal(p1, p2)
+        assert np.abs(i1[0, :4] / sp.intr_gt[0, :4] - 1).max() < 2e-3
+    gp.close()
+
+
+@pytest.mark.parametrize("model", ["eucm", "kb4"])
+@pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
+def test_ragged_solve_against_the_oracle(gpu_ctx, oracle, model, method):
+    """2 500 ragged frames (the three-launch form with the binned Gram launch): same iteration count, accept / reject sequence and
+    optimum as the oracle."""
+    sp = synth.make_problem(2500, model, ragged=True, seed=0xAB5, outlier_frac=0.01)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    oracle.set_solve_threads(8)
+    try:
+        intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+    finally:
+        oracle.set_solve_threads(1)
+    intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+    assert rep.status == rep_o.status == 0
+    assert (rep.iterations, rep.lm_accepted, rep.lm_rejected) == (rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected)
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+    P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+    assert (np.abs(intr[0, :P] - intr_o[0, :P]) / np.maximum(np.abs(intr_o[0, :P]), 1e-3)).max() <= 1e-6
+    np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+    gp.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # configs[0] stand-in
 # ---------------------------------------------------------------------------------------------------------------

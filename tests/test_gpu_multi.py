@@ -319,6 +319,11 @@ def _child_create_errors(q):
     mc = MultiContext([0], transport=_ffi.TRANSPORT_RCCL)
     out["one_rank"] = (mc.transport, mc.rccl_ranks)
     mc.close()
+    try:                                                     # ONE device and the in-process transport by name: never "none" silently
+        MultiContext([0], transport=_ffi.TRANSPORT_INPROC)
+        out["inproc_one"] = "created"
+    except CcalError as e:
+        out["inproc_one"] = (e.code, str(e))
     mc = MultiContext([0, 0], transport=_ffi.TRANSPORT_INPROC)
     sp = synth.make_problem(20, "eucm", seed=8)
     mpb = MultiProblem.from_synth(mc, sp)
@@ -340,6 +345,7 @@ def test_named_transports_and_create_errors():
     assert res["rccl_dup"][0] == _ffi.ERR_UNSUPPORTED and "RCCL" in res["rccl_dup"][1]
     assert res["bad_dev"][0] == _ffi.ERR_HIP and "97" in res["bad_dev"][1]
     assert res["one_rank"] == (_ffi.TRANSPORT_RCCL, 1)
+    assert res["inproc_one"][0] == _ffi.ERR_UNSUPPORTED and "two shards" in res["inproc_one"][1]
     assert res["inproc"] == (_ffi.TRANSPORT_INPROC, 0, _ffi.OK)
     assert res["hook_inert"] == _ffi.OK
 

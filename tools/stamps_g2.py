@@ -21,6 +21,10 @@ lib.ccal_debug_fcbuf(p.handle, buf.ctypes.data_as(C.c_void_p), n)
 st = buf.reshape(-1, 32)
 ok = st[:, 0] > 0
 st = st[ok]
+if len(st) == 0:
+    # no wavefront left its stamps: the library is not a -DCCAL_STAMPS build, or this size / model does not take k_gram2
+    print(f"{model} {F} frames: no stamps (CCAL_LIB must point at a -DCCAL_STAMPS build; CCAL_GRAM2=1 for sizes / models that take k_gram1v by default)")
+    sys.exit(0)
 t0 = st[:, 0].min()
 nw = len(st)
 names = ["state+ids", "prologue", "corner loop", "reduction", "scatter", "fused tail"]
@@ -29,8 +33,11 @@ half = nw // 2
 for label, sel in (("first half of the dispatch (older on their SIMD)", slice(0, half)), ("second half (younger)", slice(half, nw))):
     s = st[sel]
     d = np.diff(s[:, :6], axis=1) / 100.0
+    if len(s) == 0:
+        continue
+    life = np.maximum(s[:, 5] - s[:, 0], 1)
     print(f"  {label}: start {np.median(s[:, 0] - t0) / 100:.2f}  " + "  ".join(f"{nm} {np.median(d[:, i]):.2f}" for i, nm in enumerate(names[1:])) +
-          f"  total {np.median(s[:, 5] - s[:, 0]) / 100:.2f}  end {np.median(s[:, 5] - t0) / 100:.2f} us")
+          f"  total {np.median(s[:, 5] - s[:, 0]) / 100:.2f}  end {np.median(s[:, 5] - t0) / 100:.2f} us  (corner loop = {100 * np.median((s[:, 2] - s[:, 1]) / life):.0f} % of the wavefront's life)")
     if s[:, 24].max() > 0:      # stations of the prologue: state + intrinsics arrived | pose arrived | exponential map done | first corner rows arrived | constants in LDS
         pro = np.concatenate([s[:, 0:1], s[:, 24:28], s[:, 1:2]], axis=1)
         dp = np.diff(pro, axis=1) / 100.0
@@ -44,4 +51,4 @@ for label, sel in (("first half of the dispatch (older on their SIMD)", slice(0,
     if s[:, 12].max() > 0:      # -DCCAL_STAMPS=2: shader cycles per pass in the sections of the corner loop
         per = s[:, 8:12] / np.maximum(s[:, 12:13], 1)
         print("      cycles per pass: " + "  ".join(f"{nm} {np.median(per[:, i]):.0f}" for i, nm in enumerate(["back", "next rows", "rows + DPP", "Gram + chain"])) +
-              f"  sum {np.median(per.sum(axis=1)):.0f}  ({np.median(s[:, 12]):.0f} passes; loop {np.median(s[:, 2] - s[:, 1]) / 100:.2f} us -> {np.median(per.sum(axis=1) * s[:, 12] / np.maximum(s[:, 2] - s[:, 1], 1)) / 10:.0f} MHz)")
+              f"  sum {np.median(per.sum(axis=1)):.0f}  ({np.median(s[:, 12]):.0f} passes; loop {np.median(s[:, 2] - s[:, 1]) / 100:.2f} us -> {np.median(per.sum(axis=1) * s[:, 12] / np.maximum(s[:, 2] - s[:, 1], 1)) / 10:.2f} GHz)")
