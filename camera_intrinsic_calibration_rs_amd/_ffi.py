@@ -108,6 +108,8 @@ SYMBOLS = [
     ("ccal_solve_batch", C.c_int, [C.POINTER(_vp), C.c_int, C.POINTER(SolverOpts), C.POINTER(_dp), C.POINTER(_dp), C.POINTER(_dp),
                                    C.POINTER(Report)]),
     ("ccal_init_poses", C.c_int, [_vp, _dp, C.c_int, _dp, _ip]),
+    ("ccal_pin_buffer", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("ccal_unpin_buffer", C.c_int, [C.c_void_p, C.c_void_p]),
     ("ccal_init_camera_extrinsic", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(Report)]),
     ("ccal_init_camera_extrinsic_opts", C.c_int, [_dp, _dp, C.c_int, _dp, C.c_int, C.POINTER(SolverOpts), C.POINTER(Report)]),
     ("ccal_se3_factor", C.c_int, [_dp, _dp, _dp, _dp, _dp]),

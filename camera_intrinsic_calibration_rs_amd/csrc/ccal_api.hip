@@ -99,6 +99,13 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
 }
 static void ctx_free(ccal_ctx* ctx) {
     ctx_worker_destroy(ctx);
+    if (!ctx->pinned.empty()) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+        for (auto& pr : ctx->pinned) (void)hipHostUnregister(pr.first);
+        (void)hipGetLastError();
+        ctx->pinned.clear();
+    }
     if (ctx->d_batch_tab || ctx->h_batch_tab) {
         (void)hipSetDevice(ctx->device);
         if (ctx->d_batch_tab) (void)hipFree(ctx->d_batch_tab);
@@ -118,6 +125,34 @@ int ccal_sync(ccal_ctx* ctx) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CCAL_OK;
+}
+
+int ccal_pin_buffer(ccal_ctx* ctx, void* host_ptr, size_t bytes) {
+    if (!ctx || !host_ptr || !bytes) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (auto& pr : ctx->pinned) if (pr.first == host_ptr) return fail(ctx, CCAL_ERR_INVALID_ARG, "ccal_pin_buffer: this address is pinned already");
+    if (pinned_device_ptr(host_ptr, bytes)) return CCAL_OK;          // pinned by the caller itself (hipHostMalloc / hipHostRegister): nothing to do
+    ctx->pinned.reserve(ctx->pinned.size() + 1);
+    const hipError_t e = hipHostRegister(host_ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(ctx, CCAL_ERR_HIP, (std::string("ccal_pin_buffer: hipHostRegister: ") + hipGetErrorString(e)).c_str()); }
+    ctx->pinned.emplace_back(host_ptr, bytes);
+    return CCAL_OK;
+    CCAL_API_CATCH(ctx)
+}
+int ccal_unpin_buffer(ccal_ctx* ctx, void* host_ptr) {
+    if (!ctx || !host_ptr) return CCAL_ERR_INVALID_ARG;
+    CCAL_API_TRY
+    for (size_t i = 0; i < ctx->pinned.size(); ++i) {
+        if (ctx->pinned[i].first != host_ptr) continue;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));             // nothing may still read or write the range
+        ctx->pinned.erase(ctx->pinned.begin() + (ptrdiff_t)i);
+        HIP_TRY(ctx, hipHostUnregister(host_ptr));
+        return CCAL_OK;
+    }
+    return CCAL_OK;                                                   // not registered through this context (the caller's own pinning): nothing to undo
+    CCAL_API_CATCH(ctx)
 }
 
 int ccal_set_defaults(ccal_solver_opts* o) {
@@ -197,6 +232,24 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
     size_t total = 5 * up256((nc + 1) * sizeof(float)) + 2 * up256((p->h_obs_off.size() + 1) * sizeof(int64_t)) +
                    2 * up256((p->h_obs_cam.size() + 1) * sizeof(int32_t)) + 2 * (up256(ni * 8) + up256(np6 * 8) + up256(ne * 8));
     for (int c = 0; c < d->n_cams; ++c) total += up256((p->cams[c].obs.size() + 1) * sizeof(int32_t));
+    // single camera, ragged frames (real sessions: 24 .. 144 corners per frame, src/data_loader.rs:15): the Gram launch works on bins of
+    // frames sorted by corner count, each bin with the lanes per frame its frames need (ccal_kernels_gram2.hip); the sorted table -
+    // { frame, first corner, corners, slot } per position - is made once, here
+    std::vector<int32_t> bin_tab;
+    if (d->n_cams == 1 && d->n_obs > 0) {
+        std::vector<int32_t> order;
+        const int m0 = p->cams[0].model;
+        p->gram_bins = gram2_bin_plan(p->h_obs_off.data(), d->n_obs, m0 == kUCM || m0 == kEUCM, &order);
+        if (p->gram_bins.n_bins > 0) {
+            bin_tab.assign((size_t)d->n_obs * 4 + 4, 0);               // (+ one spare entry: a 16-byte load never ends outside the slice)
+            for (int i = 0; i < d->n_obs; ++i) {
+                const int o = order[(size_t)i];
+                bin_tab[4 * (size_t)i] = o; bin_tab[4 * (size_t)i + 1] = (int32_t)p->h_obs_off[o];
+                bin_tab[4 * (size_t)i + 2] = (int32_t)(p->h_obs_off[o + 1] - p->h_obs_off[o]); bin_tab[4 * (size_t)i + 3] = p->h_obs_slot[o];
+            }
+            total += up256((bin_tab.size() + 1) * sizeof(int32_t));
+        }
+    }
     HIP_TRY(ctx, hipMalloc((void**)&p->d_block, total));
     HIP_TRY(ctx, hipMemsetAsync(p->d_block, 0, total, ctx->stream));
     {
@@ -214,6 +267,7 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
         HIP_TRY(ctx, put(&p->d_obs_cam, (const int32_t*)p->h_obs_cam.data(), p->h_obs_cam.size()));
         HIP_TRY(ctx, put(&p->d_obs_slot, (const int32_t*)p->h_obs_slot.data(), p->h_obs_slot.size()));
         for (int c = 0; c < d->n_cams; ++c) HIP_TRY(ctx, put(&p->cams[c].d_obs, (const int32_t*)p->cams[c].obs.data(), p->cams[c].obs.size()));
+        if (!bin_tab.empty()) HIP_TRY(ctx, put(&p->d_bin_tab, (const int32_t*)bin_tab.data(), bin_tab.size()));
         double** bufs[6] = { &p->d_intr, &p->d_poses, &p->d_extr, &p->d_intr_c, &p->d_poses_c, &p->d_extr_c };
         const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
         for (int i = 0; i < 6; ++i) { *bufs[i] = reinterpret_cast<double*>(q); q += up256(sz[i] * 8); }

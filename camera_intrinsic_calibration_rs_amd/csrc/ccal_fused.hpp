@@ -326,6 +326,9 @@ struct FusedArgs {
     // the slot's first observation frame (g_owner) writes the candidate pose and the model decrease
     int32_t gen_backsub, g_K, g_PF;
     const double* g_pf; const double* g_dc; double* g_mc_slot; const int8_t* g_owner;
+    // ragged single-camera problems (k_gram2b): the sorted table - int4 { frame, first corner, corners, slot } per position - and the bins
+    const int32_t* bin_tab;
+    int32_t n_bins, bin_lpf[kGramMaxBins], bin_first[kGramMaxBins], bin_count[kGramMaxBins], bin_wg0[kGramMaxBins + 1];
 };
 
 // per-frame record of the single-camera Gram kernels (doubles), rotation columns in the phi basis:

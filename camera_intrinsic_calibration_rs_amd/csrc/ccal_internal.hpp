@@ -67,7 +67,24 @@ struct ccal_ctx {
     // ccal_solve_batch, session sizes: the argument blocks of a batch's problems, one launch per step for all of them
     // (k_gram1v_batch reads the table on the device; h_: its pinned staging) - grown on demand, freed with the context
     char* d_batch_tab = nullptr; char* h_batch_tab = nullptr; size_t batch_tab_bytes = 0;
+    // ccal_pin_buffer: the caller's ranges this context registered (unregistered by ccal_unpin_buffer or with the context)
+    std::vector<std::pair<void*, size_t>> pinned;
 };
+namespace ccal {
+// The device-side address of caller memory that is pinned (registered with ccal_pin_buffer / hipHostRegister, or allocated with
+// hipHostMalloc) for all of [host, host + bytes); nullptr: ordinary pageable memory - the library stages it.
+inline void* pinned_device_ptr(const void* host, size_t bytes) {
+    if (!host || !bytes) return nullptr;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    hipPointerAttribute_t at2;                     // the range's last byte lies in the same registration
+    if (hipPointerGetAttributes(&at2, static_cast<const char*>(host) + bytes - 1) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at2.type != hipMemoryTypeHost || !at2.devicePointer ||
+        static_cast<char*>(at2.devicePointer) - static_cast<char*>(at.devicePointer) != (ptrdiff_t)(bytes - 1)) return nullptr;
+    return at.devicePointer;
+}
+}  // namespace ccal
 namespace ccal {
 void ctx_worker_destroy(ccal_ctx* ctx);
 // the context's conventions as the kernels take them
@@ -81,6 +98,21 @@ inline ModelRt model_rt(const ccal_ctx* ctx) {
 inline bool ocv5_identity(const ccal_ctx* ctx) { return model_rt(ctx).ocv5_perm == kOcv5IdentityPerm; }
 }  // namespace ccal
 
+namespace ccal {
+// Ragged single-camera problems: the bins of a Gram launch (gram2_bin_plan, ccal_kernels_gram2.hip).  Bin b: bin_count[b] frames - positions
+// bin_first[b] .. of the problem's table of frames sorted by corner count - with bin_lpf[b] lanes per frame, worked on by the
+// workgroups bin_wg0[b] .. bin_wg0[b + 1] - 1 of ONE launch.
+constexpr int kGramMaxBins = 5;
+struct GramBins {
+    int32_t n_bins = 0;               // 0: no bins (every frame the same lanes per frame, frames in table order)
+    int32_t lpf[kGramMaxBins] = {}, first[kGramMaxBins] = {}, count[kGramMaxBins] = {}, wg0[kGramMaxBins + 1] = {};
+};
+// The plan for corner counts n[0 .. n_obs) (host): which frames go together and with how many lanes each; order = the sorted table
+// (frame indices, bins in launch order).  n_bins == 0: binning does not pay (uniform frames, too few of them).
+GramBins gram2_bin_plan(const int64_t* obs_off, int n_obs, bool two_per_simd, std::vector<int32_t>* order);
+
+}  // namespace ccal
+
 struct ccal_problem {
     ccal_ctx* ctx = nullptr;
     int n_cams = 0, n_slots = 0, n_obs = 0, K = 0;
@@ -91,6 +123,10 @@ struct ccal_problem {
     std::vector<int64_t> h_obs_off, h_joff;
     std::vector<int32_t> h_obs_cam, h_obs_slot;
     bool slot_ident = false;       // h_obs_slot[o] == o for every observation frame
+    // single camera, ragged frames: the bins of the Gram launch and the sorted table int4 { frame, first corner, corners, slot } per
+    // position (a slice of d_block); gram_bins.n_bins == 0: none
+    ccal::GramBins gram_bins;
+    int32_t* d_bin_tab = nullptr;
     // device-resident inputs
     char* d_scratch = nullptr; size_t scratch_bytes = 0;      // validation()'s temporaries (grown on demand, kept between calls)
     char* d_block = nullptr;       // ONE device allocation: the corner arrays, the frame tables and the six parameter arrays are slices of it

@@ -168,10 +168,10 @@ template <int MODEL> __host__ __device__ constexpr int g2_slices() { return (MOD
 #define G2_EP(i) do { g2_ep[i] = wall_clock64(); } while (0)
 #define G2_PRO(i, dep) do { asm volatile("" :: "v"(dep)); g2_pro[i] = wall_clock64(); } while (0)     /* a station of the prologue: once `dep` has arrived */
 #define G2_EP_PTR , g2_ep + 3
-#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + i_] = (double)g2_stamps[i_]; \
-                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 8 + i_] = (double)g2_cyc[i_]; \
-                                                       for (int i_ = 0; i_ < 8; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 16 + i_] = (double)g2_ep[i_]; \
-                                                       for (int i_ = 0; i_ < 4; ++i_) a.fcbuf[32 * (blockIdx.x * CCAL_GRAMV_WPB + wave) + 24 + i_] = (double)g2_pro[i_]; } } while (0)
+#define G2_STAMPS_FLUSH do { if (!GEN && lane == 0) { for (int i_ = 0; i_ < 6; ++i_) a.fcbuf[32 * wrow + i_] = (double)g2_stamps[i_]; \
+                                                       for (int i_ = 0; i_ < 5; ++i_) a.fcbuf[32 * wrow + 8 + i_] = (double)g2_cyc[i_]; \
+                                                       for (int i_ = 0; i_ < 8; ++i_) a.fcbuf[32 * wrow + 16 + i_] = (double)g2_ep[i_]; \
+                                                       for (int i_ = 0; i_ < 4; ++i_) a.fcbuf[32 * wrow + 24 + i_] = (double)g2_pro[i_]; } } while (0)
 // -DCCAL_STAMPS=2: shader cycles (s_memtime) spent in the sections of the corner loop, summed over the passes:
 // 2 projection + rows + DPP, 3 Gram products, 4 passes
 #if CCAL_STAMPS >= 2
@@ -217,9 +217,17 @@ __device__ __forceinline__ double g2_from_partner(double v) {
 
 // LPF = lanes per frame, EVEN: LPF corners of a frame per pass, every lane evaluates one.  The frame's lanes are contiguous (grp = lane / LPF), so
 // the prologue and the fused tail are those of k_gram1w.
-template <int MODEL, bool OF, int LPF, bool GEN>
-__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2(const FusedArgs a) {
+// The body of a workgroup.  BIN = false: workgroup `wg` of a launch in which every frame has LPF lanes; the frames are a.n_obs
+// observation frames in their own order (GEN: a.list).  BIN = true (single camera, ragged frames): the launch is cut into BINS of
+// frames sorted by corner count, each with the lanes per frame ITS frames need (k_gram2b below) - this workgroup is number `wg` of a bin
+// whose frames are positions frame0 .. frame0 + nfr - 1 of the sorted table a.bin_tab (frame | first corner | corners | slot:
+// ONE 16-byte load instead of the offsets' and the slot table's).  The per-frame buffers of the loop (records, model decrease, cost)
+// are then indexed by POSITION in that table - they never leave the single-camera kernels -, poses and elimination records by slot
+// as ever; a wavefront's row of partial sums is its number in the launch, so the rows are added in the same order every time.
+template <int MODEL, bool OF, int LPF, bool GEN, bool BIN>
+__device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, const int wg, const int frame0, const int nfr) {
     static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 pairs of a u lane and a v lane");
+    static_assert(!(GEN && BIN), "bins: the single-camera loop");
     constexpr int NS = g2_slices<MODEL>();
     using Map = RowMap<MODEL, OF, GEN, NS>;
     static_assert(Map().ok, "accumulator numbering: a slice splits a mirrored pair");
@@ -234,7 +242,6 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
     constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
     constexpr int WSL = (G * FCS + RED + NEF + 1) & ~1;        // per wave: G frames' constants | reduction buffer / records | item table
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const DevState* st = a.st;
     const bool fuse = !GEN && a.fuse_elim != 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -245,9 +252,13 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     const int gl = lane_ok ? lane - grp * LPF : (lane & 1);
     G2_STAMPS_DECL;
     G2_STAMP(0);
-    const int f = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G + grp;
-    const bool active = lane_ok && f < a.n_obs;
-    const int fa_ = GEN ? a.list[active ? f : 0] : (active ? f : 0);
+    const int wrow = blockIdx.x * CCAL_GRAMV_WPB + wave;          // the wavefront's number in the launch: its row of partial sums
+    const int fpos = (wg * CCAL_GRAMV_WPB + wave) * G + grp;       // the frame's position among the nfr frames this launch / bin works on
+    const bool active = lane_ok && fpos < nfr;
+    const int f = frame0 + (active ? fpos : 0);                    // index of the loop's per-frame buffers (BIN: the position in the sorted table)
+    int4 btab = make_int4(0, 0, 0, 0);
+    if constexpr (BIN) btab = reinterpret_cast<const int4*>(a.bin_tab)[f];
+    const int fa_ = BIN ? btab.x : (GEN ? a.list[active ? fpos : 0] : (active ? fpos : 0));
     const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FCS;
@@ -273,8 +284,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     // FusedArgs::gen_backsub - is the one the state does NOT pick)
     double th_b[2][th_len<MODEL>()], pose_b[2][6], ex_b[2][GEN ? 6 : 1];
     int slot_e;
-    if (!GEN && a.slot_ident) slot_e = fa_; else slot_e = a.obs_slot[fa_];
-    const int64_t start_e = a.obs_off[fa_], end_e = a.obs_off[fa_ + 1];
+    int64_t start_e, end_e;
+    if constexpr (BIN) { slot_e = btab.w; start_e = btab.y; end_e = (int64_t)btab.y + btab.z; }
+    else {
+        if (!GEN && a.slot_ident) slot_e = fa_; else slot_e = a.obs_slot[fa_];
+        start_e = a.obs_off[fa_]; end_e = a.obs_off[fa_ + 1];
+    }
     {
         const int th_off = (GEN && a.obs_cam) ? camf * CCAL_PMAX : 0;
         load_theta<MODEL, OF>(a.intr[0] + th_off, a.rt, th_b[0]);
@@ -298,12 +313,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
             int slot_r = 0;
             if (active) {
                 const double* rec = a.praw[cur] + (int64_t)f * a.PRAW;
-                slot_r = a.obs_slot[f];
+                slot_r = BIN ? slot_e : a.obs_slot[f];
                 for (int e = gl; e < REC_; e += LPF) R[e] = rec[e];
                 if (gl == 0) mcv = a.mc_f[f];
             }
             wsync();
-            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
             return;
         }
     }
@@ -605,12 +620,12 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     }
 
     G2_STAMP(2);
-    const int fbase = (blockIdx.x * CCAL_GRAMV_WPB + wave) * G;
+    const int pbase = (wg * CCAL_GRAMV_WPB + wave) * G;              // first of the wavefront's frames among the launch's / the bin's
     // fused elimination: what its tail needs from memory is requested now, behind the reductions
     int slot_t = 0;
     double mc_t = 0.0;
     if constexpr (!GEN) {
-        if (fuse && active) { slot_t = a.slot_ident ? f : a.obs_slot[f]; if (gl == 0) mc_t = a.mc_f[f]; }
+        if (fuse && active) { slot_t = BIN ? slot_e : (a.slot_ident ? f : a.obs_slot[f]); if (gl == 0) mc_t = a.mc_f[f]; }
     }
     // the frame's LPF partial row Grams -> one Gram of the block, through LDS, slice by slice: an item = one entry of the
     // full triangle = the sum over the frame's u lanes and / or v lanes of one row-local entry
@@ -678,8 +693,8 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         double* const praw_es = a.praw[es];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int ff = fbase + g;
-            if (ff >= a.n_obs) break;                                  // wave-uniform
+            if (pbase + g >= nfr) break;                               // wave-uniform
+            const int ff = frame0 + pbase + g;
             double* rec = praw_es + (GEN ? a.rec_off[a.list[ff]] : (int64_t)ff * a.PRAW);
             for (int e = lane; e < RLEN; e += 64) rec[e] = red[g * RSTR + e];
             if (!GEN && lane == 0) a.cost_f[ff] = red[g * RSTR + 21 + 6 * K1 + K * K1 + K];      // r x r
@@ -689,11 +704,37 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         if (fuse) {
             if (keep_rec) wsync();                                     // the tail reuses the records' rows
             G2_STAMP(4);
-            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)(blockIdx.x * CCAL_GRAMV_WPB + wave) * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
+            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
         }
     }
     G2_STAMP(5);
     G2_STAMPS_FLUSH;
+}
+
+template <int MODEL, bool OF, int LPF, bool GEN>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    gram2_body<MODEL, OF, LPF, GEN, false>(a, smem, blockIdx.x, 0, a.n_obs);
+}
+// Ragged frames (real sessions hold 24 .. 144 corners per frame, /root/reference/src/data_loader.rs:15): ONE launch whose workgroups
+// belong to bins of frames with different lanes per frame (gram2_bin_plan), so that a wavefront's trip count is what ITS frames need
+// and not the largest frame's of a group picked in table order.  Bin b = workgroups bin_wg0[b] .. bin_wg0[b + 1] - 1.
+template <int MODEL, bool OF>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2b(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // (constant indices only: a dynamically indexed kernel argument would be copied to scratch)
+    int wg0 = 0, frame0 = a.bin_first[0], nfr = a.bin_count[0], lpf = a.bin_lpf[0];
+#pragma unroll
+    for (int i = 1; i < kGramMaxBins; ++i)
+        if (i < a.n_bins && (int)blockIdx.x >= a.bin_wg0[i]) { wg0 = a.bin_wg0[i]; frame0 = a.bin_first[i]; nfr = a.bin_count[i]; lpf = a.bin_lpf[i]; }
+    const int wg = blockIdx.x - wg0;
+    switch (lpf) {
+        case 6: gram2_body<MODEL, OF, 6, false, true>(a, smem, wg, frame0, nfr); break;
+        case 8: gram2_body<MODEL, OF, 8, false, true>(a, smem, wg, frame0, nfr); break;
+        case 12: gram2_body<MODEL, OF, 12, false, true>(a, smem, wg, frame0, nfr); break;
+        case 16: gram2_body<MODEL, OF, 16, false, true>(a, smem, wg, frame0, nfr); break;
+        default: gram2_body<MODEL, OF, 32, false, true>(a, smem, wg, frame0, nfr); break;
+    }
 }
 
 #ifdef CCAL_G2_PROBE      // register-allocation probes (developer): a few instantiations, no launchers
@@ -701,6 +742,8 @@ template __global__ void k_gram2<kEUCM, false, 12, false>(const FusedArgs);
 template __global__ void k_gram2<kKB4, false, 12, false>(const FusedArgs);
 template __global__ void k_gram2<kOCV5, false, 12, false>(const FusedArgs);
 template __global__ void k_gram2<kOCV5, true, 12, true>(const FusedArgs);
+template __global__ void k_gram2b<kEUCM, false>(const FusedArgs);
+template __global__ void k_gram2b<kKB4, false>(const FusedArgs);
 }  // namespace ccal
 #else
 template <int MODEL, bool OF, int LPF, bool GEN>
@@ -752,8 +795,116 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
     return best;
 }
 
+// ---- ragged frames: the bins of one launch ------------------------------------------------------------------------------------
+// What a wavefront costs the SIMD it runs on, in corner passes: its trip count + what its prologue, reductions and fused
+// elimination are worth (the c0 of gram2_lanes_per_frame).
+static inline double g2_wave_cost(int lpf, int passes) { return (lpf == 6 ? 7.0 : 6.0) + (double)passes; }
+// The time of a launch whose wavefronts cost c[0 .. W) in launch order on `simds` SIMDs: wavefront i, i + simds, i + 2 simds ... share
+// a SIMD (the dispatcher fills the chip in launch order).  Two resident wavefronts interleave at 0.65 of their summed cost
+// (gram2_lanes_per_frame's occupancy fit); one per SIMD (KB4 / OPENCV5: 296+ registers) run one after the other.
+static double g2_launch_cost(const std::vector<double>& c, int simds, bool two_per_simd) {
+    double worst = 0.0;
+    const int W = (int)c.size();
+    for (int i = 0; i < simds && i < W; ++i) {
+        double sum = 0.0, longest = 0.0;
+        for (int k = i; k < W; k += simds) { sum += c[(size_t)k]; longest = std::max(longest, c[(size_t)k]); }
+        worst = std::max(worst, two_per_simd ? std::max(longest, 0.65 * sum) : sum);
+    }
+    return worst;
+}
+GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::vector<int32_t>* order) {
+    GramBins none;
+#ifdef CCAL_G2_NO_BINS        // A/B builds (tools/build_tu_variants.sh ccal_kernels_gram2 "nobins:-DCCAL_G2_NO_BINS"): the launch without bins
+    return none;
+#endif
+    if (!off || n_obs < 2000 || !order) return none;                 // (below: k_gram1v's single-launch groups, one wavefront per SIMD)
+    static const int lpfs[kGramMaxBins] = { 32, 16, 12, 8, 6 };       // launch order: the bins of the large frames first
+    const int simds = 1024;
+    int64_t nmin = INT64_MAX, nmax = 0, total = 0;
+    for (int o = 0; o < n_obs; ++o) { const int64_t n = off[o + 1] - off[o]; nmin = std::min(nmin, n); nmax = std::max(nmax, n); total += n; }
+    if (nmin == nmax || nmax > 32 * 64) return none;                  // uniform frames: nothing to sort
+    // frames by corner count, largest first (stable: ties in table order) - for every trip-count limit T the bins are contiguous ranges
+    std::vector<int32_t> ord((size_t)n_obs);
+    for (int o = 0; o < n_obs; ++o) ord[(size_t)o] = o;
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+    auto cnt = [&](int pos) { return (int)(off[ord[(size_t)pos] + 1] - off[ord[(size_t)pos]]); };
+    // the launch as it is without bins: one mapping for all frames (gram2_lanes_per_frame), frames in table order
+    double cost_plain;
+    {
+        const int avg = (int)(total / std::max(n_obs, 1));
+        const int lpf = gram2_lanes_per_frame(n_obs, avg, two_per_simd, false, 0, (int64_t)1 << 40, 1), g = 64 / lpf;
+        std::vector<double> c;
+        for (int o = 0; o < n_obs; o += g) {
+            int64_t mx = 0;
+            for (int q = o; q < std::min(n_obs, o + g); ++q) mx = std::max(mx, off[q + 1] - off[q]);
+            c.push_back(g2_wave_cost(lpf, (int)((mx + lpf - 1) / lpf)));
+        }
+        cost_plain = g2_launch_cost(c, simds, two_per_simd);
+    }
+    GramBins best;
+    double best_cost = 1e300;
+    std::vector<double> c;
+    for (int T = 2; T <= 64; ++T) {
+        if ((nmax + 31) / 32 > T) continue;                          // the widest mapping cannot cover the largest frame in T passes
+        GramBins gb;
+        c.clear();
+        int pos = 0, wgs = 0;
+        for (int b = 0; b < kGramMaxBins && pos < n_obs; ++b) {
+            const int lpf = lpfs[b], g = 64 / lpf;
+            // this bin: the frames that need more than T passes with the next narrower mapping (the narrowest takes the rest)
+            int end = pos;
+            if (b == kGramMaxBins - 1) end = n_obs;
+            else while (end < n_obs && cnt(end) > T * lpfs[b + 1]) ++end;
+            if (end == pos) continue;
+            const int k = gb.n_bins++;
+            gb.lpf[k] = lpf; gb.first[k] = pos; gb.count[k] = end - pos; gb.wg0[k] = wgs;
+            const int waves = (end - pos + g - 1) / g;
+            for (int w = 0; w < waves; ++w) c.push_back(g2_wave_cost(lpf, (cnt(pos + w * g) + lpf - 1) / lpf));
+            if (waves % CCAL_GRAMV_WPB) c.push_back(0.0);            // (a workgroup belongs to one bin: its idle second wavefront)
+            wgs += (waves + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB;
+            pos = end;
+        }
+        gb.wg0[gb.n_bins] = wgs;
+        const double cost = g2_launch_cost(c, simds, two_per_simd);
+        if (cost < best_cost) { best_cost = cost; best = gb; }
+    }
+    if (best.n_bins == 0 || best_cost > 0.93 * cost_plain) return none;       // (the sorted table costs the prologue a dependent load: it has to pay)
+    *order = std::move(ord);
+    return best;
+}
+
+// the binned launch: a.n_bins / a.bin_* / a.bin_tab filled in by the caller (make_fused_args)
+template <int MODEL, bool OF>
+static hipError_t launch_gram2_binned(FusedArgs& a, hipStream_t s) {
+    constexpr int NS = g2_slices<MODEL>();
+    using Map = RowMap<MODEL, OF, false, NS>;
+    constexpr int K = block_dim(MODEL, OF, false) - 6, K1 = K + 1;
+    constexpr int LS = Map::CH | 1;
+    constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+    size_t lds = 0;
+    for (int b = 0; b < a.n_bins; ++b) {
+        const int G = 64 / a.bin_lpf[b];
+        const int RED = (G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
+        const int WSL = (G * (FC_N0P + 12) + RED + Map::NEF + 1) & ~1;
+        lds = std::max(lds, sizeof(double) * WSL * CCAL_GRAMV_WPB);
+    }
+    void (*kern)(const FusedArgs) = k_gram2b<MODEL, OF>;
+    static DynLdsGuard lds_guard;
+    if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
+    const int wgs = a.bin_wg0[a.n_bins];
+    a.n_part = wgs * CCAL_GRAMV_WPB;
+    a.fuse_elim = 1; a.elim_fused = 1;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
+    return hipGetLastError();
+}
+
 template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
+    if constexpr (!GEN) {
+        // ragged frames: the problem came with a plan (ccal_problem_create); the fused elimination's rows must fit, and a forced
+        // mapping (developer switch of the second library) means the plain launch
+        if (a.n_bins > 0 && a.fuse_elim && !a.lpf_force && a.bin_wg0[a.n_bins] * CCAL_GRAMV_WPB <= a.part_cap) return launch_gram2_binned<MODEL, OF>(a, s);
+    }
     const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL) >= 2, GEN, a.lpf_force, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap, a.share);
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;
     const bool fuse = !GEN && a.fuse_elim != 0 && waves <= a.part_cap;

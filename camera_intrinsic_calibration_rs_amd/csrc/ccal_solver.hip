@@ -416,6 +416,11 @@ static FusedArgs make_fused_args(const ccal_problem* p, double min_diag, double 
     fa.dc = w->dc; fa.st = f->d_state; fa.partial = f->partial; fa.red = f->red;
     fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
     fa.part_cap = f->n_pw;
+    // ragged frames: the bins ccal_problem_create planned for the Gram launch (n_bins == 0: none)
+    const GramBins& gb = p->gram_bins;
+    fa.n_bins = (gb.n_bins > 0 && p->d_bin_tab) ? gb.n_bins : 0; fa.bin_tab = p->d_bin_tab;
+    for (int b = 0; b < kGramMaxBins; ++b) { fa.bin_lpf[b] = gb.lpf[b]; fa.bin_first[b] = gb.first[b]; fa.bin_count[b] = gb.count[b]; fa.bin_wg0[b] = gb.wg0[b]; }
+    fa.bin_wg0[kGramMaxBins] = gb.wg0[kGramMaxBins];
     return fa;
 }
 // Second library only: the separate elimination launch (k_schur1m, four frames per wavefront) fits the partial-sum buffer; sets fa.n_pw.
@@ -608,6 +613,7 @@ struct FusedJob : SolveJob {
     double* h_poses = nullptr;
     size_t np6 = 0;
     bool zero_copy = false;           // session-sized ccal_solve: poses read from / result written to pinned host memory by the kernels
+    void* pinned_dev = nullptr;       // large ccal_solve whose caller pinned poses_io (ccal_pin_buffer): its device-side address - no staging copy either way
     using SolveJob::SolveJob;
     HostStatus* status() override { return f->h_status; }
     const DevState* dev_state() override { return iter_rows ? iter_state(seq + 1) : f->d_state; }     // (read once the stream has drained)
@@ -646,7 +652,12 @@ struct FusedJob : SolveJob {
             ua.np6 = (int64_t)np6; ua.poses_on_device = host_io ? 0 : 1;
             ua.intr0 = p->d_intr; ua.intr1 = p->d_intr_c; ua.poses0 = p->d_poses; ua.poses1 = p->d_poses_c;
             ua.st = iter_rows ? iter_state(1) : f->d_state; ua.cols = w->cols;
-            if (host_io) {
+            pinned_dev = (host_io && !zero_copy && np6) ? pinned_device_ptr(poses_io, np6 * sizeof(double)) : nullptr;
+            if (host_io && pinned_dev) {
+                // the caller's poses are pinned: k_unpack1 reads them where they are (no copy into the staging block, no DMA)
+                std::memcpy(ua.intr_h, intr_io, CCAL_PMAX * sizeof(double));
+                ua.poses_src = static_cast<const double*>(pinned_dev);
+            } else if (host_io) {
                 std::memcpy(ua.intr_h, intr_io, CCAL_PMAX * sizeof(double));
                 std::memcpy(h_poses, poses_io, np6 * sizeof(double));
                 if (zero_copy || np6 == 0) ua.poses_src = h_poses;
@@ -782,6 +793,13 @@ struct FusedJob : SolveJob {
                 // has just read: nothing to copy, nothing to wait for
                 std::memcpy(intr_io, const_cast<const double*>(f->h_result), CCAL_PMAX * sizeof(double));
                 std::memcpy(poses_io, const_cast<const double*>(f->h_result) + CCAL_PMAX, np6 * sizeof(double));
+            } else if (pinned_dev) {
+                // the caller's array is pinned: ONE DMA writes the result where the caller reads it
+                double* h_intr = h_poses;
+                HIP_TRY(ctx, hipMemcpyAsync(poses_io, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));
+                HIP_TRY(ctx, hipMemcpyAsync(h_intr, p->d_intr, CCAL_PMAX * sizeof(double), hipMemcpyDeviceToHost, dl));
+                HIP_TRY(ctx, hipStreamSynchronize(dl));
+                std::memcpy(intr_io, h_intr, CCAL_PMAX * sizeof(double));
             } else {
                 double* h_intr = h_poses + np6;
                 if (np6) HIP_TRY(ctx, hipMemcpyAsync(h_poses, p->d_poses, np6 * sizeof(double), hipMemcpyDeviceToHost, dl));

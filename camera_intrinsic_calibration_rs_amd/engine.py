@@ -53,6 +53,21 @@ class Context:
         if rc != _ffi.OK:
             raise CcalError(rc, "ccal_sync", self.last_error())
 
+    # -- pinned caller memory (ccal_pin_buffer): arrays the library reads and writes in place, no staging copy -----
+    def pin(self, a: np.ndarray) -> np.ndarray:
+        """Page-lock a C-contiguous array for the GPU (hipHostRegister through the library); it must outlive the pinning."""
+        if not a.flags["C_CONTIGUOUS"]:
+            raise ValueError("pin: a C-contiguous array")
+        rc = self.lib.ccal_pin_buffer(self.handle, C.c_void_p(a.ctypes.data), a.nbytes)
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_pin_buffer", self.last_error())
+        return a
+
+    def unpin(self, a: np.ndarray):
+        rc = self.lib.ccal_unpin_buffer(self.handle, C.c_void_p(a.ctypes.data))
+        if rc != _ffi.OK:
+            raise CcalError(rc, "ccal_unpin_buffer", self.last_error())
+
     # -- model conventions (what this build assumes about the absent camera-intrinsic-model crate) -----------
     def model_conventions(self) -> _ffi.ModelConventions:
         cv = _ffi.ModelConventions()
@@ -463,9 +478,17 @@ class Problem:
     def build_normal_dev(self, lam=0.0):
         self._check(self.lib.ccal_build_normal_dev(self.handle, float(lam)), "ccal_build_normal_dev")
 
-    def solve(self, intr, poses, extr=None, opts: _ffi.SolverOpts | None = None, raise_on_error=True):
+    def solve(self, intr, poses, extr=None, opts: _ffi.SolverOpts | None = None, raise_on_error=True, pinned=False):
         intr, poses, extr = self._params(intr, poses, extr)
-        intr, poses, extr = intr.copy(), poses.copy(), extr.copy()
+        if pinned:
+            # the host keeps its pose array pinned (ccal_pin_buffer, once per problem): the library reads the start from it and
+            # writes the result into it, no staging copy either way.  The arrays returned are that buffer (valid until the next call)
+            if getattr(self, "_pin_poses", None) is None:
+                self._pin_poses = self.ctx.pin(np.zeros((max(self.n_slots, 1), 6)))
+            np.copyto(self._pin_poses[:self.n_slots], poses)
+            intr, poses, extr = intr.copy(), self._pin_poses[:self.n_slots], extr.copy()
+        else:
+            intr, poses, extr = intr.copy(), poses.copy(), extr.copy()
         opts = opts or default_opts()
         rep = _ffi.Report()
         rc = self.lib.ccal_solve(self.handle, C.byref(opts), _dp(intr), _dp(poses), _dp(extr), C.byref(rep))
@@ -537,6 +560,11 @@ class Problem:
 
     def close(self):
         if getattr(self, "handle", None):
+            if getattr(self, "_pin_poses", None) is not None and getattr(self.ctx, "handle", None):
+                try:
+                    self.ctx.unpin(self._pin_poses)          # (before the array goes: the registration must not outlive the memory)
+                finally:
+                    self._pin_poses = None
             self.lib.ccal_problem_destroy(self.handle)
             self.handle = None
 

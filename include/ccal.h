@@ -203,6 +203,15 @@ int ccal_model_num_params(int model);            /* 5 / 6 / 8 / 9 (/ 8 for the E
 int ccal_get_model_conventions(const ccal_ctx* ctx, ccal_model_conventions* out);
 int ccal_set_model_conventions(ccal_ctx* ctx, const ccal_model_conventions* in);
 
+/* Host memory the caller hands to ccal_solve* / ccal_upload_params / ccal_download_params can be PINNED once (page-locked and
+ * mapped for the GPU): the library then moves it without its intermediate staging copy - the kernels read the starting poses where
+ * the caller keeps them, the result is written there by one DMA (10 000 frames: ~85 us of a 240-us ccal_solve are the two staging
+ * copies of 480 KB of poses; src/util.rs:384-390 hands such a map over per call).  ccal_pin_buffer registers [host_ptr, host_ptr +
+ * bytes) (hipHostRegister; memory the caller allocated pinned itself - hipHostMalloc - is recognised without it); the range must
+ * stay allocated until ccal_unpin_buffer or ccal_ctx_destroy.  Pinning never changes a result (same kernels, same bits). */
+int ccal_pin_buffer(ccal_ctx* ctx, void* host_ptr, size_t bytes);
+int ccal_unpin_buffer(ccal_ctx* ctx, void* host_ptr);
+
 /* ---- problem ---------------------------------------------------------------------------- */
 /* One problem holds at most 2^30 - 1 corners (CCAL_ERR_INVALID_ARG beyond: shard the frames, ccal_multi_problem_create). */
 int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* desc, ccal_problem** out);
@@ -252,7 +261,8 @@ int ccal_build_normal(ccal_problem* p, const double* intr, const double* poses, 
 int ccal_build_normal_dev(ccal_problem* p, double lambda);   /* uses uploaded params; result stays on device */
 
 /* ---- the optimizer loop --------------------------------------------------------------------
- * ccal_solve: host pointers in and out (poses staged through pinned memory both ways).
+ * ccal_solve: host pointers in and out (poses staged through pinned memory both ways - unless the caller's arrays are pinned
+ * themselves, ccal_pin_buffer: then they are read and written in place).
  * ccal_solve_dev: the starting point is what ccal_upload_params (or a previous solve) left on the device, the result
  * stays there (ccal_download_params fetches it); the call itself moves ~1 KB to the device and polls a status word. */
 int ccal_solve(ccal_problem* p, const ccal_solver_opts* opts,

@@ -228,3 +228,30 @@ def test_convert_model_roundtrip_identity(gpu_ctx):
 def test_convert_model_size_mismatch():
     with pytest.raises(ValueError):
         api.convert_model(api.GenericModel("eucm", _EUCM_GT, 512, 512), api.GenericModel("kb4", [0.0] * 8, 640, 480))
+
+
+def test_pinned_caller_buffers_give_the_same_bits(gpu_ctx):
+    """ccal_pin_buffer: a pose array the caller pinned is read and written in place by ccal_solve (no staging copy) - large problems
+    (the three-launch form stages 480 KB both ways otherwise), session sizes, a rig (the general loop's copies become true DMAs) -
+    and nothing changes in the result; pinning twice is refused, unpinning something never pinned is a no-op, a pinned range that
+    the caller allocated pinned itself needs no registration (recognised through the pointer's attributes)."""
+    import ctypes as C
+    from camera_intrinsic_calibration_rs_amd import _ffi, synth
+    from camera_intrinsic_calibration_rs_amd.engine import CcalError, Problem, default_opts
+    for frames, model, n_cams in ((3000, "eucm", 1), (400, "kb4", 1), (300, "eucm", 2)):
+        sp = synth.make_problem(frames, model, n_cams=n_cams, seed=5 + frames)
+        gp = Problem.from_synth(gpu_ctx, sp)
+        for method in (0, 1):
+            i_a, p_a, e_a, r_a = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+            i_b, p_b, e_b, r_b = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method), pinned=True)
+            assert (r_a.status, r_a.iterations) == (r_b.status, r_b.iterations) == (0, r_a.iterations)
+            np.testing.assert_array_equal(i_a, i_b); np.testing.assert_array_equal(p_a, np.array(p_b)); np.testing.assert_array_equal(e_a, e_b)
+        with pytest.raises(CcalError):
+            gpu_ctx.pin(gp._pin_poses)                           # the same address twice
+        gp.close()                                               # unpins
+    a = np.zeros(1024)
+    gpu_ctx.unpin(a)                                             # never pinned: nothing to undo
+    gpu_ctx.pin(a); gpu_ctx.unpin(a)
+    lib = _ffi.load()
+    assert lib.ccal_pin_buffer(gpu_ctx.handle, None, 8) == _ffi.ERR_INVALID_ARG
+    assert lib.ccal_pin_buffer(gpu_ctx.handle, C.c_void_p(a.ctypes.data), 0) == _ffi.ERR_INVALID_ARG

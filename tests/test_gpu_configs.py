@@ -179,6 +179,26 @@ def test_ragged_solve_against_the_oracle(gpu_ctx, oracle, model, method):
     gp.close()
 
 
+def test_ragged_lm_with_rejected_steps_in_the_binned_launch(gpu_ctx, oracle):
+    """LM from a bad start on 3 000 ragged frames: rejected steps and missed speculations run the re-elimination groups of the binned
+    Gram kernel (records indexed by position in the sorted table) - same accept / reject sequence as the oracle."""
+    sp = synth.make_problem(3000, "eucm", ragged=True, outlier_frac=0.05, init_perturb=0.8, seed=1)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    oracle.set_solve_threads(8)
+    try:
+        intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    finally:
+        oracle.set_solve_threads(1)
+    intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_LM))
+    assert rep.status == rep_o.status
+    assert (rep.iterations, rep.lm_accepted, rep.lm_rejected) == (rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected)
+    assert rep.lm_rejected + rep.lm_spec_misses > 0          # the re-elimination path ran
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+    np.testing.assert_allclose(intr[0, :6], intr_o[0, :6], rtol=1e-6)
+    gp.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # configs[0] stand-in
 # ---------------------------------------------------------------------------------------------------------------

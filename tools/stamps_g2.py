@@ -1,6 +1,8 @@
 """Developer tool: where a wavefront of k_gram2 spends its life (100 MHz clock at the phase boundaries; library built with
 -DCCAL_STAMPS: tools/build_tu_variants.sh ccal_kernels_gram2 "stamps:-DCCAL_STAMPS"; CCAL_LIB selects it, CCAL_GRAM2=1 for
-the models that do not take k_gram2 by default).   python tools/stamps_g2.py [frames] [model] [lm]"""
+the models that do not take k_gram2 by default).   python tools/stamps_g2.py [frames] [model] [ragged]
+`ragged`: 24 .. 144 corners per frame - the binned launch (k_gram2b); the table is then per quarter of the launch order (the bins
+of the large frames come first)."""
 import os, sys, ctypes as C, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -8,7 +10,8 @@ from camera_intrinsic_calibration_rs_amd import synth, _ffi
 from camera_intrinsic_calibration_rs_amd.engine import Context, Problem
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 model = sys.argv[2] if len(sys.argv) > 2 else "eucm"
-sp = synth.make_problem(F, model)
+RAGGED = "ragged" in sys.argv[3:]
+sp = synth.make_problem(F, model, ragged=RAGGED, seed=0xC0FFEE + 77) if RAGGED else synth.make_problem(F, model)
 ctx = Context(0); p = Problem.from_synth(ctx, sp)
 p.upload_params(sp.intr0, sp.poses0, sp.extr0)
 for _ in range(30): p.build_normal_dev(0.0)
@@ -30,7 +33,11 @@ nw = len(st)
 names = ["state+ids", "prologue", "corner loop", "reduction", "scatter", "fused tail"]
 print(f"{model} {F} frames: {nw} wavefronts, start spread {(st[:, 0].max() - t0) / 100:.2f} us, last end {(st[:, 5].max() - t0) / 100:.2f} us")
 half = nw // 2
-for label, sel in (("first half of the dispatch (older on their SIMD)", slice(0, half)), ("second half (younger)", slice(half, nw))):
+parts = [("first half of the dispatch (older on their SIMD)", slice(0, half)), ("second half (younger)", slice(half, nw))]
+if RAGGED:
+    q = max(nw // 8, 1)
+    parts = [(f"wavefronts {i * q} .. {min((i + 1) * q, nw) - 1}", slice(i * q, min((i + 1) * q, nw))) for i in range((nw + q - 1) // q)]
+for label, sel in parts:
     s = st[sel]
     d = np.diff(s[:, :6], axis=1) / 100.0
     if len(s) == 0:
