@@ -99,6 +99,8 @@ int ccal_ctx_create(int device_id, void* hip_stream, ccal_ctx** out) {
 }
 static void ctx_free(ccal_ctx* ctx) {
     ctx_worker_destroy(ctx);
+    (void)hipSetDevice(ctx->device);
+    ctx_cache_clear(ctx);
     if (!ctx->pinned.empty()) {
         (void)hipSetDevice(ctx->device);
         if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -250,14 +252,30 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
             total += up256((bin_tab.size() + 1) * sizeof(int32_t));
         }
     }
-    HIP_TRY(ctx, hipMalloc((void**)&p->d_block, total));
-    HIP_TRY(ctx, hipMemsetAsync(p->d_block, 0, total, ctx->stream));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&p->d_block, total));
+    // Session-sized problems (up to 8 MB of inputs) are packed into ONE pinned staging block laid out like the device block and
+    // uploaded with ONE copy: ten hipMemcpyAsync calls from pageable memory - each staged by the runtime on its own - were
+    // ~0.1 ms of ccal_problem_create's 0.2 ms at 600 frames.  Larger problems keep the per-array copies (packing 29 MB on the
+    // host would cost more than it saves).
+    char* h_pack = nullptr;
+    struct PackGuard { ccal_ctx* c; char*& p; ~PackGuard() { if (p) { (void)hipStreamSynchronize(c->stream); ccal::ctx_release(c, p, true); } } } pack_guard{ ctx, h_pack };      // (a copy may still read it on an error exit)
+    if (total <= ((size_t)8 << 20)) HIP_TRY(ctx, ctx_host_alloc(ctx, (void**)&h_pack, total));
+    if (!h_pack) HIP_TRY(ctx, hipMemsetAsync(p->d_block, 0, total, ctx->stream));
     {
         char* q = p->d_block;
         auto put = [&](auto** dst, const auto* src, size_t n) -> hipError_t {
             using T = std::remove_pointer_t<std::remove_pointer_t<decltype(dst)>>;
             *dst = reinterpret_cast<T*>(q);
-            q += up256((n + 1) * sizeof(T));
+            const size_t room = up256((n + 1) * sizeof(T));
+            if (h_pack) {                 // (the slack behind the data must be zeros: the kernels load - and mask - one element past an empty last frame)
+                char* h = h_pack + (q - p->d_block);
+                const size_t nb = (n && src) ? n * sizeof(T) : 0;
+                if (nb) std::memcpy(h, src, nb);
+                std::memset(h + nb, 0, room - nb);
+                q += room;
+                return hipSuccess;
+            }
+            q += room;
             return (n && src) ? hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
         };
         HIP_TRY(ctx, put(&p->d_x, d->p3d_x, nc)); HIP_TRY(ctx, put(&p->d_y, d->p3d_y, nc)); HIP_TRY(ctx, put(&p->d_z, d->p3d_z, nc));
@@ -270,8 +288,13 @@ int ccal_problem_create(ccal_ctx* ctx, const ccal_problem_desc* d, ccal_problem*
         if (!bin_tab.empty()) HIP_TRY(ctx, put(&p->d_bin_tab, (const int32_t*)bin_tab.data(), bin_tab.size()));
         double** bufs[6] = { &p->d_intr, &p->d_poses, &p->d_extr, &p->d_intr_c, &p->d_poses_c, &p->d_extr_c };
         const size_t sz[6] = { ni, np6, ne, ni, np6, ne };
+        const size_t packed = (size_t)(q - p->d_block);                     // the uploaded arrays; the parameter sets behind them start as zeros
         for (int i = 0; i < 6; ++i) { *bufs[i] = reinterpret_cast<double*>(q); q += up256(sz[i] * 8); }
         if ((size_t)(q - p->d_block) > total) return fail(ctx, CCAL_ERR_HIP, "problem block layout");
+        if (h_pack) {
+            HIP_TRY(ctx, hipMemcpyAsync(p->d_block, h_pack, packed, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(p->d_block + packed, 0, total - packed, ctx->stream));
+        }
     }
     p->lo.assign(ni, 0.0); p->hi.assign(ni, 0.0); p->has_bound.assign(ni, 0); p->fixed.assign(ni, 0);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(ctx, CCAL_ERR_HIP, "upload failed");
@@ -292,10 +315,18 @@ void ccal_problem_destroy(ccal_problem* p) {
         p->nws->tail_pending = false;
         if (p->nws->fws) p->nws->fws->tail_pending = false;
     }
-    void* ptrs[] = { p->d_block, p->d_r, p->d_J, p->d_err, p->d_scratch };          // (corner arrays, frame tables, parameter arrays: slices of d_block)
-    for (void* q : ptrs) if (q) (void)hipFree(q);
-    normal_ws_destroy(p);
     ccal_ctx* ctx = p->ctx;
+    // nothing of this problem may still run when its blocks go back to the context (the next problem gets them at once): the
+    // stream is drained - it is idle after every blocking entry point; a device-resident solve may have left its last launches
+    // (a caller-provided stream may be gone already when a binding's garbage collector gets here: the device is drained then)
+    if (ctx && (p->d_block || p->nws)) {
+        (void)hipSetDevice(ctx->device);
+        if (ctx->own_stream && ctx->stream) (void)hipStreamSynchronize(ctx->stream); else (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+    }
+    void* ptrs[] = { p->d_block, p->d_r, p->d_J, p->d_err, p->d_scratch };          // (corner arrays, frame tables, parameter arrays: slices of d_block)
+    for (void* q : ptrs) if (q) ctx_release(ctx, q, false);
+    normal_ws_destroy(p);
     const bool counted = p->counted;
     delete p;
     if (ctx && counted && --ctx->n_problems == 0 && ctx->destroy_requested) ctx_free(ctx);
@@ -422,8 +453,8 @@ int ccal_eval(ccal_problem* p, const double* intr, const double* poses, const do
     ccal_ctx* ctx = p->ctx;
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
-    if (!p->d_r) HIP_TRY(ctx, hipMalloc((void**)&p->d_r, sizeof(double) * std::max<int64_t>(2 * p->n_corners, 2)));
-    if (!p->d_J) HIP_TRY(ctx, hipMalloc((void**)&p->d_J, sizeof(double) * std::max<int64_t>(p->j_len, 2)));
+    if (!p->d_r) HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&p->d_r, sizeof(double) * std::max<int64_t>(2 * p->n_corners, 2)));
+    if (!p->d_J) HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&p->d_J, sizeof(double) * std::max<int64_t>(p->j_len, 2)));
     rc = ccal_eval_dev(p, apply_loss, p->d_r, p->d_J);
     if (rc != CCAL_OK) return rc;
     if (p->n_corners) {
@@ -440,7 +471,7 @@ int reprojection_errors_dev(ccal_problem* p, const double* intr, const double* p
     ccal_ctx* ctx = p->ctx;
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
-    if (!p->d_err) HIP_TRY(ctx, hipMalloc((void**)&p->d_err, sizeof(double) * std::max<int64_t>(p->n_corners, 1)));
+    if (!p->d_err) HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&p->d_err, sizeof(double) * std::max<int64_t>(p->n_corners, 1)));
     for (int c = 0; c < p->n_cams; ++c) {
         KArgs a = make_args(p, c);
         a.err_out = p->d_err;
@@ -471,9 +502,9 @@ int ccal_init_poses(ccal_problem* p, const double* intr, int min_points, double*
     // the two temporaries are slices of the problem's scratch block (kept for the next call: no hipMalloc / hipFree pair per call)
     const size_t b_po = (no * 6 * sizeof(double) + 255) & ~(size_t)255, b_va = (no * sizeof(int32_t) + 255) & ~(size_t)255;
     if (p->scratch_bytes < b_po + b_va) {
-        if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
-        const size_t want = std::max(b_po + b_va, problem_scratch_hint(p));       // (room for validation()'s temporaries too: growing the block later costs a hipFree)
-        HIP_TRY(ctx, hipMalloc((void**)&p->d_scratch, want));
+        if (p->d_scratch) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); ctx_release(ctx, p->d_scratch, false); p->d_scratch = nullptr; p->scratch_bytes = 0; }
+        const size_t want = std::max(b_po + b_va, problem_scratch_hint(p));       // (room for validation()'s temporaries too: growing the block later costs a free)
+        HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&p->d_scratch, want));
         p->scratch_bytes = want;
     }
     double* d_po = reinterpret_cast<double*>(p->d_scratch);
@@ -498,7 +529,7 @@ int ccal_validation(ccal_problem* p, int cam, const double* intr, const double* 
     if (p->cams[cam].obs.empty()) return fail(ctx, CCAL_ERR_INVALID_ARG, "camera has no observations");
     int rc = ccal_upload_params(p, intr, poses, extr);
     if (rc != CCAL_OK) return rc;
-    if (!p->d_err) HIP_TRY(ctx, hipMalloc((void**)&p->d_err, sizeof(double) * std::max<int64_t>(p->n_corners, 1)));
+    if (!p->d_err) HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&p->d_err, sizeof(double) * std::max<int64_t>(p->n_corners, 1)));
     KArgs a = make_args(p, cam);
     a.err_out = p->d_err;
     HIP_TRY(ctx, launch_reproj_err(p, cam, a, ctx->stream));

@@ -69,7 +69,78 @@ struct ccal_ctx {
     char* d_batch_tab = nullptr; char* h_batch_tab = nullptr; size_t batch_tab_bytes = 0;
     // ccal_pin_buffer: the caller's ranges this context registered (unregistered by ccal_unpin_buffer or with the context)
     std::vector<std::pair<void*, size_t>> pinned;
+    // Blocks of device and pinned host memory (and side streams) that destroyed problems of this context gave back: a calibration
+    // session creates a problem per camera and per retry (src/bin/camera_calibration.rs:205-265) - hipMalloc / hipHostMalloc /
+    // hipStreamCreate and their frees were a third of a 600-frame session's create + first solve.  A few blocks, bounded sizes;
+    // freed with the context.  `live`: what is handed out (pointer -> bytes, second = 1 for pinned host memory).
+    struct Block { void* p; size_t bytes; };
+    std::vector<Block> cache_dev, cache_host;
+    std::vector<hipStream_t> cache_streams;
+    std::vector<std::pair<void*, std::pair<size_t, int>>> live;
 };
+namespace ccal {
+constexpr size_t kCacheDevMaxBytes = (size_t)1 << 30, kCacheHostMaxBytes = (size_t)64 << 20;
+constexpr size_t kCacheMaxBlocks = 12;
+// a block of at least `bytes` (256-byte granularity): from the context's cache when one fits without wasting more than a quarter
+inline hipError_t ctx_alloc(ccal_ctx* ctx, void** out, size_t bytes, bool host, unsigned host_flags = 0) {
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    std::vector<ccal_ctx::Block>& cache = host ? ctx->cache_host : ctx->cache_dev;
+    size_t best = cache.size();
+    for (size_t i = 0; i < cache.size(); ++i)
+        if (cache[i].bytes >= bytes && cache[i].bytes <= bytes + bytes / 4 + 4096 && (best == cache.size() || cache[i].bytes < cache[best].bytes)) best = i;
+    void* p = nullptr;
+    size_t got = bytes;
+    if (best != cache.size()) { p = cache[best].p; got = cache[best].bytes; cache.erase(cache.begin() + (ptrdiff_t)best); }
+    else {
+        const hipError_t e = host ? hipHostMalloc(&p, bytes, host_flags) : hipMalloc(&p, bytes);
+        if (e != hipSuccess) return e;
+    }
+    try { ctx->live.emplace_back(p, std::make_pair(got, host ? 1 : 0)); }
+    catch (...) { if (host) (void)hipHostFree(p); else (void)hipFree(p); throw; }
+    *out = p;
+    return hipSuccess;
+}
+inline hipError_t ctx_dev_alloc(ccal_ctx* ctx, void** out, size_t bytes) { return ctx_alloc(ctx, out, bytes, false); }
+// pinned, mapped, coherent host memory (every pinned block of the library is allocated that way: one kind in the cache)
+inline hipError_t ctx_host_alloc(ccal_ctx* ctx, void** out, size_t bytes) { return ctx_alloc(ctx, out, bytes, true, hipHostMallocCoherent | hipHostMallocMapped); }
+// give a block back (anything not handed out by ctx_alloc - or with no context left - is simply freed).  The caller has made sure
+// nothing in flight still uses it.
+inline void ctx_release(ccal_ctx* ctx, void* p, bool host) {
+    if (!p) return;
+    if (ctx) {
+        for (size_t i = 0; i < ctx->live.size(); ++i) {
+            if (ctx->live[i].first != p) continue;
+            const size_t bytes = ctx->live[i].second.first;
+            const bool is_host = ctx->live[i].second.second != 0;
+            ctx->live.erase(ctx->live.begin() + (ptrdiff_t)i);
+            std::vector<ccal_ctx::Block>& cache = is_host ? ctx->cache_host : ctx->cache_dev;
+            size_t total = bytes;
+            for (const auto& b : cache) total += b.bytes;
+            if (!ctx->destroy_requested && cache.size() < kCacheMaxBlocks && total <= (is_host ? kCacheHostMaxBytes : kCacheDevMaxBytes)) {
+                try { cache.push_back({ p, bytes }); return; } catch (...) { }
+            }
+            if (is_host) (void)hipHostFree(p); else (void)hipFree(p);
+            return;
+        }
+    }
+    if (host) (void)hipHostFree(p); else (void)hipFree(p);
+}
+inline hipError_t ctx_stream_get(ccal_ctx* ctx, hipStream_t* out) {
+    if (!ctx->cache_streams.empty()) { *out = ctx->cache_streams.back(); ctx->cache_streams.pop_back(); return hipSuccess; }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+inline void ctx_stream_put(ccal_ctx* ctx, hipStream_t s) {
+    if (!s) return;
+    if (ctx && !ctx->destroy_requested && ctx->cache_streams.size() < 4) { try { ctx->cache_streams.push_back(s); return; } catch (...) { } }
+    (void)hipStreamDestroy(s);
+}
+inline void ctx_cache_clear(ccal_ctx* ctx) {
+    for (auto& b : ctx->cache_dev) (void)hipFree(b.p);
+    for (auto& b : ctx->cache_host) (void)hipHostFree(b.p);
+    for (hipStream_t s : ctx->cache_streams) (void)hipStreamDestroy(s);
+    ctx->cache_dev.clear(); ctx->cache_host.clear(); ctx->cache_streams.clear();
+}
+}  // namespace ccal
 namespace ccal {
 // The device-side address of caller memory that is pinned (registered with ccal_pin_buffer / hipHostRegister, or allocated with
 // hipHostMalloc) for all of [host, host + bytes); nullptr: ordinary pageable memory - the library stages it.

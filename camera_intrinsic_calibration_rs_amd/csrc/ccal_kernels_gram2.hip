@@ -817,6 +817,26 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
 #ifdef CCAL_G2_NO_BINS        // A/B builds (tools/build_tu_variants.sh ccal_kernels_gram2 "nobins:-DCCAL_G2_NO_BINS"): the launch without bins
     return none;
 #endif
+#ifdef CCAL_G2_PLAN_ENV       // experiment builds: the plan from the environment, "lpf:frames+lpf:frames+..." in launch order over the frames sorted by size
+    if (const char* e = std::getenv("CCAL_G2_PLAN"); e && off && order && n_obs > 0) {
+        std::vector<int32_t> ord((size_t)n_obs);
+        for (int o = 0; o < n_obs; ++o) ord[(size_t)o] = o;
+        std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
+        GramBins gb;
+        int pos = 0, wgs = 0;
+        while (*e && gb.n_bins < kGramMaxBins && pos < n_obs) {
+            const int lpf = std::atoi(e); while (*e && *e != ':') ++e; if (*e) ++e;
+            int cnt = std::atoi(e); while (*e && *e != ',' && *e != '+') ++e; if (*e) ++e;
+            cnt = std::min(cnt > 0 ? cnt : n_obs, n_obs - pos);
+            const int k = gb.n_bins++, g = 64 / lpf;
+            gb.lpf[k] = lpf; gb.first[k] = pos; gb.count[k] = cnt; gb.wg0[k] = wgs;
+            wgs += ((cnt + g - 1) / g + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB;
+            pos += cnt;
+        }
+        gb.wg0[gb.n_bins] = wgs;
+        if (pos == n_obs) { *order = std::move(ord); return gb; }
+    }
+#endif
     if (!off || n_obs < 2000 || !order) return none;                 // (below: k_gram1v's single-launch groups, one wavefront per SIMD)
     static const int lpfs[kGramMaxBins] = { 32, 16, 12, 8, 6 };       // launch order: the bins of the large frames first
     const int simds = 1024;

@@ -274,9 +274,9 @@ hipError_t order_stats_device(const double* d_vals, int64_t n, char* work, doubl
 
 static hipError_t ensure_scratch(ccal_problem* p, size_t total) {
     if (p->scratch_bytes >= total) return hipSuccess;
-    if (p->d_scratch) { (void)hipFree(p->d_scratch); p->d_scratch = nullptr; p->scratch_bytes = 0; }
+    if (p->d_scratch) { (void)hipStreamSynchronize(p->ctx->stream); ctx_release(p->ctx, p->d_scratch, false); p->d_scratch = nullptr; p->scratch_bytes = 0; }
     const size_t want = std::max(total, problem_scratch_hint(p));
-    const hipError_t e = hipMalloc((void**)&p->d_scratch, want);
+    const hipError_t e = ctx_dev_alloc(p->ctx, (void**)&p->d_scratch, want);
     if (e == hipSuccess) p->scratch_bytes = want;
     return e;
 }

@@ -58,17 +58,19 @@ void normal_ws_destroy(ccal_problem* p) {
     }
     void* ptrs[] = { w->G[0], w->G[1], w->cost_o[0], w->cost_o[1], w->d_goff, w->d_slot_off, w->d_slot_obs, w->d_obs_cam,
                      w->d_caminfo, w->partial, w->red, w->pf, w->dc, w->mc_slot, w->scal, w->flags, w->cols, w->d_slot_desc, w->d_slot_rec, w->d_all_obs, w->d_obs_owner };
-    for (void* q : ptrs) if (q) (void)hipFree(q);
+    // (the blocks go back to the context's cache - ccal_internal.hpp - for its next problem; ccal_problem_destroy has drained the stream)
+    ccal_ctx* ctx = p->ctx;
+    for (void* q : ptrs) if (q) ctx_release(ctx, q, false);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
-    if (w->d_gstate) (void)hipFree(w->d_gstate);
-    if (w->side) (void)hipStreamDestroy(w->side);
-    if (w->h_gstatus) (void)hipHostFree(w->h_gstatus);
+    if (w->d_gstate) ctx_release(ctx, w->d_gstate, false);
+    if (w->side) { (void)hipStreamSynchronize(w->side); ctx_stream_put(ctx, w->side); }
+    if (w->h_gstatus) ctx_release(ctx, w->h_gstatus, true);
     if (w->h_gstate) (void)hipHostFree(w->h_gstate);
     if (FusedWs* f = w->fws) {
-        if (f->d_block) (void)hipFree(f->d_block);          // every device buffer of the workspace is a slice of it
-        if (f->h_block) (void)hipHostFree(f->h_block);      // h_status | h_result | h_stage
+        if (f->side) { (void)hipStreamSynchronize(f->side); ctx_stream_put(ctx, f->side); }      // (the result's download ran there)
+        if (f->d_block) ctx_release(ctx, f->d_block, false);          // every device buffer of the workspace is a slice of it
+        if (f->h_block) ctx_release(ctx, f->h_block, true);           // h_status | h_result | h_stage
         if (f->fcbuf) (void)hipFree(f->fcbuf);
-        if (f->side) (void)hipStreamDestroy(f->side);
         delete f;
     }
     delete w;
@@ -124,7 +126,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     const size_t zeroed = 2 * b_pf + 2 * b_praw + b_part + 2 * b_red;              // the slices that must start as zeros come first (red: two buffers,
                                                                                   // the in-process transport alternates between them)
     const size_t d_total = zeroed + 2 * b_no + b_state + b_stage;
-    HIP_TRY(ctx, hipMalloc((void**)&f->d_block, d_total));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&f->d_block, d_total));
     HIP_TRY(ctx, hipMemsetAsync(f->d_block, 0, zeroed, ctx->stream));             // (stream-ordered in front of everything that uses the workspace)
     {
         char* q = f->d_block;
@@ -144,20 +146,20 @@ static int fused_ws_ensure(ccal_problem* p) {
     {
         const bool zc = ns * 6 * sizeof(double) <= kZeroCopyBytes;
         const size_t b_hs = up(sizeof(HostStatus)), b_res = zc ? up((ns * 6 + CCAL_PMAX) * sizeof(double)) : 0;
-        HIP_TRY(ctx, hipHostMalloc((void**)&f->h_block, b_hs + b_res + b_stage, hipHostMallocCoherent | hipHostMallocMapped));
+        HIP_TRY(ctx, ctx_host_alloc(ctx, (void**)&f->h_block, b_hs + b_res + b_stage));
         char* q = f->h_block;
         f->h_status = reinterpret_cast<HostStatus*>(q); q += b_hs;
         f->h_result = zc ? reinterpret_cast<double*>(q) : nullptr; q += b_res;
         f->h_stage = reinterpret_cast<double*>(q);
     }
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+    HIP_TRY(ctx, ctx_stream_get(ctx, &f->side));
     std::memset((void*)f->h_status, 0, sizeof(HostStatus));
     return CCAL_OK;
 }
 
 template <class T>
 static int dev_upload(ccal_ctx* ctx, T** dst, const std::vector<T>& src) {
-    HIP_TRY(ctx, hipMalloc((void**)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)dst, std::max<size_t>(src.size(), 1) * sizeof(T)));
     if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return CCAL_OK;
 }
@@ -173,8 +175,8 @@ int normal_ws_ensure(ccal_problem* p) {
     NormalWs* w = new NormalWs();
     p->nws = w;
     w->K = p->K; w->RB = red_size(p->K); w->PF = pf_size(p->K);
-    HIP_TRY(ctx, hipMalloc((void**)&w->dc, CCAL_KMAX * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->dc, CCAL_KMAX * sizeof(double)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->cols, CCAL_KMAX * sizeof(ColInfo)));
     return CCAL_OK;
 }
 int normal_ws_ensure_general(ccal_problem* p) {
@@ -286,28 +288,28 @@ int normal_ws_ensure_general(ccal_problem* p) {
         return rc;
     const size_t gbytes = std::max<int64_t>(gl, 1) * sizeof(double);
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(ctx, hipMalloc((void**)&w->G[i], gbytes));
+        HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->G[i], gbytes));
         HIP_TRY(ctx, hipMemsetAsync(w->G[i], 0, gbytes, ctx->stream));     // tile (1,0) of two-tile blocks is never written
-        HIP_TRY(ctx, hipMalloc((void**)&w->cost_o[i], std::max(p->n_obs, 1) * sizeof(double)));
+        HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->cost_o[i], std::max(p->n_obs, 1) * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(w->cost_o[i], 0, std::max(p->n_obs, 1) * sizeof(double), ctx->stream));
     }
-    HIP_TRY(ctx, hipMalloc((void**)&w->partial, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->partial, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double)));
     // (every clear of this function is ordered on the context's stream: it does not synchronise with the null stream, and the
     // kernels rely on what is never written staying zero - holes in the record buffers, upper-triangle rows of `partial`)
     // k_schurq writes the lower triangle and the extras only: the rows of the upper triangle stay zero.  On the context's
     // stream: it does not synchronise with the null stream, a plain hipMemset could still be running when the first
     // elimination writes the buffer
     HIP_TRY(ctx, hipMemsetAsync(w->partial, 0, (size_t)w->RB * std::max(n_pw, w->n_rows) * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMalloc((void**)&w->red, 2 * (size_t)(w->RB + 8) * sizeof(double)));      // two buffers: the in-process transport alternates
-    HIP_TRY(ctx, hipMalloc((void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc((void**)&w->mc_slot, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->red, 2 * (size_t)(w->RB + 8) * sizeof(double)));      // two buffers: the in-process transport alternates
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->pf, (size_t)std::max(p->n_slots, 1) * w->PF * sizeof(double)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->mc_slot, (size_t)std::max(p->n_slots, 1) * sizeof(double)));
     HIP_TRY(ctx, hipMemsetAsync(w->mc_slot, 0, (size_t)std::max(p->n_slots, 1) * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMalloc((void**)&w->scal, 8 * sizeof(double)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->scal, 8 * sizeof(double)));
     HIP_TRY(ctx, hipMemsetAsync(w->scal, 0, 8 * sizeof(double), ctx->stream));
-    HIP_TRY(ctx, hipMalloc((void**)&w->flags, 4 * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc((void**)&w->d_gstate, sizeof(DevState)));
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&w->side, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstatus, sizeof(HostStatus), hipHostMallocCoherent | hipHostMallocMapped));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->flags, 4 * sizeof(int32_t)));
+    HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&w->d_gstate, sizeof(DevState)));
+    HIP_TRY(ctx, ctx_stream_get(ctx, &w->side));
+    HIP_TRY(ctx, ctx_host_alloc(ctx, (void**)&w->h_gstatus, sizeof(HostStatus)));
     HIP_TRY(ctx, hipHostMalloc((void**)&w->h_gstate, sizeof(DevState), hipHostMallocDefault));
     std::memset((void*)w->h_gstatus, 0, sizeof(HostStatus));
     HIP_TRY(ctx, hipMemsetAsync(w->flags, 0, 4 * sizeof(int32_t), ctx->stream));
