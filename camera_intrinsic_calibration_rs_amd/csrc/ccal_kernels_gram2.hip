@@ -733,6 +733,10 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
         case 8: gram2_body<MODEL, OF, 8, false, true>(a, smem, wg, frame0, nfr); break;
         case 12: gram2_body<MODEL, OF, 12, false, true>(a, smem, wg, frame0, nfr); break;
         case 16: gram2_body<MODEL, OF, 16, false, true>(a, smem, wg, frame0, nfr); break;
+#ifdef CCAL_G2_MORE_LPF      // experiment builds: lane mappings that leave lanes idle (10: six frames on 60 lanes, 20: three)
+        case 10: gram2_body<MODEL, OF, 10, false, true>(a, smem, wg, frame0, nfr); break;
+        case 20: gram2_body<MODEL, OF, 20, false, true>(a, smem, wg, frame0, nfr); break;
+#endif
         default: gram2_body<MODEL, OF, 32, false, true>(a, smem, wg, frame0, nfr); break;
     }
 }
