@@ -15,14 +15,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    """The rendezvous of a test's process group: a FILE store (init_method file://...) in a fresh temporary directory - no TCP
+    port to pick and lose to another process before the group binds it (EADDRINUSE on a busy box)."""
+    import tempfile
+    return "file://" + os.path.join(tempfile.mkdtemp(prefix="ccal_rdv_"), "store")
 
 
 def _worker(rank, world, port, model, n_cams, method, n_frames, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     from camera_intrinsic_calibration_rs_amd import synth
     from camera_intrinsic_calibration_rs_amd.dist import gather_poses, make_allreduce_hook
     from camera_intrinsic_calibration_rs_amd.engine import default_opts
@@ -140,8 +142,7 @@ def test_two_rank_solve_over_the_products_cut(oracle):
 def _worker_cut(rank, world, port, first, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     from camera_intrinsic_calibration_rs_amd import synth
     from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
     from camera_intrinsic_calibration_rs_amd.engine import default_opts

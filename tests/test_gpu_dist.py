@@ -73,11 +73,9 @@ def test_solve_with_rccl_hook_single_rank():
     import torch
     import torch.distributed as dist
     from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.init_process_group("nccl", init_method=_free_port(), rank=0, world_size=1, device_id=dev)
     try:
         stream = torch.cuda.Stream(device=dev)
         ctx = Context(0, stream=stream.cuda_stream)
@@ -116,7 +114,10 @@ def test_solve_with_rccl_hook_single_rank():
 
 
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    """The rendezvous of a test's process group: a FILE store (init_method file://...) in a fresh temporary directory - no TCP
+    port to pick and lose to another process before the group binds it (EADDRINUSE on a busy box)."""
+    import tempfile
+    return "file://" + os.path.join(tempfile.mkdtemp(prefix="ccal_rdv_"), "store")
 
 
 def _gpu_worker(rank, world, port, model, n_cams, method, n_frames, q):
@@ -127,8 +128,7 @@ def _gpu_worker(rank, world, port, model, n_cams, method, n_frames, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     from camera_intrinsic_calibration_rs_amd.dist import gather_poses, make_allreduce_hook
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -203,8 +203,7 @@ def _ahead_worker(rank, world, port, scenario, method, n_cams, q):
     os.environ["CCAL_FUSED_DEPTH_HOOK"] = "2"              # read once per process by the library: set before it loads
     import torch
     import torch.distributed as dist
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=port, rank=rank, world_size=world)
     from camera_intrinsic_calibration_rs_amd.dist import make_allreduce_hook
     from camera_intrinsic_calibration_rs_amd.engine import make_desc
     torch.cuda.set_device(0)

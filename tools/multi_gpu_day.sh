@@ -12,7 +12,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$R" || exit 1
 TAG=${1:-r06}
-O=profiles/$TAG/multi_gpu
+O=${CCAL_DAY_OUT:-profiles/$TAG/multi_gpu}      # (through gpurun only gpurun_out/ travels back: CCAL_DAY_OUT=gpurun_out/multi_gpu_$TAG, then copy)
 mkdir -p "$O"
 export HSA_ENABLE_IPC_MODE_LEGACY=${HSA_ENABLE_IPC_MODE_LEGACY:-0}
 NVIS=$(python3 -c 'import torch; print(torch.cuda.device_count())' 2>/dev/null || echo 0)
