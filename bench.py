@@ -112,6 +112,8 @@ def _summary(out):
             s[key] = {"corners": r.get("corners"), "E_ms": _sig(g(r, "mode_E", "kernel_ms")), "E_frac_hbm": _sig(g(r, "mode_E", "frac_hbm")),
                       "N_build_ms": _sig(g(r, "mode_N", "build_ms")), "N_frac_fp64": _sig(g(r, "mode_N", "frac_fp64")),
                       "gn_ms": pair(r, "gn"), "lm_ms": pair(r, "lm")}
+            if isinstance(r.get("two_cameras"), dict):
+                s[key]["cam2_build_ms"] = _sig(g(r, "two_cameras", "build_ms")); s[key]["cam2_gn_ms"] = pair(r.get("two_cameras"), "gn")
         elif r is not None:
             s[key] = "error"
     sh = g(ex, "single_process_sharded")
@@ -810,6 +812,22 @@ def main():
                             blk["lm"] = solve_stats(pr_, spr, 1, False); blk["lm_device_resident"] = solve_stats(pr_, spr, 1, True)
                         intr_r = pr_.download_params()[0]
                         blk["max_rel_intrinsics_err_vs_gt"] = float(np.abs(intr_r[0, :4] / spr.intr_gt[0, :4] - 1).max())
+                        if key == "ragged" and not args.no_rig:
+                            # the same for a two-camera rig (BASELINE configs[4] shape) of ragged observation frames: one Gram launch for both cameras,
+                            # its list sorted by corner count and binned (k_gram2g)
+                            sp2r = synth.make_problem(nfr, args.model, n_cams=2, ragged=True, seed=0xC0FFEE + 78)
+                            p2r = Problem.from_synth(ctx, sp2r)
+                            p2r.upload_params(sp2r.intr0, sp2r.poses0, sp2r.extr0)
+                            with torch.cuda.stream(stream):
+                                ramp(lambda: p2r.build_normal_dev(0.0))
+                                a.record(stream)
+                                for _ in range(100):
+                                    p2r.build_normal_dev(0.0)
+                                b.record(stream)
+                                torch.cuda.synchronize()
+                            blk["two_cameras"] = {"frames": sp2r.n_slots, "corners": sp2r.n_corners, "build_ms": a.elapsed_time(b) / 100,
+                                                  "gn": solve_stats(p2r, sp2r, 0, False), "gn_device_resident": solve_stats(p2r, sp2r, 0, True)}
+                            p2r.close()
                         del Jr, rr
                         pr_.close()
                         extra[key] = blk

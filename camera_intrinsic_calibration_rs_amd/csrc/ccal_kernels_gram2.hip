@@ -258,7 +258,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     const int f = frame0 + (active ? fpos : 0);                    // index of the loop's per-frame buffers (BIN: the position in the sorted table)
     int4 btab = make_int4(0, 0, 0, 0);
     if constexpr (BIN) btab = reinterpret_cast<const int4*>(a.bin_tab)[f];
-    const int fa_ = BIN ? btab.x : (GEN ? a.list[active ? fpos : 0] : (active ? fpos : 0));
+    const int fa_ = BIN ? btab.x : (GEN ? a.list[f] : (active ? fpos : 0));
     const int camf = (GEN && a.obs_cam) ? a.obs_cam[fa_] : a.cam;          // GEN, merged launch: the frame's camera
     double* fcw = smem + wave * WSL;
     double* fc = fcw + grp * FCS;
@@ -741,6 +741,25 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     }
 }
 
+// The same for one camera's (or, merged, every camera's) blocks of a rig: the launch's LIST of observation frames comes sorted by corner
+// count (normal_ws_ensure_general), the bins are ranges of it; records, slots and cameras are looked up by observation frame as ever.
+template <int MODEL, bool OF>
+__global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2g(const FusedArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    int wg0 = 0, frame0 = a.bin_first[0], nfr = a.bin_count[0], lpf = a.bin_lpf[0];
+#pragma unroll
+    for (int i = 1; i < kGramMaxBins; ++i)
+        if (i < a.n_bins && (int)blockIdx.x >= a.bin_wg0[i]) { wg0 = a.bin_wg0[i]; frame0 = a.bin_first[i]; nfr = a.bin_count[i]; lpf = a.bin_lpf[i]; }
+    const int wg = blockIdx.x - wg0;
+    switch (lpf) {
+        case 6: gram2_body<MODEL, OF, 6, true, false>(a, smem, wg, frame0, nfr); break;
+        case 8: gram2_body<MODEL, OF, 8, true, false>(a, smem, wg, frame0, nfr); break;
+        case 12: gram2_body<MODEL, OF, 12, true, false>(a, smem, wg, frame0, nfr); break;
+        case 16: gram2_body<MODEL, OF, 16, true, false>(a, smem, wg, frame0, nfr); break;
+        default: gram2_body<MODEL, OF, 32, true, false>(a, smem, wg, frame0, nfr); break;
+    }
+}
+
 #ifdef CCAL_G2_PROBE      // register-allocation probes (developer): a few instantiations, no launchers
 template __global__ void k_gram2<kEUCM, false, 12, false>(const FusedArgs);
 template __global__ void k_gram2<kKB4, false, 12, false>(const FusedArgs);
@@ -897,27 +916,26 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
     return best;
 }
 
-// the binned launch: a.n_bins / a.bin_* / a.bin_tab filled in by the caller (make_fused_args)
-template <int MODEL, bool OF>
+// the binned launch: a.n_bins / a.bin_* filled in by the caller (single camera: make_fused_args, + a.bin_tab; rigs: launch_gram_dev, a.list sorted)
+template <int MODEL, bool OF, bool GEN>
 static hipError_t launch_gram2_binned(FusedArgs& a, hipStream_t s) {
     constexpr int NS = g2_slices<MODEL>();
-    using Map = RowMap<MODEL, OF, false, NS>;
+    using Map = RowMap<MODEL, OF, GEN, NS>;
     constexpr int K = block_dim(MODEL, OF, false) - 6, K1 = K + 1;
     constexpr int LS = Map::CH | 1;
     constexpr int GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
     size_t lds = 0;
     for (int b = 0; b < a.n_bins; ++b) {
         const int G = 64 / a.bin_lpf[b];
-        const int RED = (G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
+        const int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
         const int WSL = (G * (FC_N0P + 12) + RED + Map::NEF + 1) & ~1;
         lds = std::max(lds, sizeof(double) * WSL * CCAL_GRAMV_WPB);
     }
-    void (*kern)(const FusedArgs) = k_gram2b<MODEL, OF>;
+    void (*kern)(const FusedArgs) = GEN ? k_gram2g<MODEL, OF> : k_gram2b<MODEL, OF>;
     static DynLdsGuard lds_guard;
     if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lds_guard); e != hipSuccess) return e;
     const int wgs = a.bin_wg0[a.n_bins];
-    a.n_part = wgs * CCAL_GRAMV_WPB;
-    a.fuse_elim = 1; a.elim_fused = 1;
+    if constexpr (!GEN) { a.n_part = wgs * CCAL_GRAMV_WPB; a.fuse_elim = 1; a.elim_fused = 1; }
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * CCAL_GRAMV_WPB), lds, s, a);
     return hipGetLastError();
 }
@@ -927,7 +945,9 @@ static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
     if constexpr (!GEN) {
         // ragged frames: the problem came with a plan (ccal_problem_create); the fused elimination's rows must fit, and a forced
         // mapping (developer switch of the second library) means the plain launch
-        if (a.n_bins > 0 && a.fuse_elim && !a.lpf_force && a.bin_wg0[a.n_bins] * CCAL_GRAMV_WPB <= a.part_cap) return launch_gram2_binned<MODEL, OF>(a, s);
+        if (a.n_bins > 0 && a.fuse_elim && !a.lpf_force && a.bin_wg0[a.n_bins] * CCAL_GRAMV_WPB <= a.part_cap) return launch_gram2_binned<MODEL, OF, false>(a, s);
+    } else {
+        if (a.n_bins > 0 && !a.lpf_force) return launch_gram2_binned<MODEL, OF, true>(a, s);      // rigs: the list came sorted, with its bins
     }
     const int lpf = gram2_lanes_per_frame(a.n_obs, a.avg_corners, CCAL_G2_MINW(MODEL) >= 2, GEN, a.lpf_force, (GEN || !a.fuse_elim) ? (int64_t)1 << 40 : a.part_cap, a.share);
     const int waves = ((a.n_obs + 64 / lpf - 1) / (64 / lpf) + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB * CCAL_GRAMV_WPB;

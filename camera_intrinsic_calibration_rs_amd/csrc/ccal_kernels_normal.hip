@@ -267,6 +267,15 @@ hipError_t launch_gram_dev_all(const ccal_problem* p, const DevState* st, hipStr
     return hipSuccess;
 }
 
+// ragged frames: the launch's list sorted by corner count and its bins, when normal_ws_ensure_general planned them (ccal_solver.hip)
+static void set_gen_bins(FusedArgs& fa, const NormalWs* w, int slot) {
+    const GramBins& gb = w->gen_bins[slot];
+    if (gb.n_bins <= 0 || !w->d_gen_sorted[slot]) return;
+    fa.list = w->d_gen_sorted[slot];
+    fa.n_bins = gb.n_bins;
+    for (int b = 0; b < kGramMaxBins; ++b) { fa.bin_lpf[b] = gb.lpf[b]; fa.bin_first[b] = gb.first[b]; fa.bin_count[b] = gb.count[b]; fa.bin_wg0[b] = gb.wg0[b]; }
+    fa.bin_wg0[kGramMaxBins] = gb.wg0[kGramMaxBins];
+}
 // cam < 0: the merged launch (w->merged_gram)
 hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, hipStream_t s) {
     const NormalWs* w = p->nws;
@@ -288,6 +297,7 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
             fa.g_owner = w->d_obs_owner; fa.min_diag = w->lm_min_diag; fa.max_diag = w->lm_max_diag;
         }
         fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
+        set_gen_bins(fa, w, 0);
         return launch_gram1v_general(p->cams[0].model, p->one_focal, fa, s);
     }
     if (w->register_gram) {
@@ -309,6 +319,7 @@ hipError_t launch_gram_dev(const ccal_problem* p, int cam, const DevState* st, h
             fa.g_owner = w->d_obs_owner; fa.min_diag = w->lm_min_diag; fa.max_diag = w->lm_max_diag;
         }
         fa.avg_corners = (int32_t)(p->n_corners / std::max(p->n_obs, 1));
+        set_gen_bins(fa, w, 1 + cam);
         return launch_gram1v_general(p->cams[cam].model, p->one_focal, fa, s);
     }
 #ifndef CCAL_LEGACY_KERNELS

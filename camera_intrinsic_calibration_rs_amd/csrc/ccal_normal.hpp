@@ -55,6 +55,10 @@ struct NormalWs {
     int32_t* d_slot_obs = nullptr;
     int32_t* d_all_obs = nullptr;              // merged Gram launch: every camera's observation frames, camera-major
     bool merged_gram = false;                  // all cameras share model and focal mode: their blocks in ONE launch of the register Gram kernel
+    // ragged frames (round 6): a Gram launch's list of observation frames sorted by corner count + the bins of the launch (gram2_bin_plan);
+    // [0]: the merged launch, [1 + c]: camera c's own launch.  n_bins == 0: the plain launch over the list in table order
+    GramBins gen_bins[1 + CCAL_MAX_CAMS];
+    int32_t* d_gen_sorted[1 + CCAL_MAX_CAMS] = {};
     int64_t* d_slot_rec = nullptr;             // k_schurq: [n_slots][2] record offset of camera 0 / 1 in that slot, -1 = none
     int64_t* d_slot_desc = nullptr;            // [n_obs] in slot order: goff * 8 + camera
     int32_t* d_obs_cam = nullptr;

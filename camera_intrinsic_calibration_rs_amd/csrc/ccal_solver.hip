@@ -61,6 +61,7 @@ void normal_ws_destroy(ccal_problem* p) {
     // (the blocks go back to the context's cache - ccal_internal.hpp - for its next problem; ccal_problem_destroy has drained the stream)
     ccal_ctx* ctx = p->ctx;
     for (void* q : ptrs) if (q) ctx_release(ctx, q, false);
+    for (int32_t* q : w->d_gen_sorted) if (q) ctx_release(ctx, q, false);
     if (w->h_pinned) (void)hipHostFree(w->h_pinned);
     if (w->d_gstate) ctx_release(ctx, w->d_gstate, false);
     if (w->side) { (void)hipStreamSynchronize(w->side); ctx_stream_put(ctx, w->side); }
@@ -276,6 +277,30 @@ int normal_ws_ensure_general(ccal_problem* p) {
         all.reserve(p->n_obs);
         for (int c = 0; c < p->n_cams; ++c) all.insert(all.end(), p->cams[c].obs.begin(), p->cams[c].obs.end());
         if ((rc = dev_upload(ctx, &w->d_all_obs, all))) return rc;
+    }
+    if (w->register_gram) {
+        // ragged frames: every Gram launch's list sorted by corner count, with the bins of the launch (the single-camera loop's plan,
+        // ccal_kernels_gram2.hip: gram2_bin_plan - uniform frames and short lists get none)
+        auto plan_list = [&](const std::vector<int32_t>& list, int slot, int model) -> int {
+            if (list.size() < 2000) return CCAL_OK;
+            std::vector<int64_t> off(list.size() + 1, 0);
+            for (size_t i = 0; i < list.size(); ++i) off[i + 1] = off[i] + (p->h_obs_off[list[i] + 1] - p->h_obs_off[list[i]]);
+            std::vector<int32_t> order;
+            const GramBins gb = gram2_bin_plan(off.data(), (int)list.size(), model == kUCM || model == kEUCM, &order);
+            if (gb.n_bins <= 0) return CCAL_OK;
+            std::vector<int32_t> sorted(list.size());
+            for (size_t i = 0; i < list.size(); ++i) sorted[i] = list[(size_t)order[i]];
+            if (int r = dev_upload(ctx, &w->d_gen_sorted[slot], sorted)) return r;
+            w->gen_bins[slot] = gb;
+            return CCAL_OK;
+        };
+        if (w->merged_gram) {
+            std::vector<int32_t> all;
+            for (int c = 0; c < p->n_cams; ++c) all.insert(all.end(), p->cams[c].obs.begin(), p->cams[c].obs.end());
+            if ((rc = plan_list(all, 0, p->cams[0].model))) return rc;
+        } else {
+            for (int c = 0; c < p->n_cams; ++c) if ((rc = plan_list(p->cams[c].obs, 1 + c, p->cams[c].model))) return rc;
+        }
     }
     if (w->schurq) {
         std::vector<int64_t> slot_rec((size_t)std::max(p->n_slots, 1) * 2, -1);

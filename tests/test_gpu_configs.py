@@ -179,6 +179,40 @@ def test_ragged_solve_against_the_oracle(gpu_ctx, oracle, model, method):
     gp.close()
 
 
+@pytest.mark.parametrize("models", [("eucm", "eucm"), ("kb4", "eucm")])
+def test_ragged_rig_binned_gram_launches(gpu_ctx, oracle, models):
+    """A two-camera rig of 2 x 2 600 ragged observation frames: cameras of one model share ONE Gram launch whose list is sorted by corner
+    count and cut into bins (k_gram2g), cameras of different models get a binned launch each: the reduced normal equations against
+    the oracle, the same bits twice, and a Gauss-Newton / LM solve with the oracle's iteration counts."""
+    ext = np.zeros((2, 6)); ext[1] = [0.05, -0.2, 0.1, 0.1, -0.02, 0.03]
+    if models[0] == models[1]:
+        sp = synth.make_problem(2600, models[0], n_cams=2, ragged=True, seed=0xA11)
+    else:
+        sp = synth.make_rig(3200, list(models), ext, seed=0xA12, drop_frac=0.15)
+    n = np.diff(sp.obs_offsets)
+    assert n.max() > 2 * n.min() and len(n) >= 4000
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    for lam in (0.0, 1e-3):
+        S, b, cost = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        So, bo, costo = op.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+        S2, b2, _ = gp.build_normal(sp.intr0, sp.poses0, sp.extr0, lam=lam)
+        np.testing.assert_array_equal(S, S2); np.testing.assert_array_equal(b, b2)
+    oracle.set_solve_threads(8)
+    try:
+        for method in (_ffi.METHOD_GN, _ffi.METHOD_LM):
+            io_, po_, eo_, ro = op.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+            ig, pg, eg, rg = gp.solve(sp.intr0, sp.poses0, sp.extr0, opts=default_opts(method))
+            assert (rg.status, rg.iterations) == (ro.status, ro.iterations) == (0, ro.iterations)
+            assert abs(rg.final_cost - ro.final_cost) <= 1e-9 * ro.final_cost
+            np.testing.assert_allclose(eg, eo_, rtol=0, atol=1e-7)
+    finally:
+        oracle.set_solve_threads(1)
+    gp.close()
+
+
 def test_ragged_lm_with_rejected_steps_in_the_binned_launch(gpu_ctx, oracle):
     """LM from a bad start on 3 000 ragged frames: rejected steps and missed speculations run the re-elimination groups of the binned
     Gram kernel (records indexed by position in the sorted table) - same accept / reject sequence as the oracle."""

@@ -27,6 +27,21 @@ for method in (0, 1):
         assert all(r.status in (0, 5) for r in reps), [r.status for r in reps]
 for p in probs:
     p.close()
+# round 6: the context's block cache under churn (problems of several sizes created, solved and destroyed on ONE context, with a batch on
+# other contexts in between), the ragged-frame plan + sorted table (from 2 000 frames), a pinned pose array read and written in place
+churn = Context(0)
+for rnd in range(3):
+    for frames, model, ragged in ((120, "eucm", True), (2400, "eucm", True), (300, "kb4", False), (120, "eucm", True), (2100, "ucm", True)):
+        sp = synth.make_problem(frames, model, seed=20 + rnd, ragged=ragged)
+        p = Problem.from_synth(churn, sp)
+        a = p.solve(sp.intr0, sp.poses0, opts=default_opts(rnd % 2))
+        b = p.solve(sp.intr0, sp.poses0, opts=default_opts(rnd % 2), pinned=True)
+        assert a[3].status == 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], np.array(b[1]))
+        v = p.validation(0, a[0], a[1])
+        po, used = p.init_poses(sp.intr0)
+        assert v[0] > 0 and used.min() >= 0
+        p.close()
+churn.close()
 mc = MultiContext([0, 0, 0])
 for model, n_cams in (("eucm", 1), ("kb4", 2)):
     sp = synth.make_problem(45, model, n_cams=n_cams, seed=6, ragged=True)
