@@ -79,7 +79,7 @@ __device__ __forceinline__ bool chol_solve_reg(const double* S, double* x) {
 
 // What head_wave reads from global memory, one element per lane - requested ahead of whatever the caller does first (the
 // single-launch form: the sum over the previous launch's rows), so that the decision does not start with a memory round trip.
-struct HeadPre { ColInfo ci; double intr_a, intr_b, stw; };
+struct HeadPre { ColInfo ci; double intr_a, intr_b, stw; double redv[4]; };      // redv: this lane's entries of the reduced sums (k_head: they sit in global memory)
 __device__ __forceinline__ HeadPre head_prefetch(const HeadIO& a, const int lane) {
     HeadPre p;
     p.ci = ColInfo{}; p.intr_a = 0.0; p.intr_b = 0.0; p.stw = 0.0;
@@ -87,6 +87,10 @@ __device__ __forceinline__ HeadPre head_prefetch(const HeadIO& a, const int lane
     if (lane < CCAL_PMAX) { p.intr_a = a.intr[0][lane]; p.intr_b = a.intr[1][lane]; }
     static_assert(sizeof(DevState) / sizeof(double) <= 64, "one element of the state per lane");
     if (lane < (int)(sizeof(DevState) / sizeof(double))) p.stw = reinterpret_cast<const double*>(a.st_in)[lane];
+    // the (all-)reduced sums travel with the same round trip (they were requested after the state had arrived: a second one)
+    static_assert(fused_red_size(kFusedMaxK) <= 4 * 64, "four entries of the sums per lane");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p.redv[q] = (a.red_g && lane + 64 * q < fused_red_size(a.K)) ? a.red_g[lane + 64 * q] : 0.0;
     return p;
 }
 
@@ -107,7 +111,10 @@ __device__ __forceinline__ void head_wave(const HeadIO& a, HeadShared& hs, const
     {   // stage state + reduced sums
         double* dst = reinterpret_cast<double*>(&S0);
         if (lane < (int)(sizeof(DevState) / sizeof(double))) dst[lane] = pre.stw;
-        if (a.red_g) for (int e = lane; e < fused_red_size(K); e += 64) red[e] = a.red_g[e];
+        if (a.red_g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (lane + 64 * q < fused_red_size(K)) red[lane + 64 * q] = pre.redv[q];
+        }
         if (lane < K) hs.fx[lane] = ci.fixed;
         if (lane == 0) { hs.early_pub = 0; hs.entry_done = 0; }
     }
