@@ -95,6 +95,14 @@ private:
 // Which GPUs a call may use: one device (an int) or several ({0, 1, ..., 7}) - still ONE call of ONE process like the
 // reference's (src/util.rs:384-390); with several the library shards the frame slots and sums the reduced system once per
 // step (ccal_multi_*, include/ccal.h).  A device listed twice = two shards on that GPU.
+// The optimizer's options every entry point below solves with: GaussNewtonOptimizer::default() (src/util.rs:443,455) as ccal_set_defaults
+// restates it.  A host changes them once - e.g. `ccal::optimizer_options().error_metric = CCAL_ERROR_NORM;` if its tiny-solver's
+// compute_error is the norm rather than the squared norm ("Stop rule").
+inline ccal_solver_opts& optimizer_options() {
+    static ccal_solver_opts o = [] { ccal_solver_opts d; ccal_set_defaults(&d); return d; }();
+    return o;
+}
+
 struct Devices {
     std::vector<int> ids;
     Devices(int device = 0) : ids{device} {}
@@ -213,7 +221,7 @@ calib_camera(const std::vector<std::optional<FrameFeature>>& frame_feature_list,
     for (size_t fi : f.slots) { const auto v = initial_poses->at(fi).as6(); poses.insert(poses.end(), v.begin(), v.end()); }
     ccal_multi_apply_reference_bounds(p.h);                                         // src/util.rs:446
     ccal_multi_disable_distortions(p.h, (int)disabled_distortions, intr.data());    // src/util.rs:447-454
-    ccal_solver_opts o; ccal_set_defaults(&o);                                      // GaussNewtonOptimizer::default()
+    ccal_solver_opts o = optimizer_options();                                      // GaussNewtonOptimizer::default()
     ccal_report rep{};
     int rc = ccal_multi_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);   // :455 - one call, every listed GPU
     if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;        // result_option.as_ref()?
@@ -260,7 +268,7 @@ calib_all_camera_with_extrinsics(const std::vector<GenericModel>& cameras, const
     ccal_multi_apply_reference_bounds(p.h);
     ccal_multi_disable_distortions(p.h, (int)disabled_distortions, intr.data());
     if (cam0_fixed_focal) ccal_multi_fix_param(p.h, 0, 0);                           // :664-667
-    ccal_solver_opts o; ccal_set_defaults(&o);
+    ccal_solver_opts o = optimizer_options();
     ccal_report rep{};
     const int rc = ccal_multi_solve(p.h, &o, intr.data(), poses.data(), extr.data(), &rep);
     if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;
@@ -317,7 +325,7 @@ init_ucm(const FrameFeature& frame_feature0, const FrameFeature& frame_feature1,
         intr = detail::intr_matrix({ucm0});
         std::vector<double> poses;
         for (const RvecTvec* rt : {&rtvec0, &rtvec1}) { const auto v = rt->as6(); poses.insert(poses.end(), v.begin(), v.end()); }
-        ccal_solver_opts o; ccal_set_defaults(&o);
+        ccal_solver_opts o = optimizer_options();
         ccal_report rep{};
         const int rc = ccal_solve(p.h, &o, intr.data(), poses.data(), nullptr, &rep);
         if (rc != CCAL_OK && rc != CCAL_ERR_NO_CONVERGENCE) return std::nullopt;
