@@ -269,8 +269,10 @@ template <int K>
 __device__ __forceinline__ void iter_reduce_combine(const double (*v)[4], double* red, double (*sh)[(iter_row_len(K) + 63) / 64][64]) {
     constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, K1 = K + 1, NA = K1 * K1;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wv < 4) {                     // (workgroups of eight wavefronts - k_gram2i - sum with their first four, like everybody: the same order)
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) sh[wv][c][lane] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+        for (int c = 0; c < NCH; ++c) sh[wv][c][lane] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
     __syncthreads();
     if (wv == 0) {
 #pragma unroll
@@ -424,6 +426,10 @@ hipError_t launch_gram_iter_batch(int model, bool one_focal, int lpf, const Fuse
 hipError_t launch_gram1v_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);   // the same for camera 0 of the general loop
 // ccal_kernels_gram2.hip: a corner's two rows on two lanes (row-local columns), same records, same fused tail
 hipError_t launch_gram2(int model, bool one_focal, FusedArgs& a, hipStream_t s);
+// single-launch groups on the two-wavefronts-per-SIMD kernel (k_gram2i: UCM / EUCM, 2 000 .. ~10 000 frames): rows (= workgroups of eight
+// wavefronts) such a launch of this problem has, 0: the form does not apply; launch: a.it filled in as for launch_gram_iter
+int gram2_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K);
+hipError_t launch_gram2_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s);
 hipError_t launch_gram2_general(int model, bool one_focal, const FusedArgs& a, hipStream_t s);
 hipError_t launch_schur1m(FusedArgs& a, hipStream_t s);   // second library only (-DCCAL_LEGACY_KERNELS): the separate elimination launch; sets a.n_part
 hipError_t launch_reduce1(const FusedArgs& a, hipStream_t s);

@@ -1291,6 +1291,15 @@ hipError_t launch_gram_iter_batch(int model, bool one_focal, int lpf, const Fuse
 // the lane mapping a single-launch group of this problem takes (what launch_gram_iter dispatches on)
 int fused_iter_lpf(int n_obs, int avg_corners, int share) { return gram_lanes_per_frame(n_obs, avg_corners, 1024, (int64_t)1 << 40, share); }
 
+// CCAL_GRAM2_ITER=0 (second library) / -DCCAL_NO_GRAM2_ITER (A/B builds): k_gram1v's single-launch form at every size
+static bool use_gram2_iter(bool batch, int share) {
+#ifdef CCAL_NO_GRAM2_ITER
+    return false;
+#else
+    static const bool on = dev_env_int("CCAL_GRAM2_ITER", 1) != 0 && dev_env_int("CCAL_ITER_ROWS", 256) > 0;      // (CCAL_ITER_ROWS=0: no single-launch groups at all)
+    return on && !batch && share <= 1;
+#endif
+}
 int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K, int share, bool batch) {
     if (K != block_dim(model, one_focal, false) - 6) return 0;      // (the kernel's compile-time column count is the problem's)
     // OPENCV5 alone: k_gram2 (fewer AGPR copies) + reduce + head stays ahead - 625 frames GN 0.132 ms against 0.139 in the single-launch
@@ -1298,9 +1307,13 @@ int fused_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K
     // for the whole batch beats n x three).  The second library's CCAL_ITER_OCV5=1 forces the single-launch form.
     static const bool ocv5 = dev_env_int("CCAL_ITER_OCV5", 0) == 1;
     if (model == kOCV5 && !ocv5 && !batch) return 0;
+    // UCM / EUCM from 2 000 frames, a problem that has the GPU to itself: the single-launch form of the two-wavefronts-per-SIMD kernel
+    // (k_gram2i, ccal_kernels_gram2.hip) - 10 000 frames: ~30 us per group against 36 with k_gram1v's 1 000 one-per-SIMD wavefronts
+    if (use_gram2_iter(batch, share)) { const int r = gram2_iter_rows(model, one_focal, n_obs, avg_corners, K); if (r > 0) return r; }
     return iter_rows_m(model, one_focal, n_obs, avg_corners, share, false, nullptr, nullptr, nullptr);
 }
 hipError_t launch_gram_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
+    if (use_gram2_iter(false, a.share) && gram2_iter_rows(model, one_focal, a.n_obs, a.avg_corners, a.K) > 0) return launch_gram2_iter(model, one_focal, a, s);
     hipError_t err = hipErrorInvalidValue;
     const int rows = iter_rows_m(model, one_focal, a.n_obs, a.avg_corners, a.share, true, &a, s, &err);
     return rows > 0 ? err : hipErrorInvalidValue;

@@ -20,7 +20,7 @@
 //   UCM / EUCM: two wavefronts per SIMD (226 registers); KB4 / OPENCV5: one (296 / 322 registers, 30 / 65 AGPR copies per pass).
 #include <algorithm>
 
-#include "ccal_gram_common.hpp"
+#include "ccal_head.hpp"
 
 namespace ccal {
 
@@ -224,10 +224,17 @@ __device__ __forceinline__ double g2_from_partner(double v) {
 // ONE 16-byte load instead of the offsets' and the slot table's).  The per-frame buffers of the loop (records, model decrease, cost)
 // are then indexed by POSITION in that table - they never leave the single-camera kernels -, poses and elimination records by slot
 // as ever; a wavefront's row of partial sums is its number in the launch, so the rows are added in the same order every time.
-template <int MODEL, bool OF, int LPF, bool GEN, bool BIN>
+// ITER (k_gram2i; single-camera loop, 2 000 .. ~10 000 frames of UCM / EUCM): a whole group in ONE launch, as k_gram1v<.., ITER> does for
+// session sizes (ccal_kernels_fused.hip) - workgroups of EIGHT wavefronts (two per SIMD: one workgroup per compute unit, <= 256 of them);
+// in front of the evaluation every workgroup sums the previous launch's rows, its first wavefront decides and solves the camera
+// system (head_wave: the same arithmetic on the same sums in every workgroup, workgroup 0 writes), the evaluation takes state, camera
+// step and candidate intrinsics from LDS, and behind it the eight wavefronts' rows are added in LDS and leave as ONE packed row.
+template <int MODEL, bool OF, int LPF, bool GEN, bool BIN, bool ITER = false>
 __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, const int wg, const int frame0, const int nfr) {
     static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 pairs of a u lane and a v lane");
     static_assert(!(GEN && BIN), "bins: the single-camera loop");
+    static_assert(!(ITER && (GEN || BIN)), "single-launch groups: the single-camera loop, frames in table order");
+    constexpr int WPB = ITER ? 8 : CCAL_GRAMV_WPB;
     constexpr int NS = g2_slices<MODEL>();
     using Map = RowMap<MODEL, OF, GEN, NS>;
     static_assert(Map().ok, "accumulator numbering: a slice splits a mirrored pair");
@@ -242,7 +249,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     constexpr int REC_ = praw_jl_off(K) + 9, GS_ = (REC_ + 6 * K1 + 1) & ~1;
     constexpr int RED = (!GEN && G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
     constexpr int WSL = (G * FCS + RED + NEF + 1) & ~1;        // per wave: G frames' constants | reduction buffer / records | item table
-    const DevState* st = a.st;
+    static_assert(!ITER || fused_red_size(K) <= G * FCS, "a wavefront's row of partial sums is parked where its frames' constants were");
     const bool fuse = !GEN && a.fuse_elim != 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // frame g: lanes [g LPF, (g + 1) LPF); even lanes take the u rows, odd lanes the v rows; gl = the lane's index within its frame
@@ -252,8 +259,8 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     const int gl = lane_ok ? lane - grp * LPF : (lane & 1);
     G2_STAMPS_DECL;
     G2_STAMP(0);
-    const int wrow = blockIdx.x * CCAL_GRAMV_WPB + wave;          // the wavefront's number in the launch: its row of partial sums
-    const int fpos = (wg * CCAL_GRAMV_WPB + wave) * G + grp;       // the frame's position among the nfr frames this launch / bin works on
+    const int wrow = blockIdx.x * WPB + wave;                     // the wavefront's number in the launch: its row of partial sums
+    const int fpos = (wg * WPB + wave) * G + grp;                  // the frame's position among the nfr frames this launch / bin works on
     const bool active = lane_ok && fpos < nfr;
     const int f = frame0 + (active ? fpos : 0);                    // index of the loop's per-frame buffers (BIN: the position in the sorted table)
     int4 btab = make_int4(0, 0, 0, 0);
@@ -294,19 +301,100 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
         const int th_off = (GEN && a.obs_cam) ? camf * CCAL_PMAX : 0;
         load_theta<MODEL, OF>(a.intr[0] + th_off, a.rt, th_b[0]);
         load_theta<MODEL, OF>(a.intr[1] + th_off, a.rt, th_b[1]);
+        // (ITER, the solve's first launch as its own k_unpack1: the starting pose from where the caller left it - pinned host memory, or set 0)
+        const bool fold_src = ITER && a.it.skip_head != 0 && a.it.fold != 0;
+        const double* ps0 = fold_src ? (a.it.poses_on_device ? a.poses[0] : a.it.poses_src) : a.poses[0];
+        const double* ps1 = fold_src ? ps0 : a.poses[1];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { pose_b[0][i] = a.poses[0][(int64_t)slot_e * 6 + i]; pose_b[1][i] = a.poses[1][(int64_t)slot_e * 6 + i]; }
+        for (int i = 0; i < 6; ++i) { pose_b[0][i] = ps0[(int64_t)slot_e * 6 + i]; pose_b[1][i] = ps1[(int64_t)slot_e * 6 + i]; }
         if constexpr (GEN) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) { ex_b[0][i] = camf > 0 ? a.extr[0][camf * 6 + i] : 0.0; ex_b[1][i] = camf > 0 ? a.extr[1][camf * 6 + i] : 0.0; }
         }
     }
-    const bool keep_rec = GEN || !fuse || st->method == CCAL_METHOD_LM;
-    if (st->done || (st->redo && !fuse)) return;
-    const int cur = st->cur, first = st->first;
+    // what the evaluation needs of the optimizer state, in registers (ITER: this launch decides itself - LDS; else global memory)
+    struct { int done, redo, cur, first, method; double lambda_solve, lam_schur; } g;
+    constexpr int PROW = ITER ? iter_row_len(K) : 1;
+    __shared__ typename std::conditional<ITER, HeadShared, int>::type hsh;
+    bool from_lds = false, fold_first = false;
+    if constexpr (ITER) {
+        const IterArgs& it = a.it;
+        fold_first = it.skip_head != 0 && it.fold != 0;
+        if (!it.skip_head) {
+            HeadIO io;
+            io.st_in = it.st_in; io.st_out = it.st_out; io.hs = it.hs; io.red_g = nullptr; io.cols = it.cols;
+            io.intr[0] = a.intr[0]; io.intr[1] = a.intr[1]; io.dc = it.dc_out; io.K = K; io.seq = it.seq;
+            io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = it.publish_all;
+            HeadPre hpre = {};
+            if (threadIdx.x < 64) hpre = head_prefetch(io, (int)threadIdx.x);
+            __shared__ double shr[4][(PROW + 63) / 64][64];
+            double vsum[(PROW + 63) / 64][4];
+            iter_reduce_load<K>(it.partial_in, it.n_part_in, vsum);           // (wavefronts 4 .. 7 find no rows of theirs: zeros)
+            iter_reduce_combine<K>(vsum, hsh.red, shr);
+            const bool writer = blockIdx.x == 0;
+            if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer, hpre);
+            __syncthreads();
+            head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer);
+            from_lds = true;
+            const DevState& S = hsh.S0;
+            g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;
+            g.lambda_solve = S.lambda_solve; g.lam_schur = schur_lambda(&S);
+        } else if (fold_first) {
+            // the solve's first launch AND its k_unpack1: state, columns and intrinsics from the argument block
+            constexpr int NSW = (int)(sizeof(DevState) / sizeof(double)), NC1 = (int)(sizeof(ColInfo) / sizeof(double));
+            if (threadIdx.x < CCAL_PMAX) hsh.cand[threadIdx.x] = it.poses_on_device ? a.intr[0][threadIdx.x] : reinterpret_cast<const double*>(it.intr_h)[threadIdx.x];
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                for (int e = threadIdx.x; e < NSW; e += 64) reinterpret_cast<double*>(it.st_out)[e] = reinterpret_cast<const double*>(&it.st0)[e];
+                for (int e = threadIdx.x; e < it.n_cols * NC1; e += 64) reinterpret_cast<double*>(it.cols_out)[e] = reinterpret_cast<const double*>(it.col0)[e];
+                if (threadIdx.x < CCAL_PMAX) {
+                    const double v = it.poses_on_device ? a.intr[0][threadIdx.x] : reinterpret_cast<const double*>(it.intr_h)[threadIdx.x];
+                    if (!it.poses_on_device) a.intr[0][threadIdx.x] = v;
+                    a.intr[1][threadIdx.x] = v;
+                }
+                if (threadIdx.x == 0) it.hs->word = status_word(it.seq, 0, 0);
+            }
+            __syncthreads();
+            from_lds = true;                       // (the intrinsics: hsh.cand; the camera step is not read in a first evaluation)
+            const DevState& S = it.st0;
+            g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;
+            g.lambda_solve = S.lambda_solve; g.lam_schur = schur_lambda(&S);
+        } else {
+            // the solve's first launch: the starting state passes through to the buffer the next launch reads
+            if (blockIdx.x == 0 && threadIdx.x < 64) {
+                const double* src = reinterpret_cast<const double*>(it.st_in);
+                double* dst = reinterpret_cast<double*>(it.st_out);
+                for (int e = threadIdx.x; e < (int)(sizeof(DevState) / sizeof(double)); e += 64) dst[e] = src[e];
+                if (threadIdx.x == 0) it.hs->word = status_word(it.seq, 0, 0);
+            }
+            const DevState* st = it.st_in;
+            g.done = st->done; g.redo = st->redo; g.cur = st->cur; g.first = st->first; g.method = st->method;
+            g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
+        }
+    } else {
+        const DevState* st = a.st;
+        g.done = st->done; g.redo = st->redo; g.cur = st->cur; g.first = st->first; g.method = st->method;
+        g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
+    }
+    // ITER: the eight wavefronts' rows (parked where their frames' constants were) -> the workgroup's row, fixed order, the two symmetric
+    // blocks as their upper triangles
+    auto iter_row_out = [&]() {
+        if constexpr (ITER) {
+            __syncthreads();
+            if (threadIdx.x < 64) for (int pe = threadIdx.x; pe < PROW; pe += 64) {
+                const int e = iter_row_src(K, pe);
+                double t = smem[e];
+#pragma unroll
+                for (int w = 1; w < WPB; ++w) t += smem[w * WSL + e];
+                a.partial[(int64_t)blockIdx.x * PROW + pe] = t;
+            }
+        }
+    };
+    const bool keep_rec = GEN || !fuse || g.method == CCAL_METHOD_LM;
+    if (g.done || (g.redo && !fuse)) return;
+    const int cur = g.cur, first = g.first;
     const int es = first ? cur : (cur ^ 1);
     if constexpr (!GEN) {
-        if (st->redo) {
+        if (g.redo) {
             // re-elimination group (LM: rejected step or missed speculation): the accepted set's stored records, new damping
             double* R = red + grp * GS_;
             double mcv = 0.0;
@@ -318,7 +406,8 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
                 if (gl == 0) mcv = a.mc_f[f];
             }
             wsync();
-            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
+            gram_fused_tail<K, LPF>(a, g.lam_schur, red, ITER ? fcw : a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
+            iter_row_out();
             return;
         }
     }
@@ -326,6 +415,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     double th[th_len<MODEL>()];
 #pragma unroll
     for (int i = 0; i < th_len<MODEL>(); ++i) th[i] = es ? th_b[1][i] : th_b[0][i];
+    if constexpr (ITER) { if (from_lds) load_theta<MODEL, OF>(hsh.cand, a.rt, th); }      // the candidate this launch has just formed (or, fold, the start)
     G2_PRO(0, th[0] + (double)first);
     // the lane's view of the intrinsics: MINE = the row it accumulates (u lanes: fx, cx; v lanes: fy, cy), OTHER = the row it
     // forms for its partner; the v lanes see the distortion in mirrored coordinates (OPENCV5: p1 and p2 exchanged)
@@ -359,7 +449,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
         for (int i = 0; i < 6; ++i) pose[i] = pset ? pose_b[1][i] : pose_b[0][i];
         if constexpr (GEN) {
             if (gbs) {
-                const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, st->lambda_solve, pose, red, grp, gl, lane_ok);
+                const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, g.lambda_solve, pose, red, grp, gl, lane_ok);
                 if (active && a.g_owner[fa_]) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
@@ -368,6 +458,8 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             }
         }
         double mc = 0.0;
+        const double* dcv = a.dc;                    // the camera step: ITER - this launch's own solve, in LDS
+        if constexpr (ITER) { if (from_lds) dcv = hsh.x; }
         if (!GEN && !first) {
             const double* pf = a.pf[cur] + (int64_t)slot * a.PF;
             if (pf[0] != 0.0) {
@@ -377,7 +469,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
                     const double* yr = pf + 21 + i * K1;
                     double t = yr[K];
 #pragma unroll
-                    for (int j = 0; j < K; ++j) t += yr[j] * a.dc[j];
+                    for (int j = 0; j < K; ++j) t += yr[j] * dcv[j];
                     dp[i] = -t;
                 }
 #pragma unroll
@@ -387,7 +479,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
                     for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
                     dp[i] = t * pf[i * (i + 1) / 2 + i];
                 }
-                const double lam = st->lambda_solve;
+                const double lam = g.lambda_solve;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
@@ -399,6 +491,12 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             if (active) {
 #pragma unroll
                 for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
+            }
+        }
+        if constexpr (ITER) {
+            if (fold_first && active) {            // k_unpack1's part of this frame: the starting pose into the parameter sets
+#pragma unroll
+                for (int i = 0; i < 6; ++i) if (gl == i) { if (!a.it.poses_on_device) a.poses[0][(int64_t)slot * 6 + i] = pose[i]; a.poses[1][(int64_t)slot * 6 + i] = pose[i]; }
             }
         }
         if (!GEN && active && gl == 0) a.mc_f[f] = mc;
@@ -620,7 +718,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     }
 
     G2_STAMP(2);
-    const int pbase = (wg * CCAL_GRAMV_WPB + wave) * G;              // first of the wavefront's frames among the launch's / the bin's
+    const int pbase = (wg * WPB + wave) * G;              // first of the wavefront's frames among the launch's / the bin's
     // fused elimination: what its tail needs from memory is requested now, behind the reductions
     int slot_t = 0;
     double mc_t = 0.0;
@@ -704,7 +802,8 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
         if (fuse) {
             if (keep_rec) wsync();                                     // the tail reuses the records' rows
             G2_STAMP(4);
-            gram_fused_tail<K, LPF>(a, schur_lambda(st), red, a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
+            gram_fused_tail<K, LPF>(a, g.lam_schur, red, ITER ? fcw : a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
+            iter_row_out();
         }
     }
     G2_STAMP(5);
@@ -715,6 +814,15 @@ template <int MODEL, bool OF, int LPF, bool GEN>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     gram2_body<MODEL, OF, LPF, GEN, false>(a, smem, blockIdx.x, 0, a.n_obs);
+}
+// Single-launch groups (ITER, see gram2_body): eight wavefronts per workgroup, one workgroup per compute unit.
+template <int MODEL, bool OF, int LPF>
+__global__ __launch_bounds__(64 * 8, CCAL_G2_MINW(MODEL)) void k_gram2i(const FusedArgs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    // (the argument block where it lies - the kernarg segment -, not the by-value parameter: the unpack branch indexes it at run time,
+    //  which would make the compiler copy all of it into scratch; k_gram1v, ccal_kernels_fused.hip)
+    const FusedArgs& a = *(const FusedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    gram2_body<MODEL, OF, LPF, false, false, true>(a, smem, blockIdx.x, 0, a.n_obs);
 }
 // Ragged frames (real sessions hold 24 .. 144 corners per frame, /root/reference/src/data_loader.rs:15): ONE launch whose workgroups
 // belong to bins of frames with different lanes per frame (gram2_bin_plan), so that a wavefront's trip count is what ITS frames need
@@ -767,6 +875,8 @@ template __global__ void k_gram2<kOCV5, false, 12, false>(const FusedArgs);
 template __global__ void k_gram2<kOCV5, true, 12, true>(const FusedArgs);
 template __global__ void k_gram2b<kEUCM, false>(const FusedArgs);
 template __global__ void k_gram2b<kKB4, false>(const FusedArgs);
+template __global__ void k_gram2i<kEUCM, false, 12>(const FusedArgs);
+template __global__ void k_gram2i<kEUCM, false, 16>(const FusedArgs);
 }  // namespace ccal
 #else
 template <int MODEL, bool OF, int LPF, bool GEN>
@@ -964,6 +1074,71 @@ static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
         default: return launch_gram2_l<MODEL, OF, 64, GEN>(a, s);
     }
 }
+// ---- single-launch groups on k_gram2i ------------------------------------------------------------------------------------------
+// Where it applies: UCM / EUCM (two wavefronts of 256 registers per SIMD), 2 000 frames and more, all wavefronts resident at once
+// (<= 2 048) in <= 256 workgroups of eight, 12 or 16 lanes per frame (the narrower mappings' frames' constants do not leave room for
+// eight wavefronts' LDS beside the decision's).  10 000 frames: 250 workgroups of eight 12-lane wavefronts.
+constexpr int kG2IterWpb = 8;
+template <int MODEL, bool OF, int LPF>
+static constexpr size_t g2_iter_lds() {
+    constexpr int NS = g2_slices<MODEL>();
+    using Map = RowMap<MODEL, OF, false, NS>;
+    constexpr int G = 64 / LPF, K = block_dim(MODEL, OF, false) - 6, K1 = K + 1;
+    constexpr int LS = Map::CH | 1, GS_ = (praw_jl_off(K) + 9 + 6 * K1 + 1) & ~1;
+    constexpr int RED = (G * GS_ > 64 * LS) ? G * GS_ : 64 * LS;
+    constexpr int WSL = (G * (FC_N0P + 12) + RED + Map::NEF + 1) & ~1;
+    return sizeof(double) * WSL * kG2IterWpb;
+}
+template <int MODEL, bool OF>
+static constexpr size_t g2_iter_static_lds() { return sizeof(HeadShared) + 4 * 2 * 64 * 8 + 512; }      // decision + the row sum's 4 x 2 x 64 + alignment
+static int g2_iter_lpf(int n_obs, int avg_corners) {
+    int best = 0;
+    double best_cost = 1e300;
+    for (int lpf : { 16, 12 }) {
+        const int g = 64 / lpf;
+        const int64_t waves = ((int64_t)n_obs + g - 1) / g;
+        if (waves > 2048 || (waves + kG2IterWpb - 1) / kG2IterWpb > 256) continue;
+        const double nw = (double)waves / 1024.0;
+        const double occ = nw <= 1.0 ? 1.0 : 1.0 + 0.3 * (nw - 1.0);
+        const double cost = occ * (6.0 + (std::max(avg_corners, 1) + lpf - 1) / lpf);
+        if (cost < best_cost) { best_cost = cost; best = lpf; }
+    }
+    return best;
+}
+template <int MODEL, bool OF>
+static int g2_iter_rows_t(int n_obs, int avg_corners, FusedArgs* a, hipStream_t s, hipError_t* err) {
+    const int lpf = g2_iter_lpf(n_obs, avg_corners);
+    if (!lpf) return 0;
+    const int g = 64 / lpf, rows = (int)((((int64_t)n_obs + g - 1) / g + kG2IterWpb - 1) / kG2IterWpb);
+    const size_t lds = lpf == 12 ? g2_iter_lds<MODEL, OF, 12>() : g2_iter_lds<MODEL, OF, 16>();
+    if (lds + g2_iter_static_lds<MODEL, OF>() > 160 * 1024) return 0;
+    if (a) {
+        void (*kern)(const FusedArgs) = lpf == 12 ? k_gram2i<MODEL, OF, 12> : k_gram2i<MODEL, OF, 16>;
+        static DynLdsGuard guard12, guard16;
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lpf == 12 ? guard12 : guard16); e != hipSuccess) { *err = e; return rows; }
+        a->fuse_elim = 1; a->elim_fused = 1; a->n_part = rows;
+        hipLaunchKernelGGL(kern, dim3(rows), dim3(64 * kG2IterWpb), lds, s, *a);
+        *err = hipGetLastError();
+    }
+    return rows;
+}
+static int g2_iter_rows_m(int model, bool one_focal, int n_obs, int avg_corners, int K, FusedArgs* a, hipStream_t s, hipError_t* err) {
+    if (n_obs < 2000 || K != block_dim(model, one_focal, false) - 6) return 0;
+    switch (model * 2 + (one_focal ? 1 : 0)) {
+        case 0: return g2_iter_rows_t<kUCM, false>(n_obs, avg_corners, a, s, err);
+        case 1: return g2_iter_rows_t<kUCM, true>(n_obs, avg_corners, a, s, err);
+        case 2: return g2_iter_rows_t<kEUCM, false>(n_obs, avg_corners, a, s, err);
+        case 3: return g2_iter_rows_t<kEUCM, true>(n_obs, avg_corners, a, s, err);
+        default: return 0;                                 // KB4 / OPENCV5: one wavefront per SIMD - k_gram1v's single-launch form
+    }
+}
+int gram2_iter_rows(int model, bool one_focal, int n_obs, int avg_corners, int K) { return g2_iter_rows_m(model, one_focal, n_obs, avg_corners, K, nullptr, nullptr, nullptr); }
+hipError_t launch_gram2_iter(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
+    hipError_t err = hipErrorInvalidValue;
+    const int rows = g2_iter_rows_m(model, one_focal, a.n_obs, a.avg_corners, a.K, &a, s, &err);
+    return rows > 0 ? err : hipErrorInvalidValue;
+}
+
 template <bool GEN>
 static hipError_t launch_gram2_m(int model, bool one_focal, FusedArgs& a, hipStream_t s) {
     switch (model * 2 + (one_focal ? 1 : 0)) {
