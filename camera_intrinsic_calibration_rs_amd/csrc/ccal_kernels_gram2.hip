@@ -1075,9 +1075,11 @@ static hipError_t launch_gram2_t(FusedArgs& a, hipStream_t s) {
     }
 }
 // ---- single-launch groups on k_gram2i ------------------------------------------------------------------------------------------
-// Where it applies: UCM / EUCM (two wavefronts of 256 registers per SIMD), 2 000 frames and more, all wavefronts resident at once
-// (<= 2 048) in <= 256 workgroups of eight, 12 or 16 lanes per frame (the narrower mappings' frames' constants do not leave room for
-// eight wavefronts' LDS beside the decision's).  10 000 frames: 250 workgroups of eight 12-lane wavefronts.
+// Where it applies: UCM / EUCM (two wavefronts of 256 registers per SIMD), all wavefronts resident at once (<= 2 048) in <= 256
+// workgroups of eight 12-lane wavefronts - and at least 224 of them: a workgroup of eight wavefronts takes a whole compute unit, so
+// the form only pays where the launch fills the chip (profiles/r06/ab_g2_single_launch_groups.txt, GN with host pointers against
+// k_gram1v's single-launch form: 10 000 frames 0.237 against 0.253 ms, 8 000 - 16 lanes - 0.212 = 0.211, 5 000: 0.188 against 0.180,
+// 2 500: 0.168 against 0.147).  10 000 frames: 250 workgroups; the window is 8 960 .. 10 240 frames.
 constexpr int kG2IterWpb = 8;
 template <int MODEL, bool OF, int LPF>
 static constexpr size_t g2_iter_lds() {
@@ -1094,10 +1096,10 @@ static constexpr size_t g2_iter_static_lds() { return sizeof(HeadShared) + 4 * 2
 static int g2_iter_lpf(int n_obs, int avg_corners) {
     int best = 0;
     double best_cost = 1e300;
-    for (int lpf : { 16, 12 }) {
+    for (int lpf : { 12 }) {
         const int g = 64 / lpf;
-        const int64_t waves = ((int64_t)n_obs + g - 1) / g;
-        if (waves > 2048 || (waves + kG2IterWpb - 1) / kG2IterWpb > 256) continue;
+        const int64_t waves = ((int64_t)n_obs + g - 1) / g, wgs = (waves + kG2IterWpb - 1) / kG2IterWpb;
+        if (waves > 2048 || wgs > 256 || wgs < 224) continue;
         const double nw = (double)waves / 1024.0;
         const double occ = nw <= 1.0 ? 1.0 : 1.0 + 0.3 * (nw - 1.0);
         const double cost = occ * (6.0 + (std::max(avg_corners, 1) + lpf - 1) / lpf);

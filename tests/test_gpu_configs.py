@@ -179,6 +179,35 @@ def test_ragged_solve_against_the_oracle(gpu_ctx, oracle, model, method):
     gp.close()
 
 
+@pytest.mark.parametrize("model,one_focal", [("eucm", False), ("ucm", True)])
+@pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
+def test_headline_size_solve_against_the_oracle(gpu_ctx, oracle, model, one_focal, method):
+    """9 800 frames x 144 corners: the size at which the single-camera solve runs single-launch groups of the two-wavefronts-per-SIMD
+    kernel (k_gram2i: 245 workgroups of eight wavefronts) - same iteration count, accept / reject sequence and optimum as the oracle,
+    host pointers and device-resident."""
+    sp = synth.make_problem(9800, model, xy_same_focal=one_focal, outlier_frac=0.01, seed=0x9800)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    oracle.set_solve_threads(8)
+    try:
+        intr_o, poses_o, _, rep_o = op.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+    finally:
+        oracle.set_solve_threads(1)
+    intr, poses, _, rep = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
+    assert rep.status == rep_o.status == 0
+    assert (rep.iterations, rep.lm_accepted, rep.lm_rejected) == (rep_o.iterations, rep_o.lm_accepted, rep_o.lm_rejected)
+    assert abs(rep.final_cost - rep_o.final_cost) <= 1e-9 * rep_o.final_cost
+    P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+    assert (np.abs(intr[0, :P] - intr_o[0, :P]) / np.maximum(np.abs(intr_o[0, :P]), 1e-3)).max() <= 1e-6
+    np.testing.assert_allclose(poses, poses_o, rtol=0, atol=1e-7)
+    gp.upload_params(sp.intr0, sp.poses0, sp.extr0)
+    rd = gp.solve_dev(default_opts(method))
+    i_d, p_d, _ = gp.download_params()
+    assert (rd.status, rd.iterations) == (rep.status, rep.iterations)
+    np.testing.assert_array_equal(i_d[0, :P], intr[0, :P]); np.testing.assert_array_equal(p_d, poses)
+    gp.close()
+
+
 @pytest.mark.parametrize("models", [("eucm", "eucm"), ("kb4", "eucm")])
 def test_ragged_rig_binned_gram_launches(gpu_ctx, oracle, models):
     """A two-camera rig of 2 x 2 600 ragged observation frames: cameras of one model share ONE Gram launch whose list is sorted by corner

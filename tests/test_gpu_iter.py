@@ -28,6 +28,9 @@ CASES = [
     (350, "kb4", False, True, 0.03, None, False, 21),
     (1100, "eucm", True, True, 0.01, None, False, 31),           # two frames per wavefront
     (2300, "ucm", False, False, 0.0, None, False, 32),           # narrower lane mappings
+    (9600, "eucm", False, False, 0.01, None, False, 41),         # k_gram2i: the single-launch form of the two-wavefronts-per-SIMD kernel (8 960 .. 10 240 frames)
+    (9100, "ucm", True, True, 0.02, None, True, 42),             #   ... one focal, ragged frames, bounds
+    (9000, "eucm", False, True, 0.05, 0.8, False, 43),           #   ... LM from a bad start: rejected steps, re-elimination groups
 ]
 
 
