@@ -28,6 +28,8 @@ def _device_sets():
         n = 1
     if n >= 2:
         sets.append((f"rccl{min(n, 8)}", list(range(min(n, 8)))))
+        # the in-process transport over REAL devices (peer access: the deciding kernels read the peers' sums over xGMI), asked for by name
+        sets.append((f"inproc_peer{min(n, 8)}", list(range(min(n, 8))), "inproc"))
     return sets
 
 
@@ -46,13 +48,14 @@ def _problem(scenario, model, n_cams):
     return synth.make_problem(41, model, n_cams=n_cams, outlier_frac=0.01, ragged=True)
 
 
-def _child_multi(q, devices, cases):
+def _child_multi(q, devices, cases, transport=None):
     """One fresh process, one device set, several problems: [(scenario, model, n_cams, method, one_focal), ...]."""
     sys.path.insert(0, ROOT)
     import dataclasses
+    from camera_intrinsic_calibration_rs_amd import _ffi
     from camera_intrinsic_calibration_rs_amd.engine import Context, MultiContext, MultiProblem, Problem, default_opts
     ctx = Context(0)
-    mc = MultiContext(devices)
+    mc = MultiContext(devices, transport=_ffi.TRANSPORT_INPROC if transport == "inproc" else None)
     results = []
     for scenario, model, n_cams, method, one_focal in cases:
         sp = _problem(scenario, model, n_cams)
@@ -139,8 +142,8 @@ HARD = [("lm_rejections", "eucm", 1, 1, False), ("lm_rejections", "eucm", 2, 1, 
 @pytest.mark.parametrize("devset", _device_sets(), ids=lambda d: d[0])
 def test_multi_solve_equals_the_unsharded_solve(devset):
     from camera_intrinsic_calibration_rs_amd import _ffi
-    name, devices = devset
-    results = _run_child(_child_multi, (devices, PLAIN), timeout=420)
+    name, devices = devset[0], devset[1]
+    results = _run_child(_child_multi, (devices, PLAIN, devset[2] if len(devset) > 2 else None), timeout=420)
     for case, res in zip(PLAIN, results):
         try:
             _check_against_single(res, res["n_slots"], _ffi.TRANSPORT_RCCL if name.startswith("rccl") else _ffi.TRANSPORT_INPROC, case[3])
@@ -154,8 +157,8 @@ def test_multi_solve_hard_cases(devset):
     """LM with rejected steps; a pose block that is singular on ONE shard (Gauss-Newton: NOT_PD for the whole solve, LM freezes
     it); shards without a single slot - same verdict, iteration count and accept / reject sequence as the unsharded solve."""
     from camera_intrinsic_calibration_rs_amd import _ffi
-    name, devices = devset
-    results = _run_child(_child_multi, (devices, HARD), timeout=420)
+    name, devices = devset[0], devset[1]
+    results = _run_child(_child_multi, (devices, HARD, devset[2] if len(devset) > 2 else None), timeout=420)
     for case, res in zip(HARD, results):
         scenario, _, n_cams, method, _ = case
         try:
