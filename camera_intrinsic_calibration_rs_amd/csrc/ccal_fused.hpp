@@ -241,12 +241,11 @@ __host__ __device__ inline int iter_row_src(int K, int pe) {
 // Two halves, so that the caller can put loads of its own between them (issued while these sums' loads are in flight, consumed
 // after the decision): iter_reduce_load = this wavefront's quarter of the rows into four accumulators per 64 packed entries;
 // iter_reduce_combine = the four wavefronts' sums through LDS (two workgroup barriers).
-// NW wavefronts of the workgroup share the rows (4: k_gram1v's workgroups; 8: k_gram2i's - 250 rows are then ONE batch of loads per wavefront)
-template <int K, int NW = 4>
+template <int K>
 __device__ __forceinline__ void iter_reduce_load(const double* partial, const int n_rows, double (*v)[4]) {
     constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, B = NCH == 1 ? 48 : 24;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per = (n_rows + NW - 1) / NW, r0 = wv * per, r1 = min(n_rows, r0 + per);
+    const int per = (n_rows + 3) >> 2, r0 = wv * per, r1 = min(n_rows, r0 + per);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { v[c][0] = 0.0; v[c][1] = 0.0; v[c][2] = 0.0; v[c][3] = 0.0; }
     for (int r = r0; r < r1; r += B) {
@@ -266,12 +265,11 @@ __device__ __forceinline__ void iter_reduce_load(const double* partial, const in
         }
     }
 }
-template <int K, int NW = 4>
+template <int K>
 __device__ __forceinline__ void iter_reduce_combine(const double (*v)[4], double* red, double (*sh)[(iter_row_len(K) + 63) / 64][64]) {
     constexpr int PROW = iter_row_len(K), NCH = (PROW + 63) / 64, K1 = K + 1, NA = K1 * K1;
-    static_assert(NW == 4 || NW == 8, "workgroups of four or eight wavefronts");
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wv < NW) {
+    if (wv < 4) {                     // (workgroups of eight wavefronts - k_gram2i - sum with their first four, like everybody: the same order)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) sh[wv][c][lane] = (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
     }
@@ -281,8 +279,7 @@ __device__ __forceinline__ void iter_reduce_combine(const double (*v)[4], double
         for (int c = 0; c < NCH; ++c) {
             const int pe = c * 64 + lane;
             if (pe < PROW) {
-                double sum = (sh[0][c][lane] + sh[1][c][lane]) + (sh[2][c][lane] + sh[3][c][lane]);
-                if constexpr (NW == 8) sum += (sh[4][c][lane] + sh[5][c][lane]) + (sh[6][c][lane] + sh[7][c][lane]);
+                const double sum = (sh[0][c][lane] + sh[1][c][lane]) + (sh[2][c][lane] + sh[3][c][lane]);
                 const int e = iter_row_src(K, pe);
                 red[e] = sum;
                 if (e < 2 * NA) {                      // the mirrored entry

@@ -312,19 +312,6 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             for (int i = 0; i < 6; ++i) { ex_b[0][i] = camf > 0 ? a.extr[0][camf * 6 + i] : 0.0; ex_b[1][i] = camf > 0 ? a.extr[1][camf * 6 + i] : 0.0; }
         }
     }
-    // ... and the frame's first corner rows (they were requested behind the state - and, ITER, behind the whole decision: the
-    // compiler does not move loads across the early exits)
-    const int64_t start = start_e;
-    const int n = active ? (int)(end_e - start) : 0;
-    // corner rows by 32-bit byte offsets from the (wave-uniform) stream pointers: no 64-bit address arithmetic per load
-    // (ccal_problem_create refuses more than 2^30 - 1 corners per problem)
-    auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
-    const uint32_t ob0 = (uint32_t)start * 4u;
-    float pX, pY, pZ, pU, pV;
-    {
-        const uint32_t g0 = ob0 + 4u * (uint32_t)(gl < n ? gl : 0);
-        pX = ldf(a.x, g0); pY = ldf(a.y, g0); pZ = ldf(a.z, g0); pU = ldf(a.u, g0); pV = ldf(a.v, g0);
-    }
     // what the evaluation needs of the optimizer state, in registers (ITER: this launch decides itself - LDS; else global memory)
     struct { int done, redo, cur, first, method; double lambda_solve, lam_schur; } g;
     constexpr int PROW = ITER ? iter_row_len(K) : 1;
@@ -340,10 +327,10 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             io.min_diag = a.min_diag; io.max_diag = a.max_diag; io.publish_all = it.publish_all;
             HeadPre hpre = {};
             if (threadIdx.x < 64) hpre = head_prefetch(io, (int)threadIdx.x);
-            __shared__ double shr[WPB][(PROW + 63) / 64][64];
+            __shared__ double shr[4][(PROW + 63) / 64][64];
             double vsum[(PROW + 63) / 64][4];
-            iter_reduce_load<K, WPB>(it.partial_in, it.n_part_in, vsum);      // (all eight wavefronts: 250 rows = one batch of loads each)
-            iter_reduce_combine<K, WPB>(vsum, hsh.red, shr);
+            iter_reduce_load<K>(it.partial_in, it.n_part_in, vsum);           // (wavefronts 4 .. 7 find no rows of theirs: zeros)
+            iter_reduce_combine<K>(vsum, hsh.red, shr);
             const bool writer = blockIdx.x == 0;
             if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer, hpre);
             __syncthreads();
@@ -436,6 +423,17 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
         if constexpr (!OF) { const double x = th[0]; th[0] = th[1]; th[1] = x; }
         { const double x = th[2]; th[2] = th[3]; th[3] = x; }
         if constexpr (MODEL == kOCV5) { const double x = th[OCV5_P1]; th[OCV5_P1] = th[OCV5_P2]; th[OCV5_P2] = x; }
+    }
+    const int64_t start = start_e;
+    const int n = active ? (int)(end_e - start) : 0;
+    // corner rows by 32-bit byte offsets from the (wave-uniform) stream pointers: no 64-bit address arithmetic per load
+    // (ccal_problem_create refuses more than 2^30 - 1 corners per problem)
+    auto ldf = [](const float* base, uint32_t byte_off) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
+    const uint32_t ob0 = (uint32_t)start * 4u;
+    float pX, pY, pZ, pU, pV;
+    {
+        const uint32_t g0 = ob0 + 4u * (uint32_t)(cl < n ? cl : 0);
+        pX = ldf(a.x, g0); pY = ldf(a.y, g0); pZ = ldf(a.z, g0); pU = ldf(a.u, g0); pV = ldf(a.v, g0);
     }
     {
         // candidate pose of this group's frame (back-substitution of the previous camera solve) + constants; the lanes of
@@ -1094,7 +1092,7 @@ static constexpr size_t g2_iter_lds() {
     return sizeof(double) * WSL * kG2IterWpb;
 }
 template <int MODEL, bool OF>
-static constexpr size_t g2_iter_static_lds() { return sizeof(HeadShared) + 8 * 2 * 64 * 8 + 512; }      // decision + the row sum's 8 x 2 x 64 + alignment
+static constexpr size_t g2_iter_static_lds() { return sizeof(HeadShared) + 4 * 2 * 64 * 8 + 512; }      // decision + the row sum's 4 x 2 x 64 + alignment
 static int g2_iter_lpf(int n_obs, int avg_corners) {
     int best = 0;
     double best_cost = 1e300;
