@@ -371,10 +371,18 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
         }
     } else {
-        const DevState* st = a.st;
-        g.done = st->done; g.redo = st->redo; g.cur = st->cur; g.first = st->first; g.method = st->method;
-        g.lambda_solve = st->lambda_solve; g.lam_schur = schur_lambda(st);
+        g.done = g.redo = g.cur = g.first = g.method = 0; g.lambda_solve = 0.0; g.lam_schur = 0.0;      // (unused: see below)
     }
+    // The fields of the state as the evaluation reads them: ITER from this launch's decision (copied out of LDS above); else straight from
+    // the state in global memory WHERE THEY ARE NEEDED, exactly as before the single-launch form existed - read up front into a struct they
+    // cost KB4 / OPENCV5, which have no register to spare, 1 us per build (profiles/r06/ab_g2_iter_body.txt)
+    auto st_done = [&]() -> int { if constexpr (ITER) return g.done; else return a.st->done; };
+    auto st_redo = [&]() -> int { if constexpr (ITER) return g.redo; else return a.st->redo; };
+    auto st_cur = [&]() -> int { if constexpr (ITER) return g.cur; else return a.st->cur; };
+    auto st_first = [&]() -> int { if constexpr (ITER) return g.first; else return a.st->first; };
+    auto st_method = [&]() -> int { if constexpr (ITER) return g.method; else return a.st->method; };
+    auto st_lambda_solve = [&]() -> double { if constexpr (ITER) return g.lambda_solve; else return a.st->lambda_solve; };
+    auto st_lam_schur = [&]() -> double { if constexpr (ITER) return g.lam_schur; else return schur_lambda(a.st); };
     // ITER: the eight wavefronts' rows (parked where their frames' constants were) -> the workgroup's row, fixed order, the two symmetric
     // blocks as their upper triangles
     auto iter_row_out = [&]() {
@@ -389,12 +397,12 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             }
         }
     };
-    const bool keep_rec = GEN || !fuse || g.method == CCAL_METHOD_LM;
-    if (g.done || (g.redo && !fuse)) return;
-    const int cur = g.cur, first = g.first;
+    const bool keep_rec = GEN || !fuse || st_method() == CCAL_METHOD_LM;
+    if (st_done() || (st_redo() && !fuse)) return;
+    const int cur = st_cur(), first = st_first();
     const int es = first ? cur : (cur ^ 1);
     if constexpr (!GEN) {
-        if (g.redo) {
+        if (st_redo()) {
             // re-elimination group (LM: rejected step or missed speculation): the accepted set's stored records, new damping
             double* R = red + grp * GS_;
             double mcv = 0.0;
@@ -406,7 +414,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
                 if (gl == 0) mcv = a.mc_f[f];
             }
             wsync();
-            gram_fused_tail<K, LPF>(a, g.lam_schur, red, ITER ? fcw : a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
+            gram_fused_tail<K, LPF>(a, st_lam_schur(), red, ITER ? fcw : a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_r, cur, mcv);
             iter_row_out();
             return;
         }
@@ -449,7 +457,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
         for (int i = 0; i < 6; ++i) pose[i] = pset ? pose_b[1][i] : pose_b[0][i];
         if constexpr (GEN) {
             if (gbs) {
-                const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, g.lambda_solve, pose, red, grp, gl, lane_ok);
+                const double mcg = gen_backsub_pose<LPF, G, RED>(a, slot, st_lambda_solve(), pose, red, grp, gl, lane_ok);
                 if (active && a.g_owner[fa_]) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) if (gl == i) a.poses[es][(int64_t)slot * 6 + i] = pose[i];
@@ -479,7 +487,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
                     for (int k = i + 1; k < 6; ++k) t -= pf[k * (k + 1) / 2 + i] * dp[k];
                     dp[i] = t * pf[i * (i + 1) / 2 + i];
                 }
-                const double lam = g.lambda_solve;
+                const double lam = st_lambda_solve();
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     const double gp = pf[21 + 6 * K1 + i], dCi = pf[21 + 6 * K1 + 6 + i];
@@ -802,7 +810,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
         if (fuse) {
             if (keep_rec) wsync();                                     // the tail reuses the records' rows
             G2_STAMP(4);
-            gram_fused_tail<K, LPF>(a, g.lam_schur, red, ITER ? fcw : a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
+            gram_fused_tail<K, LPF>(a, st_lam_schur(), red, ITER ? fcw : a.partial + (int64_t)wrow * fused_red_size(K), grp, gl, lane_ok, active, slot_t, es, mc_t G2_EP_PTR);
             iter_row_out();
         }
     }
