@@ -161,7 +161,12 @@ class CcalLibraryMissing(RuntimeError):
 
 def _bind(path, mode):
     lib = C.CDLL(path, mode=mode)
+    # A/B TOOLS ONLY: an OLDER build named through CCAL_LIB (tools/ab_build.py against a previous round's library) may lack the newest
+    # entry points; CCAL_LIB_ALLOW_MISSING=1 binds what is there.  The product path never sets it: a missing export raises.
+    tolerant = os.environ.get("CCAL_LIB_ALLOW_MISSING") == "1" and "CCAL_LIB" in os.environ
     for name, res, args in SYMBOLS:
+        if tolerant and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)   # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
