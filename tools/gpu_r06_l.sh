@@ -12,15 +12,6 @@ python tools/ab_build.py "base,prev@prev" eucm 10000 3 --ragged
 python tools/ab_build.py "base,prev@prev" eucm 10000 3 --cams 2
 } > $O/ab_early_rows.txt 2>&1
 cat $O/ab_early_rows.txt
-python - <<'PY'
-import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from camera_intrinsic_calibration_rs_amd import synth, _ffi
-from camera_intrinsic_calibration_rs_amd.engine import Context, Problem, default_opts
-R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-for tag, lib in (("base", None), ("prev", _ffi.C.CDLL(R + "/camera_intrinsic_calibration_rs_amd/lib/variants/libccal_prev.so") if False else None),):
-    pass
-PY
 for L in base prev; do
   if [ $L = prev ]; then export CCAL_LIB=$R/camera_intrinsic_calibration_rs_amd/lib/variants/libccal_prev.so; else unset CCAL_LIB; fi
   python - <<'PY'
