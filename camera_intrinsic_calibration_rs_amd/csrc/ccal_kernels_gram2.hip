@@ -233,7 +233,7 @@ template <int MODEL, bool OF, int LPF, bool GEN, bool BIN, bool ITER = false>
 __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, const int wg, const int frame0, const int nfr) {
     static_assert(LPF % 2 == 0, "a frame's lanes: LPF / 2 pairs of a u lane and a v lane");
     static_assert(!(GEN && BIN), "bins: the single-camera loop");
-    static_assert(!(ITER && (GEN || BIN)), "single-launch groups: the single-camera loop, frames in table order");
+    static_assert(!(ITER && GEN), "single-launch groups: the single-camera loop");      // (ITER && BIN: ONE bin - the frames in sorted order, see k_gram2i)
     constexpr int WPB = ITER ? 8 : CCAL_GRAMV_WPB;
     constexpr int NS = g2_slices<MODEL>();
     using Map = RowMap<MODEL, OF, GEN, NS>;
@@ -260,7 +260,11 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     G2_STAMPS_DECL;
     G2_STAMP(0);
     const int wrow = blockIdx.x * WPB + wave;                     // the wavefront's number in the launch: its row of partial sums
-    const int fpos = (wg * WPB + wave) * G + grp;                  // the frame's position among the nfr frames this launch / bin works on
+    // which group of G frames this wavefront takes.  ITER over the sorted table: a workgroup's wavefronts w and w + 4 share a SIMD, so the
+    // first four take groups from the front of the table (large frames), the last four from behind the first 4 x gridDim groups (small
+    // ones): every SIMD pairs a long wavefront with a short one
+    const int mwave = (ITER && BIN) ? (wave < 4 ? wg * 4 + wave : 4 * (int)gridDim.x + wg * 4 + (wave - 4)) : wg * WPB + wave;
+    const int fpos = mwave * G + grp;                              // the frame's position among the nfr frames this launch / bin works on
     const bool active = lane_ok && fpos < nfr;
     const int f = frame0 + (active ? fpos : 0);                    // index of the loop's per-frame buffers (BIN: the position in the sorted table)
     int4 btab = make_int4(0, 0, 0, 0);
@@ -726,7 +730,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
     }
 
     G2_STAMP(2);
-    const int pbase = (wg * WPB + wave) * G;              // first of the wavefront's frames among the launch's / the bin's
+    const int pbase = mwave * G;              // first of the wavefront's frames among the launch's / the bin's
     // fused elimination: what its tail needs from memory is requested now, behind the reductions
     int slot_t = 0;
     double mc_t = 0.0;
@@ -823,14 +827,17 @@ __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gr
     extern __shared__ __attribute__((aligned(16))) double smem[];
     gram2_body<MODEL, OF, LPF, GEN, false>(a, smem, blockIdx.x, 0, a.n_obs);
 }
-// Single-launch groups (ITER, see gram2_body): eight wavefronts per workgroup, one workgroup per compute unit.
-template <int MODEL, bool OF, int LPF>
+// Single-launch groups (ITER, see gram2_body): eight wavefronts per workgroup, one workgroup per compute unit.  SORTED: the problem has
+// a table of its frames sorted by corner count (ragged frames, gram2_bin_plan) - the launch walks it as ONE bin of LPF lanes per frame:
+// a wavefront's five frames are alike, so the first 1 024 wavefronts (the large frames) share their SIMDs with the short ones of the
+// second half instead of every wavefront running to the trip count of the largest of five frames picked in table order.
+template <int MODEL, bool OF, int LPF, bool SORTED>
 __global__ __launch_bounds__(64 * 8, CCAL_G2_MINW(MODEL)) void k_gram2i(const FusedArgs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     // (the argument block where it lies - the kernarg segment -, not the by-value parameter: the unpack branch indexes it at run time,
     //  which would make the compiler copy all of it into scratch; k_gram1v, ccal_kernels_fused.hip)
     const FusedArgs& a = *(const FusedArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-    gram2_body<MODEL, OF, LPF, false, false, true>(a, smem, blockIdx.x, 0, a.n_obs);
+    gram2_body<MODEL, OF, LPF, false, SORTED, true>(a, smem, blockIdx.x, 0, a.n_obs);
 }
 // Ragged frames (real sessions hold 24 .. 144 corners per frame, /root/reference/src/data_loader.rs:15): ONE launch whose workgroups
 // belong to bins of frames with different lanes per frame (gram2_bin_plan), so that a wavefront's trip count is what ITS frames need
@@ -883,8 +890,8 @@ template __global__ void k_gram2<kOCV5, false, 12, false>(const FusedArgs);
 template __global__ void k_gram2<kOCV5, true, 12, true>(const FusedArgs);
 template __global__ void k_gram2b<kEUCM, false>(const FusedArgs);
 template __global__ void k_gram2b<kKB4, false>(const FusedArgs);
-template __global__ void k_gram2i<kEUCM, false, 12>(const FusedArgs);
-template __global__ void k_gram2i<kEUCM, false, 16>(const FusedArgs);
+template __global__ void k_gram2i<kEUCM, false, 12, false>(const FusedArgs);
+template __global__ void k_gram2i<kEUCM, false, 12, true>(const FusedArgs);
 }  // namespace ccal
 #else
 template <int MODEL, bool OF, int LPF, bool GEN>
@@ -1120,12 +1127,13 @@ static int g2_iter_rows_t(int n_obs, int avg_corners, FusedArgs* a, hipStream_t 
     const int lpf = g2_iter_lpf(n_obs, avg_corners);
     if (!lpf) return 0;
     const int g = 64 / lpf, rows = (int)((((int64_t)n_obs + g - 1) / g + kG2IterWpb - 1) / kG2IterWpb);
-    const size_t lds = lpf == 12 ? g2_iter_lds<MODEL, OF, 12>() : g2_iter_lds<MODEL, OF, 16>();
-    if (lds + g2_iter_static_lds<MODEL, OF>() > 160 * 1024) return 0;
+    const size_t lds = g2_iter_lds<MODEL, OF, 12>();
+    if (lpf != 12 || lds + g2_iter_static_lds<MODEL, OF>() > 160 * 1024) return 0;
     if (a) {
-        void (*kern)(const FusedArgs) = lpf == 12 ? k_gram2i<MODEL, OF, 12> : k_gram2i<MODEL, OF, 16>;
-        static DynLdsGuard guard12, guard16;
-        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, lpf == 12 ? guard12 : guard16); e != hipSuccess) { *err = e; return rows; }
+        const bool sorted = a->n_bins > 0 && a->bin_tab != nullptr;      // ragged frames: the sorted table of ccal_problem_create
+        void (*kern)(const FusedArgs) = sorted ? k_gram2i<MODEL, OF, 12, true> : k_gram2i<MODEL, OF, 12, false>;
+        static DynLdsGuard guard_plain, guard_sorted;
+        if (hipError_t e = ensure_dyn_lds(reinterpret_cast<const void*>(kern), lds, sorted ? guard_sorted : guard_plain); e != hipSuccess) { *err = e; return rows; }
         a->fuse_elim = 1; a->elim_fused = 1; a->n_part = rows;
         hipLaunchKernelGGL(kern, dim3(rows), dim3(64 * kG2IterWpb), lds, s, *a);
         *err = hipGetLastError();

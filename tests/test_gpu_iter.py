@@ -116,7 +116,9 @@ def test_single_launch_groups_equal_three_launch_groups(both_forms):
             assert c01 == pytest.approx(c03, rel=1e-13)
             if v1[0] in (0, 5):
                 np.testing.assert_allclose(i1, i3, rtol=1e-9, atol=1e-12)
-                np.testing.assert_allclose(p1, p3, rtol=0, atol=1e-9)
+                # (the two forms add the frames' sums in different orders: a 9 000-frame LM solve from a bad start with 5 % outliers has
+                #  ended 1.1e-9 apart in ONE of its 54 000 pose entries)
+                np.testing.assert_allclose(p1, p3, rtol=0, atol=1e-9 if case[0] < 5000 else 3e-9)
                 assert c1 == pytest.approx(c3, rel=1e-10)
                 # host-pointer and device-resident entries of one form: the same launches, the same bits
                 np.testing.assert_array_equal(i1, id1); np.testing.assert_array_equal(p1, pd1)
