@@ -177,6 +177,7 @@ constexpr int kGramMaxBins = 5;
 struct GramBins {
     int32_t n_bins = 0;               // 0: no bins (every frame the same lanes per frame, frames in table order)
     int32_t lpf[kGramMaxBins] = {}, first[kGramMaxBins] = {}, count[kGramMaxBins] = {}, wg0[kGramMaxBins + 1] = {};
+    int32_t fold = 0;                 // > 0: ONE bin, the table folded at this position (frames behind it smallest first)
 };
 // The plan for corner counts n[0 .. n_obs) (host): which frames go together and with how many lanes each; order = the sorted table
 // (frame indices, bins in launch order).  n_bins == 0: binning does not pay (uniform frames, too few of them).

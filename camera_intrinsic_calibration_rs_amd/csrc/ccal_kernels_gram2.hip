@@ -19,6 +19,8 @@
 // update in front of the loop and the fused elimination behind it (ccal_gram_common.hpp) are shared.
 //   UCM / EUCM: two wavefronts per SIMD (226 registers); KB4 / OPENCV5: one (296 / 322 registers, 30 / 65 AGPR copies per pass).
 #include <algorithm>
+#include <cstdio>
+#include <cstring>
 
 #include "ccal_head.hpp"
 
@@ -948,25 +950,43 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
 // elimination are worth (the c0 of gram2_lanes_per_frame).
 static inline double g2_wave_cost(int lpf, int passes) { return (lpf == 6 ? 7.0 : 6.0) + (double)passes; }
 // The time of a launch whose wavefronts cost c[0 .. W) in launch order on `simds` SIMDs: wavefront i, i + simds, i + 2 simds ... share
-// a SIMD (the dispatcher fills the chip in launch order).  Two resident wavefronts interleave at 0.65 of their summed cost
-// (gram2_lanes_per_frame's occupancy fit); one per SIMD (KB4 / OPENCV5: 296+ registers) run one after the other.
+// a SIMD (the dispatcher fills the chip in launch order).  Two resident wavefronts each advance at 1 / 1.3 of the rate of one alone
+// (gram2_lanes_per_frame's occupancy fit: a pair of equals takes 0.65 of the summed cost), a wavefront whose partner has finished runs
+// at full rate: a pair costs max + 0.3 min - EQUAL partners are the cheapest way to get through a given sum (measured, folded against
+// equalised plans: profiles/r06/ab_g2_fold.txt).  One per SIMD (KB4 / OPENCV5: 296+ registers): one after the other.
 static double g2_launch_cost(const std::vector<double>& c, int simds, bool two_per_simd) {
     double worst = 0.0;
     const int W = (int)c.size();
     for (int i = 0; i < simds && i < W; ++i) {
-        double sum = 0.0, longest = 0.0;
-        for (int k = i; k < W; k += simds) { sum += c[(size_t)k]; longest = std::max(longest, c[(size_t)k]); }
-        worst = std::max(worst, two_per_simd ? std::max(longest, 0.65 * sum) : sum);
+        double t = 0.0;
+        if (!two_per_simd) { for (int k = i; k < W; k += simds) t += c[(size_t)k]; }
+        else {
+            double r0 = c[(size_t)i], r1 = 0.0;
+            int k = i + simds;
+            if (k < W) { r1 = c[(size_t)k]; k += simds; }
+            while (r0 > 0.0 && r1 > 0.0) {
+                const double m = std::min(r0, r1);
+                t += 1.3 * m; r0 -= m; r1 -= m;
+                if (r0 <= 0.0 && k < W) { r0 = c[(size_t)k]; k += simds; }
+                if (r1 <= 0.0 && k < W) { r1 = c[(size_t)k]; k += simds; }
+            }
+            t += std::max(r0, r1);
+        }
+        worst = std::max(worst, t);
     }
     return worst;
 }
+static int g2_iter_lpf(int n_obs, int avg_corners);
 GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::vector<int32_t>* order) {
     GramBins none;
 #ifdef CCAL_G2_NO_BINS        // A/B builds (tools/build_tu_variants.sh ccal_kernels_gram2 "nobins:-DCCAL_G2_NO_BINS"): the launch without bins
     return none;
 #endif
 #ifdef CCAL_G2_PLAN_ENV       // experiment builds: the plan from the environment, "lpf:frames+lpf:frames+..." in launch order over the frames sorted by size
-    if (const char* e = std::getenv("CCAL_G2_PLAN"); e && off && order && n_obs > 0) {
+    int only_T = 0, only_fold = 0;                // "T:9": the equalised plan of that trip-count limit; "fold:16": the folded plan of that mapping
+    if (const char* e = std::getenv("CCAL_G2_PLAN"); e && !std::strncmp(e, "T:", 2)) only_T = std::atoi(e + 2);
+    else if (e && !std::strncmp(e, "fold:", 5)) only_fold = std::atoi(e + 5);
+    else if (e && off && order && n_obs > 0) {
         std::vector<int32_t> ord((size_t)n_obs);
         for (int o = 0; o < n_obs; ++o) ord[(size_t)o] = o;
         std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return off[x + 1] - off[x] > off[y + 1] - off[y]; });
@@ -1014,6 +1034,9 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
     std::vector<double> c;
     for (int T = 2; T <= 64; ++T) {
         if ((nmax + 31) / 32 > T) continue;                          // the widest mapping cannot cover the largest frame in T passes
+#ifdef CCAL_G2_PLAN_ENV
+        if ((only_T && T != only_T) || only_fold) continue;
+#endif
         GramBins gb;
         c.clear();
         int pos = 0, wgs = 0;
@@ -1036,7 +1059,54 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
         const double cost = g2_launch_cost(c, simds, two_per_simd);
         if (cost < best_cost) { best_cost = cost; best = gb; }
     }
+#ifndef CCAL_G2_NO_FOLD
+    // Two wavefronts per SIMD: ONE bin whose table is FOLDED - the larger half of the frames largest first, then the smaller half
+    // smallest first - so that the wavefronts that share a SIMD (i and i + simds of the launch; k_gram2i: w and w + 4 of a workgroup)
+    // are a long one and a short one and every SIMD has the same work, whatever the distribution of the frame sizes.  Where the
+    // mapping makes ~2 048 wavefronts of the frames this is the plan (8 000 / 16 000 / 20 000 frames U{24..144}: 26.7 / 37.6 / 45.5 us
+    // against 28.6 / 41.4 / 48.4 for the best equalised plan).  Where the solve runs single-launch groups of k_gram2i (12 lanes) the
+    // table is folded for THAT launch whatever the model says of the build (10 000 frames: build 30.5 against 30.3 us, GN 0.213
+    // against 0.223 ms; profiles/r06/ab_g2_plans_folded.txt).
+    if (two_per_simd) {
+        const bool iter12 = g2_iter_lpf(n_obs, (int)(total / std::max(n_obs, 1))) == 12;
+        for (int b = 0; b < kGramMaxBins; ++b) {
+            const int lpf = lpfs[b], g = 64 / lpf;
+            const int waves = (n_obs + g - 1) / g;
+            if (waves > 2 * simds || (nmax + lpf - 1) / lpf > 64) continue;
+#ifndef CCAL_G2_PLAN_ENV
+            if (lpf == 6) continue;                   // (20 000 frames: 45.8 us folded against 44.8 for the equalised plan the model ranks behind it)
+#else
+            if ((only_fold && lpf != only_fold) || only_T) continue;
+#endif
+            const int fold = std::min(n_obs, 4 * ((waves + 7) / 8) * g);           // (k_gram2i's split: the first four wavefronts of its workgroups)
+            auto at = [&](int pos) { return pos < fold ? cnt(pos) : cnt(n_obs - 1 - (pos - fold)); };
+            c.clear();
+            for (int w = 0; w < waves; ++w) {
+                int mx = 0;
+                for (int q = w * g; q < std::min(n_obs, (w + 1) * g); ++q) mx = std::max(mx, at(q));
+                c.push_back(g2_wave_cost(lpf, (mx + lpf - 1) / lpf));
+            }
+            double cost = g2_launch_cost(c, simds, true);
+#ifndef CCAL_G2_PLAN_ENV
+            if (iter12) { if (lpf != 12) continue; cost = std::min(cost, best_cost); }
+#endif
+            if (cost <= best_cost) {
+                best_cost = cost;
+                best = GramBins();
+                best.n_bins = 1; best.lpf[0] = lpf; best.first[0] = 0; best.count[0] = n_obs; best.wg0[0] = 0;
+                best.wg0[1] = (waves + CCAL_GRAMV_WPB - 1) / CCAL_GRAMV_WPB;
+                best.fold = fold;
+            }
+        }
+        (void)iter12;
+    }
+#endif
+#ifdef CCAL_G2_PLAN_ENV
+    if (std::getenv("CCAL_G2_PLAN_PRINT")) std::fprintf(stderr, "gram2_bin_plan %d frames: model cost %.2f (no bins: %.2f), %d bins, fold %d\n", n_obs, best_cost, cost_plain, best.n_bins, best.fold);
+    if ((only_T || only_fold) && best.n_bins > 0) cost_plain = 1e300;
+#endif
     if (best.n_bins == 0 || best_cost > 0.93 * cost_plain) return none;       // (the sorted table costs the prologue a dependent load: it has to pay)
+    if (best.fold > 0) std::reverse(ord.begin() + best.fold, ord.end());
     *order = std::move(ord);
     return best;
 }

@@ -1,6 +1,6 @@
 // Host-only check of the ragged-frame plan of the Gram launch (ccal::gram2_bin_plan, csrc/ccal_kernels_gram2.hip; declarations
 // repeated from csrc/ccal_internal.hpp - plain data, no HIP): every frame exactly once, bins contiguous in the order sorted by
-// corner count, every frame covered by its bin's lanes within the launch's trip-count limit, workgroup ranges consistent;
+// corner count (or ONE bin over the FOLDED order), every frame covered by its bin's lanes within the launch's trip-count limit, workgroup ranges consistent;
 // uniform frames and small problems are left alone.
 #include <algorithm>
 #include <cstdint>
@@ -13,6 +13,7 @@ constexpr int kGramMaxBins = 5;
 struct GramBins {
     int32_t n_bins = 0;
     int32_t lpf[kGramMaxBins] = {}, first[kGramMaxBins] = {}, count[kGramMaxBins] = {}, wg0[kGramMaxBins + 1] = {};
+    int32_t fold = 0;
 };
 GramBins gram2_bin_plan(const int64_t* obs_off, int n_obs, bool two_per_simd, std::vector<int32_t>* order);
 }  // namespace ccal
@@ -29,6 +30,20 @@ static int check(const std::vector<int64_t>& off, bool two, bool expect_bins, co
     std::vector<char> seen((size_t)n_obs, 0);
     for (int32_t o : order) { if (o < 0 || o >= n_obs || seen[(size_t)o]) return fail("order is not a permutation"); seen[(size_t)o] = 1; }
     auto cnt = [&](int pos) { return off[order[(size_t)pos] + 1] - off[order[(size_t)pos]]; };
+    if (gb.fold > 0) {
+        // ONE bin, the table folded: the larger half largest first, the smaller half smallest first; the fold sits where the single-launch
+        // groups split their workgroups (four wavefronts of eight)
+        const int g = 64 / gb.lpf[0], waves = (n_obs + g - 1) / g;
+        if (gb.n_bins != 1 || !two) return fail("a folded plan has one bin (two wavefronts per SIMD)");
+        if (gb.fold != std::min(n_obs, 4 * ((waves + 7) / 8) * g)) return fail("fold position");
+        for (int i = 1; i < gb.fold; ++i) if (cnt(i) > cnt(i - 1)) return fail("front half not sorted largest first");
+        for (int i = gb.fold + 1; i < n_obs; ++i) if (cnt(i) < cnt(i - 1)) return fail("back half not sorted smallest first");
+        if (gb.fold < n_obs && cnt(n_obs - 1) > cnt(gb.fold - 1)) return fail("the halves overlap");
+        if (gb.first[0] != 0 || gb.count[0] != n_obs || gb.wg0[0] != 0 || gb.wg0[1] != (waves + 1) / 2) return fail("folded bin range");
+        std::printf("%s: folded at %d, %d lanes x %d frames, %d workgroups, trip counts %d .. %d\n", label, gb.fold, gb.lpf[0], n_obs, gb.wg0[1],
+                    (int)((cnt(gb.fold) + gb.lpf[0] - 1) / gb.lpf[0]), (int)((cnt(0) + gb.lpf[0] - 1) / gb.lpf[0]));
+        return 0;
+    }
     for (int i = 1; i < n_obs; ++i) if (cnt(i) > cnt(i - 1)) return fail("not sorted by corner count");
     int pos = 0, wgs = 0, T = 0;
     for (int b = 0; b < gb.n_bins; ++b) {

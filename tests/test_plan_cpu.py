@@ -16,5 +16,7 @@ def test_gram_bin_plan_invariants(tmp_path):
                            "-L", LIBDIR, "-lccal_hip", f"-Wl,-rpath,{LIBDIR}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.check_output([exe], env=dict(os.environ, LD_LIBRARY_PATH=LIBDIR + ":/opt/rocm/lib")).decode()
     assert "PLAN-OK" in out, out
-    # the plan for the bench's ragged workload shape: a handful of bins, every wavefront at most nine passes
-    assert "10000 frames U{24..144}, two wavefronts per SIMD: 4 bins, T = 9" in out, out
+    # the plan for the bench's ragged workload shape: the solve runs single-launch groups of 12-lane wavefronts there - ONE bin, the table
+    # folded so that every SIMD pairs a long wavefront with a short one; a problem beyond two wavefronts per SIMD: equalised bins
+    assert "10000 frames U{24..144}, two wavefronts per SIMD: folded at 5000, 12 lanes x 10000 frames" in out, out
+    assert "50000 frames U{24..144}: 3 bins, T = " in out, out
