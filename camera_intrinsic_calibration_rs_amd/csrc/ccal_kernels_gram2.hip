@@ -843,7 +843,9 @@ __global__ __launch_bounds__(64 * 8, CCAL_G2_MINW(MODEL)) void k_gram2i(const Fu
 }
 // Ragged frames (real sessions hold 24 .. 144 corners per frame, /root/reference/src/data_loader.rs:15): ONE launch whose workgroups
 // belong to bins of frames with different lanes per frame (gram2_bin_plan), so that a wavefront's trip count is what ITS frames need
-// and not the largest frame's of a group picked in table order.  Bin b = workgroups bin_wg0[b] .. bin_wg0[b + 1] - 1.
+// and not the largest frame's of a group picked in table order.  Bin b = workgroups bin_wg0[b] .. bin_wg0[b + 1] - 1.  (A FOLDED plan is
+// one bin over a table whose second half runs smallest first: nothing for the kernel to know - a wavefront's trip count is the largest
+// of ITS frames wherever they sit.)
 template <int MODEL, bool OF>
 __global__ __launch_bounds__(64 * CCAL_GRAMV_WPB, CCAL_G2_MINW(MODEL)) void k_gram2b(const FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];

@@ -156,6 +156,35 @@ def test_ragged_frames_at_headline_size(gpu_ctx, oracle, model, one_focal):
     gp.close()
 
 
+@pytest.mark.parametrize("frames,model", [(8000, "eucm"), (16000, "ucm"), (12000, "eucm"), (7300, "ucm")])
+def test_ragged_plans_of_other_sizes(gpu_ctx, oracle, frames, model):
+    """The planner's other shapes (csrc/ccal_kernels_gram2.hip: gram2_bin_plan): 8 000 ragged frames take ONE folded bin of 16 lanes, 16 000 one
+    of 8 lanes (larger half of the frames largest first, smaller half smallest first), 12 000 equalised bins: the reduced normal equations
+    against the oracle, the same bits twice, and a Gauss-Newton solve that ends where the oracle's does."""
+    sp = synth.make_problem(frames, model, ragged=True, seed=0xF01D + frames)
+    gp = Problem.from_synth(gpu_ctx, sp)
+    op = oracle.OracleProblem.from_synth(sp)
+    for lam in (0.0, 1e-3):
+        S, b, cost = gp.build_normal(sp.intr0, sp.poses0, lam=lam)
+        So, bo, costo = op.build_normal(sp.intr0, sp.poses0, lam=lam)
+        assert abs(cost - costo) <= 1e-12 * costo
+        assert np.abs(S - So).max() <= 1e-9 * np.abs(So).max() and np.abs(b - bo).max() <= 1e-9 * np.abs(bo).max()
+        S2, b2, cost2 = gp.build_normal(sp.intr0, sp.poses0, lam=lam)
+        np.testing.assert_array_equal(S, S2); np.testing.assert_array_equal(b, b2); assert cost == cost2
+    oracle.set_solve_threads(8)
+    try:
+        io, po, _, ro = op.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
+    finally:
+        oracle.set_solve_threads(1)
+    ig, pg, _, rg = gp.solve(sp.intr0, sp.poses0, opts=default_opts(_ffi.METHOD_GN))
+    assert rg.status == ro.status == 0 and rg.iterations == ro.iterations
+    assert abs(rg.final_cost - ro.final_cost) <= 1e-9 * ro.final_cost
+    P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+    assert (np.abs(ig[0, :P] - io[0, :P]) / np.maximum(np.abs(io[0, :P]), 1e-3)).max() <= 1e-6
+    np.testing.assert_allclose(pg, po, rtol=0, atol=1e-7)
+    gp.close()
+
+
 @pytest.mark.parametrize("model", ["eucm", "kb4"])
 @pytest.mark.parametrize("method", [_ffi.METHOD_GN, _ffi.METHOD_LM])
 def test_ragged_solve_against_the_oracle(gpu_ctx, oracle, model, method):

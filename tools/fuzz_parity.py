@@ -16,6 +16,7 @@ ap.add_argument("--shards", type=int, default=0, help="also solve every case thr
 ap.add_argument("--batch", type=int, default=0, help="also re-solve the cases in groups of this many through ONE ccal_solve_batch call per group "
                 "(lockstep groups for session-sized single-camera problems of one model, per-context drivers for the rest) and hold every member "
                 "against its own ccal_solve: verdict, iterations, intrinsics, poses")
+ap.add_argument("--huge", action="store_true", help="big cases also take 7 400 / 9 300 frames (ragged: the folded one-bin plans of 16 / 12 lanes; the oracle solve of one takes seconds)")
 ap.add_argument("--big", type=float, default=0.04, help="probability that a single-camera case has 1 100 / 2 300 / 5 200 frames (from 2 000 ragged frames "
                 "the Gram launch is binned by corner count, k_gram2b): raise it for a sweep of that launch")
 args = ap.parse_args()
@@ -51,7 +52,7 @@ while time.time() - t0 < args.seconds:
     n_cams = int(rng.choice([1, 1, 1, 1, 2, 2, 3, 3, 5, 8]))      # 5 and 8 cameras: reduced systems of 64 .. 114 columns
     frames = int(rng.choice([3, 7, 20, 45, 130, 300])) if n_cams == 1 else int(rng.choice([5, 12, 30]))
     if n_cams == 1 and rng.random() < args.big:        # every lanes-per-frame mapping / both register-Gram kernels / k_schur1m
-        frames = int(rng.choice([1100, 2300, 5200]))
+        frames = int(rng.choice([1100, 2300, 5200] + ([7400, 9300] if args.huge else [])))
     kw = dict(n_cams=n_cams, seed=int(rng.integers(1, 1 << 30)), ragged=bool(rng.integers(0, 2)),
               xy_same_focal=bool(rng.integers(0, 2)), outlier_frac=float(rng.choice([0.0, 0.01, 0.05])))
     force_rig = n_cams >= 5 and model == "opencv5"      # narrow field of view: no pose that every camera of a big rig sees
