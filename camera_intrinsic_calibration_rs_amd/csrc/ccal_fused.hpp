@@ -211,6 +211,7 @@ struct IterArgs {
     const double* partial_in; int32_t n_part_in;       // the previous launch's rows (this launch's go to FusedArgs::partial)
     HostStatus* hs; const ColInfo* cols; double* dc_out;
     double* result_host; int64_t np6;                  // see HeadArgs
+    double* result_poses; int32_t* done_cnt;           // != NULL: EVERY workgroup of the finishing launch writes its slice of the poses there (head_finish, SPREAD)
     // The solve's FIRST launch as its own k_unpack1 (`fold`; every slot has an observation frame): the starting state, the column
     // table and the intrinsics ride in THIS argument block, every frame's lanes read their slot's starting pose where the caller
     // left it (pinned host memory, or parameter set 0 for device-resident solves) and write it to the parameter sets; workgroup 0

@@ -232,22 +232,47 @@ __device__ __forceinline__ void head_wave(const HeadIO& a, HeadShared& hs, const
 // every wavefront of the workgroup, 16-byte stores (tools/ubench/host_publish.hip: 30 KB in 2.9 us with four wavefronts,
 // 8.2 us with one and 8-byte stores) - and then, last, the status word.  The accepted poses were written by an earlier launch;
 // the accepted intrinsics: no group writes set `cur` (candidates go to cur ^ 1), global memory holds them.
+// SPREAD (single-launch groups of problems beyond the session sizes, spread_poses != NULL): every workgroup of the launch has taken the
+// same decision on the same sums, so every workgroup copies ITS slice of the accepted poses to the caller's side of the bus (up to 256 KB:
+// one workgroup would need ~12 us, a DMA behind the launch costs the host a stream round trip; beyond that the DMA's larger packets win) and counts itself in
+// (*done_cnt, device scope, behind its own system-scope fence); the workgroup that counts last resets the counter and publishes the word:
+// (1) - (3) hold per workgroup, and the word is behind every workgroup's fence.
 __device__ __forceinline__ void head_finish(const HeadIO& a, HeadShared& hs, double* result_host, const double* poses0, const double* poses1,
-                                            const int64_t np6, const bool writer) {
+                                            const int64_t np6, const bool writer, double* spread_poses = nullptr, int32_t* done_cnt = nullptr) {
     const DevState* st = &hs.S0;
-    if (!writer) return;
-    if (st->done && result_host && !hs.entry_done) {
+    const bool fin = st->done && result_host && !hs.entry_done;
+    const bool spread = fin && spread_poses != nullptr;
+    if (!writer && !spread) return;
+    if (fin) {
         typedef double dv2 __attribute__((ext_vector_type(2)));
         const int cur = st->cur;
         const dv2* pi = reinterpret_cast<const dv2*>(cur ? a.intr[1] : a.intr[0]);
         const dv2* pp = reinterpret_cast<const dv2*>(cur ? poses1 : poses0);
         dv2* out = reinterpret_cast<dv2*>(result_host);
         static_assert(CCAL_PMAX % 2 == 0, "16-byte stores");
-        for (int e = threadIdx.x; e < CCAL_PMAX / 2; e += blockDim.x) out[e] = pi[e];
-        for (int64_t e = threadIdx.x; e < np6 / 2; e += blockDim.x) out[CCAL_PMAX / 2 + e] = pp[e];          // (np6 = 6 x slots: even)
+        if (writer) for (int e = threadIdx.x; e < CCAL_PMAX / 2; e += blockDim.x) out[e] = pi[e];
+        if (spread) {
+            dv2* outp = reinterpret_cast<dv2*>(spread_poses);
+            const int64_t n2 = np6 / 2, per = (n2 + gridDim.x - 1) / gridDim.x;          // (np6 = 6 x slots: even)
+            const int64_t e1 = per * (blockIdx.x + 1) < n2 ? per * (blockIdx.x + 1) : n2;
+            for (int64_t e = per * blockIdx.x + threadIdx.x; e < e1; e += blockDim.x) outp[e] = pp[e];
+        } else {
+            for (int64_t e = threadIdx.x; e < np6 / 2; e += blockDim.x) out[CCAL_PMAX / 2 + e] = pp[e];
+        }
         __threadfence_system();
     }
     __syncthreads();
+    if (spread) {
+        if (threadIdx.x == 0) {
+            const int old = __hip_atomic_fetch_add(done_cnt, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (int)gridDim.x - 1) {
+                __hip_atomic_store(done_cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                if (!hs.early_pub) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
+            }
+        }
+        return;
+    }
     if (threadIdx.x == 0 && !hs.early_pub) publish_host_status(a.hs, st, a.seq, a.publish_all != 0);
 }
 

@@ -359,7 +359,7 @@ __device__ __forceinline__ void gram1v_body(const FusedArgs& a, const IterDyn& d
             if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer, hpre);
             __syncthreads();
             G1V_STAMP(8);                                   // decided, camera system solved
-            head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer);
+            head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer, it.result_poses, it.done_cnt);
             G1V_STAMP(9);
             from_lds = true;
             const DevState& S = hsh.S0;

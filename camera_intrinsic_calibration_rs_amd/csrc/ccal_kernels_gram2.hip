@@ -340,7 +340,7 @@ __device__ __forceinline__ void gram2_body(const FusedArgs& a, double* smem, con
             const bool writer = blockIdx.x == 0;
             if (threadIdx.x < 64) head_wave(io, hsh, (int)threadIdx.x, writer, hpre);
             __syncthreads();
-            head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer);
+            head_finish(io, hsh, it.result_host, a.poses[0], a.poses[1], it.np6, writer, it.result_poses, it.done_cnt);
             from_lds = true;
             const DevState& S = hsh.S0;
             g.done = S.done; g.redo = S.redo; g.cur = S.cur; g.first = S.first; g.method = S.method;

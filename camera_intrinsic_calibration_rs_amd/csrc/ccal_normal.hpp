@@ -106,6 +106,8 @@ struct FusedWs {
     double* h_stage = nullptr;                 // pinned staging of the caller's poses (read by k_unpack1 in place when small)
     double* d_stage = nullptr;                 // their device image (large problems: one copy per solve, k_unpack1 distributes it)
     double* h_result = nullptr;                // pinned, host-coherent: [intr | poses] written by the k_head that finishes a session-sized solve
+                                               // (up to kSpreadBytes of poses: by every workgroup of a finishing single-launch group, head_finish SPREAD)
+    int32_t* done_cnt = nullptr;               // SPREAD: the workgroups that have written their slice (zero between solves)
     hipStream_t side = nullptr;                // result download: does not queue behind the early-exit groups
     bool tail_pending = false;                 // early-exit groups of the previous solve may still be in flight
     int all_slots_observed = -1;               // every frame slot has an observation frame (-1: not looked yet): the first single-launch group may unpack for itself

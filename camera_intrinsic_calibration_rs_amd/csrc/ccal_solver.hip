@@ -94,6 +94,10 @@ int drain_pending_groups(ccal_problem* p) {
 // problems stage through device copies (a kernel reading / writing half a megabyte across the bus one wavefront wide would
 // cost more than the DMA it saves).
 constexpr size_t kZeroCopyBytes = 96 * 1024;
+// poses a finishing single-launch group writes to the host with ALL its workgroups: up to 5 461 frames.  Stores of a shader cross the bus in
+// 64-byte packets, the DMA engine's in 256+: 2 500 frames GN 0.150 -> 0.136 ms, 5 000: 0.184 -> 0.178, but 10 000: 0.238 -> 0.255 and, from a
+// table sorted by corner count, scattered pose READS over the bus on top (0.219 -> 0.256): profiles/r06/ab_result_spread.txt
+constexpr size_t kSpreadBytes = 256 * 1024;
 
 // rows of the single-camera loop's partial-sum buffer (fused_ws_ensure)
 static int fused_partial_rows(int n_obs) {
@@ -124,7 +128,8 @@ static int fused_ws_ensure(ccal_problem* p) {
     const size_t b_pf = up(ns * w->PF * sizeof(double)), b_praw = up(no * f->PRAW * sizeof(double)), b_no = up(no * sizeof(double));
     const size_t b_part = up((size_t)f->RB1 * f->n_pw * sizeof(double)), b_red = up((size_t)(f->RB1 + 7) * sizeof(double));
     const size_t b_state = up(3 * sizeof(DevState)), b_stage = up(stage_bytes);
-    const size_t zeroed = 2 * b_pf + 2 * b_praw + b_part + 2 * b_red;              // the slices that must start as zeros come first (red: two buffers,
+    const size_t b_cnt = 256;
+    const size_t zeroed = 2 * b_pf + 2 * b_praw + b_part + 2 * b_red + b_cnt;              // the slices that must start as zeros come first (red: two buffers,
                                                                                   // the in-process transport alternates between them)
     const size_t d_total = zeroed + 2 * b_no + b_state + b_stage;
     HIP_TRY(ctx, ctx_dev_alloc(ctx, (void**)&f->d_block, d_total));
@@ -135,6 +140,7 @@ static int fused_ws_ensure(ccal_problem* p) {
         for (int i = 0; i < 2; ++i) { f->praw[i] = reinterpret_cast<double*>(q); q += b_praw; }
         f->partial = reinterpret_cast<double*>(q); q += b_part;
         f->red = reinterpret_cast<double*>(q); q += 2 * b_red; f->red_stride = b_red / sizeof(double);
+        f->done_cnt = reinterpret_cast<int32_t*>(q); q += b_cnt;
         f->mc_f = reinterpret_cast<double*>(q); q += b_no;
         f->cost_f = reinterpret_cast<double*>(q); q += b_no;
         f->d_state = reinterpret_cast<DevState*>(q); q += b_state;      // [0] the loops' state; [1], [2]: single-launch groups alternate
@@ -145,7 +151,7 @@ static int fused_ws_ensure(ccal_problem* p) {
     HIP_TRY(ctx, hipMalloc((void**)&f->fcbuf, std::max<size_t>(no * 40, 32768) * sizeof(double)));
 #endif
     {
-        const bool zc = ns * 6 * sizeof(double) <= kZeroCopyBytes;
+        const bool zc = ns * 6 * sizeof(double) <= kSpreadBytes;         // (beyond kZeroCopyBytes: single-launch groups only, FusedJob::begin)
         const size_t b_hs = up(sizeof(HostStatus)), b_res = zc ? up((ns * 6 + CCAL_PMAX) * sizeof(double)) : 0;
         HIP_TRY(ctx, ctx_host_alloc(ctx, (void**)&f->h_block, b_hs + b_res + b_stage));
         char* q = f->h_block;
@@ -640,6 +646,7 @@ struct FusedJob : SolveJob {
     double* h_poses = nullptr;
     size_t np6 = 0;
     bool zero_copy = false;           // session-sized ccal_solve: poses read from / result written to pinned host memory by the kernels
+    bool spread = false;              // zero_copy of a larger problem: every workgroup of the finishing single-launch group writes its slice of the poses
     void* pinned_dev = nullptr;       // large ccal_solve whose caller pinned poses_io (ccal_pin_buffer): its device-side address - no staging copy either way
     using SolveJob::SolveJob;
     HostStatus* status() override { return f->h_status; }
@@ -657,7 +664,6 @@ struct FusedJob : SolveJob {
         if (f->tail_pending) { HIP_TRY(ctx, hipStreamSynchronize(st)); f->tail_pending = false; }   // stale k_head must not publish into this solve
         np6 = (size_t)p->n_slots * 6;
         h_poses = f->h_stage;
-        zero_copy = host_io && f->h_result != nullptr;
         fa = make_fused_args(p, o->lm_min_diagonal, o->lm_max_diagonal);
         sharded = p->sharded();
         fa.share = share;
@@ -666,6 +672,13 @@ struct FusedJob : SolveJob {
             const int rows = fused_iter_rows(p->cams[0].model, p->one_focal, p->n_obs, fa.avg_corners, K, share, batch_member);
             if (rows > 0 && 2 * rows <= f->n_pw) iter_rows = rows;
         }
+        // the result straight into pinned host memory: session sizes (one workgroup writes it: k_head or the single-launch group's
+        // workgroup 0); larger problems only where EVERY workgroup of the finishing launch writes a slice (single-launch groups, not
+        // the members of a lockstep batch).  CCAL_RESULT_SPREAD=0 (developer switch): the DMA behind the last launch.
+        static const bool spread_off = dev_env_int("CCAL_RESULT_SPREAD", 1) == 0;
+        const bool large = np6 * sizeof(double) > kZeroCopyBytes;
+        spread = host_io && large && f->h_result != nullptr && iter_rows > 0 && !batch_member && !spread_off;
+        zero_copy = host_io && f->h_result != nullptr && (!large || spread);
         {
             // state, column table and intrinsics travel in k_unpack1's argument block; the poses are read in place from
             // pinned host memory (session sizes) or staged with one copy (large problems)
@@ -679,7 +692,7 @@ struct FusedJob : SolveJob {
             ua.np6 = (int64_t)np6; ua.poses_on_device = host_io ? 0 : 1;
             ua.intr0 = p->d_intr; ua.intr1 = p->d_intr_c; ua.poses0 = p->d_poses; ua.poses1 = p->d_poses_c;
             ua.st = iter_rows ? iter_state(1) : f->d_state; ua.cols = w->cols;
-            pinned_dev = (host_io && !zero_copy && np6) ? pinned_device_ptr(poses_io, np6 * sizeof(double)) : nullptr;
+            pinned_dev = (host_io && large && np6) ? pinned_device_ptr(poses_io, np6 * sizeof(double)) : nullptr;
             if (host_io && pinned_dev) {
                 // the caller's poses are pinned: k_unpack1 reads them where they are (no copy into the staging block, no DMA)
                 std::memcpy(ua.intr_h, intr_io, CCAL_PMAX * sizeof(double));
@@ -733,6 +746,7 @@ struct FusedJob : SolveJob {
         it.on = 1; it.publish_all = o->verbose ? 1 : 0; it.n_part_in = iter_rows;
         it.hs = f->h_status; it.cols = w->cols; it.dc_out = w->dc;
         it.result_host = zero_copy ? f->h_result : nullptr; it.np6 = (int64_t)np6;
+        it.result_poses = nullptr; it.done_cnt = nullptr;          // (a lockstep batch's members: session sizes)
         it.n_cols = ua0.n_cols; it.poses_on_device = ua0.poses_on_device; it.poses_src = ua0.poses_src; it.cols_out = ua0.cols;
         it.st0 = ua0.st0;
         for (int i = 0; i < kFusedMaxK; ++i) it.col0[i] = ua0.col0[i];
@@ -760,6 +774,8 @@ struct FusedJob : SolveJob {
             it.partial_in = iter_partial(sq - 1); it.n_part_in = iter_rows; fa.partial = iter_partial(sq);
             it.hs = f->h_status; it.cols = w->cols; it.dc_out = w->dc;
             it.result_host = zero_copy ? f->h_result : nullptr; it.np6 = (int64_t)np6;
+            it.result_poses = spread ? (pinned_dev ? static_cast<double*>(pinned_dev) : f->h_result + CCAL_PMAX) : nullptr;
+            it.done_cnt = spread ? f->done_cnt : nullptr;
             it.fold = (fold && sq == 1) ? 1 : 0;
             if (it.fold) {
                 it.n_cols = ua0.n_cols; it.poses_on_device = ua0.poses_on_device; it.poses_src = ua0.poses_src; it.cols_out = ua0.cols;
@@ -819,7 +835,7 @@ struct FusedJob : SolveJob {
                 // the k_head that set `done` wrote the result into pinned memory before it published the word this thread
                 // has just read: nothing to copy, nothing to wait for
                 std::memcpy(intr_io, const_cast<const double*>(f->h_result), CCAL_PMAX * sizeof(double));
-                std::memcpy(poses_io, const_cast<const double*>(f->h_result) + CCAL_PMAX, np6 * sizeof(double));
+                if (!(spread && pinned_dev)) std::memcpy(poses_io, const_cast<const double*>(f->h_result) + CCAL_PMAX, np6 * sizeof(double));     // (pinned: written in place)
             } else if (pinned_dev) {
                 // the caller's array is pinned: ONE DMA writes the result where the caller reads it
                 double* h_intr = h_poses;

@@ -235,14 +235,18 @@ def test_zero_copy_result_is_the_device_state(gpu_ctx):
     next one early)."""
     from camera_intrinsic_calibration_rs_amd import synth
     from camera_intrinsic_calibration_rs_amd.engine import Problem, default_opts
-    for frames, model in ((60, "eucm"), (625, "eucm"), (300, "kb4"), (2500, "eucm")):
-        sp = synth.make_problem(frames, model, seed=frames, outlier_frac=0.01)
+    for frames, model, ragged in ((60, "eucm", False), (625, "eucm", False), (300, "kb4", False), (2500, "eucm", False),
+                                  (5000, "ucm", True), (9700, "eucm", False), (10000, "eucm", True), (7000, "kb4", True)):
+        # (from 2 049 frames every workgroup of the finishing single-launch group writes its slice of the poses, the last one to
+        #  count itself in publishes the word: head_finish, SPREAD - k_gram1v's form, k_gram2i, k_gram2i over the folded table)
+        sp = synth.make_problem(frames, model, seed=frames, outlier_frac=0.01, ragged=ragged)
         gp = Problem.from_synth(gpu_ctx, sp)
         for method in (0, 1, 0):
-            i, p, _, r = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method))
-            i_d, p_d, _ = gp.download_params()              # synchronises the stream, reads the accepted set
-            assert r.status == 0
-            np.testing.assert_array_equal(p, p_d)
-            P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
-            np.testing.assert_array_equal(i[0, :P], i_d[0, :P])
+            for pinned in ((False, True) if frames > 2048 else (False,)):
+                i, p, _, r = gp.solve(sp.intr0, sp.poses0, opts=default_opts(method), pinned=pinned)
+                i_d, p_d, _ = gp.download_params()              # synchronises the stream, reads the accepted set
+                assert r.status == 0
+                np.testing.assert_array_equal(p, p_d)
+                P = synth.MODEL_NPARAMS[synth.MODEL_NAMES[model]]
+                np.testing.assert_array_equal(i[0, :P], i_d[0, :P])
         gp.close()
