@@ -181,7 +181,7 @@ struct GramBins {
 };
 // The plan for corner counts n[0 .. n_obs) (host): which frames go together and with how many lanes each; order = the sorted table
 // (frame indices, bins in launch order).  n_bins == 0: binning does not pay (uniform frames, too few of them).
-GramBins gram2_bin_plan(const int64_t* obs_off, int n_obs, bool two_per_simd, std::vector<int32_t>* order);
+GramBins gram2_bin_plan(const int64_t* obs_off, int n_obs, bool two_per_simd, std::vector<int32_t>* order, bool rig_list = false);
 
 }  // namespace ccal
 

@@ -948,9 +948,12 @@ static int gram2_lanes_per_frame(int n_obs, int avg_corners, bool two_per_simd, 
 }
 
 // ---- ragged frames: the bins of one launch ------------------------------------------------------------------------------------
-// What a wavefront costs the SIMD it runs on, in corner passes: its trip count + what its prologue, reductions and fused
-// elimination are worth (the c0 of gram2_lanes_per_frame).
-static inline double g2_wave_cost(int lpf, int passes) { return (lpf == 6 ? 7.0 : 6.0) + (double)passes; }
+// What a wavefront costs the SIMD it runs on, in corner passes: its trip count + what its prologue, reductions and fused elimination are
+// worth - which grow with the frames it holds (4 + frames per wavefront).  Fitted, with the pair rule below, to the PICKS among 198 hand-made
+// plans (equalised T = 3 .. 20, folds of 8 .. 32 lanes) over sixteen problem sizes from 2 000 to 30 000 ragged frames
+// (profiles/r06/ab_g2_plans_folded.txt, ab_g2_plans_between.txt, ab_g2_plans_small.txt; a constant 6 ranked equalised plans of many narrow
+// bins in front of the 16-lane fold that wins from 4 000 to 8 000 frames by 5-9 %).
+static inline double g2_wave_cost(int lpf, int passes) { return 4.0 + (double)(64 / lpf) + (double)passes; }
 // The time of a launch whose wavefronts cost c[0 .. W) in launch order on `simds` SIMDs: wavefront i, i + simds, i + 2 simds ... share
 // a SIMD (the dispatcher fills the chip in launch order).  Two resident wavefronts each advance at 1 / 1.3 of the rate of one alone
 // (gram2_lanes_per_frame's occupancy fit: a pair of equals takes 0.65 of the summed cost), a wavefront whose partner has finished runs
@@ -979,7 +982,7 @@ static double g2_launch_cost(const std::vector<double>& c, int simds, bool two_p
     return worst;
 }
 static int g2_iter_lpf(int n_obs, int avg_corners);
-GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::vector<int32_t>* order) {
+GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::vector<int32_t>* order, bool rig_list) {
     GramBins none;
 #ifdef CCAL_G2_NO_BINS        // A/B builds (tools/build_tu_variants.sh ccal_kernels_gram2 "nobins:-DCCAL_G2_NO_BINS"): the launch without bins
     return none;
@@ -1069,14 +1072,21 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
     // against 28.6 / 41.4 / 48.4 for the best equalised plan).  Where the solve runs single-launch groups of k_gram2i (12 lanes) the
     // table is folded for THAT launch whatever the model says of the build (10 000 frames: build 30.5 against 30.3 us, GN 0.213
     // against 0.223 ms; profiles/r06/ab_g2_plans_folded.txt).
+    bool forced = false;
     if (two_per_simd) {
-        const bool iter12 = g2_iter_lpf(n_obs, (int)(total / std::max(n_obs, 1))) == 12;
+        // two sizes ranges where the table's shape is not the model's to choose: the single-launch groups' 12 lanes, and 3 500 .. 8 192 frames
+        // of clearly ragged sets, where the 16-lane fold was the best of every plan tried at 4 000, 5 000, 6 000, 7 000 and 8 000 frames
+        // (20.8 / 23.0 / 24.5 / 25.8 / 26.7 us; the plain launch at 4 000 / 5 000: 22.5 / 25.3) and the model sees it only from 5 000
+        const bool iter12 = !rig_list && g2_iter_lpf(n_obs, (int)(total / std::max(n_obs, 1))) == 12;       // (a rig's Gram lists: the model's choice only)
+        const bool mid16 = !rig_list && !iter12 && n_obs > 3500 && n_obs <= 8192 && nmax <= 16 * 64 && (double)total <= 0.8 * (double)nmax * (double)n_obs;
+        const int force_lpf = iter12 ? 12 : (mid16 ? 16 : 0);
         for (int b = 0; b < kGramMaxBins; ++b) {
             const int lpf = lpfs[b], g = 64 / lpf;
             const int waves = (n_obs + g - 1) / g;
             if (waves > 2 * simds || (nmax + lpf - 1) / lpf > 64) continue;
 #ifndef CCAL_G2_PLAN_ENV
             if (lpf == 6) continue;                   // (20 000 frames: 45.8 us folded against 44.8 for the equalised plan the model ranks behind it)
+            if (lpf == 32 && n_obs > 3500) continue;  // (4 000 frames: 22.9 us against 20.8 with 16 lanes - pairs of 32-lane wavefronts slow each other more than the model's 1.3)
 #else
             if ((only_fold && lpf != only_fold) || only_T) continue;
 #endif
@@ -1090,7 +1100,7 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
             }
             double cost = g2_launch_cost(c, simds, true);
 #ifndef CCAL_G2_PLAN_ENV
-            if (iter12) { if (lpf != 12) continue; cost = std::min(cost, best_cost); }
+            if (force_lpf) { if (lpf != force_lpf) continue; cost = std::min(cost, best_cost); forced = mid16; }
 #endif
             if (cost <= best_cost) {
                 best_cost = cost;
@@ -1100,14 +1110,14 @@ GramBins gram2_bin_plan(const int64_t* off, int n_obs, bool two_per_simd, std::v
                 best.fold = fold;
             }
         }
-        (void)iter12;
+        (void)force_lpf;
     }
 #endif
 #ifdef CCAL_G2_PLAN_ENV
     if (std::getenv("CCAL_G2_PLAN_PRINT")) std::fprintf(stderr, "gram2_bin_plan %d frames: model cost %.2f (no bins: %.2f), %d bins, fold %d\n", n_obs, best_cost, cost_plain, best.n_bins, best.fold);
     if ((only_T || only_fold) && best.n_bins > 0) cost_plain = 1e300;
 #endif
-    if (best.n_bins == 0 || best_cost > 0.93 * cost_plain) return none;       // (the sorted table costs the prologue a dependent load: it has to pay)
+    if (best.n_bins == 0 || (!forced && best_cost > 0.97 * cost_plain)) return none;       // (the sorted table costs the prologue a dependent load: it has to pay)
     if (best.fold > 0) std::reverse(ord.begin() + best.fold, ord.end());
     *order = std::move(ord);
     return best;

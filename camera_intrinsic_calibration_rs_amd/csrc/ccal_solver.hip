@@ -292,7 +292,7 @@ int normal_ws_ensure_general(ccal_problem* p) {
             std::vector<int64_t> off(list.size() + 1, 0);
             for (size_t i = 0; i < list.size(); ++i) off[i + 1] = off[i] + (p->h_obs_off[list[i] + 1] - p->h_obs_off[list[i]]);
             std::vector<int32_t> order;
-            const GramBins gb = gram2_bin_plan(off.data(), (int)list.size(), model == kUCM || model == kEUCM, &order);
+            const GramBins gb = gram2_bin_plan(off.data(), (int)list.size(), model == kUCM || model == kEUCM, &order, true);
             if (gb.n_bins <= 0) return CCAL_OK;
             std::vector<int32_t> sorted(list.size());
             for (size_t i = 0; i < list.size(); ++i) sorted[i] = list[(size_t)order[i]];

@@ -15,7 +15,7 @@ struct GramBins {
     int32_t lpf[kGramMaxBins] = {}, first[kGramMaxBins] = {}, count[kGramMaxBins] = {}, wg0[kGramMaxBins + 1] = {};
     int32_t fold = 0;
 };
-GramBins gram2_bin_plan(const int64_t* obs_off, int n_obs, bool two_per_simd, std::vector<int32_t>* order);
+GramBins gram2_bin_plan(const int64_t* obs_off, int n_obs, bool two_per_simd, std::vector<int32_t>* order, bool rig_list = false);
 }  // namespace ccal
 
 static int fail(const char* what) { std::printf("PLAN-FAIL %s\n", what); return 1; }

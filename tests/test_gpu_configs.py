@@ -156,10 +156,10 @@ def test_ragged_frames_at_headline_size(gpu_ctx, oracle, model, one_focal):
     gp.close()
 
 
-@pytest.mark.parametrize("frames,model", [(8000, "eucm"), (16000, "ucm"), (12000, "eucm"), (7300, "ucm")])
+@pytest.mark.parametrize("frames,model", [(8000, "eucm"), (16000, "ucm"), (12000, "eucm"), (7300, "ucm"), (4200, "eucm"), (2600, "ucm")])
 def test_ragged_plans_of_other_sizes(gpu_ctx, oracle, frames, model):
-    """The planner's other shapes (csrc/ccal_kernels_gram2.hip: gram2_bin_plan): 8 000 ragged frames take ONE folded bin of 16 lanes, 16 000 one
-    of 8 lanes (larger half of the frames largest first, smaller half smallest first), 12 000 equalised bins: the reduced normal equations
+    """The planner's other shapes (csrc/ccal_kernels_gram2.hip: gram2_bin_plan): 4 200 .. 8 000 ragged frames take ONE folded bin of 16 lanes, 16 000 one
+    of 8 lanes, 2 600 one of 32 (larger half of the frames largest first, smaller half smallest first), 12 000 equalised bins: the reduced normal equations
     against the oracle, the same bits twice, and a Gauss-Newton solve that ends where the oracle's does."""
     sp = synth.make_problem(frames, model, ragged=True, seed=0xF01D + frames)
     gp = Problem.from_synth(gpu_ctx, sp)
