@@ -16,13 +16,14 @@ ap.add_argument("--joff-mb", type=int, default=0, help="place J this many MiB in
 ap.add_argument("--pad-mb", type=int, default=0, help="allocate (and keep) this much before the outputs")
 ap.add_argument("--one-focal", action="store_true")
 ap.add_argument("--ragged", action="store_true", help="24 .. 144 corners per frame (the real sessions' shape) instead of 144")
+ap.add_argument("--outliers", type=float, default=0.0, help="fraction of corners moved 5 .. 30 px off (the Huber branch of the kernels)")
 ap.add_argument("--what", default="eval,normal,solve")
 ap.add_argument("--tag", default=os.environ.get("CCAL_LIB", "default"))
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev)
 ctx = Context(0, stream=stream.cuda_stream)
-sp = synth.make_problem(args.frames, args.model, n_cams=args.cams, xy_same_focal=args.one_focal, ragged=args.ragged)
+sp = synth.make_problem(args.frames, args.model, n_cams=args.cams, xy_same_focal=args.one_focal, ragged=args.ragged, outlier_frac=args.outliers)
 prob = Problem.from_synth(ctx, sp)
 prob.upload_params(sp.intr0, sp.poses0, sp.extr0)
 out = {"tag": os.path.basename(args.tag), "frames": args.frames, "model": args.model, "cams": args.cams}
